@@ -1,0 +1,153 @@
+"""Pin the CPU oracle (oracle/gpexp_oracle.py) against vectors produced by the reference itself.
+
+CPU-only (-m "not gpu").  Tolerances: kernel values are the same arithmetic -> 1e-15 relative
+(bit-equal in practice); pinv-based quantities -> 1e-12 (same LAPACK routine, same inputs);
+index selections -> exact.
+"""
+import numpy as np
+import pytest
+
+from oracle import gpexp_oracle as orc
+
+GP_CASES = ["kat1_demo", "kat2_matern32", "kat3_mehler", "se_iso_d3_n96", "se_ard_d8_n130",
+            "matern32_d8_n200", "mehler_d3_n64", "se_ard_d2_n77_ppnoise", "se_iso_d3_n300"]
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=float)
+    b = np.asarray(b, dtype=float)
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+def test_case_list_complete(golden):
+    assert golden.cases("gp") == sorted(GP_CASES)
+
+
+@pytest.mark.parametrize("case", GP_CASES)
+def test_cov_matrix(golden, case):
+    spec = golden.index[case]["kernel"]
+    K = orc.cov_matrix(spec, golden(case, "X"), golden.noise(case))
+    assert rel(K, golden(case, "K")) <= 1e-15
+    K2 = orc.cov_matrix(spec, golden(case, "X"), golden.noise(case), row_loop=False)
+    assert rel(K2, golden(case, "K")) <= 1e-15
+
+
+@pytest.mark.parametrize("case", GP_CASES)
+def test_fit_posterior_loglike(golden, case):
+    spec = golden.index[case]["kernel"]
+    X, y, Z = golden(case, "X"), golden(case, "y"), golden(case, "Z")
+    nz = golden.noise(case)
+    m = orc.fit(spec, X, y, nz)
+    assert rel(m["P"], golden(case, "precision")) <= 1e-12
+    assert rel(m["coeff"], golden(case, "coeff")) <= 1e-12
+    mean, var = orc.posterior(spec, m, Z)
+    assert rel(mean, golden(case, "mean")) <= 1e-12
+    assert rel(var, golden(case, "var")) <= 1e-11
+    assert rel(np.abs(var), golden(case, "absvar")) <= 1e-11
+    nc = golden(case, "cov").shape[0]
+    _, cov = orc.posterior(spec, m, Z[:nc], compvar=2)
+    assert rel(cov, golden(case, "cov")) <= 1e-11
+    assert abs(orc.loglike(spec, X, y, nz) - golden(case, "loglike")) <= 1e-12 * abs(golden(case, "loglike"))
+
+
+def test_kat_values_from_survey(golden):
+    # literal known answers recorded in SURVEY.md 8(c)
+    assert golden("kat1_demo", "loglike") == pytest.approx(-4.705147601138354, rel=1e-14)
+    np.testing.assert_allclose(golden("kat1_demo", "coeff"),
+                               [1.129102155488872, 6.72619400122942, -4.16813203194361, -3.028072053762631],
+                               rtol=1e-12)
+    np.testing.assert_allclose(golden("kat2_matern32", "K")[0],
+                               [1.51, 1.0449383511052257, 0.5270701365102183, 0.5695911182475639,
+                                0.4059379417516994], rtol=1e-14)
+    np.testing.assert_allclose(golden("kat3_mehler", "K_nugget0")[0],
+                               [1.2257592875140175, 1.186269163829426, 1.1293652131683352,
+                                1.1894019150846535, 0.9853718220041967], rtol=1e-14)
+    assert float(golden("kat4_ivar", "ivar")) == pytest.approx(0.6575280616031077, rel=1e-13)
+
+
+@pytest.mark.parametrize("nm", ["se", "matern32", "mehler"])
+def test_evaluate_shapes(golden, nm):
+    case = "evaluate_" + nm
+    spec = golden.index[case]["kernel"]
+    A, B = golden(case, "A"), golden(case, "B")
+    assert rel(orc.kernel_eval(spec, A, B), golden(case, "paired")) <= 1e-15
+    assert rel(orc.kernel_eval(spec, A, B[:1]), golden(case, "n_vs_1")) <= 1e-15
+    assert rel(orc.kernel_eval(spec, A[:1], B), golden(case, "1_vs_n")) <= 1e-15
+    with pytest.raises(AssertionError):
+        orc.kernel_eval(spec, A[:3], B[:2])  # only paired or 1-vs-n shapes are legal
+
+
+def test_nugget_types(golden):
+    spec = golden.index["kat2_matern32"]["kernel"]
+    X = golden("kat2_matern32", "X")
+    with pytest.raises(TypeError):
+        orc.cov_matrix(spec, X, 1)  # int nugget is an error in the reference too
+
+
+def test_ivar(golden):
+    spec = golden.index["kat4_ivar"]["kernel"]
+    v = orc.ivar(spec, golden("kat4_ivar", "X"), golden("kat4_ivar", "mc"), 1e-3)
+    assert v == pytest.approx(float(golden("kat4_ivar", "ivar")), rel=1e-12)
+
+
+def test_greedy_var_indices(golden):
+    c = "kat5_greedy"
+    spec = golden.index[c]["kernel"]
+    C = golden(c, "C")
+    assert orc.greedy_var(spec, C, 8, keep_start=[0]) == list(golden(c, "gvar_idx"))
+    assert orc.greedy_var(spec, C, 10, keep_start=[7]) == list(golden(c, "gvar_idx_from7"))
+    assert orc.greedy_var(spec, C, 9, weights=golden(c, "weights"), keep_start=[3, 11]) == \
+        list(golden(c, "gvar_idx_weighted"))
+    np.testing.assert_array_equal(C[list(golden(c, "gvar_idx"))], golden(c, "gvar_pts"))
+    # empty start: first pick is the arg-max of the prior variance = index 0 for a stationary kernel
+    assert orc.greedy_var(spec, C, 3)[0] == 0
+
+
+def test_greedy_ivar_indices(golden):
+    c = "kat5_greedy"
+    spec = golden.index[c]["kernel"]
+    idx, costs, allc = orc.greedy_ivar(spec, golden(c, "X0"), golden(c, "C"), golden(c, "Z"), 1e-3, 2)
+    assert idx == list(golden(c, "givar_idx")[:2])
+    assert rel(costs, golden(c, "givar_cost")[:2]) <= 1e-12
+    assert rel(allc, golden(c, "givar_allcosts")[:2]) <= 1e-11
+
+
+def test_mi(golden):
+    c = "kat6_mi"
+    spec = golden.index[c]["kernel"]
+    C = golden(c, "C")
+    assert orc.mi_evaluate(spec, C, 1e-3, 5, [0, 14]) == pytest.approx(float(golden(c, "eval_5_given_0_14").ravel()[0]), rel=1e-9)
+    got = np.array([orc.mi_evaluate(spec, C, 1e-3, j, [0]) for j in range(1, 40)])
+    assert rel(got, golden(c, "eval_all_given_0").ravel()) <= 1e-9
+    keep, _ = orc.greedy_mi(spec, C, 1e-3, 4)
+    assert keep == list(golden(c, "mi_idx")[:4])
+    keep9, _ = orc.greedy_mi(spec, C, 1e-3, 3, start=9)
+    assert keep9 == list(golden(c, "mi_idx_start9")[:3])
+
+
+def test_loglike_grad_vs_finite_differences(golden):
+    """UNPINNED sub-path: the analytic gradient restated from gp.py:444-466 vs central differences of
+    the reference's runnable loglikeParams (fixture lml_fd)."""
+    c = "lml_fd"
+    spec = golden.index[c]["kernel"]
+    nz = golden.index[c]["noise"]
+    val, g = orc.loglike_grad(spec, golden(c, "X"), golden(c, "y"), nz)
+    assert val == pytest.approx(float(golden(c, "loglike")), rel=1e-12)
+    fd = golden(c, "fd_grad_raw")
+    keys = golden.index[c]["keys"]
+    assert keys == orc.hyp_keys(spec)
+    for k, f in zip(keys, fd):
+        want = f * (2.0 * nz) if k == "noise" else f  # gp.py:463-464 scales the noise entry
+        assert g[k] == pytest.approx(want, rel=2e-6), k
+
+
+def test_matern52_unpinned_sanity():
+    # no reference oracle (kernels.py:85-91); sanity: k(x,x)=s and monotone decay, below matern32 smoothness tail
+    s52 = dict(kind="matern52", rho=0.5, signalSize=1.3, d=2)
+    x = np.zeros((4, 2))
+    z = np.array([[0, 0], [0.1, 0], [0.5, 0], [2.0, 0]], dtype=float)
+    k = orc.kernel_eval(s52, x, z)
+    assert k[0] == pytest.approx(1.3)
+    assert np.all(np.diff(k) < 0)
+    t = np.sqrt(5) * 0.5 / 0.5
+    assert k[2] == pytest.approx(1.3 * (1 + t + t * t / 3) * np.exp(-t), rel=1e-15)
