@@ -1,0 +1,104 @@
+"""ctypes binding of libgpx_hip.so (C ABI in include/gpx.h).
+
+The library is the product: there is no CPU fallback.  `load()` raises ImportError when the
+shared object has not been built (run `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C gpexp_amd/csrc`), and `Context()` raises RuntimeError when no MI355X is visible.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgpx_hip.so")
+
+c_i64 = C.c_int64
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(c_i64)
+c_vp = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/gpx.h one to one
+_SIGS = {
+    "gpx_abi_version": (C.c_int, []),
+    "gpx_last_error": (C.c_char_p, []),
+    "gpx_create": (C.c_int, [C.c_int, C.POINTER(c_vp)]),
+    "gpx_destroy": (C.c_int, [c_vp]),
+    "gpx_sync": (C.c_int, [c_vp]),
+    "gpx_trim": (C.c_int, [c_vp]),
+    "gpx_device_info": (C.c_int, [c_vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), c_ip, C.POINTER(C.c_int)]),
+    "gpx_mat_from_host": (C.c_int, [c_vp, c_dp, c_i64, c_i64, C.c_int, C.POINTER(c_vp)]),
+    "gpx_mat_alloc": (C.c_int, [c_vp, c_i64, c_i64, C.c_int, C.POINTER(c_vp)]),
+    "gpx_mat_free": (C.c_int, [c_vp, c_vp]),
+    "gpx_mat_shape": (C.c_int, [c_vp, c_ip, c_ip, c_ip]),
+    "gpx_mat_to_host": (C.c_int, [c_vp, c_vp, c_dp, C.c_int]),
+    "gpx_kfill": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_dp, c_i64, C.POINTER(c_vp)]),
+    "gpx_kfill_into": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_dp, c_i64, c_vp]),
+    "gpx_kdiag": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_dp]),
+    "gpx_potrf": (C.c_int, [c_vp, c_vp]),
+    "gpx_potrs": (C.c_int, [c_vp, c_vp, c_dp, c_dp]),
+    "gpx_logdet": (C.c_int, [c_vp, c_vp, c_dp]),
+    "gpx_potri": (C.c_int, [c_vp, c_vp, C.POINTER(c_vp)]),
+    "gpx_posterior": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_dp, c_vp, c_dp, c_dp]),
+    "gpx_posterior_cov": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_dp]),
+    "gpx_ivar": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_dp]),
+    "gpx_greedy_var": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_dp, c_ip, c_i64, c_i64, c_ip]),
+    "gpx_greedy_ivar_step": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_vp,
+                                       C.c_double, c_dp, c_ip]),
+    "gpx_profile_enable": (C.c_int, [c_vp, C.c_int]),
+    "gpx_profile_reset": (C.c_int, [c_vp]),
+    "gpx_profile_get": (C.c_int, [c_vp, C.c_int, c_ip, c_dp, c_dp, c_dp]),
+    "gpx_dbg_gemm": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library and attach signatures; ImportError if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "gpexp_amd: %s not found - the HIP library is required (no CPU fallback). "
+            "Build it with `make -C gpexp_amd/csrc` or __graft_entry__.build()." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gpx_abi_version() != 1:
+        raise ImportError("gpexp_amd: libgpx_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+class GpxError(RuntimeError):
+    pass
+
+
+class NotPositiveDefinite(GpxError):
+    def __init__(self, pivot):
+        super().__init__("covariance matrix is not positive definite: pivot %d <= 0 "
+                         "(the reference's pinv would silently truncate here, gp.py:181)" % pivot)
+        self.pivot = pivot
+
+
+def check(rc):
+    if rc == 0:
+        return
+    if rc > 0:
+        raise NotPositiveDefinite(rc)
+    raise GpxError("libgpx_hip: " + load().gpx_last_error().decode("utf-8", "replace"))
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def dptr(a):
+    return a.ctypes.data_as(c_dp) if a is not None else None

@@ -1,0 +1,559 @@
+// extern "C" entry points of libgpx_hip.so (declared in include/gpx.h) and the small amount of
+// host-side state behind them: one HIP stream per context, an exact-size caching allocator so that
+// optimiser loops (gp.py:635 calls loglikeParams ~40x) do not hit hipMalloc, event-based per-class
+// kernel timing for bench.py's roofline line.
+#include "gpx_internal.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <stdlib.h>
+
+static thread_local char g_err[1024] = "";
+
+void gpx_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---- allocator -------------------------------------------------------------------------------------
+int gpx_dev_alloc(gpx_ctx* ctx, int64_t bytes, void** out) {
+  if (bytes <= 0) bytes = 8;
+  bytes = gpx_round_up(bytes, 256);
+  auto it = ctx->pool.find(bytes);
+  if (it != ctx->pool.end()) {
+    *out = it->second;
+    ctx->pool.erase(it);
+    ctx->pool_bytes -= bytes;
+    return 0;
+  }
+  hipError_t e = hipMalloc(out, (size_t)bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    gpx_trim(ctx);
+    e = hipMalloc(out, (size_t)bytes);
+  }
+  if (e != hipSuccess) {
+    gpx_set_error("hipMalloc(%lld bytes) failed: %s", (long long)bytes, hipGetErrorString(e));
+    return -2;
+  }
+  return 0;
+}
+
+void gpx_dev_release(gpx_ctx* ctx, void* p, int64_t bytes) {
+  if (!p) return;
+  if (bytes <= 0) bytes = 8;
+  bytes = gpx_round_up(bytes, 256);
+  ctx->pool.insert({bytes, p});
+  ctx->pool_bytes += bytes;
+}
+
+// ---- profiling -------------------------------------------------------------------------------------
+ProfScope::ProfScope(gpx_ctx* c, int cls, double flops, double bytes) : ctx(c), idx(-1) {
+  if (!c->prof_on) return;
+  ProfRec r;
+  r.cls = cls;
+  hipEvent_t ev[2];
+  for (int i = 0; i < 2; ++i) {
+    if (!c->ev_free.empty()) {
+      ev[i] = c->ev_free.back();
+      c->ev_free.pop_back();
+    } else if (hipEventCreate(&ev[i]) != hipSuccess) {
+      return;
+    }
+  }
+  r.a = ev[0];
+  r.b = ev[1];
+  hipEventRecord(r.a, c->stream);
+  c->prof_recs.push_back(r);
+  idx = (int)c->prof_recs.size() - 1;
+  c->prof_launches[cls] += 1;
+  c->prof_flops[cls] += flops;
+  c->prof_bytes[cls] += bytes;
+}
+
+ProfScope::~ProfScope() {
+  if (idx >= 0) hipEventRecord(ctx->prof_recs[idx].b, ctx->stream);
+}
+
+int gpx_prof_flush(gpx_ctx* ctx) {
+  if (ctx->prof_recs.empty()) return 0;
+  GPX_HIP(hipStreamSynchronize(ctx->stream));
+  for (auto& r : ctx->prof_recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) ctx->prof_ms[r.cls] += ms;
+    ctx->ev_free.push_back(r.a);
+    ctx->ev_free.push_back(r.b);
+  }
+  ctx->prof_recs.clear();
+  return 0;
+}
+
+// ---- kernel parameters -----------------------------------------------------------------------------
+int gpx_make_kparams(int kind, int d, const double* hyp, int nhyp, KParams* kp) {
+  GPX_ARG(d >= 1 && d <= GPX_MAXD, "dimension must be in [1, GPX_MAX_DIM]");
+  GPX_ARG(hyp != nullptr, "hyp is NULL");
+  memset(kp, 0, sizeof(*kp));
+  kp->kind = kind;
+  kp->d = d;
+  switch (kind) {
+    case GPX_K_SE:
+      GPX_ARG(nhyp == d + 1, "SE needs d correlation lengths + signalSize");
+      for (int k = 0; k < d; ++k) kp->scale[k] = 1.0 / hyp[k];
+      kp->sig = hyp[d];
+      break;
+    case GPX_K_MATERN32:
+    case GPX_K_MATERN52: {
+      GPX_ARG(nhyp == 2, "Matern needs {rho, signalSize}");
+      const double c = (kind == GPX_K_MATERN32 ? sqrt(3.0) : sqrt(5.0)) / hyp[0];
+      for (int k = 0; k < d; ++k) kp->scale[k] = c;
+      kp->sig = hyp[1];
+      break;
+    }
+    case GPX_K_MEHLER: {
+      GPX_ARG(nhyp == d, "Mehler needs d parameters t_k");
+      double s = 1.0;
+      for (int k = 0; k < d; ++k) {
+        const double t = hyp[k], om = 1.0 - t * t;
+        kp->scale[k] = 1.0;
+        kp->c1[k] = t * t / (2.0 * om);
+        kp->c2[k] = t / om;
+        s *= pow(om, -0.5);
+      }
+      kp->sig = s;
+      break;
+    }
+    default: gpx_set_error("unknown kernel kind %d", kind); return -1;
+  }
+  return 0;
+}
+
+// ---- matrices ----------------------------------------------------------------------------------------
+int gpx_mat_new(gpx_ctx* ctx, int64_t rows, int64_t cols, int pad, gpx_mat** out) {
+  GPX_ARG(rows >= 0 && cols >= 0, "negative shape");
+  gpx_mat* m = new gpx_mat();
+  m->rows = rows;
+  m->cols = cols;
+  m->prows = pad ? gpx_round_up(rows > 0 ? rows : 1, GPX_TILE) : (rows > 0 ? rows : 1);
+  m->pcols = pad ? gpx_round_up(cols > 0 ? cols : 1, GPX_TILE) : (cols > 0 ? cols : 1);
+  m->bytes = m->prows * m->pcols * (int64_t)sizeof(double);
+  m->aux = nullptr;
+  m->aux_bytes = 0;
+  m->factored = 0;
+  void* p = nullptr;
+  int r = gpx_dev_alloc(ctx, m->bytes, &p);
+  if (r != 0) {
+    delete m;
+    return r;
+  }
+  m->p = (double*)p;
+  *out = m;
+  return 0;
+}
+
+extern "C" {
+
+int gpx_abi_version(void) { return GPX_ABI_VERSION; }
+const char* gpx_last_error(void) { return g_err; }
+
+int gpx_create(int device, gpx_ctx** out) {
+  GPX_ARG(out != nullptr, "out is NULL");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    gpx_set_error("no HIP device available (%s): libgpx_hip has no CPU fallback", hipGetErrorString(e));
+    return -2;
+  }
+  GPX_ARG(device >= 0 && device < ndev, "device ordinal out of range");
+  GPX_HIP(hipSetDevice(device));
+  gpx_ctx* c = new gpx_ctx();
+  c->device = device;
+  c->pool_bytes = 0;
+  c->prof_on = 0;
+  for (int i = 0; i < GPX_PROF_NCLASS; ++i) {
+    c->prof_launches[i] = 0;
+    c->prof_ms[i] = c->prof_flops[i] = c->prof_bytes[i] = 0.0;
+  }
+  GPX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  hipDeviceProp_t prop;
+  GPX_HIP(hipGetDeviceProperties(&prop, device));
+  c->cus = prop.multiProcessorCount;
+  GPX_HIP(hipMalloc((void**)&c->d_info, 256));
+  GPX_HIP(hipMalloc((void**)&c->d_scal, 64 * sizeof(double)));
+  GPX_HIP(hipMemset(c->d_info, 0, 256));
+  *out = c;
+  return 0;
+}
+
+int gpx_trim(gpx_ctx* ctx) {
+  GPX_ARG(ctx != nullptr, "ctx is NULL");
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& kv : ctx->pool) (void)hipFree(kv.second);
+  ctx->pool.clear();
+  ctx->pool_bytes = 0;
+  return 0;
+}
+
+int gpx_destroy(gpx_ctx* ctx) {
+  if (!ctx) return 0;
+  (void)hipSetDevice(ctx->device);
+  gpx_prof_flush(ctx);
+  gpx_trim(ctx);
+  for (auto ev : ctx->ev_free) (void)hipEventDestroy(ev);
+  (void)hipFree(ctx->d_info);
+  (void)hipFree(ctx->d_scal);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return 0;
+}
+
+int gpx_sync(gpx_ctx* ctx) {
+  GPX_ARG(ctx != nullptr, "ctx is NULL");
+  GPX_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int gpx_device_info(gpx_ctx* ctx, char* name, int name_len, int* cus, int64_t* hbm_bytes, int* clock_mhz) {
+  GPX_ARG(ctx != nullptr, "ctx is NULL");
+  hipDeviceProp_t prop;
+  GPX_HIP(hipGetDeviceProperties(&prop, ctx->device));
+  if (name && name_len > 0) {
+    snprintf(name, (size_t)name_len, "%s (%s)", prop.name, prop.gcnArchName);
+  }
+  if (cus) *cus = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+  if (clock_mhz) *clock_mhz = prop.clockRate / 1000;
+  return 0;
+}
+
+int gpx_mat_alloc(gpx_ctx* ctx, int64_t rows, int64_t cols, int pad, gpx_mat** out) {
+  GPX_ARG(ctx && out, "NULL argument");
+  GPX_TRY(gpx_mat_new(ctx, rows, cols, pad, out));
+  GPX_HIP(hipMemsetAsync((*out)->p, 0, (size_t)(*out)->bytes, ctx->stream));
+  return 0;
+}
+
+int gpx_mat_from_host(gpx_ctx* ctx, const double* src, int64_t rows, int64_t cols, int pad, gpx_mat** out) {
+  GPX_ARG(ctx && out && (src || rows * cols == 0), "NULL argument");
+  GPX_TRY(gpx_mat_alloc(ctx, rows, cols, pad, out));
+  gpx_mat* m = *out;
+  if (rows > 0 && cols > 0)
+    GPX_HIP(hipMemcpy2DAsync(m->p, (size_t)m->pcols * 8, src, (size_t)cols * 8, (size_t)cols * 8, (size_t)rows,
+                             hipMemcpyHostToDevice, ctx->stream));
+  GPX_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int gpx_mat_free(gpx_ctx* ctx, gpx_mat* m) {
+  if (!m) return 0;
+  GPX_ARG(ctx != nullptr, "ctx is NULL");
+  // work queued on the stream may still reference the buffers: order the reuse behind it
+  (void)hipStreamSynchronize(ctx->stream);
+  gpx_dev_release(ctx, m->p, m->bytes);
+  if (m->aux) gpx_dev_release(ctx, m->aux, m->aux_bytes);
+  delete m;
+  return 0;
+}
+
+int gpx_mat_shape(const gpx_mat* m, int64_t* rows, int64_t* cols, int64_t* ld) {
+  GPX_ARG(m != nullptr, "matrix is NULL");
+  if (rows) *rows = m->rows;
+  if (cols) *cols = m->cols;
+  if (ld) *ld = m->pcols;
+  return 0;
+}
+
+int gpx_mat_to_host(gpx_ctx* ctx, const gpx_mat* m, double* dst, int tri) {
+  GPX_ARG(ctx && m && dst, "NULL argument");
+  GPX_ARG(tri >= 0 && tri <= 2, "tri must be 0, 1 or 2");
+  GPX_ARG(tri == 0 || m->rows == m->cols, "triangular extraction needs a square matrix");
+  if (m->rows == 0 || m->cols == 0) return 0;
+  GPX_HIP(hipMemcpy2DAsync(dst, (size_t)m->cols * 8, m->p, (size_t)m->pcols * 8, (size_t)m->cols * 8,
+                           (size_t)m->rows, hipMemcpyDeviceToHost, ctx->stream));
+  GPX_HIP(hipStreamSynchronize(ctx->stream));
+  const int64_t n = m->rows;
+  if (tri == 1) {
+    for (int64_t i = 0; i < n; ++i)
+      for (int64_t j = i + 1; j < n; ++j) dst[i * n + j] = 0.0;
+  } else if (tri == 2) {
+    for (int64_t i = 0; i < n; ++i)
+      for (int64_t j = i + 1; j < n; ++j) dst[i * n + j] = dst[j * n + i];
+  }
+  return 0;
+}
+
+// ---- covariance assembly -----------------------------------------------------------------------------
+int gpx_kfill_into(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* X, const gpx_mat* Z,
+                   const double* nugget, int64_t nugget_len, gpx_mat* K) {
+  GPX_ARG(ctx && X && K, "NULL argument");
+  KParams kp;
+  GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
+  GPX_ARG(X->cols == d && X->pcols == d, "X must be an unpadded (N x d) point set");
+  const int symmetric = (Z == nullptr);
+  const gpx_mat* Bp = symmetric ? X : Z;
+  GPX_ARG(Bp->cols == d && Bp->pcols == d, "Z must be an unpadded (M x d) point set");
+  GPX_ARG(K->rows == X->rows && K->cols == Bp->rows, "output matrix has the wrong shape");
+  GPX_ARG(K->prows % GPX_TILE == 0 && K->pcols % GPX_TILE == 0, "output matrix must be padded");
+  GPX_ARG(nugget_len == 0 || nugget_len == 1 || nugget_len == X->rows, "nugget_len must be 0, 1 or N");
+  GPX_ARG(symmetric || nugget_len == 0, "nugget only applies to the symmetric form");
+  GPX_ARG(nugget_len == 0 || nugget != nullptr, "nugget is NULL");
+  double* d_nug = nullptr;
+  int64_t nug_bytes = 0;
+  double nscal = 0.0;
+  if (nugget_len == 1) nscal = nugget[0];
+  if (nugget_len > 1) {
+    nug_bytes = nugget_len * 8;
+    void* p;
+    GPX_TRY(gpx_dev_alloc(ctx, nug_bytes, &p));
+    d_nug = (double*)p;
+    GPX_HIP(hipMemcpyAsync(d_nug, nugget, (size_t)nug_bytes, hipMemcpyHostToDevice, ctx->stream));
+  }
+  int r = launch_kfill(ctx, kp, X->p, X->rows, Bp->p, Bp->rows, symmetric, d_nug, nugget_len, nscal, K->p,
+                       K->prows, K->pcols, K->pcols);
+  if (d_nug) {
+    (void)hipStreamSynchronize(ctx->stream);
+    gpx_dev_release(ctx, d_nug, nug_bytes);
+  }
+  K->factored = 0;
+  return r;
+}
+
+int gpx_kfill(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* X, const gpx_mat* Z,
+              const double* nugget, int64_t nugget_len, gpx_mat** outK) {
+  GPX_ARG(ctx && X && outK, "NULL argument");
+  gpx_mat* K = nullptr;
+  GPX_TRY(gpx_mat_new(ctx, X->rows, Z ? Z->rows : X->rows, 1, &K));
+  int r = gpx_kfill_into(ctx, kind, d, hyp, nhyp, X, Z, nugget, nugget_len, K);
+  if (r != 0) {
+    gpx_mat_free(ctx, K);
+    return r;
+  }
+  *outK = K;
+  return 0;
+}
+
+int gpx_kdiag(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* Z, double* out) {
+  GPX_ARG(ctx && Z && out, "NULL argument");
+  KParams kp;
+  GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
+  GPX_ARG(Z->cols == d && Z->pcols == d, "Z must be an unpadded (M x d) point set");
+  if (Z->rows == 0) return 0;
+  void* p;
+  GPX_TRY(gpx_dev_alloc(ctx, Z->rows * 8, &p));
+  int r = launch_kdiag(ctx, kp, Z->p, Z->rows, (double*)p);
+  if (r == 0) {
+    hipError_t e = hipMemcpyAsync(out, p, (size_t)Z->rows * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e != hipSuccess) r = -2;
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  gpx_dev_release(ctx, p, Z->rows * 8);
+  return r;
+}
+
+// ---- factorisation and solves ----------------------------------------------------------------------
+int gpx_potrf(gpx_ctx* ctx, gpx_mat* K) {
+  GPX_ARG(ctx && K, "NULL argument");
+  GPX_ARG(K->rows == K->cols && K->prows == K->pcols && K->prows % GPX_TILE == 0, "potrf needs a padded square matrix");
+  if (!K->aux) {
+    K->aux_bytes = K->prows * GPX_TILE * 8;
+    void* p;
+    GPX_TRY(gpx_dev_alloc(ctx, K->aux_bytes, &p));
+    K->aux = (double*)p;
+  }
+  GPX_TRY(chol_potrf(ctx, K->p, K->pcols, K->prows, K->aux, K->rows));
+  int info = 0;
+  GPX_HIP(hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  GPX_HIP(hipStreamSynchronize(ctx->stream));
+  K->factored = (info == 0);
+  if (info != 0) gpx_set_error("potrf: matrix is not positive definite (pivot %d <= 0)", info);
+  return info;
+}
+
+static int need_factor(const gpx_mat* L) {
+  GPX_ARG(L != nullptr, "factor is NULL");
+  GPX_ARG(L->factored && L->aux, "matrix has not been factored by gpx_potrf");
+  return 0;
+}
+
+int gpx_potrs(gpx_ctx* ctx, const gpx_mat* L, const double* y, double* alpha) {
+  GPX_ARG(ctx && y && alpha, "NULL argument");
+  GPX_TRY(need_factor(L));
+  const int64_t n = L->rows, np = L->prows;
+  void* p;
+  GPX_TRY(gpx_dev_alloc(ctx, np * 8, &p));
+  double* dv = (double*)p;
+  int r = 0;
+  do {
+    if (hipMemsetAsync(dv, 0, (size_t)np * 8, ctx->stream) != hipSuccess) { r = -2; break; }
+    if (hipMemcpyAsync(dv, y, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { r = -2; break; }
+    if ((r = chol_trsv(ctx, L->p, L->pcols, L->aux, dv, np, false)) != 0) break;
+    if ((r = chol_trsv(ctx, L->p, L->pcols, L->aux, dv, np, true)) != 0) break;
+    if (hipMemcpyAsync(alpha, dv, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { r = -2; break; }
+  } while (0);
+  (void)hipStreamSynchronize(ctx->stream);
+  gpx_dev_release(ctx, dv, np * 8);
+  if (r == -2) gpx_set_error("potrs: HIP copy failed");
+  return r;
+}
+
+int gpx_logdet(gpx_ctx* ctx, const gpx_mat* L, double* out) {
+  GPX_ARG(ctx && out, "NULL argument");
+  GPX_TRY(need_factor(L));
+  GPX_TRY(launch_logdet(ctx, L->p, L->pcols, L->rows, ctx->d_scal));
+  GPX_HIP(hipMemcpyAsync(out, ctx->d_scal, 8, hipMemcpyDeviceToHost, ctx->stream));
+  GPX_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// ---- posterior / IVAR ---------------------------------------------------------------------------------
+// chunk of evaluation points handled at once: keep the (N x Mc) cross matrix under ~16 GiB
+static int64_t eval_chunk(int64_t np) {
+  int64_t budget = (int64_t)16 << 30;
+  const char* e = getenv("GPX_CROSS_BYTES");
+  if (e && atoll(e) > 0) budget = atoll(e);
+  int64_t mc = budget / (np * 8) / GPX_TILE * GPX_TILE;
+  if (mc < GPX_TILE) mc = GPX_TILE;
+  return mc;
+}
+
+// Shared body: for every chunk of Z build B = K(X, Zc), optionally mean = B^T alpha, then
+// W = L^-1 B and var = k(z,z) - colsum(W^2).  mean/var are host arrays of length M (nullable).
+static int posterior_impl(gpx_ctx* ctx, const KParams& kp, const gpx_mat* L, const gpx_mat* X, const double* alpha,
+                          const gpx_mat* Z, double* mean, double* var) {
+  const int64_t n = L->rows, np = L->prows, M = Z->rows, d = kp.d;
+  GPX_ARG(X->rows == n, "X does not match the factor");
+  if (M == 0) return 0;
+  const int64_t mcmax = eval_chunk(np);
+  const int64_t mc_alloc = gpx_round_up(M < mcmax ? M : mcmax, GPX_TILE);
+  void *pB = nullptr, *pal = nullptr, *pout = nullptr, *ppart = nullptr, *pkd = nullptr;
+  const int64_t bytesB = np * mc_alloc * 8, bytes_out = mc_alloc * 8;
+  const int64_t bytes_part = colreduce_partial_elems(np, mc_alloc) * 8 + 8;
+  int r = 0;
+  std::vector<double> hbuf((size_t)mc_alloc), hk((size_t)mc_alloc);
+  do {
+    if ((r = gpx_dev_alloc(ctx, bytesB, &pB)) != 0) break;
+    if ((r = gpx_dev_alloc(ctx, bytes_out, &pout)) != 0) break;
+    if ((r = gpx_dev_alloc(ctx, bytes_out, &pkd)) != 0) break;
+    if ((r = gpx_dev_alloc(ctx, bytes_part, &ppart)) != 0) break;
+    if (mean) {
+      if ((r = gpx_dev_alloc(ctx, np * 8, &pal)) != 0) break;
+      if (hipMemsetAsync(pal, 0, (size_t)np * 8, ctx->stream) != hipSuccess ||
+          hipMemcpyAsync(pal, alpha, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        r = -2;
+        break;
+      }
+    }
+    for (int64_t j0 = 0; j0 < M && r == 0; j0 += mcmax) {
+      const int64_t mc = (M - j0) < mcmax ? (M - j0) : mcmax;
+      const int64_t mcp = gpx_round_up(mc, GPX_TILE);
+      double* B = (double*)pB;
+      const double* Zc = Z->p + j0 * d;
+      if ((r = launch_kfill(ctx, kp, X->p, n, Zc, mc, 0, nullptr, 0, 0.0, B, np, mcp, mcp)) != 0) break;
+      if (mean) {
+        if ((r = launch_colreduce(ctx, B, mcp, n, mcp, (const double*)pal, (double*)pout, (double*)ppart)) != 0) break;
+        if (hipMemcpyAsync(mean + j0, pout, (size_t)mc * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) {
+          r = -2;
+          break;
+        }
+      }
+      if (var) {
+        if ((r = chol_trsm_left(ctx, L->p, L->pcols, L->aux, B, mcp, np, mcp)) != 0) break;
+        if ((r = launch_colreduce(ctx, B, mcp, n, mcp, nullptr, (double*)pout, (double*)ppart)) != 0) break;
+        if ((r = launch_kdiag(ctx, kp, Zc, mc, (double*)pkd)) != 0) break;
+        if (hipMemcpyAsync(hbuf.data(), pout, (size_t)mc * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(hk.data(), pkd, (size_t)mc * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+          r = -2;
+          break;
+        }
+        for (int64_t j = 0; j < mc; ++j) var[j0 + j] = hk[(size_t)j] - hbuf[(size_t)j];
+      }
+    }
+  } while (0);
+  (void)hipStreamSynchronize(ctx->stream);
+  gpx_dev_release(ctx, pB, bytesB);
+  gpx_dev_release(ctx, pout, bytes_out);
+  gpx_dev_release(ctx, pkd, bytes_out);
+  gpx_dev_release(ctx, ppart, bytes_part);
+  if (pal) gpx_dev_release(ctx, pal, np * 8);
+  if (r == -2) gpx_set_error("posterior: HIP copy failed: %s", hipGetErrorString(hipGetLastError()));
+  return r;
+}
+
+int gpx_posterior(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
+                  const double* alpha, const gpx_mat* Z, double* mean, double* var) {
+  GPX_ARG(ctx && X && Z, "NULL argument");
+  GPX_TRY(need_factor(L));
+  GPX_ARG(mean == nullptr || alpha != nullptr, "alpha is required for the mean");
+  KParams kp;
+  GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
+  GPX_ARG(X->cols == d && X->pcols == d && Z->cols == d && Z->pcols == d, "point sets must be unpadded (n x d)");
+  return posterior_impl(ctx, kp, L, X, alpha, Z, mean, var);
+}
+
+int gpx_ivar(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
+             const gpx_mat* Z, double* out) {
+  GPX_ARG(ctx && X && Z && out, "NULL argument");
+  GPX_TRY(need_factor(L));
+  KParams kp;
+  GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
+  GPX_ARG(X->cols == d && X->pcols == d && Z->cols == d && Z->pcols == d, "point sets must be unpadded (n x d)");
+  GPX_ARG(Z->rows > 0, "IVAR needs at least one integration point");
+  std::vector<double> var((size_t)Z->rows);
+  GPX_TRY(posterior_impl(ctx, kp, L, X, nullptr, Z, nullptr, var.data()));
+  // fixed-order pairwise sum (deterministic, independent of chunking)
+  int64_t m = Z->rows;
+  std::vector<double>& v = var;
+  while (m > 1) {
+    int64_t h = (m + 1) / 2;
+    for (int64_t i = 0; i + h < m; ++i) v[(size_t)i] += v[(size_t)(i + h)];
+    m = h;
+  }
+  *out = v[0] / (double)Z->rows;
+  return 0;
+}
+
+// ---- measurement ---------------------------------------------------------------------------------------
+int gpx_profile_enable(gpx_ctx* ctx, int on) {
+  GPX_ARG(ctx != nullptr, "ctx is NULL");
+  if (!on) GPX_TRY(gpx_prof_flush(ctx));
+  ctx->prof_on = on ? 1 : 0;
+  return 0;
+}
+
+int gpx_profile_reset(gpx_ctx* ctx) {
+  GPX_ARG(ctx != nullptr, "ctx is NULL");
+  GPX_TRY(gpx_prof_flush(ctx));
+  for (int i = 0; i < GPX_PROF_NCLASS; ++i) {
+    ctx->prof_launches[i] = 0;
+    ctx->prof_ms[i] = ctx->prof_flops[i] = ctx->prof_bytes[i] = 0.0;
+  }
+  return 0;
+}
+
+int gpx_profile_get(gpx_ctx* ctx, int cls, int64_t* launches, double* ms, double* flops, double* bytes) {
+  GPX_ARG(ctx != nullptr, "ctx is NULL");
+  GPX_ARG(cls >= 0 && cls < GPX_PROF_NCLASS, "unknown profile class");
+  GPX_TRY(gpx_prof_flush(ctx));
+  if (launches) *launches = ctx->prof_launches[cls];
+  if (ms) *ms = ctx->prof_ms[cls];
+  if (flops) *flops = ctx->prof_flops[cls];
+  if (bytes) *bytes = ctx->prof_bytes[cls];
+  return 0;
+}
+
+// ---- test hooks ------------------------------------------------------------------------------------------
+int gpx_dbg_gemm(gpx_ctx* ctx, const gpx_mat* A, const gpx_mat* B, gpx_mat* C, int bt, int accumulate, int lower) {
+  GPX_ARG(ctx && A && B && C, "NULL argument");
+  const int64_t m = C->prows, n = C->pcols, k = A->pcols;
+  GPX_ARG(A->prows == m, "A rows");
+  GPX_ARG(bt ? (B->prows == n && B->pcols == k) : (B->prows == k && B->pcols == n), "B shape");
+  GPX_TRY(launch_gemm(ctx, A->p, A->pcols, B->p, B->pcols, C->p, C->pcols, m, n, k, bt != 0, accumulate != 0,
+                      lower != 0));
+  GPX_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+}  // extern "C"

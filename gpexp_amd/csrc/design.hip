@@ -1,0 +1,386 @@
+// Design-cost evaluators and the on-request dense inverses -- gfx950.
+//
+//  gpx_greedy_var        performGreedyVarExperimentalDesign (experimentalDesign.py:787-845): the reference
+//                        re-inverts K(sel,sel) with pinv and loops over all M candidates in Python at every
+//                        step; here the same conditional variances are carried incrementally as a partial
+//                        pivoted Cholesky of K(C,C): one kernel row + one O(M*n) update per step.
+//  gpx_greedy_ivar_step  one step of discrete greedy IVAR (composition oracle):
+//                        IVAR(X u {c}) = [sum_z var(z|X) - sum_z cov(z,c|X)^2 / (var(c|X)+noise)] / nMC with
+//                        cov(Z,C|X) = K(Z,C) - W_Z^T W_C as one MFMA GEMM instead of M refits.
+//  gpx_posterior_cov     GP.evaluate(compvar=2) (gp.py:146-152).
+//  gpx_potri             explicit K^-1 for the lazy GP.precisionMatrix attribute (gp.py:181).
+#include "gpx_internal.h"
+#include <math.h>
+#include <stdlib.h>
+
+namespace {
+
+// ---- 32x32 tiled transpose: out[j][i] = in[i][j] ----------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ in, int64_t ldi,
+                                                        double* __restrict__ out, int64_t ldo) {
+  __shared__ double tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int64_t i0 = (int64_t)blockIdx.y * 32, j0 = (int64_t)blockIdx.x * 32;
+  for (int r = ty; r < 32; r += 8) tile[r][tx] = in[(i0 + r) * ldi + j0 + tx];
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) out[(j0 + r) * ldo + i0 + tx] = tile[tx][r];
+}
+
+int launch_transpose(gpx_ctx* ctx, const double* in, int64_t rows, int64_t cols, int64_t ldi, double* out,
+                     int64_t ldo) {
+  dim3 grid((unsigned)(cols / 32), (unsigned)(rows / 32));
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, ctx->stream, in, ldi, out, ldo);
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void set_identity_kernel(double* __restrict__ A, int64_t n, int64_t ld) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx < n) A[idx * ld + idx] = 1.0;
+}
+
+// ---- covariance value for a pair of points given in global memory (generic d) -------------------------
+__device__ __forceinline__ double kpair(const KParams& kp, const double* __restrict__ a, const double* __restrict__ b) {
+  double acc = 0.0;
+  if (kp.kind == GPX_K_MEHLER) {
+    double pa = 0.0, pb = 0.0, cr = 0.0;
+    for (int k = 0; k < kp.d; ++k) {
+      const double x = a[k], y = b[k];
+      pa = fma(kp.c1[k] * x, x, pa);
+      pb = fma(kp.c1[k] * y, y, pb);
+      cr = fma(kp.c2[k] * x, y, cr);
+    }
+    return kp.sig * exp(-(pa + pb - cr));
+  }
+  for (int k = 0; k < kp.d; ++k) {
+    const double e = a[k] * kp.scale[k] - b[k] * kp.scale[k];
+    acc = fma(e, e, acc);
+  }
+  if (kp.kind == GPX_K_SE) return kp.sig * exp(-0.5 * acc);
+  const double t = sqrt(acc);
+  if (kp.kind == GPX_K_MATERN32) return kp.sig * (1.0 + t) * exp(-t);
+  return kp.sig * (1.0 + t + acc * (1.0 / 3.0)) * exp(-t);
+}
+
+// ---- greedy variance ---------------------------------------------------------------------------------------
+// One selection step.  sel[cur] holds the index s chosen for this step.  For every candidate c:
+//   w_c = (k(c_s, c) - sum_{t<cur} W[t][s] W[t][c]) / sqrt(d_s);  W[cur][c] = w_c;  d_out[c] = d_in[c] - w_c^2
+// A pivot with d_s <= tol*prior_s adds no information (the reference's pinv truncates it): w = 0.
+__global__ __launch_bounds__(256) void greedy_row_kernel(KParams kp, const double* __restrict__ Cp, int64_t M,
+                                                         const int64_t* __restrict__ sel, int cur,
+                                                         double* __restrict__ W, int64_t ldw,
+                                                         const double* __restrict__ prior,
+                                                         const double* __restrict__ d_in, double* __restrict__ d_out) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= M) return;
+  const int64_t s = sel[cur];
+  const double ds = d_in[s];
+  double w = 0.0;
+  if (ds > 1e-13 * prior[s]) {
+    double dot = 0.0;
+    for (int t = 0; t < cur; ++t) dot = fma(W[(int64_t)t * ldw + s], W[(int64_t)t * ldw + c], dot);
+    w = (kpair(kp, Cp + s * kp.d, Cp + c * kp.d) - dot) / sqrt(ds);
+  }
+  W[(int64_t)cur * ldw + c] = w;
+  d_out[c] = fma(-w, w, d_in[c]);
+}
+
+// first-maximum arg-max of d[c]*w[c] (np.argmax tie rule: lowest index), two stages, deterministic
+struct VI {
+  double v;
+  int64_t i;
+};
+__device__ __forceinline__ VI vi_max(VI a, VI b) {
+  if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
+  return a;
+}
+
+__global__ __launch_bounds__(256) void argmax_stage1(const double* __restrict__ d, const double* __restrict__ w,
+                                                     int64_t M, double* __restrict__ pv, int64_t* __restrict__ pi) {
+  __shared__ double sv[256];
+  __shared__ int64_t si[256];
+  VI best;
+  best.v = -INFINITY;
+  best.i = INT64_MAX;
+  for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < M; c += (int64_t)gridDim.x * 256) {
+    VI x;
+    x.v = w ? d[c] * w[c] : d[c];
+    x.i = c;
+    best = vi_max(best, x);
+  }
+  sv[threadIdx.x] = best.v;
+  si[threadIdx.x] = best.i;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) {
+    if (threadIdx.x < h) {
+      VI a{sv[threadIdx.x], si[threadIdx.x]}, b{sv[threadIdx.x + h], si[threadIdx.x + h]};
+      VI m = vi_max(a, b);
+      sv[threadIdx.x] = m.v;
+      si[threadIdx.x] = m.i;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    pv[blockIdx.x] = sv[0];
+    pi[blockIdx.x] = si[0];
+  }
+}
+
+__global__ __launch_bounds__(256) void argmax_stage2(const double* __restrict__ pv, const int64_t* __restrict__ pi,
+                                                     int nb, int64_t* __restrict__ sel, int slot) {
+  __shared__ double sv[256];
+  __shared__ int64_t si[256];
+  VI best;
+  best.v = -INFINITY;
+  best.i = INT64_MAX;
+  for (int b = threadIdx.x; b < nb; b += 256) best = vi_max(best, VI{pv[b], pi[b]});
+  sv[threadIdx.x] = best.v;
+  si[threadIdx.x] = best.i;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) {
+    if (threadIdx.x < h) {
+      VI m = vi_max(VI{sv[threadIdx.x], si[threadIdx.x]}, VI{sv[threadIdx.x + h], si[threadIdx.x + h]});
+      sv[threadIdx.x] = m.v;
+      si[threadIdx.x] = m.i;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sel[slot] = si[0] == INT64_MAX ? 0 : si[0];  // all-NaN scores: index 0 like np.argmax
+}
+
+// cost_j = | (S0 - q_j / (kcc_j - ssc_j + noise)) / nmc |
+__global__ __launch_bounds__(256) void ivar_cost_kernel(const double* __restrict__ q, const double* __restrict__ kcc,
+                                                        const double* __restrict__ ssc, double noise, double s0,
+                                                        double inv_nmc, int64_t M, double* __restrict__ cost) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= M) return;
+  cost[j] = fabs((s0 - q[j] / (kcc[j] - ssc[j] + noise)) * inv_nmc);
+}
+
+struct Scratch {  // pooled device buffers released together
+  gpx_ctx* ctx;
+  std::vector<std::pair<void*, int64_t>> bufs;
+  explicit Scratch(gpx_ctx* c) : ctx(c) {}
+  int get(int64_t bytes, void** out) {
+    int r = gpx_dev_alloc(ctx, bytes, out);
+    if (r == 0) bufs.push_back({*out, bytes});
+    return r;
+  }
+  ~Scratch() {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& b : bufs) gpx_dev_release(ctx, b.first, b.second);
+  }
+};
+
+int check_points(const gpx_mat* P, int d) {
+  GPX_ARG(P && P->cols == d && P->pcols == d, "point sets must be unpadded (n x d)");
+  return 0;
+}
+
+double pairwise_sum(std::vector<double>& v, int64_t m) {
+  if (m == 0) return 0.0;
+  while (m > 1) {
+    int64_t h = (m + 1) / 2;
+    for (int64_t i = 0; i + h < m; ++i) v[(size_t)i] += v[(size_t)(i + h)];
+    m = h;
+  }
+  return v[0];
+}
+
+}  // namespace
+
+extern "C" {
+
+int gpx_posterior_cov(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
+                      const gpx_mat* Z, double* cov) {
+  GPX_ARG(ctx && L && X && Z && cov, "NULL argument");
+  GPX_ARG(L->factored && L->aux, "matrix has not been factored by gpx_potrf");
+  KParams kp;
+  GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
+  GPX_TRY(check_points(X, d));
+  GPX_TRY(check_points(Z, d));
+  const int64_t n = L->rows, np = L->prows, m = Z->rows, mp = gpx_round_up(m > 0 ? m : 1, GPX_TILE);
+  GPX_ARG(X->rows == n, "X does not match the factor");
+  if (m == 0) return 0;
+  Scratch sc(ctx);
+  void *pW, *pWt, *pK;
+  GPX_TRY(sc.get(np * mp * 8, &pW));
+  GPX_TRY(sc.get(np * mp * 8, &pWt));
+  GPX_TRY(sc.get(mp * mp * 8, &pK));
+  GPX_TRY(launch_kfill(ctx, kp, X->p, n, Z->p, m, 0, nullptr, 0, 0.0, (double*)pW, np, mp, mp));
+  GPX_TRY(chol_trsm_left(ctx, L->p, L->pcols, L->aux, (double*)pW, mp, np, mp));
+  GPX_TRY(launch_transpose(ctx, (double*)pW, np, mp, mp, (double*)pWt, np));
+  GPX_TRY(launch_kfill(ctx, kp, Z->p, m, Z->p, m, 1, nullptr, 0, 0.0, (double*)pK, mp, mp, mp));
+  GPX_TRY(launch_gemm(ctx, (double*)pWt, np, (double*)pWt, np, (double*)pK, mp, mp, mp, np, true, true, false));
+  GPX_HIP(hipMemcpy2DAsync(cov, (size_t)m * 8, pK, (size_t)mp * 8, (size_t)m * 8, (size_t)m, hipMemcpyDeviceToHost,
+                           ctx->stream));
+  GPX_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int gpx_potri(gpx_ctx* ctx, const gpx_mat* L, gpx_mat** outP) {
+  GPX_ARG(ctx && L && outP, "NULL argument");
+  GPX_ARG(L->factored && L->aux, "matrix has not been factored by gpx_potrf");
+  const int64_t np = L->prows;
+  gpx_mat* P = nullptr;
+  GPX_TRY(gpx_mat_new(ctx, L->rows, L->cols, 1, &P));
+  Scratch sc(ctx);
+  void *pI, *pT;
+  int r = 0;
+  do {
+    if ((r = sc.get(np * np * 8, &pI)) != 0) break;
+    if ((r = sc.get(np * np * 8, &pT)) != 0) break;
+    if (hipMemsetAsync(pI, 0, (size_t)(np * np * 8), ctx->stream) != hipSuccess) { r = -2; break; }
+    hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (double*)pI, np, np);
+    if ((r = chol_trsm_left(ctx, L->p, L->pcols, L->aux, (double*)pI, np, np, np)) != 0) break;  // L^-1
+    if ((r = launch_transpose(ctx, (double*)pI, np, np, np, (double*)pT, np)) != 0) break;       // L^-T
+    // K^-1 = L^-T L^-1 = T T^T
+    if ((r = launch_gemm(ctx, (double*)pT, np, (double*)pT, np, P->p, np, np, np, np, true, false, false)) != 0) break;
+  } while (0);
+  if (r != 0) {
+    gpx_mat_free(ctx, P);
+    if (r == -2) gpx_set_error("potri: HIP call failed");
+    return r;
+  }
+  GPX_HIP(hipStreamSynchronize(ctx->stream));
+  *outP = P;
+  return 0;
+}
+
+int gpx_greedy_var(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* Cm, const double* w,
+                   const int64_t* keep, int64_t nkeep, int64_t nsel, int64_t* out_idx) {
+  GPX_ARG(ctx && Cm && out_idx, "NULL argument");
+  GPX_ARG(nkeep >= 0 && nsel >= nkeep && (nkeep == 0 || keep), "bad keep/nsel");
+  KParams kp;
+  GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
+  GPX_TRY(check_points(Cm, d));
+  const int64_t M = Cm->rows;
+  GPX_ARG(M > 0, "no candidates");
+  for (int64_t i = 0; i < nkeep; ++i) GPX_ARG(keep[i] >= 0 && keep[i] < M, "keep index out of range");
+  if (nsel == 0) return 0;
+  Scratch sc(ctx);
+  const int nb = (int)(((M + 255) / 256) < 1024 ? ((M + 255) / 256) : 1024);
+  void *pW, *pd0, *pd1, *pprior, *psel, *ppv, *ppi, *pw = nullptr;
+  GPX_TRY(sc.get(nsel * M * 8, &pW));
+  GPX_TRY(sc.get(M * 8, &pd0));
+  GPX_TRY(sc.get(M * 8, &pd1));
+  GPX_TRY(sc.get(M * 8, &pprior));
+  GPX_TRY(sc.get(nsel * 8, &psel));
+  GPX_TRY(sc.get(nb * 8, &ppv));
+  GPX_TRY(sc.get(nb * 8, &ppi));
+  if (w) {
+    GPX_TRY(sc.get(M * 8, &pw));
+    GPX_HIP(hipMemcpyAsync(pw, w, (size_t)M * 8, hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (nkeep > 0) GPX_HIP(hipMemcpyAsync(psel, keep, (size_t)nkeep * 8, hipMemcpyHostToDevice, ctx->stream));
+  GPX_TRY(launch_kdiag(ctx, kp, Cm->p, M, (double*)pprior));
+  GPX_HIP(hipMemcpyAsync(pd0, pprior, (size_t)M * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  double* din = (double*)pd0;
+  double* dout = (double*)pd1;
+  const dim3 gridM((unsigned)((M + 255) / 256));
+  {
+    ProfScope ps(ctx, GPX_PROF_GREEDY, (double)M * nsel * nsel, 0.0);
+    for (int64_t cur = 0; cur < nsel; ++cur) {
+      if (cur >= nkeep) {
+        hipLaunchKernelGGL(argmax_stage1, dim3(nb), dim3(256), 0, ctx->stream, din, (const double*)pw, M, (double*)ppv,
+                           (int64_t*)ppi);
+        hipLaunchKernelGGL(argmax_stage2, dim3(1), dim3(256), 0, ctx->stream, (const double*)ppv, (const int64_t*)ppi,
+                           nb, (int64_t*)psel, (int)cur);
+      }
+      if (cur + 1 < nsel) {  // the last pick needs no further conditioning
+        hipLaunchKernelGGL(greedy_row_kernel, gridM, dim3(256), 0, ctx->stream, kp, Cm->p, M, (const int64_t*)psel,
+                           (int)cur, (double*)pW, M, (const double*)pprior, (const double*)din, dout);
+        double* t = din;
+        din = dout;
+        dout = t;
+      }
+    }
+  }
+  GPX_HIP(hipGetLastError());
+  GPX_HIP(hipMemcpyAsync(out_idx, psel, (size_t)nsel * 8, hipMemcpyDeviceToHost, ctx->stream));
+  GPX_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int gpx_greedy_ivar_step(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L,
+                         const gpx_mat* X, const gpx_mat* Cm, const gpx_mat* Z, double noise, double* out_cost,
+                         int64_t* out_best) {
+  GPX_ARG(ctx && L && X && Cm && Z && out_best, "NULL argument");
+  GPX_ARG(L->factored && L->aux, "matrix has not been factored by gpx_potrf");
+  KParams kp;
+  GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
+  GPX_TRY(check_points(X, d));
+  GPX_TRY(check_points(Cm, d));
+  GPX_TRY(check_points(Z, d));
+  const int64_t n = L->rows, np = L->prows, M = Cm->rows, nmc = Z->rows;
+  GPX_ARG(X->rows == n, "X does not match the factor");
+  GPX_ARG(M > 0 && nmc > 0, "need candidates and integration points");
+  const int64_t zp = gpx_round_up(nmc, GPX_TILE);
+  // candidate chunk: W_C (np x mc) + G (zp x mc) under ~24 GiB
+  int64_t budget = (int64_t)24 << 30;
+  const char* e = getenv("GPX_CROSS_BYTES");
+  if (e && atoll(e) > 0) budget = atoll(e);
+  int64_t mcmax = budget / ((np + zp) * 8) / GPX_TILE * GPX_TILE;
+  if (mcmax < GPX_TILE) mcmax = GPX_TILE;
+  const int64_t mc_alloc = gpx_round_up(M < mcmax ? M : mcmax, GPX_TILE);
+
+  Scratch sc(ctx);
+  void *pWz, *pWzt, *pWc, *pG, *pss, *pkd, *pq, *ppart, *pcost;
+  GPX_TRY(sc.get(np * zp * 8, &pWz));
+  GPX_TRY(sc.get(np * zp * 8, &pWzt));
+  GPX_TRY(sc.get(np * mc_alloc * 8, &pWc));
+  GPX_TRY(sc.get(zp * mc_alloc * 8, &pG));
+  const int64_t wide = zp > mc_alloc ? zp : mc_alloc;
+  GPX_TRY(sc.get(wide * 8, &pss));
+  GPX_TRY(sc.get(wide * 8, &pkd));
+  GPX_TRY(sc.get(wide * 8, &pq));
+  GPX_TRY(sc.get(wide * 8, &pcost));
+  int64_t part = colreduce_partial_elems(np, wide);
+  int64_t part2 = colreduce_partial_elems(zp, wide);
+  GPX_TRY(sc.get((part > part2 ? part : part2) * 8 + 8, &ppart));
+
+  // ---- integration points: W_Z = L^-1 K(X,Z), var_z, S0 ----
+  GPX_TRY(launch_kfill(ctx, kp, X->p, n, Z->p, nmc, 0, nullptr, 0, 0.0, (double*)pWz, np, zp, zp));
+  GPX_TRY(chol_trsm_left(ctx, L->p, L->pcols, L->aux, (double*)pWz, zp, np, zp));
+  GPX_TRY(launch_colreduce(ctx, (double*)pWz, zp, n, zp, nullptr, (double*)pss, (double*)ppart));
+  GPX_TRY(launch_kdiag(ctx, kp, Z->p, nmc, (double*)pkd));
+  std::vector<double> hs((size_t)nmc), hk((size_t)nmc);
+  GPX_HIP(hipMemcpyAsync(hs.data(), pss, (size_t)nmc * 8, hipMemcpyDeviceToHost, ctx->stream));
+  GPX_HIP(hipMemcpyAsync(hk.data(), pkd, (size_t)nmc * 8, hipMemcpyDeviceToHost, ctx->stream));
+  GPX_TRY(launch_transpose(ctx, (double*)pWz, np, zp, zp, (double*)pWzt, np));
+  GPX_HIP(hipStreamSynchronize(ctx->stream));
+  for (int64_t j = 0; j < nmc; ++j) hk[(size_t)j] -= hs[(size_t)j];
+  const double s0 = pairwise_sum(hk, nmc);
+
+  // ---- candidates, chunked ----
+  std::vector<double> cost((size_t)M);
+  for (int64_t j0 = 0; j0 < M; j0 += mcmax) {
+    const int64_t mc = (M - j0) < mcmax ? (M - j0) : mcmax;
+    const int64_t mcp = gpx_round_up(mc, GPX_TILE);
+    const double* Cc = Cm->p + j0 * d;
+    GPX_TRY(launch_kfill(ctx, kp, X->p, n, Cc, mc, 0, nullptr, 0, 0.0, (double*)pWc, np, mcp, mcp));
+    GPX_TRY(chol_trsm_left(ctx, L->p, L->pcols, L->aux, (double*)pWc, mcp, np, mcp));
+    GPX_TRY(launch_colreduce(ctx, (double*)pWc, mcp, n, mcp, nullptr, (double*)pss, (double*)ppart));
+    GPX_TRY(launch_kdiag(ctx, kp, Cc, mc, (double*)pkd));
+    // G = K(Z,C) - W_Z^T W_C
+    GPX_TRY(launch_kfill(ctx, kp, Z->p, nmc, Cc, mc, 0, nullptr, 0, 0.0, (double*)pG, zp, mcp, mcp));
+    GPX_TRY(launch_gemm(ctx, (double*)pWzt, np, (double*)pWc, mcp, (double*)pG, mcp, zp, mcp, np, false, true, false));
+    GPX_TRY(launch_colreduce(ctx, (double*)pG, mcp, nmc, mcp, nullptr, (double*)pq, (double*)ppart));
+    hipLaunchKernelGGL(ivar_cost_kernel, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const double*)pq, (const double*)pkd, (const double*)pss, noise, s0, 1.0 / (double)nmc, mc,
+                       (double*)pcost);
+    GPX_HIP(hipGetLastError());
+    GPX_HIP(hipMemcpyAsync(cost.data() + j0, pcost, (size_t)mc * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GPX_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  int64_t best = 0;
+  for (int64_t j = 1; j < M; ++j)
+    if (cost[(size_t)j] < cost[(size_t)best]) best = j;  // first minimum (np.argmin)
+  *out_best = best;
+  if (out_cost)
+    for (int64_t j = 0; j < M; ++j) out_cost[j] = cost[(size_t)j];
+  return 0;
+}
+
+}  // extern "C"

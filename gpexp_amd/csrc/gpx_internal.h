@@ -1,0 +1,132 @@
+// Internal declarations shared by the HIP translation units of libgpx_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <map>
+#include "../../include/gpx.h"
+
+#define GPX_TILE 128          // padding / GEMM tile / Cholesky leaf size
+#define GPX_MAXD GPX_MAX_DIM
+
+// ---- error plumbing ---------------------------------------------------------------------------
+void gpx_set_error(const char* fmt, ...);
+#define GPX_HIP(call)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (call);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      gpx_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+      return -2;                                                                        \
+    }                                                                                   \
+  } while (0)
+#define GPX_ARG(cond, msg)                                   \
+  do {                                                       \
+    if (!(cond)) {                                           \
+      gpx_set_error("%s:%d bad argument: %s", __FILE__, __LINE__, msg); \
+      return -1;                                             \
+    }                                                        \
+  } while (0)
+#define GPX_TRY(call)        \
+  do {                       \
+    int r_ = (call);         \
+    if (r_ != 0) return r_;  \
+  } while (0)
+
+static inline int64_t gpx_round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+// ---- covariance-function parameters, passed to kernels by value ---------------------------------
+// Coordinates are pre-multiplied by `scale` when staged into LDS so that
+//   SE       : k = sig * exp(-0.5 * |a-b|^2)            scale_k = 1/cl_k          (kernels.py:121-122)
+//   Matern32 : t = |a-b|, k = sig*(1+t)*exp(-t)          scale   = sqrt(3)/rho     (kernels.py:87-89)
+//   Matern52 : t = |a-b|, k = sig*(1+t+t^2/3)*exp(-t)    scale   = sqrt(5)/rho     (not in reference)
+//   Mehler   : k = sig * exp(-sum_k c1_k (a^2+b^2) - c2_k a b), sig = prod (1-t^2)^-1/2,
+//              c1_k = t^2/(2(1-t^2)), c2_k = t/(1-t^2), scale = 1               (kernels.py:282-285)
+struct KParams {
+  int kind;
+  int d;
+  double sig;
+  double scale[GPX_MAXD];
+  double c1[GPX_MAXD];
+  double c2[GPX_MAXD];
+};
+int gpx_make_kparams(int kind, int d, const double* hyp, int nhyp, KParams* out);
+
+// ---- objects --------------------------------------------------------------------------------------
+struct gpx_mat {
+  double* p;
+  int64_t rows, cols;    // logical
+  int64_t prows, pcols;  // allocated (ld == pcols)
+  int64_t bytes;
+  double* aux;        // after gpx_potrf: inverses of the 128x128 diagonal blocks, (prows/128) x 128 x 128
+  int64_t aux_bytes;
+  int factored;
+};
+
+struct ProfRec {
+  hipEvent_t a, b;
+  int cls;
+};
+
+struct gpx_ctx {
+  int device;
+  hipStream_t stream;
+  int cus;
+  // cached device allocations (exact-size reuse)
+  std::multimap<int64_t, void*> pool;
+  int64_t pool_bytes;
+  // scalars
+  int* d_info;      // first failing pivot (1-based), 0 = ok
+  double* d_scal;   // small scalar workspace (>= 64 doubles)
+  // profiling
+  int prof_on;
+  std::vector<ProfRec> prof_recs;
+  std::vector<hipEvent_t> ev_free;
+  int64_t prof_launches[GPX_PROF_NCLASS];
+  double prof_ms[GPX_PROF_NCLASS];
+  double prof_flops[GPX_PROF_NCLASS];
+  double prof_bytes[GPX_PROF_NCLASS];
+};
+
+int gpx_dev_alloc(gpx_ctx* ctx, int64_t bytes, void** out);
+void gpx_dev_release(gpx_ctx* ctx, void* p, int64_t bytes);
+int gpx_mat_new(gpx_ctx* ctx, int64_t rows, int64_t cols, int pad, gpx_mat** out);
+
+// RAII-ish profiling bracket: records events around launches of one class when profiling is on
+struct ProfScope {
+  gpx_ctx* ctx;
+  int idx;
+  ProfScope(gpx_ctx* c, int cls, double flops, double bytes);
+  ~ProfScope();
+};
+int gpx_prof_flush(gpx_ctx* ctx);
+
+// ---- kernel launchers (all asynchronous on ctx->stream) ------------------------------------------
+// kfill.hip
+int launch_kfill(gpx_ctx* ctx, const KParams& kp, const double* A, int64_t na, const double* B, int64_t nb,
+                 int symmetric, const double* d_nugget, int64_t nugget_len, double nugget_scalar,
+                 double* out, int64_t prows, int64_t pcols, int64_t ld);
+int launch_kdiag(gpx_ctx* ctx, const KParams& kp, const double* Z, int64_t m, double* out);
+
+// gemm_f64.hip:  C[m x n] = (accumulate ? C - A*op(B) : A*op(B)),  m,n multiples of 128, k multiple of 16
+int launch_gemm(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
+                int64_t m, int64_t n, int64_t k, bool bt, bool accumulate, bool lower);
+
+// chol.hip
+int launch_leaf(gpx_ctx* ctx, double* A, int64_t ld, double* inv, int64_t base_index, int64_t n_valid);
+int chol_potrf(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double* invd, int64_t n_valid);
+// X <- X * L^-T (right, lower, transposed): X is m x n (ld ldx), L n x n lower with leaf inverses invd
+int chol_trsm_right(gpx_ctx* ctx, const double* L, int64_t ldl, const double* invd, double* X, int64_t ldx,
+                    int64_t m, int64_t n);
+// B <- L^-1 B (left, lower): B is n x m
+int chol_trsm_left(gpx_ctx* ctx, const double* L, int64_t ldl, const double* invd, double* B, int64_t ldb,
+                   int64_t n, int64_t m);
+int chol_trsv(gpx_ctx* ctx, const double* L, int64_t ld, const double* invd, double* y, int64_t n, bool transposed);
+int launch_logdet(gpx_ctx* ctx, const double* L, int64_t ld, int64_t n, double* d_out);
+
+// reduce.hip
+// out[j] = sum_i B[i][j] * v[i]   (v == nullptr: sum_i B[i][j]^2), i < rows, j < pcols; deterministic
+int launch_colreduce(gpx_ctx* ctx, const double* B, int64_t ld, int64_t rows, int64_t pcols, const double* v,
+                     double* out, double* d_partial);
+int64_t colreduce_partial_elems(int64_t rows, int64_t pcols);
+int launch_sum(gpx_ctx* ctx, const double* x, int64_t n, double* d_out);

@@ -1,0 +1,105 @@
+// Deterministic column reductions over the (training point x evaluation point) matrices.
+//
+//   v != nullptr : out[j] = sum_i B[i][j] * v[i]      posterior mean  k_j^T alpha       (gp.py:137)
+//   v == nullptr : out[j] = sum_i B[i][j]^2           k_j^T K^-1 k_j = |L^-1 k_j|^2     (gp.py:142-144, 253-255)
+//
+// Fixed summation order (row chunks in order, then chunks in order) so that results -- and the
+// arg-max / arg-min selections built on them -- do not depend on scheduling.
+#include "gpx_internal.h"
+
+namespace {
+
+constexpr int ROWS_PER_CHUNK_MIN = 128;
+
+__global__ __launch_bounds__(256) void colreduce_kernel(const double* __restrict__ B, int64_t ld, int64_t rows,
+                                                        int64_t chunk, const double* __restrict__ v,
+                                                        double* __restrict__ partial, int64_t pcols) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.y * chunk;
+  int64_t r1 = r0 + chunk;
+  if (r1 > rows) r1 = rows;
+  if (j >= pcols) return;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  const double* p = B + r0 * ld + j;
+  int64_t i = r0;
+  if (v) {
+    for (; i + 4 <= r1; i += 4, p += 4 * ld) {
+      s0 = fma(p[0], v[i], s0);
+      s1 = fma(p[ld], v[i + 1], s1);
+      s2 = fma(p[2 * ld], v[i + 2], s2);
+      s3 = fma(p[3 * ld], v[i + 3], s3);
+    }
+    for (; i < r1; ++i, p += ld) s0 = fma(p[0], v[i], s0);
+  } else {
+    for (; i + 4 <= r1; i += 4, p += 4 * ld) {
+      double a = p[0], b = p[ld], c = p[2 * ld], d = p[3 * ld];
+      s0 = fma(a, a, s0);
+      s1 = fma(b, b, s1);
+      s2 = fma(c, c, s2);
+      s3 = fma(d, d, s3);
+    }
+    for (; i < r1; ++i, p += ld) s0 = fma(p[0], p[0], s0);
+  }
+  partial[(int64_t)blockIdx.y * pcols + j] = (s0 + s1) + (s2 + s3);
+}
+
+__global__ __launch_bounds__(256) void colreduce_final_kernel(const double* __restrict__ partial, int64_t nchunk,
+                                                              int64_t pcols, double* __restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= pcols) return;
+  double s = 0.0;
+  for (int64_t c = 0; c < nchunk; ++c) s += partial[c * pcols + j];
+  out[j] = s;
+}
+
+__global__ __launch_bounds__(256) void sum_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += x[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+
+inline void plan(int64_t rows, int64_t pcols, int64_t* chunk, int64_t* nchunk) {
+  int64_t colblocks = (pcols + 255) / 256;
+  int64_t want = 2048 / colblocks;
+  if (want < 1) want = 1;
+  int64_t maxc = (rows + ROWS_PER_CHUNK_MIN - 1) / ROWS_PER_CHUNK_MIN;
+  if (maxc < 1) maxc = 1;
+  if (want > maxc) want = maxc;
+  *chunk = (rows + want - 1) / want;
+  if (*chunk < 1) *chunk = 1;
+  *nchunk = (rows + *chunk - 1) / *chunk;
+  if (*nchunk < 1) *nchunk = 1;
+}
+
+}  // namespace
+
+int64_t colreduce_partial_elems(int64_t rows, int64_t pcols) {
+  int64_t chunk, nchunk;
+  plan(rows, pcols, &chunk, &nchunk);
+  return nchunk * pcols;
+}
+
+int launch_colreduce(gpx_ctx* ctx, const double* B, int64_t ld, int64_t rows, int64_t pcols, const double* v,
+                     double* out, double* d_partial) {
+  int64_t chunk, nchunk;
+  plan(rows, pcols, &chunk, &nchunk);
+  ProfScope ps(ctx, GPX_PROF_REDUCE, 2.0 * (double)rows * pcols, 8.0 * (double)rows * pcols);
+  dim3 grid((unsigned)((pcols + 255) / 256), (unsigned)nchunk);
+  hipLaunchKernelGGL(colreduce_kernel, grid, dim3(256), 0, ctx->stream, B, ld, rows, chunk, v, d_partial, pcols);
+  hipLaunchKernelGGL(colreduce_final_kernel, dim3(grid.x), dim3(256), 0, ctx->stream, d_partial, nchunk, pcols, out);
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_sum(gpx_ctx* ctx, const double* x, int64_t n, double* d_out) {
+  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, ctx->stream, x, n, d_out);
+  GPX_HIP(hipGetLastError());
+  return 0;
+}

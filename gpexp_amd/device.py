@@ -1,0 +1,245 @@
+"""Thin Python objects over the C ABI: Context (one per process/GPU), DeviceMatrix, and the
+function wrappers the GPEXP-API classes call.  All arithmetic happens in libgpx_hip.so."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, as_f64, dptr, c_vp, c_i64
+
+K_SE, K_MATERN32, K_MATERN52, K_MEHLER = 0, 1, 2, 3
+PROF_CLASSES = ["kfill", "gemm", "leaf", "trsv", "reduce", "greedy", "comm"]
+
+_ctx = None
+
+
+class Context:
+    """Owns the gpx_ctx for this process.  device defaults to LOCAL_RANK (one process per GPU)."""
+
+    def __init__(self, device=None):
+        self.lib = _lib.load()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        h = c_vp()
+        rc = self.lib.gpx_create(int(device), C.byref(h))
+        if rc != 0:
+            raise RuntimeError("gpexp_amd needs an MI355X: " + self.lib.gpx_last_error().decode())
+        self.h = h
+        self.device = int(device)
+
+    def close(self):
+        if self.h:
+            self.lib.gpx_destroy(self.h)
+            self.h = None
+
+    def sync(self):
+        check(self.lib.gpx_sync(self.h))
+
+    def trim(self):
+        check(self.lib.gpx_trim(self.h))
+
+    def info(self):
+        name = C.create_string_buffer(256)
+        cus = C.c_int()
+        mem = c_i64()
+        clk = C.c_int()
+        check(self.lib.gpx_device_info(self.h, name, 256, C.byref(cus), C.byref(mem), C.byref(clk)))
+        return dict(name=name.value.decode(), cus=cus.value, hbm_bytes=mem.value, clock_mhz=clk.value)
+
+    # ---- profiling ----
+    def profile(self, on):
+        check(self.lib.gpx_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        check(self.lib.gpx_profile_reset(self.h))
+
+    def profile_get(self):
+        out = {}
+        for i, nm in enumerate(PROF_CLASSES):
+            n = c_i64()
+            ms = C.c_double()
+            fl = C.c_double()
+            by = C.c_double()
+            check(self.lib.gpx_profile_get(self.h, i, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)))
+            out[nm] = dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)
+        return out
+
+
+def context():
+    """Process-wide context, created on first use (fails loudly without a GPU)."""
+    global _ctx
+    if _ctx is None:
+        _ctx = Context()
+    return _ctx
+
+
+class DeviceMatrix:
+    """Library-owned fp64 device matrix (row-major, padded to multiples of 128 when pad=True)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self.h = handle
+
+    @classmethod
+    def from_host(cls, ctx, a, pad=False):
+        a = as_f64(a)
+        if a.ndim == 1:
+            a = a.reshape(-1, 1)
+        h = c_vp()
+        check(ctx.lib.gpx_mat_from_host(ctx.h, dptr(a), a.shape[0], a.shape[1], 1 if pad else 0, C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def zeros(cls, ctx, rows, cols, pad=True):
+        h = c_vp()
+        check(ctx.lib.gpx_mat_alloc(ctx.h, rows, cols, 1 if pad else 0, C.byref(h)))
+        return cls(ctx, h)
+
+    @property
+    def shape(self):
+        r, c, ld = c_i64(), c_i64(), c_i64()
+        check(self.ctx.lib.gpx_mat_shape(self.h, C.byref(r), C.byref(c), C.byref(ld)))
+        return (r.value, c.value)
+
+    def to_host(self, tri=0):
+        r, c = self.shape
+        out = np.empty((r, c), dtype=np.float64)
+        check(self.ctx.lib.gpx_mat_to_host(self.ctx.h, self.h, dptr(out), int(tri)))
+        return out
+
+    def free(self):
+        if self.h and self.ctx.h:
+            self.ctx.lib.gpx_mat_free(self.ctx.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class KernelSpec:
+    """Flat (kind, d, hyp[]) form of a covariance kernel, as the C ABI takes it."""
+
+    def __init__(self, kind, d, hyp):
+        self.kind = int(kind)
+        self.d = int(d)
+        self.hyp = as_f64(np.asarray(hyp, dtype=float).ravel())
+
+    def args(self):
+        return (self.kind, self.d, dptr(self.hyp), int(self.hyp.size))
+
+
+def points(ctx, x):
+    """Upload an (n, d) point set unpadded."""
+    x = as_f64(x)
+    assert x.ndim == 2
+    return DeviceMatrix.from_host(ctx, x, pad=False)
+
+
+def _nugget_args(nugget, n):
+    """float -> scalar on the diagonal; ndarray (n,) -> per point (gp_kernel_utilities.py:62-65)."""
+    if isinstance(nugget, float):
+        if nugget == 0.0:
+            return None, 0
+        a = as_f64([nugget])
+        return a, 1
+    if isinstance(nugget, np.ndarray):
+        a = as_f64(nugget.ravel())
+        assert a.size == n, "per-point nugget must have one entry per point"
+        return a, n
+    raise TypeError("nugget must be a float or an ndarray (an int raises in the reference too, "
+                    "gp_kernel_utilities.py:62-67)")
+
+
+def kfill(ctx, spec, X, Z=None, nugget=0.0):
+    """K(X,X)+diag(nugget) (Z None) or K(X,Z); X, Z are DeviceMatrix point sets."""
+    n = X.shape[0]
+    nug, nlen = _nugget_args(nugget, n) if Z is None else (None, 0)
+    h = c_vp()
+    check(ctx.lib.gpx_kfill(ctx.h, *spec.args(), X.h, Z.h if Z is not None else None, dptr(nug), nlen, C.byref(h)))
+    return DeviceMatrix(ctx, h)
+
+
+def kfill_into(ctx, spec, X, K, Z=None, nugget=0.0):
+    n = X.shape[0]
+    nug, nlen = _nugget_args(nugget, n) if Z is None else (None, 0)
+    check(ctx.lib.gpx_kfill_into(ctx.h, *spec.args(), X.h, Z.h if Z is not None else None, dptr(nug), nlen, K.h))
+    return K
+
+
+def kdiag(ctx, spec, Z):
+    out = np.empty(Z.shape[0])
+    check(ctx.lib.gpx_kdiag(ctx.h, *spec.args(), Z.h, dptr(out)))
+    return out
+
+
+def potrf(ctx, K):
+    check(ctx.lib.gpx_potrf(ctx.h, K.h))
+    return K
+
+
+def potrs(ctx, L, y):
+    y = as_f64(y)
+    out = np.empty_like(y)
+    check(ctx.lib.gpx_potrs(ctx.h, L.h, dptr(y), dptr(out)))
+    return out
+
+
+def logdet(ctx, L):
+    v = C.c_double()
+    check(ctx.lib.gpx_logdet(ctx.h, L.h, C.byref(v)))
+    return v.value
+
+
+def potri(ctx, L):
+    h = c_vp()
+    check(ctx.lib.gpx_potri(ctx.h, L.h, C.byref(h)))
+    return DeviceMatrix(ctx, h)
+
+
+def posterior(ctx, spec, L, X, alpha, Z, want_mean=True, want_var=True):
+    m = Z.shape[0]
+    mean = np.empty(m) if want_mean else None
+    var = np.empty(m) if want_var else None
+    al = as_f64(alpha) if (alpha is not None and want_mean) else None
+    check(ctx.lib.gpx_posterior(ctx.h, *spec.args(), L.h, X.h, dptr(al), Z.h, dptr(mean), dptr(var)))
+    return mean, var
+
+
+def posterior_cov(ctx, spec, L, X, Z):
+    m = Z.shape[0]
+    cov = np.empty((m, m))
+    check(ctx.lib.gpx_posterior_cov(ctx.h, *spec.args(), L.h, X.h, Z.h, dptr(cov)))
+    return cov
+
+
+def ivar(ctx, spec, L, X, Z):
+    v = C.c_double()
+    check(ctx.lib.gpx_ivar(ctx.h, *spec.args(), L.h, X.h, Z.h, C.byref(v)))
+    return v.value
+
+
+def greedy_var(ctx, spec, Cpts, nsel, keep=(), weights=None):
+    keep = np.ascontiguousarray(np.asarray(list(keep), dtype=np.int64))
+    out = np.empty(int(nsel), dtype=np.int64)
+    w = as_f64(weights) if weights is not None else None
+    check(ctx.lib.gpx_greedy_var(ctx.h, *spec.args(), Cpts.h, dptr(w),
+                                 keep.ctypes.data_as(_lib.c_ip), int(keep.size), int(nsel),
+                                 out.ctypes.data_as(_lib.c_ip)))
+    return out
+
+
+def greedy_ivar_step(ctx, spec, L, X, Cpts, Z, noise, want_costs=True):
+    m = Cpts.shape[0]
+    costs = np.empty(m) if want_costs else None
+    best = c_i64()
+    check(ctx.lib.gpx_greedy_ivar_step(ctx.h, *spec.args(), L.h, X.h, Cpts.h, Z.h, float(noise), dptr(costs),
+                                       C.byref(best)))
+    return best.value, costs
+
+
+def dbg_gemm(ctx, A, B, Cm, bt, accumulate, lower=False):
+    check(ctx.lib.gpx_dbg_gemm(ctx.h, A.h, B.h, Cm.h, int(bt), int(accumulate), int(lower)))

@@ -1,0 +1,144 @@
+/* gpx.h -- C ABI of libgpx_hip.so: the MI355X (gfx950) GP-inference hot path behind GPEXP's API.
+ *
+ * The reference (goroda/GPEXP) is pure Python and has NO existing FFI/plugin layer;
+ * its boundary is the Python class API.  Each entry point below replaces the NumPy/LAPACK work
+ * of the reference call site cited next to it (file:line relative to the reference root) and is
+ * bound from Python by ctypes in gpexp_amd/_lib.py (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no C++/torch types.
+ *  - All matrices/vectors are IEEE fp64.  Host buffers are C-contiguous row-major (NumPy default),
+ *    caller-owned, and must outlive the call only.
+ *  - gpx_mat is a library-owned dense device matrix (row-major, leading dimension >= cols, storage
+ *    padded to a multiple of 128 in both dimensions; the padding is kept as an identity / zero
+ *    extension so that factorisations and solves never see an edge tile).  Free with gpx_mat_free.
+ *  - Return value: 0 = ok; >0 = 1-based index of the first non-positive Cholesky pivot
+ *    (the reference never fails here because numpy.linalg.pinv silently truncates, gp.py:181);
+ *    <0 = argument / HIP / RCCL error, text via gpx_last_error().
+ *  - Calls are blocking unless stated; one gpx_ctx per process (= per GPU); not thread-safe by
+ *    contract (the reference's callers are single-threaded).
+ *  - Covariance kernels are passed flat as (kind, d, hyp[nhyp]):
+ *      GPX_K_SE        hyp = {cl_0..cl_{d-1}, signalSize}          kernels.py:100-123
+ *      GPX_K_MATERN32  hyp = {rho, signalSize}                      kernels.py:72-91
+ *      GPX_K_MATERN52  hyp = {rho, signalSize}                      (absent from the reference)
+ *      GPX_K_MEHLER    hyp = {t_0..t_{d-1}}                         kernels.py:183-228, 250-293
+ */
+#ifndef GPX_H
+#define GPX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPX_ABI_VERSION 1
+#define GPX_MAX_DIM 32
+
+typedef struct gpx_ctx gpx_ctx;
+typedef struct gpx_mat gpx_mat;
+
+enum gpx_kernel_kind { GPX_K_SE = 0, GPX_K_MATERN32 = 1, GPX_K_MATERN52 = 2, GPX_K_MEHLER = 3 };
+
+/* names of the timed kernel classes reported by gpx_profile_get */
+enum gpx_prof_class {
+  GPX_PROF_KFILL = 0,   /* covariance assembly (HBM-bound: 8*rows*cols bytes written) */
+  GPX_PROF_GEMM = 1,    /* fp64 MFMA GEMM/SYRK/TRSM-update tiles (MFMA-bound: 2*m*n*k flops) */
+  GPX_PROF_LEAF = 2,    /* 128x128 diagonal potf2 + trtri */
+  GPX_PROF_TRSV = 3,    /* potrs sweeps */
+  GPX_PROF_REDUCE = 4,  /* column reductions / logdet */
+  GPX_PROF_GREEDY = 5,  /* greedy-design scoring kernels */
+  GPX_PROF_COMM = 6,    /* RCCL collectives */
+  GPX_PROF_NCLASS = 7
+};
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+int gpx_abi_version(void);
+const char* gpx_last_error(void);
+/* device = HIP ordinal (LOCAL_RANK in the one-process-per-GPU launch).  Fails (<0) when no GPU. */
+int gpx_create(int device, gpx_ctx** out);
+int gpx_destroy(gpx_ctx* ctx);
+int gpx_sync(gpx_ctx* ctx);
+/* release cached workspace back to HIP */
+int gpx_trim(gpx_ctx* ctx);
+/* device facts for reports: name[<=256], CU count, HBM bytes, clock MHz */
+int gpx_device_info(gpx_ctx* ctx, char* name, int name_len, int* cus, int64_t* hbm_bytes, int* clock_mhz);
+
+/* ---- device matrices ------------------------------------------------------------------------- */
+/* upload a (rows x cols) host array; pad != 0 pads storage to multiples of 128 (zero filled) */
+int gpx_mat_from_host(gpx_ctx* ctx, const double* src, int64_t rows, int64_t cols, int pad, gpx_mat** out);
+int gpx_mat_alloc(gpx_ctx* ctx, int64_t rows, int64_t cols, int pad, gpx_mat** out);
+int gpx_mat_free(gpx_ctx* ctx, gpx_mat* m);
+int gpx_mat_shape(const gpx_mat* m, int64_t* rows, int64_t* cols, int64_t* ld);
+/* tri: 0 = as stored, 1 = lower triangle (strict upper written as 0), 2 = lower mirrored to upper.
+ * Backs the lazy GP.covarianceMatrix / GP.precisionMatrix attributes (gp.py:178-181). */
+int gpx_mat_to_host(gpx_ctx* ctx, const gpx_mat* m, double* dst, int tri);
+
+/* ---- L0/L1: covariance assembly -------------------------------------------------------------- */
+/* K[i][j] = k(X_i, X_j) + nugget_i*delta_ij  (Z == NULL; N x N)      gp_kernel_utilities.py:34-68
+ * K[i][j] = k(X_i, Z_j)                      (Z != NULL; N x M)      gp.py:132-135, 246-249;
+ *                                                                    experimentalDesign.py:829-831
+ * X, Z: device point sets (rows = points, cols = d).  nugget: host, nugget_len in {0,1,N}. */
+int gpx_kfill(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp,
+              const gpx_mat* X, const gpx_mat* Z, const double* nugget, int64_t nugget_len,
+              gpx_mat** outK);
+/* same, into an existing matrix of the right shape (no allocation inside timed loops) */
+int gpx_kfill_into(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp,
+                   const gpx_mat* X, const gpx_mat* Z, const double* nugget, int64_t nugget_len,
+                   gpx_mat* K);
+/* k(Z_j, Z_j) for every point -> host out[M]                          gp.py:140, 251 */
+int gpx_kdiag(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* Z, double* out);
+
+/* ---- L2: factorisation and solves (replace numpy.linalg.pinv / slogdet) ---------------------- */
+/* in-place lower Cholesky K = L L^T (strict upper left undefined); replaces pinv at gp.py:181, 400 */
+int gpx_potrf(gpx_ctx* ctx, gpx_mat* K);
+/* alpha = K^{-1} y from the factor; y, alpha host (N)                 gp.py:101, 435 */
+int gpx_potrs(gpx_ctx* ctx, const gpx_mat* L, const double* y, double* alpha);
+/* log det K = 2 sum log L_ii                                          gp.py:434 (slogdet) */
+int gpx_logdet(gpx_ctx* ctx, const gpx_mat* L, double* out);
+/* explicit inverse (lower triangle valid) for the lazy precisionMatrix attribute and lml_grad */
+int gpx_potri(gpx_ctx* ctx, const gpx_mat* L, gpx_mat** outP);
+
+/* posterior at M points: mean_j = k_j^T alpha (gp.py:137), var_j = k(z_j,z_j) - k_j^T K^{-1} k_j
+ * (signed, gp.py:253-256; the caller applies abs for GP.evaluate, gp.py:145).
+ * alpha (host, N) may be NULL when mean == NULL; mean / var (host, M) may each be NULL. */
+int gpx_posterior(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp,
+                  const gpx_mat* L, const gpx_mat* X, const double* alpha,
+                  const gpx_mat* Z, double* mean, double* var);
+/* full M x M posterior covariance (compvar=2, gp.py:146-152) -> host cov[M*M] */
+int gpx_posterior_cov(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp,
+                      const gpx_mat* L, const gpx_mat* X, const gpx_mat* Z, double* cov);
+
+/* ---- L3: design-cost evaluators ---------------------------------------------------------------- */
+/* IVAR = (1/M) sum_j var_j (signed mean; caller applies abs)          experimentalDesign.py:104-117 */
+int gpx_ivar(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp,
+             const gpx_mat* L, const gpx_mat* X, const gpx_mat* Z, double* out);
+/* greedy maximum-posterior-variance selection among M candidates, nugget 0 (experimentalDesign.py:787-845).
+ * keep[nkeep] = indices already selected; selects until nsel indices in total; out_idx[nsel] receives
+ * keep followed by the new picks; w (host, M) optional weights; first-max tie rule (np.argmax). */
+int gpx_greedy_var(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp,
+                   const gpx_mat* C, const double* w, const int64_t* keep, int64_t nkeep,
+                   int64_t nsel, int64_t* out_idx);
+/* one-step-lookahead greedy IVAR among candidates C for a GP already factored on X (L):
+ * cost_j = IVAR(X u {c_j}) over MC points Z with noise variance `noise` on the new point;
+ * out_cost[M] (host, nullable) all costs, *out_best = first arg-min.  Composition oracle: SURVEY.md 8c. */
+int gpx_greedy_ivar_step(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp,
+                         const gpx_mat* L, const gpx_mat* X, const gpx_mat* C, const gpx_mat* Z,
+                         double noise, double* out_cost, int64_t* out_best);
+
+/* ---- measurement ------------------------------------------------------------------------------- */
+/* when enabled every kernel launch of a class is bracketed by HIP events on the launch stream */
+int gpx_profile_enable(gpx_ctx* ctx, int on);
+int gpx_profile_reset(gpx_ctx* ctx);
+/* sums since reset: launches, elapsed ms (HIP events), algorithmic flops and bytes */
+int gpx_profile_get(gpx_ctx* ctx, int prof_class, int64_t* launches, double* ms, double* flops, double* bytes);
+
+/* ---- kernel-level test hooks (used by tests/ only; same kernels the entry points above launch) -- */
+/* C (m x n) = beta*C + alpha*A*op(B); bt != 0: B is (n x k) used transposed; alpha,beta in {(-1,1),(1,0)};
+ * lower != 0: only tiles on/below the diagonal are touched */
+int gpx_dbg_gemm(gpx_ctx* ctx, const gpx_mat* A, const gpx_mat* B, gpx_mat* C, int bt, int accumulate, int lower);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPX_H */

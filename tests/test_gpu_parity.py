@@ -1,0 +1,237 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against
+(1) the golden vectors produced by the reference and (2) the CPU oracle on seeded inputs.
+
+Tolerances (fp64):
+  kernel-matrix entries      1e-13 relative (max-norm): same formula, different rounding order/exp
+  posterior mean / variance  1e-10 relative (BASELINE.json north_star), max-norm
+  log-marginal likelihood    1e-10 relative
+  index selections           exact
+The reference factorises with pinv (SVD), the GPU with Cholesky; all fixtures have cond(K) < 1e4
+("pinv != Cholesky").
+"""
+import numpy as np
+import pytest
+
+from oracle import gpexp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+KIND = {"se": 0, "matern32": 1, "matern52": 2, "mehler": 3}
+GP_CASES = ["kat1_demo", "kat2_matern32", "kat3_mehler", "se_iso_d3_n96", "se_ard_d8_n130",
+            "matern32_d8_n200", "mehler_d3_n64", "se_ard_d2_n77_ppnoise", "se_iso_d3_n300"]
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=float)
+    b = np.asarray(b, dtype=float)
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from gpexp_amd import device
+    return device
+
+
+@pytest.fixture(scope="module")
+def ctx(dev):
+    return dev.context()
+
+
+def spec_of(dev, s):
+    k = s["kind"]
+    d = s["d"]
+    if k == "se":
+        cl = np.asarray(s["cl"], dtype=float)
+        if cl.size == 1:
+            cl = np.tile(cl, d)
+        return dev.KernelSpec(KIND[k], d, list(cl) + [s["signalSize"]])
+    if k in ("matern32", "matern52"):
+        return dev.KernelSpec(KIND[k], d, [s["rho"], s["signalSize"]])
+    return dev.KernelSpec(KIND[k], d, list(s["t"]))
+
+
+def test_library_is_native(ctx):
+    info = ctx.info()
+    assert "gfx950" in info["name"], info
+    assert info["cus"] == 256
+
+
+@pytest.mark.parametrize("case", GP_CASES)
+def test_kfill_vs_reference(dev, ctx, golden, case):
+    s = golden.index[case]["kernel"]
+    X = dev.points(ctx, golden(case, "X"))
+    K = dev.kfill(ctx, spec_of(dev, s), X, nugget=golden.noise(case)).to_host()
+    assert rel(K, golden(case, "K")) <= 1e-13
+    np.testing.assert_allclose(K, golden(case, "K"), rtol=2e-12, atol=1e-300)
+
+
+@pytest.mark.parametrize("kind,d", [("se", 5), ("se", 8), ("se", 10), ("se", 17), ("matern32", 8), ("matern52", 8),
+                                    ("matern52", 3), ("mehler", 4), ("mehler", 8)])
+def test_kfill_rect_vs_oracle(dev, ctx, kind, d):
+    rng = np.random.default_rng(11 + d)
+    X = rng.uniform(-1, 1, (150, d))
+    Z = rng.uniform(-1, 1, (70, d))
+    if kind == "se":
+        s = dict(kind="se", cl=list(0.4 + 0.05 * np.arange(d)), signalSize=1.7, d=d)
+    elif kind == "mehler":
+        s = dict(kind="mehler", t=list(0.2 + 0.05 * np.arange(d)), d=d)
+    else:
+        s = dict(kind=kind, rho=0.8, signalSize=1.2, d=d)
+    Kxz = dev.kfill(ctx, spec_of(dev, s), dev.points(ctx, X), Z=dev.points(ctx, Z)).to_host()
+    want = orc.cross_matrix(s, Z, X).T  # oracle builds (M,N); the device keeps (N,M)
+    assert Kxz.shape == (150, 70)
+    assert rel(Kxz, want) <= 1e-13
+    kd = dev.kdiag(ctx, spec_of(dev, s), dev.points(ctx, Z))
+    assert rel(kd, orc.kernel_diag(s, Z)) <= 1e-13
+
+
+@pytest.mark.parametrize("bt", [0, 1])
+@pytest.mark.parametrize("acc", [0, 1])
+def test_gemm_mfma_vs_numpy(dev, ctx, bt, acc):
+    rng = np.random.default_rng(5)
+    m, n, k = 256, 384, 128 + 16 * 3
+    A = rng.standard_normal((m, k))
+    B = rng.standard_normal((n, k) if bt else (k, n))
+    C0 = rng.standard_normal((m, n))
+    dA = dev.DeviceMatrix.from_host(ctx, A, pad=False)
+    dB = dev.DeviceMatrix.from_host(ctx, B, pad=False)
+    dC = dev.DeviceMatrix.from_host(ctx, C0, pad=False)
+    dev.dbg_gemm(ctx, dA, dB, dC, bt, acc)
+    prod = A @ (B.T if bt else B)
+    want = C0 - prod if acc else prod
+    assert rel(dC.to_host(), want) <= 1e-13
+
+
+def test_gemm_lower_only(dev, ctx):
+    rng = np.random.default_rng(6)
+    A = rng.standard_normal((384, 64))
+    C0 = rng.standard_normal((384, 384))
+    dA = dev.DeviceMatrix.from_host(ctx, A)
+    dC = dev.DeviceMatrix.from_host(ctx, C0)
+    dev.dbg_gemm(ctx, dA, dA, dC, 1, 1, lower=True)
+    got = dC.to_host()
+    want = C0 - A @ A.T
+    for bi in range(3):
+        for bj in range(3):
+            blk = (slice(128 * bi, 128 * bi + 128), slice(128 * bj, 128 * bj + 128))
+            if bj <= bi:
+                assert rel(got[blk], want[blk]) <= 1e-13
+            else:
+                np.testing.assert_array_equal(got[blk], C0[blk])  # untouched above the diagonal
+
+
+@pytest.mark.parametrize("n", [1, 5, 128, 129, 300, 1000])
+def test_potrf_potrs_logdet_vs_lapack(dev, ctx, n):
+    rng = np.random.default_rng(n)
+    d = 3
+    X = rng.uniform(-1, 1, (n, d))
+    s = dict(kind="se", cl=[0.3], signalSize=1.0, d=d)
+    K = orc.cov_matrix(s, X, 0.05, row_loop=False)
+    y = rng.standard_normal(n)
+    dK = dev.kfill(ctx, spec_of(dev, s), dev.points(ctx, X), nugget=0.05)
+    dev.potrf(ctx, dK)
+    L = dK.to_host(tri=1)
+    Lref = np.linalg.cholesky(K)
+    assert rel(L, Lref) <= 1e-11
+    alpha = dev.potrs(ctx, dK, y)
+    assert rel(alpha, np.linalg.solve(K, y)) <= 1e-10
+    assert dev.logdet(ctx, dK) == pytest.approx(np.linalg.slogdet(K)[1], rel=1e-11, abs=1e-11)
+
+
+def test_potrf_reports_non_positive_pivot(dev, ctx):
+    from gpexp_amd._lib import NotPositiveDefinite
+    X = np.array([[0.1], [0.1], [0.5]])  # duplicate point, nugget 0 -> singular
+    s = dict(kind="se", cl=[0.3], signalSize=1.0, d=1)
+    dK = dev.kfill(ctx, spec_of(dev, s), dev.points(ctx, X), nugget=0.0)
+    with pytest.raises(NotPositiveDefinite) as e:
+        dev.potrf(ctx, dK)
+    assert e.value.pivot == 2
+
+
+@pytest.mark.parametrize("case", GP_CASES)
+def test_fit_posterior_loglike_vs_reference(dev, ctx, golden, case):
+    s = golden.index[case]["kernel"]
+    sp = spec_of(dev, s)
+    Xh, y, Zh = golden(case, "X"), golden(case, "y"), golden(case, "Z")
+    X, Z = dev.points(ctx, Xh), dev.points(ctx, Zh)
+    L = dev.potrf(ctx, dev.kfill(ctx, sp, X, nugget=golden.noise(case)))
+    alpha = dev.potrs(ctx, L, y)
+    assert rel(alpha, golden(case, "coeff")) <= 1e-10
+    mean, var = dev.posterior(ctx, sp, L, X, alpha, Z)
+    assert rel(mean, golden(case, "mean")) <= 1e-10
+    assert rel(var, golden(case, "var")) <= 1e-10
+    n = len(y)
+    ll = -0.5 * y @ alpha - 0.5 * dev.logdet(ctx, L) - n / 2.0 * np.log(2 * np.pi)
+    assert ll == pytest.approx(float(golden(case, "loglike")), rel=1e-10)
+    nc = golden(case, "cov").shape[0]
+    cov = dev.posterior_cov(ctx, sp, L, X, dev.points(ctx, Zh[:nc]))
+    assert rel(cov, golden(case, "cov")) <= 1e-10
+    P = dev.potri(ctx, L).to_host()
+    assert rel(P, golden(case, "precision")) <= 1e-9
+
+
+def test_ivar_vs_reference(dev, ctx, golden):
+    c = "kat4_ivar"
+    sp = spec_of(dev, golden.index[c]["kernel"])
+    X, Z = dev.points(ctx, golden(c, "X")), dev.points(ctx, golden(c, "mc"))
+    L = dev.potrf(ctx, dev.kfill(ctx, sp, X, nugget=1e-3))
+    assert abs(dev.ivar(ctx, sp, L, X, Z)) == pytest.approx(float(golden(c, "ivar")), rel=1e-10)
+
+
+def test_greedy_var_indices_bit_exact(dev, ctx, golden):
+    c = "kat5_greedy"
+    sp = spec_of(dev, golden.index[c]["kernel"])
+    C = dev.points(ctx, golden(c, "C"))
+    np.testing.assert_array_equal(dev.greedy_var(ctx, sp, C, 8, keep=[0]), golden(c, "gvar_idx"))
+    np.testing.assert_array_equal(dev.greedy_var(ctx, sp, C, 10, keep=[7]), golden(c, "gvar_idx_from7"))
+    np.testing.assert_array_equal(dev.greedy_var(ctx, sp, C, 9, keep=[3, 11], weights=golden(c, "weights")),
+                                  golden(c, "gvar_idx_weighted"))
+    assert dev.greedy_var(ctx, sp, C, 3)[0] == 0  # empty start: arg-max of the prior variance
+
+
+def test_greedy_ivar_indices_bit_exact(dev, ctx, golden):
+    c = "kat5_greedy"
+    sp = spec_of(dev, golden.index[c]["kernel"])
+    Ch, Zh = golden(c, "C"), golden(c, "Z")
+    Xh = golden(c, "X0").copy()
+    C, Z = dev.points(ctx, Ch), dev.points(ctx, Zh)
+    for step in range(4):
+        X = dev.points(ctx, Xh)
+        L = dev.potrf(ctx, dev.kfill(ctx, sp, X, nugget=1e-3))
+        best, costs = dev.greedy_ivar_step(ctx, sp, L, X, C, Z, 1e-3)
+        assert best == golden(c, "givar_idx")[step]
+        assert rel(costs, golden(c, "givar_allcosts")[step]) <= 1e-10
+        assert costs[best] == pytest.approx(golden(c, "givar_cost")[step], rel=1e-10)
+        Xh = np.vstack((Xh, Ch[best:best + 1]))
+
+
+def test_posterior_chunked_equals_unchunked(dev, ctx, monkeypatch):
+    """ragged sizes + forced chunking of the evaluation set (size-independent property)."""
+    rng = np.random.default_rng(9)
+    s = dict(kind="matern52", rho=0.6, signalSize=1.1, d=4)
+    sp = spec_of(dev, s)
+    Xh = rng.uniform(-1, 1, (333, 4))
+    Zh = rng.uniform(-1, 1, (517, 4))
+    y = rng.standard_normal(333)
+    X, Z = dev.points(ctx, Xh), dev.points(ctx, Zh)
+    L = dev.potrf(ctx, dev.kfill(ctx, sp, X, nugget=0.1))
+    alpha = dev.potrs(ctx, L, y)
+    m0, v0 = dev.posterior(ctx, sp, L, X, alpha, Z)
+    monkeypatch.setenv("GPX_CROSS_BYTES", str(384 * 128 * 8))  # -> 128-column chunks
+    m1, v1 = dev.posterior(ctx, sp, L, X, alpha, Z)
+    np.testing.assert_array_equal(m0, m1)
+    np.testing.assert_array_equal(v0, v1)
+    # oracle (pinv) on the same inputs
+    model = orc.fit(s, Xh, y, 0.1)
+    mo, vo = orc.posterior(s, model, Zh)
+    assert rel(m0, mo) <= 1e-10 and rel(v0, vo) <= 1e-10
+
+
+def test_empty_evaluation_set(dev, ctx):
+    s = dict(kind="se", cl=[0.3], signalSize=1.0, d=2)
+    sp = spec_of(dev, s)
+    X = dev.points(ctx, np.random.default_rng(1).uniform(-1, 1, (10, 2)))
+    L = dev.potrf(ctx, dev.kfill(ctx, sp, X, nugget=0.1))
+    m, v = dev.posterior(ctx, sp, L, X, np.zeros(10), dev.points(ctx, np.zeros((0, 2))))
+    assert m.shape == (0,) and v.shape == (0,)
