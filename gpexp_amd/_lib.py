@@ -34,6 +34,7 @@ _SIGS = {
     "gpx_kfill": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_dp, c_i64, C.POINTER(c_vp)]),
     "gpx_kfill_into": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_dp, c_i64, c_vp]),
     "gpx_kdiag": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_dp]),
+    "gpx_kernel_eval": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_dp, c_i64, c_dp, c_i64, c_dp]),
     "gpx_potrf": (C.c_int, [c_vp, c_vp]),
     "gpx_potrs": (C.c_int, [c_vp, c_vp, c_dp, c_dp]),
     "gpx_logdet": (C.c_int, [c_vp, c_vp, c_dp]),
@@ -44,6 +45,8 @@ _SIGS = {
     "gpx_greedy_var": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_dp, c_ip, c_i64, c_i64, c_ip]),
     "gpx_greedy_ivar_step": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_vp,
                                        C.c_double, c_dp, c_ip]),
+    "gpx_mi_greedy": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, C.c_double, c_i64, c_i64, c_ip, c_dp]),
+    "gpx_lml_grad": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_dp, c_dp]),
     "gpx_profile_enable": (C.c_int, [c_vp, C.c_int]),
     "gpx_profile_reset": (C.c_int, [c_vp]),
     "gpx_profile_get": (C.c_int, [c_vp, C.c_int, c_ip, c_dp, c_dp, c_dp]),

@@ -148,6 +148,13 @@ __global__ __launch_bounds__(256) void argmax_stage2(const double* __restrict__ 
   if (threadIdx.x == 0) sel[slot] = si[0] == INT64_MAX ? 0 : si[0];  // all-NaN scores: index 0 like np.argmax
 }
 
+__global__ __launch_bounds__(256) void keval_kernel(KParams kp, const double* __restrict__ A, int64_t sa,
+                                                    const double* __restrict__ B, int64_t sb, int64_t n,
+                                                    double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = kpair(kp, A + i * sa, B + i * sb);
+}
+
 // cost_j = | (S0 - q_j / (kcc_j - ssc_j + noise)) / nmc |
 __global__ __launch_bounds__(256) void ivar_cost_kernel(const double* __restrict__ q, const double* __restrict__ kcc,
                                                         const double* __restrict__ ssc, double noise, double s0,
@@ -190,6 +197,28 @@ double pairwise_sum(std::vector<double>& v, int64_t m) {
 }  // namespace
 
 extern "C" {
+
+int gpx_kernel_eval(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const double* A, int64_t na,
+                    const double* B, int64_t nb, double* out) {
+  GPX_ARG(ctx && A && B && out, "NULL argument");
+  GPX_ARG(na >= 1 && nb >= 1 && (na == nb || na == 1 || nb == 1), "evaluate needs paired or one-vs-n point sets");
+  KParams kp;
+  GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
+  const int64_t n = na > nb ? na : nb;
+  Scratch sc(ctx);
+  void *pa, *pb, *po;
+  GPX_TRY(sc.get(na * d * 8, &pa));
+  GPX_TRY(sc.get(nb * d * 8, &pb));
+  GPX_TRY(sc.get(n * 8, &po));
+  GPX_HIP(hipMemcpyAsync(pa, A, (size_t)(na * d * 8), hipMemcpyHostToDevice, ctx->stream));
+  GPX_HIP(hipMemcpyAsync(pb, B, (size_t)(nb * d * 8), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(keval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, kp, (const double*)pa,
+                     (int64_t)(na == 1 ? 0 : d), (const double*)pb, (int64_t)(nb == 1 ? 0 : d), n, (double*)po);
+  GPX_HIP(hipGetLastError());
+  GPX_HIP(hipMemcpyAsync(out, po, (size_t)(n * 8), hipMemcpyDeviceToHost, ctx->stream));
+  GPX_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
 
 int gpx_posterior_cov(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
                       const gpx_mat* Z, double* cov) {

@@ -176,6 +176,14 @@ def kdiag(ctx, spec, Z):
     return out
 
 
+def kernel_eval(ctx, spec, x1, x2):
+    """Paired / one-vs-n evaluation on host arrays (Kernel.evaluate, kernels.py:49-65)."""
+    x1, x2 = as_f64(x1), as_f64(x2)
+    out = np.empty(max(x1.shape[0], x2.shape[0]))
+    check(ctx.lib.gpx_kernel_eval(ctx.h, *spec.args(), dptr(x1), x1.shape[0], dptr(x2), x2.shape[0], dptr(out)))
+    return out
+
+
 def potrf(ctx, K):
     check(ctx.lib.gpx_potrf(ctx.h, K.h))
     return K
@@ -239,6 +247,22 @@ def greedy_ivar_step(ctx, spec, L, X, Cpts, Z, noise, want_costs=True):
     check(ctx.lib.gpx_greedy_ivar_step(ctx.h, *spec.args(), L.h, X.h, Cpts.h, Z.h, float(noise), dptr(costs),
                                        C.byref(best)))
     return best.value, costs
+
+
+def mi_greedy(ctx, spec, Cpts, noise, nsel, start=0):
+    out = np.empty(int(nsel), dtype=np.int64)
+    ratios = np.empty(max(int(nsel) - 1, 0))
+    check(ctx.lib.gpx_mi_greedy(ctx.h, *spec.args(), Cpts.h, float(noise), int(nsel), int(start),
+                                out.ctypes.data_as(_lib.c_ip), dptr(ratios) if ratios.size else None))
+    return out, ratios
+
+
+def lml_grad(ctx, spec, L, X, alpha):
+    """[d/d hyp_0 .. d/d hyp_{n-1}, raw d/d noise] of the log marginal likelihood (SE kernel)."""
+    alpha = as_f64(alpha)
+    out = np.empty(spec.hyp.size + 1)
+    check(ctx.lib.gpx_lml_grad(ctx.h, *spec.args(), L.h, X.h, dptr(alpha), dptr(out)))
+    return out
 
 
 def dbg_gemm(ctx, A, B, Cm, bt, accumulate, lower=False):

@@ -1,0 +1,274 @@
+"""Experimental-design cost functions and greedy designs with the reference's interface
+(gpExp/experimentalDesign.py), evaluated on the GPU.
+
+Hot-path pieces:
+  costFunctionGP_IVAR.evaluate        refit on the design + mean posterior variance over the MC points
+                                      (experimentalDesign.py:79-117)            -> gpx_potrf + gpx_ivar
+  performGreedyVarExperimentalDesign  greedy maximum posterior variance (:787-845) -> gpx_greedy_var
+  costFunctionGP_MI / performGreedyMIExperimentalDesign (:223-285, :753-785)       -> gpx_mi_greedy
+  greedyIVARStep                      discrete one-step-lookahead IVAR (the composition SURVEY.md 8c pins;
+                                      the reference has no such function)        -> gpx_greedy_ivar_step
+
+Host drivers kept because demo.py needs them: ExperimentalDesign.boundsFunction,
+ExperimentalDesignDerivative.begin / beginWithVarGreedy (SciPy SLSQP branch).  The Mercer-basis "version 0" of
+IVAR is dead code in the reference (no kernel defines `eigenvalues`, :122,129,193) and is not provided; the
+COBYLA / greedy-continuation drivers (:500-751) and the space-filling / Bayesian-optimisation helpers (:852-1003)
+are outside the hot path.
+"""
+import copy
+import itertools
+import sys
+
+import numpy as np
+
+try:
+    from scipy.optimize import fmin_slsqp as slsqp
+except ImportError:  # pragma: no cover
+    slsqp = None
+import scipy.optimize as optimize
+
+from . import device as _dev
+from . import gp_kernel_utilities  # noqa: F401  (the reference module exposes it)
+
+NLOPT = False
+
+__all__ = ["costFunctionBase", "costFunctionGP_IVAR", "costFunctionGP_MI", "ExperimentalDesign",
+           "ExperimentalDesignDerivative", "performGreedyVarExperimentalDesign",
+           "performGreedyMIExperimentalDesign", "greedyIVARStep", "np"]
+
+
+class costFunctionBase(object):
+
+    def __init__(self, nInputs, space):
+        self.numInputs = nInputs
+        self.space = space
+
+
+class costFunctionGP_IVAR(costFunctionBase):
+    """Integrated posterior variance of a GP trained at the design points, estimated over MC points."""
+
+    def __init__(self, gaussianProcess, nInputs, space, version=1, **kwargs):
+        super(costFunctionGP_IVAR, self).__init__(nInputs, space)
+        self.gaussianProcess = copy.copy(gaussianProcess)
+        self.version = version
+        if self.version != 1:
+            raise NotImplementedError("IVAR version 0 needs a Mercer eigen-basis that no kernel class provides "
+                                      "(dead code in the reference, experimentalDesign.py:119-146)")
+        if 'mcPoints' in kwargs:
+            self.mcPoints = kwargs['mcPoints']
+            self.nMC = len(self.mcPoints)
+        else:
+            self.nMC = 10000
+            self.mcPoints = space.sample((self.nMC, space.dimension))
+        self._mc_dev = None  # MC points stay resident in HBM across optimiser evaluations
+
+    def _mc(self):
+        if self._mc_dev is None:
+            self._mc_dev = _dev.points(_dev.context(), self.mcPoints)
+        return self._mc_dev
+
+    def evaluate(self, inputPoints):
+        """|mean_z var(z | design = inputPoints)| (experimentalDesign.py:100-117)."""
+        assert inputPoints.shape == (self.numInputs, self.space.dimension), \
+            ("inputPoints are the wrong size: ", inputPoints.shape)
+        gp = self.gaussianProcess
+        if self.space.noiseFunc is None:
+            gp.addNodesAndComputeCovariance(inputPoints)
+        else:
+            gp.addNodesAndComputeCovariance(inputPoints, self.space.noiseFunc(inputPoints))
+        cost = _dev.ivar(_dev.context(), gp.kernel._spec(), gp._L, gp._X, self._mc())
+        return np.abs(cost)
+
+    def derivative(self, inputPoints):
+        """d IVAR / d design coordinates, flattened (experimentalDesign.py:168-179)."""
+        gp = self.gaussianProcess
+        if self.space.noiseFunc is None:
+            gp.addNodesAndComputeCovariance(inputPoints)
+            out = gp.evaluateVarianceDerivative(self.mcPoints)
+        else:
+            gp.addNodesAndComputeCovariance(inputPoints, noiseIn=self.space.noiseFunc(inputPoints))
+            out = gp.evaluateVarianceDerivative(self.mcPoints, noiseFunc=self.space.noiseFunc)
+        return np.sum(out, axis=1) / float(self.nMC)
+
+
+class costFunctionGP_MI(costFunctionBase):
+    """Mutual-information ratio var(c | A) / var(c | all \\ A \\ c) among a fixed candidate set."""
+
+    def __init__(self, gaussianProcess, nInputs, space, nmc=None, mcpoints=None, square=False):
+        super(costFunctionGP_MI, self).__init__(nInputs, space)
+        self.gaussianProcess = gaussianProcess  # NOT copied: the reference mutates the caller's GP (:227,240)
+        if nmc is not None:
+            self.nMC = nmc
+            self.mcPoints = np.copy(mcpoints)
+        elif space.dimension == 2 and square is True:
+            x = np.linspace(-1, 1, 10)
+            self.nMC = len(x) * len(x)
+            self.mcPoints = np.array(list(itertools.product(x, x)))
+        else:
+            self.nMC = 200
+            self.mcPoints = space.sample((self.nMC, space.dimension))
+        self.gaussianProcess.addNodesAndComputeCovariance(self.mcPoints)
+
+    def add_candidates(self, nCandidates, candidates):
+        self.nMC = nCandidates
+        self.mcPoints = copy.deepcopy(candidates)
+        self.gaussianProcess.addNodesAndComputeCovariance(self.mcPoints)
+
+    # the reference caches dense copies that evaluate() never uses (:241-242); kept as lazy views
+    @property
+    def cov(self):
+        return self.gaussianProcess.covarianceMatrix
+
+    @property
+    def invcov(self):
+        return self.gaussianProcess.precisionMatrix
+
+    def _cond_var(self, rows, point):
+        """var(f(point) | noisy observations at mcPoints[rows]) through a fresh factorisation."""
+        gp = self.gaussianProcess
+        ctx = _dev.context()
+        spec = gp.kernel._spec()
+        if len(rows) == 0:
+            return _dev.kernel_eval(ctx, spec, point, point)[0]
+        X, L, _ = gp._factor(self.mcPoints[rows, :], gp.noise)
+        _, var = _dev.posterior(ctx, spec, L, X, None, _dev.points(ctx, point), want_mean=False)
+        return var[0]
+
+    def evaluate(self, index, indexAdded):
+        """Ratio for candidate `index` given the already selected `indexAdded` (experimentalDesign.py:249-285)."""
+        point = self.mcPoints[index, :].reshape((1, self.space.dimension))
+        added = list(indexAdded)
+        left = np.setdiff1d(np.setdiff1d(np.arange(self.nMC), added), [index])
+        return self._cond_var(added, point) / self._cond_var(list(left), point)
+
+
+class ExperimentalDesign(object):
+    """Base class of the continuous design optimisers."""
+    nMCpoints = 10000
+
+    def __init__(self, costFunction, nPoints, nDims, **kwargs):
+        self.costFunction = costFunction
+        self.nPoints = nPoints
+        self.nDims = nDims
+        super(ExperimentalDesign, self).__init__()
+
+    def boundsFunction(self, optPoints):
+        """+1 if every point has non-zero probability density, else -1 (experimentalDesign.py:312-343)."""
+        if len(np.shape(optPoints)) == 1:
+            optPoints = np.reshape(optPoints, (int(len(optPoints) / self.nDims), self.nDims))
+        out = np.array(self.costFunction.space.probDensity(optPoints), dtype=float)
+        out[out == 0.0] = -1e0
+        return -1e0 if np.min(out) < 0.0 else 1e0
+
+
+class ExperimentalDesignDerivative(ExperimentalDesign):
+    """Gradient-based continuous design (SciPy SLSQP; the nlopt branch of the reference is not provided)."""
+
+    def __init__(self, costFunction, nPoints, nDims):
+        self.addObj = lambda x: 0
+        self.addGrad = lambda x: 0
+        super(ExperimentalDesignDerivative, self).__init__(costFunction, nPoints, nDims)
+
+    def addPenaltyToObjective(self, addObj, addGrad):
+        self.addObj = addObj
+        self.addGrad = addGrad
+
+    def objFunc(self, in1, gradIn):
+        in0 = np.reshape(in1, (int(len(in1) / self.nDims), self.nDims))
+        if gradIn.size > 0:
+            gradIn[:] = self.costFunction.derivative(in0)
+        out = self.costFunction.evaluate(in0) - 10.0 * np.min(np.array([self.boundsFunction(in0), 0.0]))
+        sys.stdout.write("\r Optimization (Cost = %s, ||g||= %s) OK\n" % (str(out), str(None)))
+        sys.stdout.flush()
+        return out
+
+    def constraint(self, in0, gradIn):
+        if gradIn.size > 0:
+            gradIn[:] = -optimize.approx_fprime(in0, self.boundsFunction, 1e-8)
+        return -self.boundsFunction(in0)
+
+    def beginWithVarGreedy(self, nodesKeep=None, lbounds=[], rbounds=[]):
+        """Start SLSQP from a greedy maximum-variance design; `nodesKeep` are pinned in front (:379-409)."""
+        kTemp = copy.copy(self.costFunction.gaussianProcess.kernel)
+        if nodesKeep is not None:
+            mcPoints = np.concatenate((nodesKeep, self.costFunction.mcPoints), axis=0)
+            indKeep = np.arange(len(nodesKeep)).tolist()
+        else:
+            try:
+                mcPoints = self.costFunction.mcPoints[:]
+            except AttributeError:
+                mcPoints = self.costFunction.space.sample((1000, self.costFunction.space.dimension))
+            indKeep = []
+        startVals = performGreedyVarExperimentalDesign(kTemp, mcPoints, self.nPoints, self.nDims,
+                                                       indKeepStart=indKeep)
+        return self.begin([startVals], lbounds, rbounds)
+
+    def begin(self, startValues, lbounds=[], rbounds=[]):
+        """Minimise the cost from every start with SLSQP (acc=1e-6) and return the best design (:463-497)."""
+
+        def func(xIn, *args):
+            in0 = np.reshape(xIn, (int(len(xIn) / self.nDims), self.nDims))
+            return self.costFunction.evaluate(in0) - 10.0 * np.min(np.array([self.boundsFunction(in0), 0.0]))
+
+        def grad(xIn, *args):
+            in0 = np.reshape(xIn, (int(len(xIn) / self.nDims), self.nDims))
+            return self.costFunction.derivative(in0)
+
+        nvar = len(startValues[0]) * self.nDims
+        if len(lbounds) == 0:
+            bounds = list(zip(-100.0 * np.ones(nvar), 100.0 * np.ones(nvar)))
+        else:
+            bounds = list(zip(lbounds, rbounds))
+        sol = []
+        obj = np.zeros((len(startValues)))
+        for ii in range(len(startValues)):
+            pts = slsqp(func, startValues[ii].reshape((nvar)), fprime=grad, bounds=bounds, acc=1e-6)
+            sol.append(pts)
+            obj[ii] = func(pts)
+        best = sol[int(np.argmin(obj))]
+        return np.reshape(best, (int(len(best) / self.nDims), self.nDims))
+
+
+def performGreedyMIExperimentalDesign(costFuncMI, nPoints, start=0):
+    """Greedy mutual-information design among costFuncMI.mcPoints, seeded with [start] (:753-785).
+
+    The reference evaluates two fresh pinv's per remaining candidate per step; gpx_mi_greedy carries the
+    numerator as an incremental Cholesky row and the denominator as diag((K_SS+noise I)^-1) with rank-one
+    down-dates of the inverse, so a step costs O(M^2)."""
+    gp = costFuncMI.gaussianProcess
+    ctx = _dev.context()
+    C = _dev.points(ctx, costFuncMI.mcPoints)
+    idx, _ = _dev.mi_greedy(ctx, gp.kernel._spec(), C, float(gp.noise), int(nPoints), int(start))
+    return costFuncMI.mcPoints[list(idx), :]
+
+
+def performGreedyVarExperimentalDesign(kernel, mcPoints, nPoints, dimension, weights=None, indKeepStart=[]):
+    """Greedy maximum-posterior-variance ("entropy") design among mcPoints (:787-845).
+
+    As in the reference the caller's `indKeepStart` list is extended in place -- that aliasing is how callers
+    get the indices back (:808) -- and mcPoints[indices] is returned.  First pick from an empty start is the
+    arg-max of the (weighted) prior variance; ties go to the lowest index (np.argmax)."""
+    if indKeepStart == []:
+        indKeep = []
+    else:
+        indKeep = indKeepStart
+    have = len(indKeep)
+    if have % 10 == 0 and have < nPoints:
+        print("Number of points we have ", have)
+    if have < nPoints:
+        ctx = _dev.context()
+        C = _dev.points(ctx, np.asarray(mcPoints, dtype=float))
+        idx = _dev.greedy_var(ctx, kernel._spec(), C, int(nPoints), keep=indKeep, weights=weights)
+        for j in idx[have:]:
+            indKeep.append(int(j))
+    return mcPoints[indKeep, :]
+
+
+def greedyIVARStep(gaussianProcess, candidates, mcPoints):
+    """One step of discrete greedy IVAR for a GP whose training set is already factored
+    (gp.addNodesAndComputeCovariance / train): returns (best_index, costs) where
+    costs[j] = costFunctionGP_IVAR(gp, n+1, space, mcPoints=mcPoints).evaluate(vstack(gp.pts, candidates[j]))."""
+    gp = gaussianProcess
+    ctx = _dev.context()
+    return _dev.greedy_ivar_step(ctx, gp.kernel._spec(), gp._L, gp._X, _dev.points(ctx, candidates),
+                                 _dev.points(ctx, mcPoints), float(gp.noise))

@@ -1,0 +1,294 @@
+"""Gaussian-process model with the reference's interface (gpExp/gp.py, class GP), computed on the GPU.
+
+What changes underneath: the reference builds K row by row in Python, inverts it with
+`numpy.linalg.pinv` (SVD) and evaluates every posterior variance as a separate `k^T P k` matvec.  Here K is
+assembled by one HIP kernel, factored once (K = L L^T, blocked fp64-MFMA Cholesky), and every later quantity is a
+triangular solve or a column reduction against L:
+
+    coeff = K^-1 y                     gpx_potrs        (gp.py:101)
+    log det K = 2 sum log L_ii         gpx_logdet       (gp.py:434)
+    mean = K(Z,X) coeff                gpx_posterior    (gp.py:137)
+    var_j = k(z_j,z_j) - |L^-1 k_j|^2  gpx_posterior    (gp.py:142-144, 253-255)
+
+`covarianceMatrix` and `precisionMatrix` remain available as attributes (external code reads them,
+experimentalDesign.py:241-242) but are materialised lazily, on first access, from the device.
+
+Rank-deficient K (e.g. noise 0.0 with coincident points): pinv truncates silently, Cholesky cannot.  Policy: the
+factorisation is retried with a relative diagonal jitter (1e-12 * mean diag, x100 per retry, at most 4 retries)
+and a RuntimeWarning names the jitter used; if that fails NotPositiveDefinite propagates.
+
+Out of scope: the FITC inducing-point branches and `generateSamples`.
+"""
+import copy
+import warnings
+
+import numpy as np
+
+from . import device as _dev
+from ._lib import NotPositiveDefinite
+from .gp_kernel_utilities import calculateCovarianceMatrix, _check_nugget  # noqa: F401  (re-export like the reference)
+
+try:  # the reference prefers nlopt and falls back to SciPy (gp.py:28-41); only the SciPy branch is provided
+    from scipy.optimize import fmin_l_bfgs_b as bfgs
+except ImportError:  # pragma: no cover
+    bfgs = None
+NLOPT = False
+
+
+class GP:
+    """Zero-prior-mean GP regression model."""
+
+    coeff = None
+    noise = None
+    pts = None
+    FITC = None
+    fitcnodes = None
+
+    def __init__(self, kernel_in, noiseIn, **kwargs):
+        try:
+            self.kernel = copy.deepcopy(kernel_in)
+        except Exception:
+            print("warning ")
+            self.kernel = copy.copy(kernel_in)
+        self.noise = noiseIn  # added to the diagonal as a VARIANCE (gp.py:68, 178)
+        if 'FITC' in kwargs and kwargs['FITC'] is not None:
+            raise NotImplementedError("the FITC sparse approximation (gp.py:182-210) is outside the GPU hot path")
+        self._X = None       # device point set
+        self._L = None       # device Cholesky factor of K(pts) + nugget
+        self._nugget = None  # nugget that went into _L
+        self._K_host = None
+        self._P_host = None
+        self.jitter = 0.0
+
+    # shallow copies (costFunctionGP_IVAR does copy.copy(gp), experimentalDesign.py:64) share device state,
+    # which is immutable once built: a refit replaces the handles instead of mutating them.
+
+    # ---- lazy dense attributes -------------------------------------------------------------------------
+    @property
+    def covarianceMatrix(self):
+        if self._K_host is None and self.pts is not None:
+            self._K_host = calculateCovarianceMatrix(self.kernel, self.pts, self._nugget)
+        return self._K_host
+
+    @covarianceMatrix.setter
+    def covarianceMatrix(self, value):
+        self._K_host = value
+
+    @property
+    def precisionMatrix(self):
+        if self._P_host is None and self._L is not None:
+            self._P_host = _dev.potri(_dev.context(), self._L).to_host()
+        return self._P_host
+
+    @precisionMatrix.setter
+    def precisionMatrix(self, value):
+        self._P_host = value
+
+    # ---- helpers --------------------------------------------------------------------------------------------
+    def gpPriorMean(self, pts):
+        return np.zeros((pts.shape[0]))
+
+    def _factor(self, nodes, nugget):
+        """Assemble K(nodes)+diag(nugget) and factor it in place on the device -> (X, L, jitter)."""
+        _check_nugget(nugget)
+        nodes = np.asarray(nodes, dtype=float)
+        assert nodes.ndim == 2 and nodes.shape[1] == self.kernel.dimension, \
+            (" Incorrect dimension of input points fed to kernel ", nodes.shape)
+        ctx = _dev.context()
+        spec = self.kernel._spec()
+        X = _dev.points(ctx, nodes)
+        K = _dev.kfill(ctx, spec, X, nugget=nugget)
+        try:
+            return X, _dev.potrf(ctx, K), 0.0
+        except NotPositiveDefinite as first:
+            base = 1e-12 * float(np.mean(_dev.kdiag(ctx, spec, X)) + np.mean(np.asarray(nugget, dtype=float)))
+            jit = base
+            for _ in range(4):
+                nz = (np.asarray(nugget, dtype=float) + jit) * np.ones(nodes.shape[0])
+                _dev.kfill_into(ctx, spec, X, K, nugget=nz)
+                try:
+                    _dev.potrf(ctx, K)
+                    warnings.warn("covariance matrix not positive definite (pivot %d); factored with diagonal "
+                                  "jitter %.3e (the reference's pinv would truncate instead)" % (first.pivot, jit),
+                                  RuntimeWarning)
+                    return X, K, jit
+                except NotPositiveDefinite:
+                    jit *= 100.0
+            raise
+
+    # ---- training ---------------------------------------------------------------------------------------------
+    def addNodesAndComputeCovariance(self, nodes, noiseIn=None):
+        """Set the training locations and factor their covariance (no function values needed)."""
+        nugget = self.noise if noiseIn is None else noiseIn
+        self._X, self._L, self.jitter = self._factor(nodes, nugget)
+        self._nugget = nugget
+        self._K_host = None
+        self._P_host = None
+        self.pts = np.array(nodes, dtype=float, copy=True)
+
+    def train(self, pts, evalsIn, noiseIn=None):
+        """Compute the GP coefficients K^-1 (y - prior mean); stored in `coeff`."""
+        assert len(evalsIn.shape) == 1, "evaluations must be an (N,) array for training GP"
+        evals = evalsIn - self.gpPriorMean(pts)
+        self.addNodesAndComputeCovariance(pts, noiseIn)
+        self.fVals = evals.copy()
+        self.coeff = _dev.potrs(_dev.context(), self._L, evals)
+
+    # ---- prediction ---------------------------------------------------------------------------------------------
+    def evaluate(self, newpt, compvar=0):
+        """Posterior mean at `newpt`; compvar=1 also |variance| (gp.py:145), compvar=2 the full covariance."""
+        assert newpt.shape[1] == self.kernel.dimension, "evaluation points for GP is incorrect shape"
+        ctx = _dev.context()
+        spec = self.kernel._spec()
+        Z = _dev.points(ctx, newpt)
+        mean, var = _dev.posterior(ctx, spec, self._L, self._X, self.coeff, Z, want_mean=True,
+                                   want_var=(compvar == 1))
+        out = mean + self.gpPriorMean(newpt)
+        if compvar == 1:
+            return out, np.abs(var)
+        elif compvar == 2:
+            return out, _dev.posterior_cov(ctx, spec, self._L, self._X, Z)
+        return out
+
+    def evaluateVariance(self, newpt, parallel=1):
+        """Signed posterior variance at `newpt` (gp.py:213-259).  `parallel` is accepted and ignored: the
+        reference forks CPU processes above 500001 points (gp.py:244-258); the GPU path never forks."""
+        assert self.pts is not None
+        assert newpt.shape[1] == self.kernel.dimension, "evaluation points for GP is incorrect shape"
+        ctx = _dev.context()
+        _, var = _dev.posterior(ctx, self.kernel._spec(), self._L, self._X, None, _dev.points(ctx, newpt),
+                                want_mean=False, want_var=True)
+        return var
+
+    # ---- variance gradients w.r.t. point locations (host-side callers of the hot path) ----------
+    def evaluateVarianceDerivWRTnewpt(self, newpt):
+        """d var(newpt_i) / d newpt_i, flattened (gp.py:261-280)."""
+        assert self.pts is not None, "must specify training points before running this"
+        assert newpt.shape[1] == self.kernel.dimension, "evaluation points for GP is incorrect shape"
+        n, d = self.pts.shape
+        derivs = np.zeros((newpt.shape[0], d, n))
+        evals = np.zeros((newpt.shape[0], n))
+        for ii in range(n):
+            p = self.pts[ii:ii + 1, :]
+            derivs[:, :, ii] = self.kernel.derivative(newpt, p)
+            evals[:, ii] = self.kernel.evaluate(p, newpt)
+        evalSigma = self.precisionMatrix @ evals.T
+        out = -2.0 * np.einsum('idn,ni->id', derivs, evalSigma)
+        return out.reshape((np.prod(newpt.shape)))
+
+    def evaluateVarianceDerivative(self, newpt, noiseFunc=None):
+        """out[k*d+l, j] = d var(newpt_j) / d pts[k, l]  (gp.py:282-341), vectorised per training point."""
+        assert self.pts is not None, "must specify training points before running this"
+        assert newpt.shape[1] == self.kernel.dimension, "evaluation points for GP is incorrect shape"
+        n, d = self.pts.shape
+        nn = len(newpt)
+        derivCov = np.zeros((n, n, d))   # [zz, i, :] = dK(pts_i, pts_zz)/d pts_i
+        totEvals = np.zeros((nn, n))
+        derivTotal = []
+        for zz in range(n):
+            p = self.pts[zz:zz + 1, :]
+            derivCov[zz, :, :] = self.kernel.derivative(self.pts, p)
+            totEvals[:, zz] = self.kernel.evaluate(p, newpt)
+            derivTotal.append(-self.kernel.derivative(newpt, p))
+            if noiseFunc is not None:
+                same = np.array([np.linalg.norm(pp - p) < 1e-10 for pp in self.pts])
+                derivCov[zz, :, :] += np.tile(same.reshape((n, 1)), d) * noiseFunc.deriv(self.pts)
+                if np.linalg.norm(p - newpt) < 1e-10:
+                    totEvals[:, zz] += noiseFunc(p)
+                    derivTotal[-1] -= noiseFunc.deriv(p)
+        e = totEvals @ self.precisionMatrix          # (nn, n)
+        out = np.zeros((n * d, nn))
+        for jj in range(n):
+            for kk in range(d):
+                c = derivCov[:, jj, kk]
+                out1 = 2.0 * e[:, jj] * derivTotal[jj][:, kk]
+                # -(e dS * e).sum(1) with dS the symmetric rank-two matrix carrying c in row/column jj
+                out2 = -e[:, jj] * (2.0 * (e @ c) - c[jj] * e[:, jj])
+                out[jj * d + kk, :] = -(out1 + out2)
+        return out
+
+    def generateSamples(self, x, noise=1e-10):
+        raise NotImplementedError("generateSamples (SVD sampling, gp.py:343-371) is outside the GPU hot path")
+
+    # ---- marginal likelihood -------------------------------------------------------------------------------------
+    def computeLogLike(self, pts, evals):
+        """Log marginal likelihood of (pts, evals) under the current hyper-parameters."""
+        return self.loglikeParams(pts, evals)
+
+    def loglikeParams(self, pts, evals, returnDeriv=0, noiseIn=None):
+        """-1/2 y^T K^-1 y - 1/2 log det K - N/2 log 2 pi  [, {key: d/d key}] (gp.py:394-468).
+
+        Does not touch the trained state.  `noiseIn` (per-point nugget) works here; in the reference that branch
+        passes an unknown keyword and raises TypeError (gp.py:429-430)."""
+        evals = np.asarray(evals, dtype=float)
+        nugget = self.noise if noiseIn is None else noiseIn
+        X, L, _ = self._factor(pts, nugget)
+        ctx = _dev.context()
+        alpha = _dev.potrs(ctx, L, evals)
+        out = -0.5 * np.dot(evals, alpha) - 0.5 * _dev.logdet(ctx, L) - len(evals) / 2.0 * np.log(2.0 * np.pi)
+        if returnDeriv == 1:
+            keys = list(self.kernel.hyperParam.keys()) + ['noise']
+            grad = _dev.lml_grad(ctx, self.kernel._spec(), L, X, alpha)
+            outD = dict(zip(keys, grad))
+            outD['noise'] *= self.noise * 2.0  # gp.py:463-464
+            return out, outD
+        return out
+
+    def getHypParamNames(self):
+        return self.kernel.hyperParam.keys()
+
+    def updateKernelParams(self, paramsIn):
+        """Set new hyper-parameters; a 'noise' entry goes to `self.noise`, the rest to the kernel."""
+        params = copy.copy(paramsIn)
+        if 'noise' in params.keys():
+            self.noise = copy.copy(params['noise'])
+            del params['noise']
+        self.kernel.updateHyperParameters(params)
+
+    # ---- hyper-parameter fit: host driver around loglikeParams -----------------------------------
+    def findOptParamsLogLike(self, pts, evals, paramsStart=None, paramLowerBounds=None, paramUpperBounds=None,
+                             useNoise=None, maxiter=40, useLastParams=True):
+        """Maximise the marginal likelihood over the kernel hyper-parameters (+ noise unless `useNoise` is given);
+        bounds default to [max(v/10, 1e-3), min(10 v, 10)], noise to [1e-12, 1] from 1e-5 (gp.py:498-590)."""
+        if paramsStart is None:
+            paramsStart = copy.deepcopy(self.kernel.hyperParam)
+        if paramLowerBounds is None:
+            paramLowerBounds = dict((k, np.max([v / 10.0, 1e-3])) for k, v in paramsStart.items())
+        if paramUpperBounds is None:
+            paramUpperBounds = dict((k, np.min([v * 10.0, 10.0])) for k, v in paramsStart.items())
+        keys = list(paramsStart.keys())
+        vals = [paramsStart[k] for k in keys]
+        lbs = [paramLowerBounds[k] for k in keys]
+        ubs = [paramUpperBounds[k] for k in keys]
+        if useNoise is None:  # last key is the noise
+            keys.append('noise')
+            lbs.append(1e-12)
+            ubs.append(1e0)
+            vals.append(1e-5)
+
+        def objFunc(in0, gradIn):
+            self.updateKernelParams(dict(zip(keys, in0)))
+            if gradIn.size > 0:
+                margLogLike, derivs = self.loglikeParams(pts, evals, returnDeriv=1)
+                gradIn[:] = -np.array([derivs[k] for k in keys])
+            else:
+                margLogLike = self.loglikeParams(pts, evals, returnDeriv=0)
+            objFunc.last_x_value = in0.copy()
+            objFunc.last_f_value = -margLogLike
+            return -margLogLike
+
+        paramsOut, optValue = self.chooseParams(lbs, ubs, vals, objFunc, maxiter=maxiter, useLastParams=useLastParams)
+        params = dict(zip(keys, paramsOut))
+        self.updateKernelParams(params)
+        return params, optValue
+
+    def chooseParams(self, paramLowerBounds, paramUpperBounds, startValues, costFunction, maxiter=40,
+                     useLastParams=True):
+        """SciPy L-BFGS-B with numerical gradients, factr=1e10, maxfun=maxiter (gp.py:615-639)."""
+        bounds = list(zip(paramLowerBounds, paramUpperBounds))
+
+        def objFunc(x):
+            return costFunction(x, np.empty(0))
+
+        sol = bfgs(objFunc, np.array(startValues), bounds=bounds, approx_grad=True, factr=1e10, maxfun=maxiter)[0]
+        return sol, objFunc(sol)

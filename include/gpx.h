@@ -89,6 +89,11 @@ int gpx_kfill_into(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp,
 /* k(Z_j, Z_j) for every point -> host out[M]                          gp.py:140, 251 */
 int gpx_kdiag(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* Z, double* out);
 
+/* Kernel.evaluate semantics (kernels.py:49-65): out[i] = k(A_i, B_i) for equally sized host point sets, or
+ * one point against n (na == 1 or nb == 1); out has max(na, nb) entries.  Any other shape pair is an error. */
+int gpx_kernel_eval(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp,
+                    const double* A, int64_t na, const double* B, int64_t nb, double* out);
+
 /* ---- L2: factorisation and solves (replace numpy.linalg.pinv / slogdet) ---------------------- */
 /* in-place lower Cholesky K = L L^T (strict upper left undefined); replaces pinv at gp.py:181, 400 */
 int gpx_potrf(gpx_ctx* ctx, gpx_mat* K);
@@ -125,6 +130,19 @@ int gpx_greedy_var(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp,
 int gpx_greedy_ivar_step(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp,
                          const gpx_mat* L, const gpx_mat* X, const gpx_mat* C, const gpx_mat* Z,
                          double noise, double* out_cost, int64_t* out_best);
+
+/* greedy mutual-information design among M candidates with noise variance `noise`, seeded with `start`
+ * (experimentalDesign.py:223-285, 753-785): out_idx[nsel] = start followed by the picks (first-max tie rule);
+ * out_ratio[nsel-1] (nullable) = winning ratio var(c|A)/var(c|all\A\c) of every step.  M <= 65535. */
+int gpx_mi_greedy(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* C, double noise,
+                  int64_t nsel, int64_t start, int64_t* out_idx, double* out_ratio);
+
+/* ---- hyper-parameter gradient -------------------------------------------------------------------- */
+/* grad[k] = 1/2 tr((alpha alpha^T - K^-1) dK/d theta_k), theta = {hyp[0..nhyp-1], noise}; the noise entry is
+ * the raw 1/2 tr(alpha alpha^T - K^-1) (the caller applies the reference's x 2*noise, gp.py:463-464).
+ * Squared-exponential kernel only (gp.py:444-466 + kernels.py:125-144; the reference raises for the others). */
+int gpx_lml_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
+                 const double* alpha, double* grad);
 
 /* ---- measurement ------------------------------------------------------------------------------- */
 /* when enabled every kernel launch of a class is bracketed by HIP events on the launch stream */

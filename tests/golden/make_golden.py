@@ -260,3 +260,84 @@ for c in ("kat1_demo", "kat2_matern32", "kat4_ivar", "kat5_greedy", "kat6_mi"):
     ks = [k for k in arrays if k.startswith(c + "/") and arrays[k].size <= 8 and "idx" in k or k.endswith("loglike") and k.startswith(c)]
     for k in ks:
         print(k, arrays[k])
+
+# --- appended: demo.py flow (config C1) and variance-derivative vectors -----------------------------------
+# Same sequence of API calls as the reference's demo.py:52-151 (1-D SE GP, log-like, hyper-parameter fit,
+# train/evaluate, IVAR design from a greedy-variance start + SLSQP), with the MC points passed explicitly so
+# the fixture does not depend on the global NumPy RNG stream.
+def demo_flow():
+    import io
+    import contextlib
+    case = "demo_flow"
+    np.random.seed(0)
+    kernel = KernelSquaredExponential([0.3], 1.0, 1)
+    gpT = GP(kernel, 0.0)
+    xTrain = np.array([-0.8, 0.2, 0.3, -0.1]).reshape((4, 1))
+    yTrain = np.sin(2.0 * np.pi * xTrain)[:, 0]
+    put(case, "xTrain", xTrain)
+    put(case, "yTrain", yTrain)
+    put(case, "loglike0", gpT.computeLogLike(xTrain, yTrain))
+    params, optval = gpT.findOptParamsLogLike(xTrain, yTrain)
+    put(case, "opt_keys_order", np.array([0]))
+    put(case, "opt_cl0", params["cl0"])
+    put(case, "opt_signalSize", params["signalSize"])
+    put(case, "opt_noise", params["noise"])
+    put(case, "opt_value", optval)
+    gpT.train(xTrain, yTrain)
+    xDemo = np.linspace(-1, 1, 1000).reshape((1000, 1))
+    m, var = gpT.evaluate(xDemo, compvar=1)
+    put(case, "mean1", m)
+    put(case, "var1", var)
+    mc = np.random.rand(10000, 1) * 2.0 - 1.0
+    put(case, "mc", mc)
+    sampler = lambda size: np.random.rand(size[0], size[1]) * 2.0 - 1.0
+    distrib = lambda points: (np.abs(points) < 1.0) * 0.5
+    space1 = Space(1, sampler, distrib)
+    cf = ED.costFunctionGP_IVAR(gpT, 8, space1, mcPoints=mc)
+    exp = ED.ExperimentalDesignDerivative(cf, 8, 1)
+    lb = np.concatenate((xTrain.flatten(), -np.ones(4)))
+    ub = np.concatenate((xTrain.flatten(), np.ones(4)))
+    with contextlib.redirect_stdout(io.StringIO()):
+        newPts = exp.beginWithVarGreedy(nodesKeep=xTrain, lbounds=lb, rbounds=ub)
+    put(case, "design", newPts)
+    put(case, "design_cost", cf.evaluate(newPts))
+    # greedy start that SLSQP began from
+    keep = [0, 1, 2, 3]
+    with contextlib.redirect_stdout(io.StringIO()):
+        start = ED.performGreedyVarExperimentalDesign(copy_kernel(gpT.kernel), np.concatenate((xTrain, mc), axis=0),
+                                                      8, 1, indKeepStart=keep)
+    put(case, "greedy_start_idx", np.array(keep, dtype=np.int64))
+    put(case, "greedy_start_cost", cf.evaluate(start))
+    put(case, "greedy_start_grad", cf.derivative(start))
+    index[case] = dict(type="demo")
+
+
+def copy_kernel(k):
+    import copy
+    return copy.copy(k)
+
+
+def varderiv_case():
+    case = "varderiv"
+    rng = np.random.default_rng(501)
+    X = rng.uniform(-1, 1, (7, 2))
+    Z = rng.uniform(-1, 1, (9, 2))
+    spec = dict(kind="se", cl=[0.4, 0.6], signalSize=1.3, d=2)
+    g = GP(make_kernel(spec), 1e-2)
+    g.addNodesAndComputeCovariance(X)
+    index[case] = dict(type="varderiv", kernel=spec, noise=1e-2)
+    put(case, "X", X)
+    put(case, "Z", Z)
+    put(case, "dvar_dpts", g.evaluateVarianceDerivative(Z))
+    put(case, "dvar_dnew", g.evaluateVarianceDerivWRTnewpt(Z))
+    put(case, "kernel_derivative", g.kernel.derivative(X, Z[:1]))
+
+
+demo_flow()
+varderiv_case()
+np.savez_compressed(os.path.join(OUT, "gpexp_golden.npz"), **arrays)
+with open(os.path.join(OUT, "gpexp_golden.json"), "w") as f:
+    json.dump(index, f, indent=1, sort_keys=True)
+print("appended demo_flow + varderiv: %d arrays, %d cases" % (len(arrays), len(index)))
+print("demo opt:", arrays["demo_flow/opt_cl0"], arrays["demo_flow/opt_signalSize"], arrays["demo_flow/opt_noise"],
+      arrays["demo_flow/opt_value"], "design", np.sort(arrays["demo_flow/design"][:, 0]), arrays["demo_flow/design_cost"])

@@ -1,0 +1,311 @@
+"""GPU tests (-m gpu) of the GPEXP class API (gpexp_amd / gpExp): same calls a user of the reference makes,
+checked against the golden vectors the reference produced for those calls.  Tolerance 1e-10 relative (fp64)."""
+import copy
+
+import numpy as np
+import pytest
+
+from oracle import gpexp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+GP_CASES = ["kat1_demo", "kat2_matern32", "kat3_mehler", "se_iso_d3_n96", "se_ard_d8_n130",
+            "matern32_d8_n200", "mehler_d3_n64", "se_ard_d2_n77_ppnoise", "se_iso_d3_n300"]
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=float)
+    b = np.asarray(b, dtype=float)
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+def make_kernel(s):
+    from gpExp.kernels import KernelSquaredExponential, KernelIsoMatern, KernelMehlerND
+    if s["kind"] == "se":
+        return KernelSquaredExponential(list(s["cl"]), s["signalSize"], s["d"])
+    if s["kind"] == "matern32":
+        return KernelIsoMatern(s["rho"], s["signalSize"], s["d"])
+    if s["kind"] == "matern52":
+        return KernelIsoMatern(s["rho"], s["signalSize"], s["d"], nu=2.5)
+    return KernelMehlerND(list(s["t"]), s["d"])
+
+
+@pytest.mark.parametrize("case", GP_CASES)
+def test_gp_class_vs_reference(golden, case):
+    from gpExp.gp import GP
+    from gpExp.gp_kernel_utilities import calculateCovarianceMatrix
+    k = make_kernel(golden.index[case]["kernel"])
+    X, y, Z = golden(case, "X"), golden(case, "y"), golden(case, "Z")
+    nz = golden.noise(case)
+    assert rel(calculateCovarianceMatrix(k, X, nz), golden(case, "K")) <= 1e-13
+    g = GP(k, nz)
+    assert g.computeLogLike(X, y) == pytest.approx(float(golden(case, "loglike")), rel=1e-10)
+    g.train(X, y)
+    assert rel(g.coeff, golden(case, "coeff")) <= 1e-10
+    assert g.pts is not X and np.array_equal(g.pts, X)
+    m, v = g.evaluate(Z, compvar=1)
+    assert rel(m, golden(case, "mean")) <= 1e-10
+    assert rel(v, golden(case, "absvar")) <= 1e-10 and np.all(v >= 0)
+    assert rel(g.evaluateVariance(Z), golden(case, "var")) <= 1e-10
+    assert rel(g.evaluate(Z), golden(case, "mean")) <= 1e-10
+    nc = golden(case, "cov").shape[0]
+    m2, c = g.evaluate(Z[:nc], compvar=2)
+    assert rel(c, golden(case, "cov")) <= 1e-10
+    # lazy dense attributes other code reads (experimentalDesign.py:241-242)
+    assert rel(g.covarianceMatrix, golden(case, "K")) <= 1e-13
+    assert rel(g.precisionMatrix, golden(case, "precision")) <= 1e-9
+
+
+@pytest.mark.parametrize("nm", ["se", "matern32", "mehler"])
+def test_kernel_evaluate_shapes(golden, nm):
+    case = "evaluate_" + nm
+    k = make_kernel(golden.index[case]["kernel"])
+    A, B = golden(case, "A"), golden(case, "B")
+    assert rel(k.evaluate(A, B), golden(case, "paired")) <= 1e-13
+    assert rel(k.evaluate(A, B[:1]), golden(case, "n_vs_1")) <= 1e-13
+    assert rel(k.evaluate(A[:1], B), golden(case, "1_vs_n")) <= 1e-13
+    assert k.evaluate(A, B).shape == (9,)
+    with pytest.raises(AssertionError):
+        k.evaluate(A[:3], B[:2])
+    with pytest.raises(AssertionError):
+        k.evaluate(A[:, :1], B[:, :1])  # wrong dimension
+    with pytest.raises(AssertionError):
+        k.evaluate(A[0], B)  # 1-D input
+
+
+def test_hyperparameter_plumbing():
+    from gpExp.kernels import KernelSquaredExponential, KernelMehlerND
+    from gpExp.gp import GP
+    k = KernelSquaredExponential([0.3], 1.0, 3)
+    assert list(k.hyperParam.keys()) == ["cl0", "cl1", "cl2", "signalSize"]
+    g = GP(k, 0.0)
+    assert g.kernel is not k  # deep copy (gp.py:63)
+    assert list(g.getHypParamNames()) == ["cl0", "cl1", "cl2", "signalSize"]
+    g.updateKernelParams({"cl0": 0.5, "cl1": 0.6, "cl2": 0.7, "signalSize": 2.0, "noise": 0.01})
+    assert g.noise == 0.01 and g.kernel.hyperParam["cl1"] == 0.6
+    with pytest.raises(AssertionError):
+        g.kernel.updateHyperParameters({"bogus": 1.0})
+    m = KernelMehlerND([0.5, 0.3], 2)
+    m.updateHyperParameters({0: 0.4, 1: 0.2})
+    assert m.oneDKern[1].hyperParam["t"] == 0.2
+    with pytest.raises(TypeError):
+        GP(k, 0).train(np.zeros((3, 3)), np.zeros(3))  # int nugget is an error in the reference too
+    with pytest.raises(AssertionError):
+        GP(k, 0.1).train(np.zeros((3, 3)), np.zeros((3, 1)))
+
+
+def test_ivar_cost_function(golden):
+    from gpExp.gp import GP
+    from gpExp.approximation import Space
+    from gpExp.experimentalDesign import costFunctionGP_IVAR
+    c = "kat4_ivar"
+    k = make_kernel(golden.index[c]["kernel"])
+    space = Space(2, lambda size: np.random.rand(size[0], size[1]) * 2 - 1, lambda p: 0.25 * np.ones(len(p)))
+    g = GP(k, 1e-3)
+    cf = costFunctionGP_IVAR(g, 5, space, mcPoints=golden(c, "mc"))
+    assert cf.gaussianProcess is not g  # shallow copy (experimentalDesign.py:64)
+    assert cf.evaluate(golden(c, "X")) == pytest.approx(float(golden(c, "ivar")), rel=1e-10)
+    with pytest.raises(AssertionError):
+        cf.evaluate(golden(c, "X")[:4])
+    # heteroscedastic noise callable -> per-point nugget (experimentalDesign.py:111-112)
+    sp2 = Space(2, space.sample, space.probDensity, noise=lambda p: 1e-3 * np.ones(len(p)))
+    cf2 = costFunctionGP_IVAR(GP(k, 1e-3), 5, sp2, mcPoints=golden(c, "mc"))
+    assert cf2.evaluate(golden(c, "X")) == pytest.approx(float(golden(c, "ivar")), rel=1e-10)
+
+
+def test_greedy_variance_design(golden, capsys):
+    from gpExp.experimentalDesign import performGreedyVarExperimentalDesign
+    c = "kat5_greedy"
+    k = make_kernel(golden.index[c]["kernel"])
+    C = golden(c, "C")
+    keep = [0]
+    pts = performGreedyVarExperimentalDesign(k, C, 8, 2, indKeepStart=keep)
+    assert keep == list(golden(c, "gvar_idx"))  # caller's list is extended in place (:808)
+    np.testing.assert_array_equal(pts, golden(c, "gvar_pts"))
+    keepw = [3, 11]
+    performGreedyVarExperimentalDesign(k, C, 9, 2, weights=golden(c, "weights"), indKeepStart=keepw)
+    assert keepw == list(golden(c, "gvar_idx_weighted"))
+    pts0 = performGreedyVarExperimentalDesign(k, C, 3, 2)
+    np.testing.assert_array_equal(pts0[0], C[0])
+
+
+def test_greedy_ivar_step_api(golden):
+    from gpExp.gp import GP
+    from gpExp.experimentalDesign import greedyIVARStep
+    c = "kat5_greedy"
+    k = make_kernel(golden.index[c]["kernel"])
+    g = GP(k, 1e-3)
+    X = golden(c, "X0").copy()
+    sel = []
+    for step in range(4):
+        g.addNodesAndComputeCovariance(X)
+        best, costs = greedyIVARStep(g, golden(c, "C"), golden(c, "Z"))
+        sel.append(best)
+        assert costs[best] == pytest.approx(golden(c, "givar_cost")[step], rel=1e-10)
+        X = np.vstack((X, golden(c, "C")[best:best + 1]))
+    assert sel == list(golden(c, "givar_idx"))
+
+
+def test_mi_design(golden):
+    from gpExp.gp import GP
+    from gpExp.approximation import Space
+    from gpExp.experimentalDesign import costFunctionGP_MI, performGreedyMIExperimentalDesign
+    c = "kat6_mi"
+    k = make_kernel(golden.index[c]["kernel"])
+    C = golden(c, "C")
+    space = Space(2, None, None)
+    g = GP(k, 1e-3)
+    cm = costFunctionGP_MI(g, 6, space, nmc=40, mcpoints=C)
+    assert cm.gaussianProcess is g and np.array_equal(g.pts, C)  # mutates the caller's GP (:227,240)
+    assert cm.evaluate(5, [0, 14]) == pytest.approx(float(golden(c, "eval_5_given_0_14").ravel()[0]), rel=1e-8)
+    got = np.array([cm.evaluate(j, [0]) for j in range(1, 40)])
+    assert rel(got, golden(c, "eval_all_given_0").ravel()) <= 1e-8
+    pts = performGreedyMIExperimentalDesign(cm, 6)
+    np.testing.assert_array_equal(pts, golden(c, "mi_pts"))
+    pts9 = performGreedyMIExperimentalDesign(cm, 5, start=9)
+    np.testing.assert_array_equal(pts9, C[list(golden(c, "mi_idx_start9"))])
+
+
+def test_mi_greedy_ratios_vs_oracle(golden):
+    from gpexp_amd import device as dev
+    c = "kat6_mi"
+    s = golden.index[c]["kernel"]
+    C = golden(c, "C")
+    ctx = dev.context()
+    idx, ratios = dev.mi_greedy(ctx, make_kernel(s)._spec(), dev.points(ctx, C), 1e-3, 6, 0)
+    keep, want = orc.greedy_mi(s, C, 1e-3, 6)
+    assert list(idx) == keep == list(golden(c, "mi_idx"))
+    assert rel(ratios, want) <= 1e-7
+
+
+def test_loglike_gradient(golden):
+    """UNPINNED sub-path (the reference's own gradient code raises): device gradient vs the oracle's restatement
+    of gp.py:444-466 and vs central differences of the reference's runnable loglike (fixture lml_fd)."""
+    from gpExp.gp import GP
+    c = "lml_fd"
+    s = golden.index[c]["kernel"]
+    nz = golden.index[c]["noise"]
+    g = GP(make_kernel(s), nz)
+    val, grad = g.loglikeParams(golden(c, "X"), golden(c, "y"), returnDeriv=1)
+    oval, ograd = orc.loglike_grad(s, golden(c, "X"), golden(c, "y"), nz)
+    assert val == pytest.approx(float(golden(c, "loglike")), rel=1e-10)
+    assert list(grad.keys()) == golden.index[c]["keys"]
+    for key in grad:
+        assert grad[key] == pytest.approx(ograd[key], rel=1e-9), key
+    fd = dict(zip(golden.index[c]["keys"], golden(c, "fd_grad_raw")))
+    for key in grad:
+        want = fd[key] * 2 * nz if key == "noise" else fd[key]
+        assert grad[key] == pytest.approx(want, rel=2e-6), key
+
+
+def test_matern52_extension_vs_oracle():
+    from gpExp.kernels import KernelIsoMatern
+    from gpExp.gp import GP
+    rng = np.random.default_rng(52)
+    X = rng.uniform(-1, 1, (150, 8))
+    y = rng.standard_normal(150)
+    Z = rng.uniform(-1, 1, (40, 8))
+    s = dict(kind="matern52", rho=0.5, signalSize=1.0, d=8)
+    g = GP(KernelIsoMatern(0.5, 1.0, 8, nu=2.5), 0.1)
+    g.train(X, y)
+    m, v = g.evaluate(Z, compvar=1)
+    model = orc.fit(s, X, y, 0.1)
+    mo, vo = orc.posterior(s, model, Z)
+    assert rel(m, mo) <= 1e-10 and rel(v, np.abs(vo)) <= 1e-10
+    with pytest.raises(NotImplementedError):
+        KernelIsoMatern(0.5, 1.0, 8, nu=0.5).evaluate(X, X)
+
+
+def test_rank_deficient_policy():
+    """noise 0.0 + coincident points: pinv truncates, Cholesky cannot -> documented jitter retry + warning."""
+    from gpExp.kernels import KernelSquaredExponential
+    from gpExp.gp import GP
+    X = np.array([[0.1], [0.1], [0.5], [-0.3]])
+    y = np.array([1.0, 1.0, 0.2, -0.4])
+    g = GP(KernelSquaredExponential([0.3], 1.0, 1), 0.0)
+    with pytest.warns(RuntimeWarning):
+        g.train(X, y)
+    assert g.jitter > 0
+    m = g.evaluate(np.array([[0.1], [0.5]]))
+    assert np.allclose(m, [1.0, 0.2], atol=1e-6)
+
+
+def test_variance_derivative_host_side_f1():
+    """SURVEY 8 f1 (host-side caller of the hot path): finite-difference check of d var / d training points."""
+    from gpExp.kernels import KernelSquaredExponential
+    from gpExp.gp import GP
+    rng = np.random.default_rng(3)
+    X = rng.uniform(-1, 1, (6, 2))
+    Z = rng.uniform(-1, 1, (5, 2))
+    # the reference's SE derivative carries signalSize twice (kernels.py:177); with signalSize=1 it is exact
+    g = GP(KernelSquaredExponential([0.4, 0.6], 1.0, 2), 1e-2)
+    g.addNodesAndComputeCovariance(X)
+    D = g.evaluateVarianceDerivative(Z)
+    assert D.shape == (12, 5)
+    h = 1e-6
+    for k in range(6):
+        for l in range(2):
+            Xp, Xm = X.copy(), X.copy()
+            Xp[k, l] += h
+            Xm[k, l] -= h
+            g.addNodesAndComputeCovariance(Xp)
+            vp = g.evaluateVariance(Z)
+            g.addNodesAndComputeCovariance(Xm)
+            vm = g.evaluateVariance(Z)
+            np.testing.assert_allclose(D[k * 2 + l], (vp - vm) / (2 * h), rtol=1e-5, atol=1e-7)
+
+
+def test_variance_derivatives_vs_reference(golden):
+    """f1 host-side functions against vectors from the reference (evaluateVarianceDerivative, gp.py:282-341)."""
+    from gpExp.gp import GP
+    c = "varderiv"
+    g = GP(make_kernel(golden.index[c]["kernel"]), 1e-2)
+    g.addNodesAndComputeCovariance(golden(c, "X"))
+    assert rel(g.kernel.derivative(golden(c, "X"), golden(c, "Z")[:1]), golden(c, "kernel_derivative")) <= 1e-12
+    assert rel(g.evaluateVarianceDerivative(golden(c, "Z")), golden(c, "dvar_dpts")) <= 1e-9
+    assert rel(g.evaluateVarianceDerivWRTnewpt(golden(c, "Z")), golden(c, "dvar_dnew")) <= 1e-9
+
+
+def test_demo_flow_config1(golden, capsys):
+    """BASELINE config C1: the call sequence of the reference's demo.py (1-D SE GP: log-likelihood,
+    hyper-parameter fit by L-BFGS-B, train/evaluate on 1000 points, IVAR design from a greedy-variance start +
+    SLSQP), on the GPU, against what the reference produced for the same inputs.  The optimisers amplify
+    round-off (pinv vs Cholesky at noise=1e-12), hence the looser tolerances on optimiser outputs."""
+    from gpExp.kernels import KernelSquaredExponential
+    from gpExp.experimentalDesign import costFunctionGP_IVAR, ExperimentalDesignDerivative, \
+        performGreedyVarExperimentalDesign
+    from gpExp.gp import GP
+    from gpExp.approximation import Space
+    c = "demo_flow"
+    gpT = GP(KernelSquaredExponential([0.3], 1.0, 1), 0.0)
+    xTrain, yTrain = golden(c, "xTrain"), golden(c, "yTrain")
+    assert gpT.computeLogLike(xTrain, yTrain) == pytest.approx(float(golden(c, "loglike0")), rel=1e-10)
+    params, optval = gpT.findOptParamsLogLike(xTrain, yTrain)
+    assert params["cl0"] == pytest.approx(float(golden(c, "opt_cl0")), rel=1e-4)
+    assert params["signalSize"] == pytest.approx(float(golden(c, "opt_signalSize")), rel=1e-4)
+    assert params["noise"] == pytest.approx(float(golden(c, "opt_noise")), rel=1e-3, abs=1e-10)
+    assert optval == pytest.approx(float(golden(c, "opt_value")), rel=1e-6)
+    # continue from the reference's optimum so that later comparisons do not inherit optimiser noise
+    gpT.updateKernelParams({"cl0": float(golden(c, "opt_cl0")), "signalSize": float(golden(c, "opt_signalSize")),
+                            "noise": float(golden(c, "opt_noise"))})
+    gpT.train(xTrain, yTrain)
+    m, var = gpT.evaluate(np.linspace(-1, 1, 1000).reshape((1000, 1)), compvar=1)
+    assert rel(m, golden(c, "mean1")) <= 1e-7
+    assert np.max(np.abs(var - golden(c, "var1"))) <= 1e-7
+    mc = golden(c, "mc")
+    space = Space(1, lambda size: np.random.rand(size[0], size[1]) * 2.0 - 1.0, lambda p: (np.abs(p) < 1.0) * 0.5)
+    cf = costFunctionGP_IVAR(gpT, 8, space, mcPoints=mc)
+    keep = [0, 1, 2, 3]
+    start = performGreedyVarExperimentalDesign(gpT.kernel, np.concatenate((xTrain, mc), axis=0), 8, 1,
+                                               indKeepStart=keep)
+    assert keep == list(golden(c, "greedy_start_idx"))
+    assert cf.evaluate(start) == pytest.approx(float(golden(c, "greedy_start_cost")), rel=1e-7)
+    assert rel(cf.derivative(start), golden(c, "greedy_start_grad")) <= 1e-5
+    exp = ExperimentalDesignDerivative(cf, 8, 1)
+    lb = np.concatenate((xTrain.flatten(), -np.ones(4)))
+    ub = np.concatenate((xTrain.flatten(), np.ones(4)))
+    design = exp.beginWithVarGreedy(nodesKeep=xTrain, lbounds=lb, rbounds=ub)
+    assert design.shape == (8, 1)
+    np.testing.assert_allclose(design[:4], xTrain, atol=1e-12)
+    assert cf.evaluate(design) == pytest.approx(float(golden(c, "design_cost")), rel=1e-3)
+    np.testing.assert_allclose(np.sort(design[:, 0]), np.sort(golden(c, "design")[:, 0]), atol=2e-3)
