@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- GP-fit + IVAR-eval on MI355X (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (SURVEY.md 8d, config C4 -- the configuration the metric is quoted on; it fits one GPU):
+    N = 32768 training points, d = 8, Matern nu=5/2 (rho=0.5, signalSize=1, noise=0.1), seed 32768,
+    X ~ U[-1,1]^(N x d), y = sin(2 pi sum(x)/d) + sqrt(noise) N(0,1), M = 32768 MC points ~ U[-1,1]^(M x d).
+One step = the whole hot path on that batch, inputs already resident in HBM:
+    K = kfill(X) + noise I  ->  L = potrf(K)  ->  alpha = potrs(L, y)  ->  logdet  ->  log marginal likelihood
+    ->  IVAR = mean_z [k(z,z) - |L^-1 k(X,z)|^2] over the M points.
+value = (N + M) points / step time (whole job, all ranks); ms_per_step is the GP-fit + IVAR-eval wall time.
+With --gpus N > 1 the same total problem is split over the ranks (strong scaling): see gpexp_amd/dist.py.
+
+Extra objects on the JSON line: "roofline" for the dominant kernel (the fp64 MFMA GEMM behind SYRK/TRSM; HIP
+events recorded on the launch stream by the library around every launch inside the timed region) and
+"cpu_baseline" (the oracle's reference-exact algorithm -- row-loop assembly + pinv + slogdet + per-point variance
+loop -- timed on the host cores on a bounded sample of the same workload, rank 0 at N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP64_MFMA_TFLOPS = 78.6   # 256 CU x 2.4 GHz x 128 flop/clk/CU (MI355X fp64 matrix = vector peak)
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E
+
+
+def workload(n, d, m, seed):
+    rng = np.random.default_rng(seed)
+    noise = 0.1
+    X = rng.uniform(-1, 1, (n, d))
+    y = np.sin(2 * np.pi * X.sum(1) / d) + np.sqrt(noise) * rng.standard_normal(n)
+    Z = rng.uniform(-1, 1, (m, d))
+    return X, y, Z, noise
+
+
+def cpu_baseline(d, seed):
+    """Reference algorithm on the host: bounded sample N=4096 (the SURVEY's C2 size), M=512."""
+    from oracle import gpexp_oracle as orc
+    n, m = 4096, 512
+    X, y, Z, noise = workload(n, d, m, seed)
+    spec = dict(kind="matern52", rho=0.5, signalSize=1.0, d=d)
+    t0 = time.perf_counter()
+    K = orc.cov_matrix(spec, X, noise, row_loop=True)          # gp_kernel_utilities.py:56-60
+    P = np.linalg.pinv(K)                                      # gp.py:181
+    _, logdet = np.linalg.slogdet(K)                           # gp.py:434
+    alpha = P @ y
+    ll = -0.5 * y @ alpha - 0.5 * logdet - n / 2.0 * np.log(2 * np.pi)
+    model = dict(K=K, P=P, X=X)
+    _, var = orc.posterior(spec, model, Z)                     # gp.py:246-256 per-point loop
+    iv = abs(var.mean())
+    dt = time.perf_counter() - t0
+    try:
+        import threadpoolctl
+        threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    return dict(value=(n + m) / dt, unit="points/s", cores=int(threads), kind="port",
+                sample="N=%d train + M=%d MC points, d=%d Matern-5/2, reference algorithm (row-loop fill + pinv + "
+                       "slogdet + per-point variance loop), %.1f s; O(N^3): NOT extrapolated to N=32768"
+                       % (n, m, d, dt),
+                seconds=dt, loglike=float(ll), ivar=float(iv))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=32768)
+    ap.add_argument("--d", type=int, default=8)
+    ap.add_argument("--m", type=int, default=32768)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+        args.gpus = world
+
+    from gpexp_amd import device as dev
+    ctx = dev.Context(local_rank)
+    dev._ctx = ctx
+    info = ctx.info()
+
+    N, d, M = args.n, args.d, args.m
+    Xh, yh, Zh, noise = workload(N, d, M, seed=N)
+    spec = dev.KernelSpec(dev.K_MATERN52, d, [0.5, 1.0])
+
+    if world > 1:
+        from gpexp_amd import dist
+        comm = dist.init_from_env(ctx)
+        runner = dist.DistFitIvar(ctx, comm, spec, Xh, yh, Zh, noise)
+        step = runner.step
+        barrier = comm.barrier
+        reduce_max = comm.max_float
+    else:
+        X = dev.points(ctx, Xh)
+        Z = dev.points(ctx, Zh)
+        K = dev.DeviceMatrix.zeros(ctx, N, N)   # allocated once; refilled in place every step
+
+        def step():
+            dev.kfill_into(ctx, spec, X, K, nugget=noise)
+            dev.potrf(ctx, K)
+            alpha = dev.potrs(ctx, K, yh)
+            logdet = dev.logdet(ctx, K)
+            ll = -0.5 * float(yh @ alpha) - 0.5 * logdet - N / 2.0 * np.log(2 * np.pi)
+            iv = abs(dev.ivar(ctx, spec, K, X, Z))
+            return ll, iv
+
+        def barrier():
+            pass
+
+        def reduce_max(v):
+            return v
+
+    def sync():
+        ctx.sync()
+        try:  # the contract's device-wide synchronize (covers the library's own HIP stream too)
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        except ImportError:
+            pass
+
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    sync()
+    ctx.profile(True)
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_get()
+    ctx.profile(False)
+    dt = reduce_max(dt)
+    ll, iv = out
+
+    if rank == 0:
+        ms = 1e3 * dt / args.steps
+        g = prof["gemm"]
+        kf = prof["kfill"]
+        ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        line = {
+            "metric": "GP-fit+IVAR-eval points/s at N=%d d=%d (wall-time in ms_per_step)" % (N, d),
+            "value": (N + M) / (dt / args.steps),
+            "unit": "points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "C4: N=%d d=%d Matern-5/2 (rho=0.5,s=1,noise=0.1) kfill+potrf+potrs+logdet+"
+                                   "IVAR over M=%d MC points" % (N, d, M),
+                       "N": N, "d": d, "M": M, "kernel": "matern52", "seed": N,
+                       "parallelism": "1 GPU" if world == 1 else "%d ranks, 1-D block-cyclic columns" % world},
+            "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel (SYRK/TRSM updates)", "achieved": ach,
+                         "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
+                         "traffic": None, "launches_per_step": g["launches"] / args.steps,
+                         "kernel_ms_per_step": g["ms"] / args.steps},
+            "kfill": {"bound": "hbm", "achieved": kf["bytes"] / (kf["ms"] * 1e-3) / 1e9 if kf["ms"] > 0 else 0.0,
+                      "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                      "frac": (kf["bytes"] / (kf["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS) if kf["ms"] > 0 else 0.0,
+                      "note": "all kfill launches of the step (square K + N x M cross matrix)"},
+            "phases_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items() if v["launches"]},
+            "results": {"loglike": ll, "ivar": iv},
+            "device": info["name"],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(d, seed=4096)
+        print(json.dumps(line), flush=True)
+    barrier()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

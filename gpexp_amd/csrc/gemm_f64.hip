@@ -32,9 +32,9 @@ struct Smem {
 };
 
 template <bool BT, bool ACC, bool LOWER>
-__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* __restrict__ A, int64_t lda,
-                                                          const double* __restrict__ B, int64_t ldb,
-                                                          double* __restrict__ C, int64_t ldc, int nk) {
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64_t lda,
+                                                          const double* B, int64_t ldb,
+                                                          double* C, int64_t ldc, int nk) {
   const int bx = blockIdx.x, by = blockIdx.y;
   if (LOWER && bx > by) return;  // tile strictly above the diagonal
   __shared__ Smem<BT> sm;
@@ -49,32 +49,42 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* __restri
   const double* Ag = A + (m0 + ar) * lda + ac;
   const double* Bg = BT ? (B + (n0 + ar) * ldb + ac) : (B + (int64_t)br * ldb + n0 + bc);
 
-  double2 ra[4], rb[4];
-  auto gload = [&](int kt) {
-    const double* ap = Ag + (int64_t)kt * KB;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const double2*>(ap + (int64_t)(32 * i) * lda);
-    if (BT) {
-      const double* bp = Bg + (int64_t)kt * KB;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const double2*>(bp + (int64_t)(32 * i) * ldb);
-    } else {
-      const double* bp = Bg + (int64_t)kt * KB * ldb;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const double2*>(bp + (int64_t)(4 * i) * ldb);
-    }
-  };
-  auto sstore = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<double2*>(&sm.a[buf][(ar + 32 * i) * SA + ac]) = ra[i];
-    if (BT) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) *reinterpret_cast<double2*>(&sm.b[buf][(ar + 32 * i) * SA + ac]) = rb[i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) *reinterpret_cast<double2*>(&sm.b[buf][(br + 4 * i) * SBN + bc]) = rb[i];
-    }
-  };
+  // staging registers (kept as named SSA values: arrays captured by lambdas end up in scratch)
+  double2 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+  const int64_t a_rs = 32 * lda;                       // A row step between the 4 staged rows
+  const int64_t b_rs = BT ? 32 * ldb : 4 * ldb;        // B^T: 32 rows apart; B (NN): 4 k-rows apart
+  const int64_t b_ks = BT ? (int64_t)KB : (int64_t)KB * ldb;  // advance per k-step
+#define GPX_GLOAD(kt_)                                                        \
+  do {                                                                        \
+    const double* ap_ = Ag + (int64_t)(kt_) * KB;                             \
+    const double* bp_ = Bg + (int64_t)(kt_) * b_ks;                           \
+    ra0 = *reinterpret_cast<const double2*>(ap_);                             \
+    ra1 = *reinterpret_cast<const double2*>(ap_ + a_rs);                      \
+    ra2 = *reinterpret_cast<const double2*>(ap_ + 2 * a_rs);                  \
+    ra3 = *reinterpret_cast<const double2*>(ap_ + 3 * a_rs);                  \
+    rb0 = *reinterpret_cast<const double2*>(bp_);                             \
+    rb1 = *reinterpret_cast<const double2*>(bp_ + b_rs);                      \
+    rb2 = *reinterpret_cast<const double2*>(bp_ + 2 * b_rs);                  \
+    rb3 = *reinterpret_cast<const double2*>(bp_ + 3 * b_rs);                  \
+  } while (0)
+  double* const sa_w = &sm.a[0][ar * SA + ac];
+  double* const sb_w = BT ? &sm.b[0][ar * SA + ac] : &sm.b[0][br * SBN + bc];
+  constexpr int A_BUF = BM * SA;
+  constexpr int B_BUF = BT ? BN * SA : KB * SBN;
+  constexpr int B_WS = BT ? 32 * SA : 4 * SBN;
+#define GPX_SSTORE(buf_)                                                               \
+  do {                                                                                 \
+    double* aw_ = sa_w + (buf_) * A_BUF;                                               \
+    double* bw_ = sb_w + (buf_) * B_BUF;                                               \
+    *reinterpret_cast<double2*>(aw_) = ra0;                                            \
+    *reinterpret_cast<double2*>(aw_ + 32 * SA) = ra1;                                  \
+    *reinterpret_cast<double2*>(aw_ + 64 * SA) = ra2;                                  \
+    *reinterpret_cast<double2*>(aw_ + 96 * SA) = ra3;                                  \
+    *reinterpret_cast<double2*>(bw_) = rb0;                                            \
+    *reinterpret_cast<double2*>(bw_ + B_WS) = rb1;                                     \
+    *reinterpret_cast<double2*>(bw_ + 2 * B_WS) = rb2;                                 \
+    *reinterpret_cast<double2*>(bw_ + 3 * B_WS) = rb3;                                 \
+  } while (0)
 
   d4 acc[4][4];
 #pragma unroll
@@ -83,30 +93,37 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* __restri
     for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 
   const int fr = lane & 15, fk = lane >> 4;
-  gload(0);
-  sstore(0);
+  const double* const as0 = &sm.a[0][(wm * 64 + fr) * SA + fk];
+  const double* const bs0 = BT ? &sm.b[0][(wn * 64 + fr) * SA + fk] : &sm.b[0][fk * SBN + wn * 64 + fr];
+#define GPX_COMPUTE(buf_)                                                                            \
+  do {                                                                                               \
+    const double* as = as0 + (buf_) * A_BUF;                                                         \
+    const double* bs = bs0 + (buf_) * B_BUF;                                                         \
+    _Pragma("unroll") for (int kk = 0; kk < KB / 4; ++kk) {                                          \
+      double af[4], bf[4];                                                                           \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) af[i] = as[(i * 16) * SA + kk * 4];              \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                  \
+          bf[j] = BT ? bs[(j * 16) * SA + kk * 4] : bs[(kk * 4) * SBN + j * 16];                     \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)    \
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);        \
+    }                                                                                                \
+  } while (0)
+
+  GPX_GLOAD(0);
+  GPX_SSTORE(0);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
+  int kt = 0;
+  for (; kt + 1 < nk; ++kt) {  // steady state: prefetch step kt+1 while the MFMAs of step kt run
     const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
-    const double* as = &sm.a[buf][(wm * 64 + fr) * SA + fk];
-    const double* bs = BT ? &sm.b[buf][(wn * 64 + fr) * SA + fk] : &sm.b[buf][fk * SBN + wn * 64 + fr];
-#pragma unroll
-    for (int kk = 0; kk < KB / 4; ++kk) {
-      double af[4], bf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = as[(i * 16) * SA + kk * 4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bf[j] = BT ? bs[(j * 16) * SA + kk * 4] : bs[(kk * 4) * SBN + j * 16];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
-    }
-    if (kt + 1 < nk) sstore(buf ^ 1);
+    GPX_GLOAD(kt + 1);
+    GPX_COMPUTE(buf);
+    GPX_SSTORE(buf ^ 1);
     __syncthreads();
   }
+  GPX_COMPUTE(kt & 1);  // last step: nothing left to prefetch
+#undef GPX_GLOAD
+#undef GPX_SSTORE
+#undef GPX_COMPUTE
 
   // epilogue: reg v of lane l -> C[(l>>4)+4v][l&15] within each 16x16 tile
   double* Cw = C + (m0 + wm * 64 + fk) * ldc + n0 + wn * 64 + fr;
