@@ -16,62 +16,161 @@ constexpr int NB = GPX_TILE;  // 128
 constexpr int LS = NB + 1;    // LDS row stride (conflict-free column walks)
 
 // ---- leaf: potf2 + trtri of one 128x128 diagonal block -------------------------------------------
-// S (LDS): lower triangle = block being factored; strict upper + pad column = inverse, stored as
-// X[i][c] (i >= c) at S[c][i+1].
+// Everything is done in 16x16 blocks held in LDS (S, row stride 129: odd, so the 16-row fragment reads of a
+// 16-lane group are bank-conflict free).  Per 16-column panel p:
+//   (1) wave 0 factors the diagonal block in registers (lane = row, pivots/columns broadcast with v_readlane)
+//       and inverts it by forward substitution (lane = column of the inverse)         -> T[p]
+//   (2) the blocks below it are multiplied by T[p]^T              (4 fp64 MFMAs per block, in place)
+//   (3) the trailing blocks get  C -= A B^T                        (4 fp64 MFMAs per block)
+// The inverse of the whole 128x128 factor is then built block column by block column, one wave per column,
+// with every intermediate X block kept in MFMA accumulator registers: the C/D layout of
+// v_mfma_f64_16x16x4_f64 (reg v of lane l = row (l>>4)+4v, col l&15) is exactly its B-operand layout for
+// k-step v, so an accumulator feeds the next product without touching LDS.
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double readlane_d(double v, int srclane) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+  return __hiloint2double(hi, lo);
+}
+
+constexpr int LB = 16;          // block edge
+constexpr int TS17 = LB + 1;    // stride of the T blocks
+
+// one block column K of X = L^-1, entirely in registers; rows of blocks I = K..7
+template <int K>
+__device__ __forceinline__ void leaf_inverse_column(const double* S, const double (*T)[LB * TS17],
+                                                    double* __restrict__ inv, int g, int q) {
+  d4 xb[8 - K];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) xb[0][v] = T[K][(g + 4 * v) * TS17 + q];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) inv[(LB * K + g + 4 * v) * NB + LB * K + q] = xb[0][v];
+#pragma unroll
+  for (int I = K + 1; I < 8; ++I) {
+    d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int J = K; J < I; ++J) {
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const double a = S[(LB * I + q) * LS + LB * J + 4 * s4 + g];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xb[J - K][s4], acc, 0, 0, 0);
+      }
+    }
+    d4 r = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const double a = -T[I][q * TS17 + 4 * s4 + g];
+      r = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[s4], r, 0, 0, 0);
+    }
+    xb[I - K] = r;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) inv[(LB * I + g + 4 * v) * NB + LB * K + q] = r[v];
+  }
+}
+
 __global__ __launch_bounds__(256) void leaf_kernel(double* __restrict__ A, int64_t ld, double* __restrict__ inv,
                                                    int64_t base_index, int64_t n_valid, int* __restrict__ info) {
   __shared__ double S[NB * LS];
+  __shared__ double T[8][LB * TS17];
   const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int g = lane >> 4, q = lane & 15;
   for (int idx = t; idx < NB * NB; idx += 256) {
-    int i = idx >> 7, j = idx & 127;
+    const int i = idx >> 7, j = idx & 127;
     if (j <= i) S[i * LS + j] = A[(int64_t)i * ld + j];
+    if ((j >> 4) > (i >> 4)) inv[idx] = 0.0;  // upper blocks of the inverse are zero; the others are written below
   }
   __syncthreads();
-  for (int j = 0; j < NB; ++j) {
-    if (t == 0) {
-      double dj = S[j * LS + j];
-      if (!(dj > 0.0)) {  // non-positive or NaN pivot: record the first one, keep going with 1.0
-        if (base_index + j < n_valid) atomicCAS(info, 0, (int)(base_index + j + 1));
-        dj = 1.0;
+
+  for (int p = 0; p < 8; ++p) {
+    const int c0 = LB * p;
+    if (wave == 0) {
+      // (1) diagonal block: lane q (all four 16-lane groups redundantly) owns row q
+      double a[LB], rinv[LB], x[LB];
+#pragma unroll
+      for (int c = 0; c < LB; ++c) a[c] = (c <= q) ? S[(c0 + q) * LS + c0 + c] : 0.0;
+#pragma unroll
+      for (int j = 0; j < LB; ++j) {
+        double piv = readlane_d(a[j], j);
+        if (!(piv > 0.0)) {  // non-positive or NaN pivot: record the first one, continue with 1.0
+          if (lane == 0 && base_index + c0 + j < n_valid) atomicCAS(info, 0, (int)(base_index + c0 + j + 1));
+          piv = 1.0;
+        }
+        const double sq = sqrt(piv);
+        const double rs = 1.0 / sq;
+        rinv[j] = rs;
+        a[j] = (q == j) ? sq : a[j] * rs;
+#pragma unroll
+        for (int c = j + 1; c < LB; ++c) {
+          const double lc = readlane_d(a[j], c);
+          a[c] = fma(-a[j], lc, a[c]);
+        }
       }
-      S[j * LS + j] = sqrt(dj);
+      // inverse of the 16x16 factor: lane q owns column q
+#pragma unroll
+      for (int r = 0; r < LB; ++r) {
+        double sacc = (r == q) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < r; ++k) {
+          const double lrk = readlane_d(a[k], r);
+          sacc = fma(-lrk, x[k], sacc);
+        }
+        x[r] = sacc * rinv[r];
+      }
+      if (lane < LB) {
+#pragma unroll
+        for (int c = 0; c < LB; ++c) S[(c0 + q) * LS + c0 + c] = (c <= q) ? a[c] : 0.0;
+#pragma unroll
+        for (int r = 0; r < LB; ++r) T[p][r * TS17 + q] = x[r];
+      }
     }
     __syncthreads();
-    const double piv = S[j * LS + j];
-    if (t > j && t < NB) S[t * LS + j] = S[t * LS + j] / piv;
+    // (2) blocks below the diagonal: B <- B * T^T
+    for (int I = p + 1 + wave; I < 8; I += 4) {
+      double af[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) af[s4] = S[(LB * I + q) * LS + c0 + 4 * s4 + g];
+      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s4], T[p][q * TS17 + 4 * s4 + g], acc, 0, 0, 0);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) S[(LB * I + g + 4 * v) * LS + c0 + q] = acc[v];
+    }
     __syncthreads();
-    // trailing update: column c = j+1+(t&127), two threads per column interleave the rows
-    const int c = j + 1 + (t & 127);
-    if (c < NB) {
-      const double lcj = S[c * LS + j];
-      for (int i = c + (t >> 7); i < NB; i += 2) S[i * LS + c] = fma(-S[i * LS + j], lcj, S[i * LS + c]);
+    // (3) trailing blocks (I,K), p < K <= I: C -= B_I B_K^T
+    const int m = 7 - p;
+    for (int idx = wave; idx < m * (m + 1) / 2; idx += 4) {
+      int ii = 0;
+      while ((ii + 1) * (ii + 2) / 2 <= idx) ++ii;
+      const int kk = idx - ii * (ii + 1) / 2;
+      const int I = p + 1 + ii, K = p + 1 + kk;
+      d4 acc;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[v] = S[(LB * I + g + 4 * v) * LS + LB * K + q];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const double a = -S[(LB * I + q) * LS + c0 + 4 * s4 + g];
+        const double b = S[(LB * K + q) * LS + c0 + 4 * s4 + g];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) S[(LB * I + g + 4 * v) * LS + LB * K + q] = acc[v];
     }
     __syncthreads();
   }
   // write L back (zero the strict upper part of the diagonal block)
   for (int idx = t; idx < NB * NB; idx += 256) {
-    int i = idx >> 7, j = idx & 127;
+    const int i = idx >> 7, j = idx & 127;
     A[(int64_t)i * ld + j] = (j <= i) ? S[i * LS + j] : 0.0;
   }
-  // inverse: thread c owns column c of X = L^-1
-  if (t < NB) {
-    const int c = t;
-    S[c * LS + c + 1] = 1.0 / S[c * LS + c];
-  }
-  __syncthreads();
-  for (int i = 1; i < NB; ++i) {
-    if (t < i) {  // c = t < i
-      const int c = t;
-      double s = 0.0;
-      for (int k = c; k < i; ++k) s = fma(S[i * LS + k], S[c * LS + k + 1], s);
-      S[c * LS + i + 1] = -s / S[i * LS + i];
-    }
-    // column c only reads its own earlier entries and L: no barrier needed between rows
-  }
-  __syncthreads();
-  for (int idx = t; idx < NB * NB; idx += 256) {
-    int i = idx >> 7, c = idx & 127;
-    inv[idx] = (c <= i) ? S[c * LS + i + 1] : 0.0;
+  // inverse: wave w builds block columns w and 7-w (balanced: 140+4 / 108+12 / 80+24 / 56+40 MFMAs)
+  switch (wave) {
+    case 0: leaf_inverse_column<0>(S, T, inv, g, q); leaf_inverse_column<7>(S, T, inv, g, q); break;
+    case 1: leaf_inverse_column<1>(S, T, inv, g, q); leaf_inverse_column<6>(S, T, inv, g, q); break;
+    case 2: leaf_inverse_column<2>(S, T, inv, g, q); leaf_inverse_column<5>(S, T, inv, g, q); break;
+    default: leaf_inverse_column<3>(S, T, inv, g, q); leaf_inverse_column<4>(S, T, inv, g, q); break;
   }
 }
 

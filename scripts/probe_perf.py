@@ -1,7 +1,7 @@
 """Ad-hoc timing probe (not the bench): phases at a given N with per-class kernel timing."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gpexp_amd import device as dev
 
 def run(N, d, M, kind="matern52"):
