@@ -77,9 +77,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=32768)
-    ap.add_argument("--d", type=int, default=8)
-    ap.add_argument("--m", type=int, default=32768)
+    ap.add_argument("--train-points", dest="n", type=int, default=32768)
+    ap.add_argument("--dim", dest="d", type=int, default=8)
+    ap.add_argument("--mc-points", dest="m", type=int, default=32768)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -101,7 +101,7 @@ def main():
     Xh, yh, Zh, noise = workload(N, d, M, seed=N)
     spec = dev.KernelSpec(dev.K_MATERN52, d, [0.5, 1.0])
 
-    if world > 1:
+    if world > 1 or os.environ.get("GPX_FORCE_DIST") == "1":  # GPX_FORCE_DIST: rehearse the RCCL runner on one GPU
         from gpexp_amd import dist
         comm = dist.init_from_env(ctx)
         runner = dist.DistFitIvar(ctx, comm, spec, Xh, yh, Zh, noise)
@@ -129,13 +129,10 @@ def main():
             return v
 
     def sync():
+        # device-wide synchronisation of everything this process enqueued.  All work of the hot path is issued on the
+        # library's own HIP stream, so this is the equivalent of torch.cuda.synchronize(); torch itself is kept out
+        # of the process because a second HIP/HSA runtime next to the system RCCL breaks ncclCommInitRank.
         ctx.sync()
-        try:  # the contract's device-wide synchronize (covers the library's own HIP stream too)
-            import torch
-            if torch.cuda.is_available():
-                torch.cuda.synchronize()
-        except ImportError:
-            pass
 
     for _ in range(args.warmup):
         out = step()

@@ -47,6 +47,19 @@ _SIGS = {
                                        C.c_double, c_dp, c_ip]),
     "gpx_mi_greedy": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, C.c_double, c_i64, c_i64, c_ip, c_dp]),
     "gpx_lml_grad": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_dp, c_dp]),
+    "gpx_mat_read": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_dp]),
+    "gpx_mat_write": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_dp]),
+    "gpx_comm_unique_id": (C.c_int, [c_vp]),
+    "gpx_comm_init": (C.c_int, [c_vp, C.c_int, C.c_int, c_vp]),
+    "gpx_comm_destroy": (C.c_int, [c_vp]),
+    "gpx_comm_bcast": (C.c_int, [c_vp, c_vp, c_i64, C.c_int]),
+    "gpx_comm_allgather_host": (C.c_int, [c_vp, c_dp, c_i64, c_dp]),
+    "gpx_dist_kfill": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_dp, c_i64, c_vp, c_i64, C.c_int,
+                                 C.c_int]),
+    "gpx_dist_panel_elems": (c_i64, [c_i64, c_i64]),
+    "gpx_dist_panel_factor": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "gpx_dist_panel_apply": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, C.c_int, C.c_int]),
+    "gpx_dist_finish": (C.c_int, [c_vp, c_vp]),
     "gpx_profile_enable": (C.c_int, [c_vp, C.c_int]),
     "gpx_profile_reset": (C.c_int, [c_vp]),
     "gpx_profile_get": (C.c_int, [c_vp, C.c_int, c_ip, c_dp, c_dp, c_dp]),

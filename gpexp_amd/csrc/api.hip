@@ -171,6 +171,9 @@ int gpx_create(int device, gpx_ctx** out) {
   gpx_ctx* c = new gpx_ctx();
   c->device = device;
   c->pool_bytes = 0;
+  c->comm = nullptr;
+  c->rank = 0;
+  c->world = 1;
   c->prof_on = 0;
   for (int i = 0; i < GPX_PROF_NCLASS; ++i) {
     c->prof_launches[i] = 0;
@@ -199,6 +202,7 @@ int gpx_trim(gpx_ctx* ctx) {
 int gpx_destroy(gpx_ctx* ctx) {
   if (!ctx) return 0;
   (void)hipSetDevice(ctx->device);
+  gpx_comm_destroy(ctx);
   gpx_prof_flush(ctx);
   gpx_trim(ctx);
   for (auto ev : ctx->ev_free) (void)hipEventDestroy(ev);
@@ -281,6 +285,22 @@ int gpx_mat_to_host(gpx_ctx* ctx, const gpx_mat* m, double* dst, int tri) {
     for (int64_t i = 0; i < n; ++i)
       for (int64_t j = i + 1; j < n; ++j) dst[i * n + j] = dst[j * n + i];
   }
+  return 0;
+}
+
+int gpx_mat_read(gpx_ctx* ctx, const gpx_mat* m, int64_t offset, int64_t count, double* dst) {
+  GPX_ARG(ctx && m && dst && offset >= 0 && count >= 0 && (offset + count) * 8 <= m->bytes, "bad raw read");
+  if (count == 0) return 0;
+  GPX_HIP(hipMemcpyAsync(dst, m->p + offset, (size_t)count * 8, hipMemcpyDeviceToHost, ctx->stream));
+  GPX_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int gpx_mat_write(gpx_ctx* ctx, gpx_mat* m, int64_t offset, int64_t count, const double* src) {
+  GPX_ARG(ctx && m && src && offset >= 0 && count >= 0 && (offset + count) * 8 <= m->bytes, "bad raw write");
+  if (count == 0) return 0;
+  GPX_HIP(hipMemcpyAsync(m->p + offset, src, (size_t)count * 8, hipMemcpyHostToDevice, ctx->stream));
+  GPX_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
 }
 

@@ -288,6 +288,11 @@ int chol_potrf(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double* invd, int
   return potrf_rec(ctx, A, ld, n, invd, 0, n_valid);
 }
 
+int chol_potrf_nozero(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double* invd, int64_t base, int64_t n_valid) {
+  GPX_ARG(n > 0 && n % NB == 0, "potrf: padded order must be a positive multiple of 128");
+  return potrf_rec(ctx, A, ld, n, invd, base, n_valid);
+}
+
 int chol_trsv(gpx_ctx* ctx, const double* L, int64_t ld, const double* invd, double* y, int64_t n, bool transposed) {
   GPX_ARG(n % NB == 0, "trsv: padded length must be a multiple of 128");
   const int64_t nblk = n / NB;

@@ -78,6 +78,9 @@ struct gpx_ctx {
   // scalars
   int* d_info;      // first failing pivot (1-based), 0 = ok
   double* d_scal;   // small scalar workspace (>= 64 doubles)
+  // multi-GPU (RCCL communicator, opaque here; see dist.hip)
+  void* comm;
+  int rank, world;
   // profiling
   int prof_on;
   std::vector<ProfRec> prof_recs;
@@ -106,6 +109,10 @@ int gpx_prof_flush(gpx_ctx* ctx);
 int launch_kfill(gpx_ctx* ctx, const KParams& kp, const double* A, int64_t na, const double* B, int64_t nb,
                  int symmetric, const double* d_nugget, int64_t nugget_len, double nugget_scalar,
                  double* out, int64_t prows, int64_t pcols, int64_t ld);
+// symmetric sub-block K[off:, off:off+pcols] of the N x N covariance (rows/cols start at point index `off`)
+int launch_kfill_offset(gpx_ctx* ctx, const KParams& kp, const double* X, int64_t n, int64_t row_off, int64_t col_off,
+                        const double* d_nugget, int64_t nugget_len, double nugget_scalar, double* out, int64_t prows,
+                        int64_t pcols, int64_t ld);
 int launch_kdiag(gpx_ctx* ctx, const KParams& kp, const double* Z, int64_t m, double* out);
 
 // gemm_f64.hip:  C[m x n] = (accumulate ? C - A*op(B) : A*op(B)),  m,n multiples of 128, k multiple of 16
@@ -115,6 +122,8 @@ int launch_gemm(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int
 // chol.hip
 int launch_leaf(gpx_ctx* ctx, double* A, int64_t ld, double* inv, int64_t base_index, int64_t n_valid);
 int chol_potrf(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double* invd, int64_t n_valid);
+// same without resetting the pivot flag; `base` = global index of A's first row (for the reported pivot)
+int chol_potrf_nozero(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double* invd, int64_t base, int64_t n_valid);
 // X <- X * L^-T (right, lower, transposed): X is m x n (ld ldx), L n x n lower with leaf inverses invd
 int chol_trsm_right(gpx_ctx* ctx, const double* L, int64_t ldl, const double* invd, double* X, int64_t ldx,
                     int64_t m, int64_t n);

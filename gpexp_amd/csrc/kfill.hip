@@ -239,6 +239,20 @@ int launch_kfill(gpx_ctx* ctx, const KParams& kp, const double* A, int64_t na, c
   return -1;
 }
 
+int launch_kfill_offset(gpx_ctx* ctx, const KParams& kp, const double* X, int64_t n, int64_t row_off, int64_t col_off,
+                        const double* d_nugget, int64_t nugget_len, double nugget_scalar, double* out, int64_t prows,
+                        int64_t pcols, int64_t ld) {
+  GPX_ARG(row_off == col_off, "kfill_offset: the sub-block must start on the diagonal");
+  int64_t na = n - row_off;
+  if (na < 0) na = 0;
+  int64_t nbp = n - col_off;
+  if (nbp < 0) nbp = 0;
+  if (nbp > pcols) nbp = pcols;
+  const double* nug = (d_nugget && nugget_len > 1) ? d_nugget + row_off : d_nugget;
+  return launch_kfill(ctx, kp, X + row_off * kp.d, na, X + col_off * kp.d, nbp, 1, nug, nugget_len, nugget_scalar, out,
+                      prows, pcols, ld);
+}
+
 int launch_kdiag(gpx_ctx* ctx, const KParams& kp, const double* Z, int64_t m, double* out) {
   if (m <= 0) return 0;
   dim3 grid((unsigned)((m + 255) / 256));

@@ -1,0 +1,313 @@
+"""Multi-GPU GP fit and evaluation: one process per GPU, RCCL over xGMI.
+
+This replaces the reference's only parallel backend -- `parallelizeMcForLoop`, a fork + `mp.Queue` helper that
+slices the evaluation points row-wise over CPU processes (parallel_utilities.py:26-80, used at gp.py:258) -- by
+two shardings:
+
+  fit   the covariance matrix is distributed by block columns (width `nb`, owner = block index mod world).
+        Assembly is communication-free; the right-looking Cholesky broadcasts one factored panel per step
+        (`gpx_comm_bcast` -> ncclBroadcast) and every rank updates the block columns it owns.  Every rank also
+        KEEPS each received panel, so at the end each GPU holds the complete factor L.
+  eval  posterior / IVAR evaluation points are split in contiguous slices [r*M/W, (r+1)*M/W), exactly the
+        chunking the reference's helper intends (parallel_utilities.py:46-60); each rank solves against its own
+        copy of L and the only exchange is an all-gather of one partial sum per rank (summed in rank order, so
+        the result does not depend on arrival order).
+
+The panel loop lives here, in Python, on top of three C-ABI primitives (gpx_dist_panel_factor /
+gpx_comm_bcast / gpx_dist_panel_apply); per step that is a handful of ctypes calls against ~10^10 flops of GPU
+work.  The communicator is an object with `bcast_panel`, `allgather`, `barrier`, `max_float`:
+  RcclComm      device-to-device over RCCL (the product path; no torch in the process, see FileRendezvous);
+  HostStagedComm  device -> host -> torch.distributed(gloo) -> device, for the world_size>1 tests that share one
+                GPU (RCCL refuses two ranks on one device) -- test infrastructure, never used by bench.py.
+The index arithmetic (ownership, slices, panel sizes) is plain Python and is unit-tested on CPU with gloo.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import device as _dev
+from ._lib import check, dptr, as_f64, c_i64
+
+TILE = 128
+
+
+# ---- pure index logic (CPU-testable) ---------------------------------------------------------------------
+def padded(n):
+    return (max(n, 1) + TILE - 1) // TILE * TILE
+
+
+def num_blocks(n, nb):
+    return (padded(n) + nb - 1) // nb
+
+
+def owner(j, world):
+    """Rank that owns block column j."""
+    return j % world
+
+
+def owned_blocks(n, nb, rank, world):
+    return [j for j in range(num_blocks(n, nb)) if owner(j, world) == rank]
+
+
+def eval_slice(m, rank, world):
+    """Contiguous slice of the M evaluation points handled by `rank` (balanced to within one point)."""
+    base, rem = divmod(m, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def panel_elems(n, nb):
+    np_ = padded(n)
+    return np_ * nb + (nb // TILE) * TILE * TILE
+
+
+def ordered_sum(parts):
+    """Sum partial results in rank order (deterministic irrespective of arrival order)."""
+    s = 0.0
+    for p in parts:
+        s += float(p)
+    return s
+
+
+def merge_argmin(values, indices):
+    """First-minimum rule across ranks: lowest value, ties -> lowest global index (np.argmin semantics)."""
+    best = None
+    for v, i in zip(values, indices):
+        if best is None or v < best[0] or (v == best[0] and i < best[1]):
+            best = (float(v), int(i))
+    return best
+
+
+# ---- communicators -----------------------------------------------------------------------------------------
+class _TorchGroup:
+    """Thin wrapper over torch.distributed (gloo, CPU tensors) for rendezvous-level exchanges."""
+
+    def __init__(self):
+        import torch
+        import torch.distributed as td
+        self.torch = torch
+        self.td = td
+        if not td.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            td.init_process_group(backend="gloo")
+        self.rank = td.get_rank()
+        self.world = td.get_world_size()
+
+    def bcast_bytes(self, b, root=0):
+        t = self.torch.zeros(len(b), dtype=self.torch.uint8)
+        if self.rank == root:
+            t = self.torch.tensor(list(b), dtype=self.torch.uint8)
+        self.td.broadcast(t, src=root)
+        return bytes(t.tolist())
+
+    def bcast_array(self, a, root):
+        t = self.torch.from_numpy(a)
+        self.td.broadcast(t, src=root)
+        return a
+
+    def allgather(self, vec):
+        vec = np.ascontiguousarray(vec, dtype=np.float64)
+        outs = [self.torch.zeros(vec.size, dtype=self.torch.float64) for _ in range(self.world)]
+        self.td.all_gather(outs, self.torch.from_numpy(vec.copy()))
+        return np.stack([o.numpy() for o in outs])
+
+    def barrier(self):
+        self.td.barrier()
+
+    def max_float(self, v):
+        t = self.torch.tensor([float(v)], dtype=self.torch.float64)
+        self.td.all_reduce(t, op=self.td.ReduceOp.MAX)
+        return float(t[0])
+
+
+class FileRendezvous:
+    """Single-node exchange of the 128-byte ncclUniqueId without any framework in the process: rank 0 writes it
+    atomically to a file keyed by the launcher's (MASTER_PORT, run id, launcher pid); the others poll for it.
+    (Importing torch next to the system RCCL loads a second, uninitialised HSA runtime into the process and
+    ncclCommInitRank then fails with "no ROCm-capable device", so the RCCL path stays torch-free.)"""
+
+    def __init__(self):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        key = "%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
+                            os.getppid())
+        self.path = os.path.join(os.environ.get("GPX_RDV_DIR", "/tmp"), "gpx_rdv_" + key)
+
+    def exchange(self, payload):
+        import time
+        if self.rank == 0:
+            tmp = self.path + ".tmp"
+            with open(tmp, "wb") as f:
+                f.write(payload)
+            os.replace(tmp, self.path)
+            return payload
+        t0 = time.time()
+        while not os.path.exists(self.path):
+            if time.time() - t0 > 300:
+                raise RuntimeError("rendezvous file %s did not appear" % self.path)
+            time.sleep(0.01)
+        with open(self.path, "rb") as f:
+            return f.read()
+
+    def cleanup(self):
+        if self.rank == 0:
+            try:
+                os.remove(self.path)
+            except OSError:
+                pass
+
+
+class RcclComm:
+    """Device-side collectives over RCCL; barriers and the timing max are RCCL all-gathers of one double."""
+
+    def __init__(self, ctx, rendezvous=None):
+        self.ctx = ctx
+        rdv = rendezvous or FileRendezvous()
+        self.rank, self.world = rdv.rank, rdv.world
+        uid = C.create_string_buffer(128)
+        if self.rank == 0:
+            check(ctx.lib.gpx_comm_unique_id(uid))
+        raw = rdv.exchange(uid.raw)
+        check(ctx.lib.gpx_comm_init(ctx.h, self.rank, self.world, C.create_string_buffer(raw, 128)))
+        self.barrier()
+        rdv.cleanup()
+
+    def bcast_panel(self, P, count, root):
+        check(self.ctx.lib.gpx_comm_bcast(self.ctx.h, P.h, int(count), int(root)))
+
+    def allgather(self, vec):
+        vec = as_f64(np.atleast_1d(vec))
+        out = np.empty((self.world, vec.size))
+        check(self.ctx.lib.gpx_comm_allgather_host(self.ctx.h, dptr(vec), vec.size, dptr(out)))
+        return out
+
+    def barrier(self):
+        self.ctx.sync()
+        self.allgather(np.array([0.0]))
+
+    def max_float(self, v):
+        return float(np.max(self.allgather(np.array([float(v)]))))
+
+    def close(self):
+        self.ctx.lib.gpx_comm_destroy(self.ctx.h)
+
+
+class HostStagedComm:
+    """Test-only communicator: panels bounce through host memory and gloo (several ranks may share one GPU)."""
+
+    def __init__(self, ctx, group=None):
+        self.ctx = ctx
+        self.group = group or _TorchGroup()
+        self.rank, self.world = self.group.rank, self.group.world
+
+    def bcast_panel(self, P, count, root):
+        buf = np.empty(int(count))
+        if self.rank == root:
+            check(self.ctx.lib.gpx_mat_read(self.ctx.h, P.h, 0, int(count), dptr(buf)))
+        self.group.bcast_array(buf, root)
+        if self.rank != root:
+            check(self.ctx.lib.gpx_mat_write(self.ctx.h, P.h, 0, int(count), dptr(buf)))
+
+    def allgather(self, vec):
+        return self.group.allgather(np.atleast_1d(vec))
+
+    def barrier(self):
+        self.ctx.sync()
+        self.group.barrier()
+
+    def max_float(self, v):
+        return self.group.max_float(v)
+
+    def close(self):
+        pass
+
+
+def init_from_env(ctx):
+    """Communicator for the process group the launcher created (RANK / WORLD_SIZE / MASTER_* in the environment)."""
+    kind = os.environ.get("GPX_COMM", "rccl")
+    return HostStagedComm(ctx) if kind == "host" else RcclComm(ctx)
+
+
+# ---- distributed operations -----------------------------------------------------------------------------------
+class DeviceOps:
+    """The device primitives the panel loop needs (the tests substitute a NumPy double for CPU runs)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def alloc_matrix(self, n):
+        return _dev.DeviceMatrix.zeros(self.ctx, n, n)
+
+    def alloc_panel(self, n, nb):
+        return _dev.DeviceMatrix.zeros(self.ctx, panel_elems(n, nb), 1, pad=False)
+
+    def kfill_owned(self, spec, X, K, nugget, nb, rank, world):
+        n = X.shape[0]
+        nug, nlen = _dev._nugget_args(nugget, n)
+        check(self.ctx.lib.gpx_dist_kfill(self.ctx.h, *spec.args(), X.h, dptr(nug), nlen, K.h, int(nb), int(rank),
+                                          int(world)))
+
+    def panel_factor(self, K, k, nb, P):
+        return self.ctx.lib.gpx_dist_panel_factor(self.ctx.h, K.h, int(k), int(nb), P.h)
+
+    def panel_apply(self, K, k, nb, P, rank, world):
+        check(self.ctx.lib.gpx_dist_panel_apply(self.ctx.h, K.h, int(k), int(nb), P.h, int(rank), int(world)))
+
+    def finish(self, K):
+        check(self.ctx.lib.gpx_dist_finish(self.ctx.h, K.h))
+
+
+def dist_potrf(ops, comm, K, n, nb, P):
+    """Right-looking block-column Cholesky of the distributed matrix K (in place); every rank ends with all of L.
+    Returns 0, or the 1-based index of the first non-positive pivot (agreed on by all ranks)."""
+    np_ = padded(n)
+    info = 0
+    for k in range(num_blocks(n, nb)):
+        root = owner(k, comm.world)
+        rows = np_ - k * nb
+        if comm.rank == root:
+            rc = ops.panel_factor(K, k, nb, P)
+            if rc < 0:
+                check(rc)
+            if rc > 0 and info == 0:
+                info = rc
+        comm.bcast_panel(P, rows * nb + (nb // TILE) * TILE * TILE, root)
+        ops.panel_apply(K, k, nb, P, comm.rank, comm.world)
+    ops.finish(K)
+    allinfo = comm.allgather(np.array([float(info)]))[:, 0]
+    bad = [int(v) for v in allinfo if v > 0]
+    return min(bad) if bad else 0
+
+
+class DistFitIvar:
+    """bench.py's multi-GPU step: distributed fit (kfill + potrf), alpha/logdet/log-likelihood, sharded IVAR."""
+
+    def __init__(self, ctx, comm, spec, Xh, yh, Zh, noise, nb=512, ops=None):
+        self.ctx, self.comm, self.spec = ctx, comm, spec
+        self.ops = ops or DeviceOps(ctx)
+        self.n, self.noise, self.nb = Xh.shape[0], float(noise), int(nb)
+        self.yh = np.ascontiguousarray(yh, dtype=np.float64)
+        self.m = Zh.shape[0]
+        self.X = _dev.points(ctx, Xh)
+        lo, hi = eval_slice(self.m, comm.rank, comm.world)
+        self.Zloc = _dev.points(ctx, Zh[lo:hi]) if hi > lo else None
+        self.K = self.ops.alloc_matrix(self.n)
+        self.P = self.ops.alloc_panel(self.n, self.nb)
+
+    def step(self):
+        ctx, comm = self.ctx, self.comm
+        self.ops.kfill_owned(self.spec, self.X, self.K, self.noise, self.nb, comm.rank, comm.world)
+        info = dist_potrf(self.ops, comm, self.K, self.n, self.nb, self.P)
+        if info:
+            from ._lib import NotPositiveDefinite
+            raise NotPositiveDefinite(info)
+        alpha = _dev.potrs(ctx, self.K, self.yh)          # every rank holds L: no exchange
+        logdet = _dev.logdet(ctx, self.K)
+        ll = -0.5 * float(self.yh @ alpha) - 0.5 * logdet - self.n / 2.0 * np.log(2 * np.pi)
+        part = 0.0
+        if self.Zloc is not None:
+            _, var = _dev.posterior(ctx, self.spec, self.K, self.X, None, self.Zloc, want_mean=False)
+            part = float(np.sum(var))
+        iv = abs(ordered_sum(comm.allgather(np.array([part]))[:, 0]) / self.m)
+        return ll, iv

@@ -74,6 +74,10 @@ int gpx_mat_shape(const gpx_mat* m, int64_t* rows, int64_t* cols, int64_t* ld);
  * Backs the lazy GP.covarianceMatrix / GP.precisionMatrix attributes (gp.py:178-181). */
 int gpx_mat_to_host(gpx_ctx* ctx, const gpx_mat* m, double* dst, int tri);
 
+/* raw access to the padded storage (element offsets); used by the host-staged communicator in tests */
+int gpx_mat_read(gpx_ctx* ctx, const gpx_mat* m, int64_t offset, int64_t count, double* dst);
+int gpx_mat_write(gpx_ctx* ctx, gpx_mat* m, int64_t offset, int64_t count, const double* src);
+
 /* ---- L0/L1: covariance assembly -------------------------------------------------------------- */
 /* K[i][j] = k(X_i, X_j) + nugget_i*delta_ij  (Z == NULL; N x N)      gp_kernel_utilities.py:34-68
  * K[i][j] = k(X_i, Z_j)                      (Z != NULL; N x M)      gp.py:132-135, 246-249;
@@ -143,6 +147,30 @@ int gpx_mi_greedy(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, co
  * Squared-exponential kernel only (gp.py:444-466 + kernels.py:125-144; the reference raises for the others). */
 int gpx_lml_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
                  const double* alpha, double* grad);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ------------------------------------------------
+ * Replaces the reference's only parallel backend, the fork + mp.Queue row-sharding helper
+ * (parallel_utilities.py:26-80; used at gp.py:258).  The covariance matrix is distributed by block columns
+ * (width nb, owner = block index mod world); see gpexp_amd/dist.py for the panel loop that drives these. */
+/* rank 0 creates the 128-byte id, the launcher's rendezvous distributes it, every rank calls gpx_comm_init */
+int gpx_comm_unique_id(void* out128);
+int gpx_comm_init(gpx_ctx* ctx, int rank, int world, const void* id128);
+int gpx_comm_destroy(gpx_ctx* ctx);
+/* broadcast the first `count` doubles of buf from root (asynchronous on the context's stream) */
+int gpx_comm_bcast(gpx_ctx* ctx, gpx_mat* buf, int64_t count, int root);
+/* out[world*n] = concatenation in rank order of every rank's in[n] (blocking; scalars such as IVAR partial sums) */
+int gpx_comm_allgather_host(gpx_ctx* ctx, const double* in, int64_t n, double* out);
+/* assemble only the block columns owned by `rank` (rows on/below the diagonal block) */
+int gpx_dist_kfill(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* X,
+                   const double* nugget, int64_t nugget_len, gpx_mat* K, int64_t nb, int rank, int world);
+/* doubles in the packed panel buffer: padded_rows*nb panel + the inverted 128x128 diagonal leaves */
+int64_t gpx_dist_panel_elems(int64_t padded_rows, int64_t nb);
+/* owner of block column k: pack the panel into P, factor it there; >0 = non-positive pivot */
+int gpx_dist_panel_factor(gpx_ctx* ctx, gpx_mat* K, int64_t k, int64_t nb, gpx_mat* P);
+/* every rank, after P has been broadcast: store the panel, update the owned block columns j > k */
+int gpx_dist_panel_apply(gpx_ctx* ctx, gpx_mat* K, int64_t k, int64_t nb, const gpx_mat* P, int rank, int world);
+/* mark K as a complete factor (every rank now holds all of L) */
+int gpx_dist_finish(gpx_ctx* ctx, gpx_mat* K);
 
 /* ---- measurement ------------------------------------------------------------------------------- */
 /* when enabled every kernel launch of a class is bracketed by HIP events on the launch stream */
