@@ -138,7 +138,8 @@ int gpx_mat_new(gpx_ctx* ctx, int64_t rows, int64_t cols, int pad, gpx_mat** out
   m->cols = cols;
   m->prows = pad ? gpx_round_up(rows > 0 ? rows : 1, GPX_TILE) : (rows > 0 ? rows : 1);
   m->pcols = pad ? gpx_round_up(cols > 0 ? cols : 1, GPX_TILE) : (cols > 0 ? cols : 1);
-  m->bytes = m->prows * m->pcols * (int64_t)sizeof(double);
+  m->ld = pad ? gpx_skew_ld(m->pcols) : m->pcols;
+  m->bytes = m->prows * m->ld * (int64_t)sizeof(double);
   m->aux = nullptr;
   m->aux_bytes = 0;
   m->factored = 0;
@@ -186,6 +187,8 @@ int gpx_create(int device, gpx_ctx** out) {
   GPX_HIP(hipMalloc((void**)&c->d_info, 256));
   GPX_HIP(hipMalloc((void**)&c->d_scal, 64 * sizeof(double)));
   GPX_HIP(hipMemset(c->d_info, 0, 256));
+  GPX_HIP(hipMalloc((void**)&c->d_counters, GPX_COUNTER_SLOTS * 8 * sizeof(int)));
+  c->counter_slot = 0;
   *out = c;
   return 0;
 }
@@ -208,6 +211,7 @@ int gpx_destroy(gpx_ctx* ctx) {
   for (auto ev : ctx->ev_free) (void)hipEventDestroy(ev);
   (void)hipFree(ctx->d_info);
   (void)hipFree(ctx->d_scal);
+  (void)hipFree(ctx->d_counters);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return 0;
@@ -244,7 +248,7 @@ int gpx_mat_from_host(gpx_ctx* ctx, const double* src, int64_t rows, int64_t col
   GPX_TRY(gpx_mat_alloc(ctx, rows, cols, pad, out));
   gpx_mat* m = *out;
   if (rows > 0 && cols > 0)
-    GPX_HIP(hipMemcpy2DAsync(m->p, (size_t)m->pcols * 8, src, (size_t)cols * 8, (size_t)cols * 8, (size_t)rows,
+    GPX_HIP(hipMemcpy2DAsync(m->p, (size_t)m->ld * 8, src, (size_t)cols * 8, (size_t)cols * 8, (size_t)rows,
                              hipMemcpyHostToDevice, ctx->stream));
   GPX_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
@@ -265,7 +269,7 @@ int gpx_mat_shape(const gpx_mat* m, int64_t* rows, int64_t* cols, int64_t* ld) {
   GPX_ARG(m != nullptr, "matrix is NULL");
   if (rows) *rows = m->rows;
   if (cols) *cols = m->cols;
-  if (ld) *ld = m->pcols;
+  if (ld) *ld = m->ld;
   return 0;
 }
 
@@ -274,7 +278,7 @@ int gpx_mat_to_host(gpx_ctx* ctx, const gpx_mat* m, double* dst, int tri) {
   GPX_ARG(tri >= 0 && tri <= 2, "tri must be 0, 1 or 2");
   GPX_ARG(tri == 0 || m->rows == m->cols, "triangular extraction needs a square matrix");
   if (m->rows == 0 || m->cols == 0) return 0;
-  GPX_HIP(hipMemcpy2DAsync(dst, (size_t)m->cols * 8, m->p, (size_t)m->pcols * 8, (size_t)m->cols * 8,
+  GPX_HIP(hipMemcpy2DAsync(dst, (size_t)m->cols * 8, m->p, (size_t)m->ld * 8, (size_t)m->cols * 8,
                            (size_t)m->rows, hipMemcpyDeviceToHost, ctx->stream));
   GPX_HIP(hipStreamSynchronize(ctx->stream));
   const int64_t n = m->rows;
@@ -331,7 +335,7 @@ int gpx_kfill_into(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, c
     GPX_HIP(hipMemcpyAsync(d_nug, nugget, (size_t)nug_bytes, hipMemcpyHostToDevice, ctx->stream));
   }
   int r = launch_kfill(ctx, kp, X->p, X->rows, Bp->p, Bp->rows, symmetric, d_nug, nugget_len, nscal, K->p,
-                       K->prows, K->pcols, K->pcols);
+                       K->prows, K->pcols, K->ld);
   if (d_nug) {
     (void)hipStreamSynchronize(ctx->stream);
     gpx_dev_release(ctx, d_nug, nug_bytes);
@@ -382,7 +386,7 @@ int gpx_potrf(gpx_ctx* ctx, gpx_mat* K) {
     GPX_TRY(gpx_dev_alloc(ctx, K->aux_bytes, &p));
     K->aux = (double*)p;
   }
-  GPX_TRY(chol_potrf(ctx, K->p, K->pcols, K->prows, K->aux, K->rows));
+  GPX_TRY(chol_potrf(ctx, K->p, K->ld, K->prows, K->aux, K->rows));
   int info = 0;
   GPX_HIP(hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   GPX_HIP(hipStreamSynchronize(ctx->stream));
@@ -408,8 +412,8 @@ int gpx_potrs(gpx_ctx* ctx, const gpx_mat* L, const double* y, double* alpha) {
   do {
     if (hipMemsetAsync(dv, 0, (size_t)np * 8, ctx->stream) != hipSuccess) { r = -2; break; }
     if (hipMemcpyAsync(dv, y, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { r = -2; break; }
-    if ((r = chol_trsv(ctx, L->p, L->pcols, L->aux, dv, np, false)) != 0) break;
-    if ((r = chol_trsv(ctx, L->p, L->pcols, L->aux, dv, np, true)) != 0) break;
+    if ((r = chol_trsv(ctx, L->p, L->ld, L->aux, dv, np, false)) != 0) break;
+    if ((r = chol_trsv(ctx, L->p, L->ld, L->aux, dv, np, true)) != 0) break;
     if (hipMemcpyAsync(alpha, dv, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { r = -2; break; }
   } while (0);
   (void)hipStreamSynchronize(ctx->stream);
@@ -421,7 +425,7 @@ int gpx_potrs(gpx_ctx* ctx, const gpx_mat* L, const double* y, double* alpha) {
 int gpx_logdet(gpx_ctx* ctx, const gpx_mat* L, double* out) {
   GPX_ARG(ctx && out, "NULL argument");
   GPX_TRY(need_factor(L));
-  GPX_TRY(launch_logdet(ctx, L->p, L->pcols, L->rows, ctx->d_scal));
+  GPX_TRY(launch_logdet(ctx, L->p, L->ld, L->rows, ctx->d_scal));
   GPX_HIP(hipMemcpyAsync(out, ctx->d_scal, 8, hipMemcpyDeviceToHost, ctx->stream));
   GPX_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
@@ -448,7 +452,8 @@ static int posterior_impl(gpx_ctx* ctx, const KParams& kp, const gpx_mat* L, con
   const int64_t mcmax = eval_chunk(np);
   const int64_t mc_alloc = gpx_round_up(M < mcmax ? M : mcmax, GPX_TILE);
   void *pB = nullptr, *pal = nullptr, *pout = nullptr, *ppart = nullptr, *pkd = nullptr;
-  const int64_t bytesB = np * mc_alloc * 8, bytes_out = mc_alloc * 8;
+  const int64_t ldb_alloc = gpx_skew_ld(mc_alloc);
+  const int64_t bytesB = np * ldb_alloc * 8, bytes_out = mc_alloc * 8;
   const int64_t bytes_part = colreduce_partial_elems(np, mc_alloc) * 8 + 8;
   int r = 0;
   std::vector<double> hbuf((size_t)mc_alloc), hk((size_t)mc_alloc);
@@ -470,17 +475,18 @@ static int posterior_impl(gpx_ctx* ctx, const KParams& kp, const gpx_mat* L, con
       const int64_t mcp = gpx_round_up(mc, GPX_TILE);
       double* B = (double*)pB;
       const double* Zc = Z->p + j0 * d;
-      if ((r = launch_kfill(ctx, kp, X->p, n, Zc, mc, 0, nullptr, 0, 0.0, B, np, mcp, mcp)) != 0) break;
+      const int64_t ldb = gpx_skew_ld(mcp);
+      if ((r = launch_kfill(ctx, kp, X->p, n, Zc, mc, 0, nullptr, 0, 0.0, B, np, mcp, ldb)) != 0) break;
       if (mean) {
-        if ((r = launch_colreduce(ctx, B, mcp, n, mcp, (const double*)pal, (double*)pout, (double*)ppart)) != 0) break;
+        if ((r = launch_colreduce(ctx, B, ldb, n, mcp, (const double*)pal, (double*)pout, (double*)ppart)) != 0) break;
         if (hipMemcpyAsync(mean + j0, pout, (size_t)mc * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) {
           r = -2;
           break;
         }
       }
       if (var) {
-        if ((r = chol_trsm_left(ctx, L->p, L->pcols, L->aux, B, mcp, np, mcp)) != 0) break;
-        if ((r = launch_colreduce(ctx, B, mcp, n, mcp, nullptr, (double*)pout, (double*)ppart)) != 0) break;
+        if ((r = chol_trsm_left(ctx, L->p, L->ld, L->aux, B, ldb, np, mcp)) != 0) break;
+        if ((r = launch_colreduce(ctx, B, ldb, n, mcp, nullptr, (double*)pout, (double*)ppart)) != 0) break;
         if ((r = launch_kdiag(ctx, kp, Zc, mc, (double*)pkd)) != 0) break;
         if (hipMemcpyAsync(hbuf.data(), pout, (size_t)mc * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipMemcpyAsync(hk.data(), pkd, (size_t)mc * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
@@ -570,7 +576,7 @@ int gpx_dbg_gemm(gpx_ctx* ctx, const gpx_mat* A, const gpx_mat* B, gpx_mat* C, i
   const int64_t m = C->prows, n = C->pcols, k = A->pcols;
   GPX_ARG(A->prows == m, "A rows");
   GPX_ARG(bt ? (B->prows == n && B->pcols == k) : (B->prows == k && B->pcols == n), "B shape");
-  GPX_TRY(launch_gemm(ctx, A->p, A->pcols, B->p, B->pcols, C->p, C->pcols, m, n, k, bt != 0, accumulate != 0,
+  GPX_TRY(launch_gemm(ctx, A->p, A->ld, B->p, B->ld, C->p, C->ld, m, n, k, bt != 0, accumulate != 0,
                       lower != 0));
   GPX_HIP(hipStreamSynchronize(ctx->stream));
   return 0;

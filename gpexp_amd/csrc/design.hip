@@ -237,7 +237,7 @@ int gpx_posterior_cov(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp
   GPX_TRY(sc.get(np * mp * 8, &pWt));
   GPX_TRY(sc.get(mp * mp * 8, &pK));
   GPX_TRY(launch_kfill(ctx, kp, X->p, n, Z->p, m, 0, nullptr, 0, 0.0, (double*)pW, np, mp, mp));
-  GPX_TRY(chol_trsm_left(ctx, L->p, L->pcols, L->aux, (double*)pW, mp, np, mp));
+  GPX_TRY(chol_trsm_left(ctx, L->p, L->ld, L->aux, (double*)pW, mp, np, mp));
   GPX_TRY(launch_transpose(ctx, (double*)pW, np, mp, mp, (double*)pWt, np));
   GPX_TRY(launch_kfill(ctx, kp, Z->p, m, Z->p, m, 1, nullptr, 0, 0.0, (double*)pK, mp, mp, mp));
   GPX_TRY(launch_gemm(ctx, (double*)pWt, np, (double*)pWt, np, (double*)pK, mp, mp, mp, np, true, true, false));
@@ -262,10 +262,10 @@ int gpx_potri(gpx_ctx* ctx, const gpx_mat* L, gpx_mat** outP) {
     if (hipMemsetAsync(pI, 0, (size_t)(np * np * 8), ctx->stream) != hipSuccess) { r = -2; break; }
     hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream,
                        (double*)pI, np, np);
-    if ((r = chol_trsm_left(ctx, L->p, L->pcols, L->aux, (double*)pI, np, np, np)) != 0) break;  // L^-1
+    if ((r = chol_trsm_left(ctx, L->p, L->ld, L->aux, (double*)pI, np, np, np)) != 0) break;  // L^-1
     if ((r = launch_transpose(ctx, (double*)pI, np, np, np, (double*)pT, np)) != 0) break;       // L^-T
     // K^-1 = L^-T L^-1 = T T^T
-    if ((r = launch_gemm(ctx, (double*)pT, np, (double*)pT, np, P->p, np, np, np, np, true, false, false)) != 0) break;
+    if ((r = launch_gemm(ctx, (double*)pT, np, (double*)pT, np, P->p, P->ld, np, np, np, true, false, false)) != 0) break;
   } while (0);
   if (r != 0) {
     gpx_mat_free(ctx, P);
@@ -371,7 +371,7 @@ int gpx_greedy_ivar_step(gpx_ctx* ctx, int kind, int d, const double* hyp, int n
 
   // ---- integration points: W_Z = L^-1 K(X,Z), var_z, S0 ----
   GPX_TRY(launch_kfill(ctx, kp, X->p, n, Z->p, nmc, 0, nullptr, 0, 0.0, (double*)pWz, np, zp, zp));
-  GPX_TRY(chol_trsm_left(ctx, L->p, L->pcols, L->aux, (double*)pWz, zp, np, zp));
+  GPX_TRY(chol_trsm_left(ctx, L->p, L->ld, L->aux, (double*)pWz, zp, np, zp));
   GPX_TRY(launch_colreduce(ctx, (double*)pWz, zp, n, zp, nullptr, (double*)pss, (double*)ppart));
   GPX_TRY(launch_kdiag(ctx, kp, Z->p, nmc, (double*)pkd));
   std::vector<double> hs((size_t)nmc), hk((size_t)nmc);
@@ -389,7 +389,7 @@ int gpx_greedy_ivar_step(gpx_ctx* ctx, int kind, int d, const double* hyp, int n
     const int64_t mcp = gpx_round_up(mc, GPX_TILE);
     const double* Cc = Cm->p + j0 * d;
     GPX_TRY(launch_kfill(ctx, kp, X->p, n, Cc, mc, 0, nullptr, 0, 0.0, (double*)pWc, np, mcp, mcp));
-    GPX_TRY(chol_trsm_left(ctx, L->p, L->pcols, L->aux, (double*)pWc, mcp, np, mcp));
+    GPX_TRY(chol_trsm_left(ctx, L->p, L->ld, L->aux, (double*)pWc, mcp, np, mcp));
     GPX_TRY(launch_colreduce(ctx, (double*)pWc, mcp, n, mcp, nullptr, (double*)pss, (double*)ppart));
     GPX_TRY(launch_kdiag(ctx, kp, Cc, mc, (double*)pkd));
     // G = K(Z,C) - W_Z^T W_C

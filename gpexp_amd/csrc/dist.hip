@@ -190,8 +190,8 @@ int gpx_dist_kfill(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, c
     const int64_t c0 = j * nb;
     const int64_t cw = (np - c0) < nb ? (np - c0) : nb;
     // rows >= c0 only (lower block column): K[c0:, c0:c0+cw]
-    r = launch_kfill_offset(ctx, kp, X->p, n, c0, c0, d_nug, nugget_len, nscal, K->p + c0 * K->pcols + c0, np - c0, cw,
-                            K->pcols);
+    r = launch_kfill_offset(ctx, kp, X->p, n, c0, c0, d_nug, nugget_len, nscal, K->p + c0 * K->ld + c0, np - c0, cw,
+                            K->ld);
   }
   if (d_nug) {
     (void)hipStreamSynchronize(ctx->stream);
@@ -213,7 +213,7 @@ int gpx_dist_panel_factor(gpx_ctx* ctx, gpx_mat* K, int64_t k, int64_t nb, gpx_m
   GPX_ARG(P->bytes >= gpx_dist_panel_elems(np, nb) * 8, "panel buffer too small");
   double* pb = P->p;
   double* pinv = P->p + rows * nb;  // leaf inverses of this panel
-  GPX_TRY(copy2d(ctx, K->p + r0 * K->pcols + r0, K->pcols, pb, nb, rows, w));
+  GPX_TRY(copy2d(ctx, K->p + r0 * K->ld + r0, K->ld, pb, nb, rows, w));
   GPX_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
   GPX_TRY(chol_potrf_nozero(ctx, pb, nb, w, pinv, r0, K->rows));
   if (rows > w) GPX_TRY(chol_trsm_right(ctx, pb, nb, pinv, pb + w * nb, nb, rows - w, w));
@@ -238,7 +238,7 @@ int gpx_dist_panel_apply(gpx_ctx* ctx, gpx_mat* K, int64_t k, int64_t nb, const 
   }
   const double* pb = P->p;
   const double* pinv = P->p + rows * nb;
-  GPX_TRY(copy2d(ctx, pb, nb, K->p + r0 * K->pcols + r0, K->pcols, rows, w));
+  GPX_TRY(copy2d(ctx, pb, nb, K->p + r0 * K->ld + r0, K->ld, rows, w));
   GPX_HIP(hipMemcpyAsync(K->aux + (r0 / GPX_TILE) * GPX_TILE * GPX_TILE, pinv,
                          (size_t)((w / GPX_TILE) * GPX_TILE * GPX_TILE * 8), hipMemcpyDeviceToDevice, ctx->stream));
   const int64_t nblk = (np + nb - 1) / nb;
@@ -247,7 +247,7 @@ int gpx_dist_panel_apply(gpx_ctx* ctx, gpx_mat* K, int64_t k, int64_t nb, const 
     const int64_t c0 = j * nb;
     const int64_t cw = (np - c0) < nb ? (np - c0) : nb;
     // C[c0:, c0:c0+cw] -= P[c0-r0:, :] * P[c0-r0 : c0-r0+cw, :]^T
-    GPX_TRY(launch_gemm(ctx, pb + (c0 - r0) * nb, nb, pb + (c0 - r0) * nb, nb, K->p + c0 * K->pcols + c0, K->pcols,
+    GPX_TRY(launch_gemm(ctx, pb + (c0 - r0) * nb, nb, pb + (c0 - r0) * nb, nb, K->p + c0 * K->ld + c0, K->ld,
                         np - c0, cw, w, true, true, false));
   }
   return 0;

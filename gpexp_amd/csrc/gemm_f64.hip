@@ -45,16 +45,11 @@ struct Stage {  // one k-step of one thread's global->LDS staging traffic: 4 x 1
   double2 a0, a1, a2, a3, b0, b1, b2, b3;
 };
 
-template <bool BT, bool ACC, bool LOWER, int PF>
-__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64_t lda, const double* B, int64_t ldb,
-                                                          double* C, int64_t ldc, int nk, int tiles_m, int tiles_n,
-                                                          int sb_cols, int sb_shift) {
-  // ---- workgroup id -> (tile row, tile col) through XCD-resident super-blocks ----
-  const int w = blockIdx.x;
-  const int xcd = w & 7, q = w >> 3;
-  // super-block edge 2^sb_shift tiles (8 for large grids, smaller when there are too few tiles to feed 8 XCDs)
-  const int sbs2 = 2 * sb_shift, sbm = (1 << sb_shift) - 1;
-  const int sblk = (q >> sbs2) * 8 + xcd, within = q & ((1 << sbs2) - 1);
+// decode a super-block index + position inside it into tile coordinates; false = nothing to do for this slot
+template <bool LOWER>
+__device__ __forceinline__ bool tile_of(int sblk, int within, int tiles_m, int tiles_n, int sb_cols, int sb_shift,
+                                        int* by, int* bx) {
+  const int sbm = (1 << sb_shift) - 1;
   int sr, sc;
   if (LOWER) {  // sblk-th super-block of the lower triangle, row-major: sr(sr+1)/2 <= sblk
     sr = (int)((sqrtf(8.0f * (float)sblk + 1.0f) - 1.0f) * 0.5f);
@@ -65,11 +60,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64
     sr = sblk / sb_cols;
     sc = sblk - sr * sb_cols;
   }
-  const int by = (sr << sb_shift) + (within >> sb_shift), bx = (sc << sb_shift) + (within & sbm);
-  if (by >= tiles_m || bx >= tiles_n) return;
-  if (LOWER && bx > by) return;  // tile strictly above the diagonal
+  *by = (sr << sb_shift) + (within >> sb_shift);
+  *bx = (sc << sb_shift) + (within & sbm);
+  if (*by >= tiles_m || *bx >= tiles_n) return false;
+  if (LOWER && *bx > *by) return false;  // tile strictly above the diagonal
+  return true;
+}
 
-  __shared__ Smem<BT> sm;
+template <bool BT, bool ACC, int PF>
+__device__ __forceinline__ void gemm_tile(Smem<BT>& sm, const double* A, int64_t lda, const double* B, int64_t ldb,
+                                          double* C, int64_t ldc, int nk, int by, int bx) {
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -232,6 +232,54 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64
     }
 }
 
+
+// one workgroup per tile; ids congruent mod 8 are assumed to share an XCD (true for the first wave of workgroups)
+template <bool BT, bool ACC, bool LOWER, int PF>
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64_t lda, const double* B, int64_t ldb,
+                                                          double* C, int64_t ldc, int nk, int tiles_m, int tiles_n,
+                                                          int sb_cols, int sb_shift) {
+  __shared__ Smem<BT> sm;
+  const int w = blockIdx.x;
+  const int xcd = w & 7, q = w >> 3;
+  const int sbs2 = 2 * sb_shift;
+  int by, bx;
+  if (!tile_of<LOWER>((q >> sbs2) * 8 + xcd, q & ((1 << sbs2) - 1), tiles_m, tiles_n, sb_cols, sb_shift, &by, &bx))
+    return;
+  gemm_tile<BT, ACC, PF>(sm, A, lda, B, ldb, C, ldc, nk, by, bx);
+}
+
+// Persistent variant for large grids: 2 workgroups per CU stay resident; each reads the XCD it really runs on
+// (HW_REG_XCC_ID) and pulls (super-block, tile) slots of THAT XCD from a per-XCD atomic counter.  After the first wave
+// the dispatcher hands workgroup ids to whichever XCD frees a slot, which smears a super-block over several L2s
+// (measured: 18-31 % L2 hit on large GEMMs against 70-81 % when every XCD works on one super-block at a time).
+// Every workgroup leaves the loop as soon as its XCD's slots are exhausted: no spinning, no inter-workgroup waits.
+// STATUS (round 1): correct, but opt-in (GPX_GEMM_PERSIST_MIN=<tiles>).  PMC FETCH_SIZE showed the hit rate does not
+// recover with exact XCD placement alone (4096x8192x16384: 51 GB fetched with or without it, 69 GB requested): the
+// first wave of a launch shares panels because it starts in lock-step; later tiles start whenever a slot frees and the
+// workgroups drift apart by more than the ~16 k-steps a 4 MiB L2 can bridge.  Next step: a bounded (performance-only)
+// per-XCD re-synchronisation every few hundred k-steps on top of this kernel.
+template <bool BT, bool ACC, bool LOWER, int PF>
+__global__ __launch_bounds__(256, 2) void gemm_f64_persistent(const double* A, int64_t lda, const double* B,
+                                                              int64_t ldb, double* C, int64_t ldc, int nk,
+                                                              int tiles_m, int tiles_n, int sb_cols, int sb_shift,
+                                                              int nsb, int* __restrict__ counters) {
+  __shared__ Smem<BT> sm;
+  __shared__ int s_slot;
+  const int xcd = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;  // HW_REG_XCC_ID[3:0]
+  const int sbs2 = 2 * sb_shift;
+  for (;;) {
+    if (threadIdx.x == 0) s_slot = atomicAdd(&counters[xcd], 1);
+    __syncthreads();
+    const int slot = s_slot;
+    __syncthreads();  // everyone has read the slot (and finished the previous tile's LDS reads) before it is reused
+    const int sblk = (slot >> sbs2) * 8 + xcd;
+    if (sblk >= nsb) break;
+    int by, bx;
+    if (!tile_of<LOWER>(sblk, slot & ((1 << sbs2) - 1), tiles_m, tiles_n, sb_cols, sb_shift, &by, &bx)) continue;
+    gemm_tile<BT, ACC, PF>(sm, A, lda, B, ldb, C, ldc, nk, by, bx);
+  }
+}
+
 }  // namespace
 
 int launch_gemm(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
@@ -255,16 +303,28 @@ int launch_gemm(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int
   GPX_ARG(wgs < ((int64_t)1 << 31), "gemm: grid too large");
   dim3 grid((unsigned)wgs);
   const int nk = (int)(k / KB);
-  double tiles = lower ? 0.5 * (double)tm * ((double)tm + 1.0) : (double)tm * (double)tn;
+  const double tiles = lower ? 0.5 * (double)tm * ((double)tm + 1.0) : (double)tm * (double)tn;
   ProfScope ps(ctx, GPX_PROF_GEMM, 2.0 * tiles * BM * BN * (double)k, 0.0);
-  static int pf = -1;
+  static int pf = -1, persist_min = -1;
   if (pf < 0) {
     const char* e = getenv("GPX_GEMM_PF");
     pf = (e && atoi(e) == 2) ? 2 : 1;
+    const char* e2 = getenv("GPX_GEMM_PERSIST_MIN");  // tiles from which the persistent kernel is used (0 = never)
+    persist_min = e2 ? atoi(e2) : 0;   // opt-in: measured neutral/slightly slower, see the kernel's comment
+  }
+  const bool persist = persist_min > 0 && tiles >= (double)persist_min && nsb >= 16;
+  int* counters = nullptr;
+  if (persist) {
+    counters = ctx->d_counters + 8 * (ctx->counter_slot++ % GPX_COUNTER_SLOTS);
+    GPX_HIP(hipMemsetAsync(counters, 0, 8 * sizeof(int), ctx->stream));
+    grid = dim3((unsigned)(2 * ctx->cus));
   }
 #define GPX_G(BT_, ACC_, LOW_)                                                                                        \
   do {                                                                                                                \
-    if (pf == 2)                                                                                                      \
+    if (persist)                                                                                                      \
+      hipLaunchKernelGGL((gemm_f64_persistent<BT_, ACC_, LOW_, 1>), grid, dim3(256), 0, ctx->stream, A, lda, B, ldb,  \
+                         C, ldc, nk, tm, tn, sbc, sb_shift, (int)nsb, counters);                                      \
+    else if (pf == 2)                                                                                                 \
       hipLaunchKernelGGL((gemm_f64_kernel<BT_, ACC_, LOW_, 2>), grid, dim3(256), 0, ctx->stream, A, lda, B, ldb, C,   \
                          ldc, nk, tm, tn, sbc, sb_shift);                                                             \
     else                                                                                                              \

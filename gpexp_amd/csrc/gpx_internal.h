@@ -9,6 +9,7 @@
 
 #define GPX_TILE 128          // padding / GEMM tile / Cholesky leaf size
 #define GPX_MAXD GPX_MAX_DIM
+#define GPX_COUNTER_SLOTS 64     // ring of per-XCD work counters for the persistent GEMM (8 ints each)
 
 // ---- error plumbing ---------------------------------------------------------------------------
 void gpx_set_error(const char* fmt, ...);
@@ -34,6 +35,10 @@ void gpx_set_error(const char* fmt, ...);
   } while (0)
 
 static inline int64_t gpx_round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+// Leading dimension for a padded row of `cols` doubles: one extra 128-byte line per row when the row stride would
+// be a large power of two (N = 32768 -> 256 KiB).  Measured NEUTRAL on MI355X (GEMM 66.98 vs 66.97 TF/s: the L2 /
+// channel address hashing already spreads such strides); kept because it decouples ld from the padded width.
+static inline int64_t gpx_skew_ld(int64_t cols) { return (cols >= 1024 && cols % 256 == 0) ? cols + 16 : cols; }
 
 // ---- covariance-function parameters, passed to kernels by value ---------------------------------
 // Coordinates are pre-multiplied by `scale` when staged into LDS so that
@@ -56,7 +61,8 @@ int gpx_make_kparams(int kind, int d, const double* hyp, int nhyp, KParams* out)
 struct gpx_mat {
   double* p;
   int64_t rows, cols;    // logical
-  int64_t prows, pcols;  // allocated (ld == pcols)
+  int64_t prows, pcols;  // padded shape
+  int64_t ld;            // leading dimension >= pcols (skewed off powers of two, see gpx_skew_ld)
   int64_t bytes;
   double* aux;        // after gpx_potrf: inverses of the 128x128 diagonal blocks, (prows/128) x 128 x 128
   int64_t aux_bytes;
@@ -78,6 +84,8 @@ struct gpx_ctx {
   // scalars
   int* d_info;      // first failing pivot (1-based), 0 = ok
   double* d_scal;   // small scalar workspace (>= 64 doubles)
+  int* d_counters;  // GPX_COUNTER_SLOTS x 8 work counters (persistent GEMM)
+  unsigned counter_slot;
   // multi-GPU (RCCL communicator, opaque here; see dist.hip)
   void* comm;
   int rank, world;

@@ -251,7 +251,7 @@ int gpx_lml_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, con
         ProfScope ps(ctx, GPX_PROF_REDUCE, 0.0, 8.0 * (double)n * n);
         dim3 grid((unsigned)tiles, (unsigned)tiles);
         size_t sh = (size_t)(2 * TS * d + 4) * sizeof(double);
-        hipLaunchKernelGGL(lmlgrad_kernel, grid, dim3(256), sh, ctx->stream, kp, X->p, n, P->p, P->pcols,
+        hipLaunchKernelGGL(lmlgrad_kernel, grid, dim3(256), sh, ctx->stream, kp, X->p, n, P->p, P->ld,
                            (const double*)pal, (double*)ppart);
         hipLaunchKernelGGL(lmlgrad_final_kernel, dim3(nq), dim3(256), 0, ctx->stream, (const double*)ppart,
                            tiles * tiles, nq, (double*)pout);
@@ -310,11 +310,11 @@ int gpx_mi_greedy(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, co
         hipLaunchKernelGGL(mi_row_kernel, gM, dim3(256), 0, ctx->stream, kp, Cm->p, M, (const int64_t*)psel, (int)cur,
                            noise, (double*)pW, M, (const double*)din, dout);
         { double* t = din; din = dout; dout = t; }
-        hipLaunchKernelGGL(mi_downdate_kernel, dim3(gM.x, (unsigned)M), dim3(256), 0, ctx->stream, P->p, P->pcols, M,
+        hipLaunchKernelGGL(mi_downdate_kernel, dim3(gM.x, (unsigned)M), dim3(256), 0, ctx->stream, P->p, P->ld, M,
                            (const int64_t*)psel, (int)cur);
         hipLaunchKernelGGL(mi_mark_kernel, dim3(1), dim3(64), 0, ctx->stream, (int*)palive, (const int64_t*)psel,
                            (int)cur);
-        hipLaunchKernelGGL(mi_ratio_kernel, gM, dim3(256), 0, ctx->stream, (const double*)P->p, P->pcols,
+        hipLaunchKernelGGL(mi_ratio_kernel, gM, dim3(256), 0, ctx->stream, (const double*)P->p, P->ld,
                            (const double*)din, (const int*)palive, noise, M, (double*)pratio);
         hipLaunchKernelGGL(argmax_block_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const double*)pratio, M,
                            (int64_t*)psel, (int)(cur + 1), (double*)pval);
