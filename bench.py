@@ -156,6 +156,16 @@ def main():
         g = prof["gemm"]
         kf = prof["kfill"]
         ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        traffic, traffic_src = None, None
+        try:  # PMC counters cannot be read from inside the process: take the committed rocprofv3 --pmc passes of this
+            # same command (profiles/), per launch like `achieved`; null when the profile is for another config
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pj = json.load(f)
+            if world == 1 and (N, d, M) == (32768, 8, 32768):
+                traffic = (pj["fetch_bytes_per_step_corrected"] + pj["write_bytes_per_step"]) / pj["launches_per_step"]
+                traffic_src = pj["source"]
+        except (OSError, KeyError, ValueError):
+            pass
         line = {
             "metric": "GP-fit+IVAR-eval points/s at N=%d d=%d (wall-time in ms_per_step)" % (N, d),
             "value": (N + M) / (dt / args.steps),
@@ -175,7 +185,11 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else "%d ranks, 1-D block-cyclic columns" % world},
             "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel (SYRK/TRSM updates)", "achieved": ach,
                          "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
-                         "traffic": None, "launches_per_step": g["launches"] / args.steps,
+                         "traffic": traffic, "traffic_unit": "bytes per launch (mean over the step's launches)",
+                         "traffic_source": traffic_src,
+                         "algorithmic_flop_per_launch": (g["flops"] / g["launches"]) if g["launches"] else 0.0,
+                         "avg_launch_ms": (g["ms"] / g["launches"]) if g["launches"] else 0.0,
+                         "launches_per_step": g["launches"] / args.steps,
                          "kernel_ms_per_step": g["ms"] / args.steps},
             "kfill": {"bound": "hbm", "achieved": kf["bytes"] / (kf["ms"] * 1e-3) / 1e9 if kf["ms"] > 0 else 0.0,
                       "peak": PEAK_HBM_GBS, "unit": "GB/s",
