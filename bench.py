@@ -104,7 +104,7 @@ def main():
     if world > 1 or os.environ.get("GPX_FORCE_DIST") == "1":  # GPX_FORCE_DIST: rehearse the RCCL runner on one GPU
         from gpexp_amd import dist
         comm = dist.init_from_env(ctx)
-        runner = dist.DistFitIvar(ctx, comm, spec, Xh, yh, Zh, noise)
+        runner = dist.DistFitIvar(ctx, comm, spec, Xh, yh, Zh, noise, nb=int(os.environ.get("GPX_DIST_NB", "512")))
         step = runner.step
         barrier = comm.barrier
         reduce_max = comm.max_float

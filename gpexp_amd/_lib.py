@@ -58,7 +58,13 @@ _SIGS = {
                                  C.c_int]),
     "gpx_dist_panel_elems": (c_i64, [c_i64, c_i64]),
     "gpx_dist_panel_factor": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp]),
-    "gpx_dist_panel_apply": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, C.c_int, C.c_int]),
+    "gpx_dist_begin": (C.c_int, [c_vp]),
+    "gpx_dist_info": (C.c_int, [c_vp, C.POINTER(C.c_int)]),
+    "gpx_dist_panel_store": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "gpx_dist_panel_update": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, C.c_int, C.c_int]),
+    "gpx_stream_select": (C.c_int, [c_vp, C.c_int]),
+    "gpx_event_record": (C.c_int, [c_vp, C.c_int]),
+    "gpx_event_wait": (C.c_int, [c_vp, C.c_int]),
     "gpx_dist_finish": (C.c_int, [c_vp, c_vp]),
     "gpx_profile_enable": (C.c_int, [c_vp, C.c_int]),
     "gpx_profile_reset": (C.c_int, [c_vp]),

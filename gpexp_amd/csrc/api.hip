@@ -80,7 +80,7 @@ ProfScope::~ProfScope() {
 
 int gpx_prof_flush(gpx_ctx* ctx) {
   if (ctx->prof_recs.empty()) return 0;
-  GPX_HIP(hipStreamSynchronize(ctx->stream));
+  GPX_HIP(hipDeviceSynchronize());  // records may sit on any of the context's streams
   for (auto& r : ctx->prof_recs) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) ctx->prof_ms[r.cls] += ms;
@@ -180,7 +180,14 @@ int gpx_create(int device, gpx_ctx** out) {
     c->prof_launches[i] = 0;
     c->prof_ms[i] = c->prof_flops[i] = c->prof_bytes[i] = 0.0;
   }
-  GPX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  {
+    int lo = 0, hi = 0;
+    GPX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));  // hi is the numerically lowest = highest priority
+    GPX_HIP(hipStreamCreateWithPriority(&c->streams[0], hipStreamNonBlocking, lo));
+    GPX_HIP(hipStreamCreateWithPriority(&c->streams[1], hipStreamNonBlocking, hi));
+    GPX_HIP(hipStreamCreateWithPriority(&c->streams[2], hipStreamNonBlocking, hi));
+    c->stream = c->streams[0];
+  }
   hipDeviceProp_t prop;
   GPX_HIP(hipGetDeviceProperties(&prop, device));
   c->cus = prop.multiProcessorCount;
@@ -212,14 +219,47 @@ int gpx_destroy(gpx_ctx* ctx) {
   (void)hipFree(ctx->d_info);
   (void)hipFree(ctx->d_scal);
   (void)hipFree(ctx->d_counters);
-  (void)hipStreamDestroy(ctx->stream);
+  for (auto ev : ctx->sync_events) (void)hipEventDestroy(ev);
+  for (int i = 0; i < 3; ++i) (void)hipStreamDestroy(ctx->streams[i]);
   delete ctx;
   return 0;
 }
 
 int gpx_sync(gpx_ctx* ctx) {
   GPX_ARG(ctx != nullptr, "ctx is NULL");
-  GPX_HIP(hipStreamSynchronize(ctx->stream));
+  GPX_HIP(hipSetDevice(ctx->device));
+  GPX_HIP(hipDeviceSynchronize());  // every stream of this process on this device
+  return 0;
+}
+
+int gpx_stream_select(gpx_ctx* ctx, int which) {
+  GPX_ARG(ctx && which >= 0 && which < 3, "stream index must be 0 (main), 1 (panel) or 2 (communication)");
+  ctx->stream = ctx->streams[which];
+  return 0;
+}
+
+static int sync_event(gpx_ctx* ctx, int id, hipEvent_t* out) {
+  GPX_ARG(ctx && id >= 0 && id < 65536, "event id out of range");
+  while ((int)ctx->sync_events.size() <= id) {
+    hipEvent_t ev;
+    GPX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    ctx->sync_events.push_back(ev);
+  }
+  *out = ctx->sync_events[(size_t)id];
+  return 0;
+}
+
+int gpx_event_record(gpx_ctx* ctx, int id) {
+  hipEvent_t ev;
+  GPX_TRY(sync_event(ctx, id, &ev));
+  GPX_HIP(hipEventRecord(ev, ctx->stream));
+  return 0;
+}
+
+int gpx_event_wait(gpx_ctx* ctx, int id) {
+  hipEvent_t ev;
+  GPX_TRY(sync_event(ctx, id, &ev));
+  GPX_HIP(hipStreamWaitEvent(ctx->stream, ev, 0));
   return 0;
 }
 

@@ -204,7 +204,23 @@ int gpx_dist_kfill(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, c
 // elements of the packed panel buffer for step k: rows x nb panel + (nb/128) inverted 128x128 leaves
 int64_t gpx_dist_panel_elems(int64_t np, int64_t nb) { return np * nb + (nb / GPX_TILE) * GPX_TILE * GPX_TILE; }
 
-// owner side of step k: pack, factor, append leaf inverses.  Returns >0 on a non-positive pivot.
+// owner side of step k: pack the panel into P, factor it there, append the leaf inverses.  Asynchronous on the
+// selected stream; non-positive pivots accumulate in the context's flag (gpx_dist_info) -- reset it with
+// gpx_dist_begin before the first panel.
+int gpx_dist_begin(gpx_ctx* ctx) {
+  GPX_ARG(ctx != nullptr, "ctx is NULL");
+  GPX_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
+  return 0;
+}
+
+int gpx_dist_info(gpx_ctx* ctx, int* info) {
+  GPX_ARG(ctx && info, "NULL argument");
+  GPX_HIP(hipSetDevice(ctx->device));
+  GPX_HIP(hipDeviceSynchronize());
+  GPX_HIP(hipMemcpy(info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost));
+  return 0;
+}
+
 int gpx_dist_panel_factor(gpx_ctx* ctx, gpx_mat* K, int64_t k, int64_t nb, gpx_mat* P) {
   GPX_ARG(ctx && K && P, "NULL argument");
   const int64_t np = K->prows, r0 = k * nb;
@@ -214,18 +230,13 @@ int gpx_dist_panel_factor(gpx_ctx* ctx, gpx_mat* K, int64_t k, int64_t nb, gpx_m
   double* pb = P->p;
   double* pinv = P->p + rows * nb;  // leaf inverses of this panel
   GPX_TRY(copy2d(ctx, K->p + r0 * K->ld + r0, K->ld, pb, nb, rows, w));
-  GPX_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
   GPX_TRY(chol_potrf_nozero(ctx, pb, nb, w, pinv, r0, K->rows));
   if (rows > w) GPX_TRY(chol_trsm_right(ctx, pb, nb, pinv, pb + w * nb, nb, rows - w, w));
-  int info = 0;
-  GPX_HIP(hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  GPX_HIP(hipStreamSynchronize(ctx->stream));
-  if (info != 0) gpx_set_error("potrf: matrix is not positive definite (pivot %d <= 0)", info);
-  return info;
+  return 0;
 }
 
-// every rank, after the broadcast of step k: keep the panel + leaf inverses, update owned block columns j > k
-int gpx_dist_panel_apply(gpx_ctx* ctx, gpx_mat* K, int64_t k, int64_t nb, const gpx_mat* P, int rank, int world) {
+// every rank, after P has arrived: keep the panel and its leaf inverses in the local matrix
+int gpx_dist_panel_store(gpx_ctx* ctx, gpx_mat* K, int64_t k, int64_t nb, const gpx_mat* P) {
   GPX_ARG(ctx && K && P, "NULL argument");
   const int64_t np = K->prows, r0 = k * nb;
   GPX_ARG(nb % GPX_TILE == 0 && r0 < np, "bad panel index");
@@ -236,19 +247,35 @@ int gpx_dist_panel_apply(gpx_ctx* ctx, gpx_mat* K, int64_t k, int64_t nb, const 
     GPX_TRY(gpx_dev_alloc(ctx, K->aux_bytes, &p));
     K->aux = (double*)p;
   }
-  const double* pb = P->p;
-  const double* pinv = P->p + rows * nb;
-  GPX_TRY(copy2d(ctx, pb, nb, K->p + r0 * K->ld + r0, K->ld, rows, w));
-  GPX_HIP(hipMemcpyAsync(K->aux + (r0 / GPX_TILE) * GPX_TILE * GPX_TILE, pinv,
+  GPX_TRY(copy2d(ctx, P->p, nb, K->p + r0 * K->ld + r0, K->ld, rows, w));
+  GPX_HIP(hipMemcpyAsync(K->aux + (r0 / GPX_TILE) * GPX_TILE * GPX_TILE, P->p + rows * nb,
                          (size_t)((w / GPX_TILE) * GPX_TILE * GPX_TILE * 8), hipMemcpyDeviceToDevice, ctx->stream));
+  return 0;
+}
+
+// apply panel k to the owned block columns j in [j0, j1):  C[j*nb:, j] -= P[j..] P[j]^T.
+// With one rank and j1 == number of blocks the whole trailing range is one lower-triangular SYRK launch.
+int gpx_dist_panel_update(gpx_ctx* ctx, gpx_mat* K, int64_t k, int64_t nb, const gpx_mat* P, int64_t j0, int64_t j1,
+                          int rank, int world) {
+  GPX_ARG(ctx && K && P, "NULL argument");
+  const int64_t np = K->prows, r0 = k * nb;
+  GPX_ARG(nb % GPX_TILE == 0 && r0 < np && world >= 1, "bad panel index");
+  const int64_t w = (np - r0) < nb ? (np - r0) : nb;
   const int64_t nblk = (np + nb - 1) / nb;
-  for (int64_t j = k + 1; j < nblk; ++j) {
+  if (j0 <= k) j0 = k + 1;
+  if (j1 > nblk) j1 = nblk;
+  const double* pb = P->p;
+  if (world == 1 && j1 == nblk && j1 - j0 > 1) {
+    const int64_t c0 = j0 * nb;
+    return launch_gemm(ctx, pb + (c0 - r0) * nb, nb, pb + (c0 - r0) * nb, nb, K->p + c0 * K->ld + c0, K->ld, np - c0,
+                       np - c0, w, true, true, true);
+  }
+  for (int64_t j = j0; j < j1; ++j) {
     if (j % world != rank) continue;
     const int64_t c0 = j * nb;
     const int64_t cw = (np - c0) < nb ? (np - c0) : nb;
-    // C[c0:, c0:c0+cw] -= P[c0-r0:, :] * P[c0-r0 : c0-r0+cw, :]^T
-    GPX_TRY(launch_gemm(ctx, pb + (c0 - r0) * nb, nb, pb + (c0 - r0) * nb, nb, K->p + c0 * K->ld + c0, K->ld,
-                        np - c0, cw, w, true, true, false));
+    GPX_TRY(launch_gemm(ctx, pb + (c0 - r0) * nb, nb, pb + (c0 - r0) * nb, nb, K->p + c0 * K->ld + c0, K->ld, np - c0,
+                        cw, w, true, true, false));
   }
   return 0;
 }

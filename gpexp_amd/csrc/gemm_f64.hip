@@ -67,7 +67,7 @@ __device__ __forceinline__ bool tile_of(int sblk, int within, int tiles_m, int t
   return true;
 }
 
-template <bool BT, bool ACC, int PF>
+template <bool BT, bool ACC, int PF, int KU>
 __device__ __forceinline__ void gemm_tile(Smem<BT>& sm, const double* A, int64_t lda, const double* B, int64_t ldb,
                                           double* C, int64_t ldc, int nk, int by, int bx) {
   const int t = threadIdx.x;
@@ -144,17 +144,22 @@ __device__ __forceinline__ void gemm_tile(Smem<BT>& sm, const double* A, int64_t
   const int fr = lane & 15, fk = lane >> 4;
   const double* const as0 = &sm.a[0][(wm * 64 + fr) * SA + fk];
   const double* const bs0 = BT ? &sm.b[0][(wn * 64 + fr) * SA + fk] : &sm.b[0][fk * SBN + wn * 64 + fr];
+// KU = k-substeps (of 4) unrolled together: 4 lets the compiler hoist every fragment read of the step (most VGPRs),
+// 2 keeps the depth-2 prefetch variant under the 256-VGPR cap without spills.
 #define GPX_COMPUTE(buf_)                                                                            \
   do {                                                                                               \
     const double* as = as0 + (buf_) * A_BUF;                                                         \
     const double* bs = bs0 + (buf_) * B_BUF;                                                         \
-    _Pragma("unroll") for (int kk = 0; kk < KB / 4; ++kk) {                                          \
-      double af[4], bf[4];                                                                           \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) af[i] = as[(i * 16) * SA + kk * 4];              \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                  \
-          bf[j] = BT ? bs[(j * 16) * SA + kk * 4] : bs[(kk * 4) * SBN + j * 16];                     \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)    \
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);        \
+    _Pragma("unroll 1") for (int kk0 = 0; kk0 < KB / 4; kk0 += KU) {                                 \
+      _Pragma("unroll") for (int ku = 0; ku < KU; ++ku) {                                            \
+        const int kk = kk0 + ku;                                                                     \
+        double af[4], bf[4];                                                                         \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) af[i] = as[(i * 16) * SA + kk * 4];            \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                \
+            bf[j] = BT ? bs[(j * 16) * SA + kk * 4] : bs[(kk * 4) * SBN + j * 16];                   \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)  \
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);      \
+      }                                                                                              \
     }                                                                                                \
   } while (0)
 
@@ -234,7 +239,7 @@ __device__ __forceinline__ void gemm_tile(Smem<BT>& sm, const double* A, int64_t
 
 
 // one workgroup per tile; ids congruent mod 8 are assumed to share an XCD (true for the first wave of workgroups)
-template <bool BT, bool ACC, bool LOWER, int PF>
+template <bool BT, bool ACC, bool LOWER, int PF, int KU>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64_t lda, const double* B, int64_t ldb,
                                                           double* C, int64_t ldc, int nk, int tiles_m, int tiles_n,
                                                           int sb_cols, int sb_shift) {
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64
   int by, bx;
   if (!tile_of<LOWER>((q >> sbs2) * 8 + xcd, q & ((1 << sbs2) - 1), tiles_m, tiles_n, sb_cols, sb_shift, &by, &bx))
     return;
-  gemm_tile<BT, ACC, PF>(sm, A, lda, B, ldb, C, ldc, nk, by, bx);
+  gemm_tile<BT, ACC, PF, KU>(sm, A, lda, B, ldb, C, ldc, nk, by, bx);
 }
 
 // Persistent variant for large grids: 2 workgroups per CU stay resident; each reads the XCD it really runs on
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64
 // first wave of a launch shares panels because it starts in lock-step; later tiles start whenever a slot frees and the
 // workgroups drift apart by more than the ~16 k-steps a 4 MiB L2 can bridge.  Next step: a bounded (performance-only)
 // per-XCD re-synchronisation every few hundred k-steps on top of this kernel.
-template <bool BT, bool ACC, bool LOWER, int PF>
+template <bool BT, bool ACC, bool LOWER, int PF, int KU>
 __global__ __launch_bounds__(256, 2) void gemm_f64_persistent(const double* A, int64_t lda, const double* B,
                                                               int64_t ldb, double* C, int64_t ldc, int nk,
                                                               int tiles_m, int tiles_n, int sb_cols, int sb_shift,
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_persistent(const double* A, i
     if (sblk >= nsb) break;
     int by, bx;
     if (!tile_of<LOWER>(sblk, slot & ((1 << sbs2) - 1), tiles_m, tiles_n, sb_cols, sb_shift, &by, &bx)) continue;
-    gemm_tile<BT, ACC, PF>(sm, A, lda, B, ldb, C, ldc, nk, by, bx);
+    gemm_tile<BT, ACC, PF, KU>(sm, A, lda, B, ldb, C, ldc, nk, by, bx);
   }
 }
 
@@ -308,7 +313,7 @@ int launch_gemm(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int
   static int pf = -1, persist_min = -1;
   if (pf < 0) {
     const char* e = getenv("GPX_GEMM_PF");
-    pf = (e && atoi(e) == 2) ? 2 : 1;
+    pf = e ? atoi(e) : 0;  // 0: default (per-variant best); 2: depth-2 prefetch; 11/12/14: depth-1 + inner unroll 1/2/4
     const char* e2 = getenv("GPX_GEMM_PERSIST_MIN");  // tiles from which the persistent kernel is used (0 = never)
     persist_min = e2 ? atoi(e2) : 0;   // opt-in: measured neutral/slightly slower, see the kernel's comment
   }
@@ -322,14 +327,23 @@ int launch_gemm(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int
 #define GPX_G(BT_, ACC_, LOW_)                                                                                        \
   do {                                                                                                                \
     if (persist)                                                                                                      \
-      hipLaunchKernelGGL((gemm_f64_persistent<BT_, ACC_, LOW_, 1>), grid, dim3(256), 0, ctx->stream, A, lda, B, ldb,  \
-                         C, ldc, nk, tm, tn, sbc, sb_shift, (int)nsb, counters);                                      \
+      hipLaunchKernelGGL((gemm_f64_persistent<BT_, ACC_, LOW_, 1, 4>), grid, dim3(256), 0, ctx->stream, A, lda, B,    \
+                         ldb, C, ldc, nk, tm, tn, sbc, sb_shift, (int)nsb, counters);                                 \
     else if (pf == 2)                                                                                                 \
-      hipLaunchKernelGGL((gemm_f64_kernel<BT_, ACC_, LOW_, 2>), grid, dim3(256), 0, ctx->stream, A, lda, B, ldb, C,   \
-                         ldc, nk, tm, tn, sbc, sb_shift);                                                             \
-    else                                                                                                              \
-      hipLaunchKernelGGL((gemm_f64_kernel<BT_, ACC_, LOW_, 1>), grid, dim3(256), 0, ctx->stream, A, lda, B, ldb, C,   \
-                         ldc, nk, tm, tn, sbc, sb_shift);                                                             \
+      hipLaunchKernelGGL((gemm_f64_kernel<BT_, ACC_, LOW_, 2, 2>), grid, dim3(256), 0, ctx->stream, A, lda, B, ldb,   \
+                         C, ldc, nk, tm, tn, sbc, sb_shift);                                                          \
+    else if (pf == 12)                                                                                                \
+      hipLaunchKernelGGL((gemm_f64_kernel<BT_, ACC_, LOW_, 1, 2>), grid, dim3(256), 0, ctx->stream, A, lda, B, ldb,   \
+                         C, ldc, nk, tm, tn, sbc, sb_shift);                                                          \
+    else if (pf == 11)                                                                                                \
+      hipLaunchKernelGGL((gemm_f64_kernel<BT_, ACC_, LOW_, 1, 1>), grid, dim3(256), 0, ctx->stream, A, lda, B, ldb,   \
+                         C, ldc, nk, tm, tn, sbc, sb_shift);                                                          \
+    else if (pf == 14)                                                                                                \
+      hipLaunchKernelGGL((gemm_f64_kernel<BT_, ACC_, LOW_, 1, 4>), grid, dim3(256), 0, ctx->stream, A, lda, B, ldb,   \
+                         C, ldc, nk, tm, tn, sbc, sb_shift);                                                          \
+    else /* default: measured best per operand form (C4 step: NT full unroll 287 vs 295 ms; NN unroll-2 534 vs 600 ms) */ \
+      hipLaunchKernelGGL((gemm_f64_kernel<BT_, ACC_, LOW_, 1, (BT_ ? 4 : 2)>), grid, dim3(256), 0, ctx->stream, A,    \
+                         lda, B, ldb, C, ldc, nk, tm, tn, sbc, sb_shift);                                             \
   } while (0)
   if (bt) {
     if (accumulate) {

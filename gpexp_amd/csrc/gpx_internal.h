@@ -76,7 +76,9 @@ struct ProfRec {
 
 struct gpx_ctx {
   int device;
-  hipStream_t stream;
+  hipStream_t stream;        // currently selected stream (all launches go here)
+  hipStream_t streams[3];    // 0 = main, 1 = panel (high priority), 2 = communication (high priority)
+  std::vector<hipEvent_t> sync_events;  // gpx_event_record / gpx_event_wait ids
   int cus;
   // cached device allocations (exact-size reuse)
   std::multimap<int64_t, void*> pool;

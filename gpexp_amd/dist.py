@@ -14,7 +14,7 @@ two shardings:
         the result does not depend on arrival order).
 
 The panel loop lives here, in Python, on top of three C-ABI primitives (gpx_dist_panel_factor /
-gpx_comm_bcast / gpx_dist_panel_apply); per step that is a handful of ctypes calls against ~10^10 flops of GPU
+gpx_comm_bcast / gpx_dist_panel_store + gpx_dist_panel_update); per step that is a handful of ctypes calls against ~10^10 flops of GPU
 work.  The communicator is an object with `bcast_panel`, `allgather`, `barrier`, `max_float`:
   RcclComm      device-to-device over RCCL (the product path; no torch in the process, see FileRendezvous);
   HostStagedComm  device -> host -> torch.distributed(gloo) -> device, for the world_size>1 tests that share one
@@ -230,6 +230,9 @@ def init_from_env(ctx):
 
 
 # ---- distributed operations -----------------------------------------------------------------------------------
+MAIN, PANEL, COMM = 0, 1, 2  # stream indices of the context (gpx_stream_select)
+
+
 class DeviceOps:
     """The device primitives the panel loop needs (the tests substitute a NumPy double for CPU runs)."""
 
@@ -248,32 +251,93 @@ class DeviceOps:
         check(self.ctx.lib.gpx_dist_kfill(self.ctx.h, *spec.args(), X.h, dptr(nug), nlen, K.h, int(nb), int(rank),
                                           int(world)))
 
-    def panel_factor(self, K, k, nb, P):
-        return self.ctx.lib.gpx_dist_panel_factor(self.ctx.h, K.h, int(k), int(nb), P.h)
+    def begin(self):
+        check(self.ctx.lib.gpx_dist_begin(self.ctx.h))
 
-    def panel_apply(self, K, k, nb, P, rank, world):
-        check(self.ctx.lib.gpx_dist_panel_apply(self.ctx.h, K.h, int(k), int(nb), P.h, int(rank), int(world)))
+    def info(self):
+        v = C.c_int(0)
+        check(self.ctx.lib.gpx_dist_info(self.ctx.h, C.byref(v)))
+        return v.value
+
+    def panel_factor(self, K, k, nb, P):
+        check(self.ctx.lib.gpx_dist_panel_factor(self.ctx.h, K.h, int(k), int(nb), P.h))
+
+    def panel_store(self, K, k, nb, P):
+        check(self.ctx.lib.gpx_dist_panel_store(self.ctx.h, K.h, int(k), int(nb), P.h))
+
+    def panel_update(self, K, k, nb, P, j0, j1, rank, world):
+        check(self.ctx.lib.gpx_dist_panel_update(self.ctx.h, K.h, int(k), int(nb), P.h, int(j0), int(j1), int(rank),
+                                                 int(world)))
 
     def finish(self, K):
         check(self.ctx.lib.gpx_dist_finish(self.ctx.h, K.h))
 
+    # stream / event plumbing of the look-ahead pipeline
+    def stream(self, which):
+        check(self.ctx.lib.gpx_stream_select(self.ctx.h, int(which)))
 
-def dist_potrf(ops, comm, K, n, nb, P):
-    """Right-looking block-column Cholesky of the distributed matrix K (in place); every rank ends with all of L.
-    Returns 0, or the 1-based index of the first non-positive pivot (agreed on by all ranks)."""
+    def record(self, ev):
+        check(self.ctx.lib.gpx_event_record(self.ctx.h, int(ev)))
+
+    def wait(self, ev):
+        check(self.ctx.lib.gpx_event_wait(self.ctx.h, int(ev)))
+
+
+# event ids of the pipeline (per step k, 4 kinds)
+def _ev(kind, k):
+    return 4 * (k + 1) + kind
+
+
+EV_COLREADY, EV_FACT, EV_BCAST, EV_APPLIED = 0, 1, 2, 3
+
+
+def dist_potrf(ops, comm, K, n, nb, panels):
+    """Right-looking block-column Cholesky of the distributed matrix K (in place) with one step of LOOK-AHEAD; every
+    rank ends with all of L.  `panels` = two packed panel buffers used alternately.
+
+    Three streams per rank.  For step k:
+      PANEL  (owner of k)  waits until block column k has received update k-1, packs + factors it      -> EV_FACT[k]
+      COMM   (all)         ncclBroadcast of the packed panel from its owner                              -> EV_BCAST[k]
+      MAIN   (all)         stores the panel, updates the owned column k+1 FIRST (-> EV_COLREADY[k+1], which releases
+                           the owner's PANEL stream for step k+1) and then the remaining owned columns   -> EV_APPLIED[k]
+    so the factorisation and broadcast of panel k+1 run underneath the bulk of update k.  A buffer is reused at step
+    k+2 only after EV_APPLIED[k].  Everything is enqueued asynchronously in step order, hence every rank issues its
+    collectives in the same order.  Returns 0 or the 1-based index of the first non-positive pivot (agreed by all).
+    """
+    nblk = num_blocks(n, nb)
     np_ = padded(n)
-    info = 0
-    for k in range(num_blocks(n, nb)):
+    ops.stream(MAIN)
+    ops.begin()
+    ops.record(_ev(EV_COLREADY, 0))  # column 0 is ready once the assembly (queued on MAIN) is done
+    for k in range(nblk):
         root = owner(k, comm.world)
+        P = panels[k & 1]
         rows = np_ - k * nb
+        count = rows * nb + (nb // TILE) * TILE * TILE
         if comm.rank == root:
-            rc = ops.panel_factor(K, k, nb, P)
-            if rc < 0:
-                check(rc)
-            if rc > 0 and info == 0:
-                info = rc
-        comm.bcast_panel(P, rows * nb + (nb // TILE) * TILE * TILE, root)
-        ops.panel_apply(K, k, nb, P, comm.rank, comm.world)
+            ops.stream(PANEL)
+            ops.wait(_ev(EV_COLREADY, k))
+            if k >= 2:
+                ops.wait(_ev(EV_APPLIED, k - 2))
+            ops.panel_factor(K, k, nb, P)
+            ops.record(_ev(EV_FACT, k))
+        ops.stream(COMM)
+        if comm.rank == root:
+            ops.wait(_ev(EV_FACT, k))
+        if k >= 2:
+            ops.wait(_ev(EV_APPLIED, k - 2))
+        comm.bcast_panel(P, count, root)
+        ops.record(_ev(EV_BCAST, k))
+        ops.stream(MAIN)
+        ops.wait(_ev(EV_BCAST, k))
+        ops.panel_store(K, k, nb, P)
+        if k + 1 < nblk:
+            ops.panel_update(K, k, nb, P, k + 1, k + 2, comm.rank, comm.world)
+            ops.record(_ev(EV_COLREADY, k + 1))
+            ops.panel_update(K, k, nb, P, k + 2, nblk, comm.rank, comm.world)
+        ops.record(_ev(EV_APPLIED, k))
+    ops.stream(MAIN)
+    info = ops.info()  # synchronises every stream
     ops.finish(K)
     allinfo = comm.allgather(np.array([float(info)]))[:, 0]
     bad = [int(v) for v in allinfo if v > 0]
@@ -293,7 +357,7 @@ class DistFitIvar:
         lo, hi = eval_slice(self.m, comm.rank, comm.world)
         self.Zloc = _dev.points(ctx, Zh[lo:hi]) if hi > lo else None
         self.K = self.ops.alloc_matrix(self.n)
-        self.P = self.ops.alloc_panel(self.n, self.nb)
+        self.P = [self.ops.alloc_panel(self.n, self.nb), self.ops.alloc_panel(self.n, self.nb)]
 
     def step(self):
         ctx, comm = self.ctx, self.comm

@@ -58,7 +58,12 @@ const char* gpx_last_error(void);
 /* device = HIP ordinal (LOCAL_RANK in the one-process-per-GPU launch).  Fails (<0) when no GPU. */
 int gpx_create(int device, gpx_ctx** out);
 int gpx_destroy(gpx_ctx* ctx);
-int gpx_sync(gpx_ctx* ctx);
+int gpx_sync(gpx_ctx* ctx);   /* device-wide: every stream of the context */
+/* Three HIP streams per context: 0 main, 1 panel factorisation (high priority), 2 communication (high priority).
+ * All entry points enqueue on the currently selected one; events order work across them (look-ahead pipeline). */
+int gpx_stream_select(gpx_ctx* ctx, int which);
+int gpx_event_record(gpx_ctx* ctx, int id);  /* id in [0, 65536): recorded on the selected stream */
+int gpx_event_wait(gpx_ctx* ctx, int id);    /* the selected stream waits for the last record of id */
 /* release cached workspace back to HIP */
 int gpx_trim(gpx_ctx* ctx);
 /* device facts for reports: name[<=256], CU count, HBM bytes, clock MHz */
@@ -165,10 +170,16 @@ int gpx_dist_kfill(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, c
                    const double* nugget, int64_t nugget_len, gpx_mat* K, int64_t nb, int rank, int world);
 /* doubles in the packed panel buffer: padded_rows*nb panel + the inverted 128x128 diagonal leaves */
 int64_t gpx_dist_panel_elems(int64_t padded_rows, int64_t nb);
-/* owner of block column k: pack the panel into P, factor it there; >0 = non-positive pivot */
+/* reset / read the accumulated pivot flag of a panel-wise factorisation (gpx_dist_info synchronises the device) */
+int gpx_dist_begin(gpx_ctx* ctx);
+int gpx_dist_info(gpx_ctx* ctx, int* info);
+/* owner of block column k: pack the panel into P and factor it there (asynchronous on the selected stream) */
 int gpx_dist_panel_factor(gpx_ctx* ctx, gpx_mat* K, int64_t k, int64_t nb, gpx_mat* P);
-/* every rank, after P has been broadcast: store the panel, update the owned block columns j > k */
-int gpx_dist_panel_apply(gpx_ctx* ctx, gpx_mat* K, int64_t k, int64_t nb, const gpx_mat* P, int rank, int world);
+/* every rank, once P has arrived: store the panel and its leaf inverses in the local matrix */
+int gpx_dist_panel_store(gpx_ctx* ctx, gpx_mat* K, int64_t k, int64_t nb, const gpx_mat* P);
+/* every rank: apply panel k to the owned block columns j0 <= j < j1 (look-ahead updates column k+1 first) */
+int gpx_dist_panel_update(gpx_ctx* ctx, gpx_mat* K, int64_t k, int64_t nb, const gpx_mat* P, int64_t j0, int64_t j1,
+                          int rank, int world);
 /* mark K as a complete factor (every rank now holds all of L) */
 int gpx_dist_finish(gpx_ctx* ctx, gpx_mat* K);
 

@@ -49,6 +49,21 @@ class NumpyOps:
             c0, c1 = j * nb, min((j + 1) * nb, np_)
             K.a[c0:, c0:c1] = full[c0:, c0:c1]
 
+    def begin(self):
+        self._info = 0
+
+    def info(self):
+        return self._info
+
+    def stream(self, which):  # the double executes synchronously: streams / events are no-ops
+        pass
+
+    def record(self, ev):
+        pass
+
+    def wait(self, ev):
+        pass
+
     def panel_factor(self, K, k, nb, P):
         np_ = K.a.shape[0]
         r0 = k * nb
@@ -59,7 +74,9 @@ class NumpyOps:
         try:
             L11 = np.linalg.cholesky(np.tril(pan[:w]) + np.tril(pan[:w], -1).T)
         except np.linalg.LinAlgError:
-            return r0 + 1
+            if self._info == 0:
+                self._info = r0 + 1
+            L11 = np.eye(w)
         pan[:w] = L11
         if rows > w:
             pan[w:] = np.linalg.solve(L11, pan[w:].T).T
@@ -69,17 +86,23 @@ class NumpyOps:
         for q in range(w // 128):
             blk = L11[q * 128:(q + 1) * 128, q * 128:(q + 1) * 128]
             P.a[rows * nb + q * 128 * 128: rows * nb + (q + 1) * 128 * 128] = np.linalg.inv(blk).ravel()
-        return 0
 
-    def panel_apply(self, K, k, nb, P, rank, world):
+    def _panel(self, K, k, nb, P):
         np_ = K.a.shape[0]
         r0 = k * nb
         w = min(nb, np_ - r0)
         rows = np_ - r0
-        pan = P.a[:rows * nb].reshape(rows, nb)[:, :w]
+        return np_, r0, w, rows, P.a[:rows * nb].reshape(rows, nb)[:, :w]
+
+    def panel_store(self, K, k, nb, P):
+        np_, r0, w, rows, pan = self._panel(K, k, nb, P)
         K.a[r0:, r0:r0 + w] = pan
         self.aux[k] = P.a[rows * nb: rows * nb + (w // 128) * 128 * 128].copy()
-        for j in range(k + 1, (np_ + nb - 1) // nb):
+
+    def panel_update(self, K, k, nb, P, j0, j1, rank, world):
+        np_, r0, w, rows, pan = self._panel(K, k, nb, P)
+        nblk = (np_ + nb - 1) // nb
+        for j in range(max(j0, k + 1), min(j1, nblk)):
             if j % world != rank:
                 continue
             c0, c1 = j * nb, min((j + 1) * nb, np_)
@@ -117,7 +140,7 @@ def run_cpu(args):
     comm = NumpyComm()
     ops = NumpyOps(spec)
     K = ops.alloc_matrix(args.n)
-    P = ops.alloc_panel(args.n, args.nb)
+    P = [ops.alloc_panel(args.n, args.nb), ops.alloc_panel(args.n, args.nb)]
     ops.kfill_owned(None, X, K, 0.05, args.nb, comm.rank, comm.world)
     info = dist.dist_potrf(ops, comm, K, args.n, args.nb, P)
     assert info == 0
