@@ -97,8 +97,14 @@ __global__ __launch_bounds__(256) void leaf_kernel(double* __restrict__ A, int64
           if (lane == 0 && base_index + c0 + j < n_valid) atomicCAS(info, 0, (int)(base_index + c0 + j + 1));
           piv = 1.0;
         }
-        const double sq = sqrt(piv);
-        const double rs = 1.0 / sq;
+        // 1/sqrt(piv) from v_rsq_f64 + two Newton steps, sqrt(piv) = piv*rs with one residual correction: ~15 dependent
+        // fp64 ops instead of a full-precision sqrt followed by a division (~100) on the serial pivot chain
+        double rs = __builtin_amdgcn_rsq(piv);
+        const double hp = 0.5 * piv;
+        rs = rs * fma(-hp * rs, rs, 1.5);
+        rs = rs * fma(-hp * rs, rs, 1.5);
+        double sq = piv * rs;
+        sq = fma(fma(-sq, sq, piv), 0.5 * rs, sq);
         rinv[j] = rs;
         a[j] = (q == j) ? sq : a[j] * rs;
 #pragma unroll
@@ -175,52 +181,65 @@ __global__ __launch_bounds__(256) void leaf_kernel(double* __restrict__ A, int64
 }
 
 // ---- TRSV pieces (potrs) ---------------------------------------------------------------------------
-// y_k <- op(invL_kk) y_k for one 128 block; one workgroup of 128 threads
-__global__ __launch_bounds__(128) void trsv_diag_kernel(const double* __restrict__ inv, double* __restrict__ y,
-                                                        int transposed) {
+// The sweeps follow the same recursion as the factorisation: solve the first half, subtract the off-diagonal block
+// times that solution from the second half as ONE bandwidth-bound GEMV over the whole block, solve the second half
+// (transposed sweep: the other way round).  Leaves multiply by the inverted 128x128 diagonal block.
+
+// y <- inv * y (forward) : wave per row, lanes across the 128 columns (coalesced 1 KiB rows), shuffle reduction
+__global__ __launch_bounds__(256) void trsv_leaf_fwd_kernel(const double* __restrict__ inv, double* __restrict__ y) {
   __shared__ double ys[NB];
-  const int t = threadIdx.x;
-  ys[t] = y[t];
+  __shared__ double out[NB];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t < NB) ys[t] = y[t];
   __syncthreads();
-  double s = 0.0;
-  if (!transposed) {
-    for (int c = 0; c <= t; ++c) s = fma(inv[t * NB + c], ys[c], s);
-  } else {
-    for (int i = t; i < NB; ++i) s = fma(inv[i * NB + t], ys[i], s);
+  const double2 v = reinterpret_cast<const double2*>(ys)[lane];
+  for (int r = wave * 32; r < wave * 32 + 32; ++r) {
+    const double2 l = reinterpret_cast<const double2*>(inv + r * NB)[lane];
+    double s = fma(l.x, v.x, l.y * v.y);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) out[r] = s;
   }
-  y[t] = s;
+  __syncthreads();
+  if (t < NB) y[t] = out[t];
 }
 
-// forward: y[r] -= L[r][k0:k0+128] . yk   for rows r in [r0, r0+rows); one wave per row (8 rows per wave)
-__global__ __launch_bounds__(256) void trsv_fwd_update_kernel(const double* __restrict__ L, int64_t ld,
-                                                              const double* __restrict__ yk, double* __restrict__ y,
-                                                              int64_t rows) {
+// z <- inv^T * z (backward): thread per column, rows walked with coalesced loads
+__global__ __launch_bounds__(128) void trsv_leaf_bwd_kernel(const double* __restrict__ inv, double* __restrict__ z) {
+  __shared__ double zs[NB];
+  const int t = threadIdx.x;
+  zs[t] = z[t];
+  __syncthreads();
+  double s0 = 0.0, s1 = 0.0;
+  for (int i = 0; i < NB; i += 2) {
+    s0 = fma(inv[i * NB + t], zs[i], s0);
+    s1 = fma(inv[(i + 1) * NB + t], zs[i + 1], s1);
+  }
+  z[t] = s0 + s1;
+}
+
+// y[r] -= sum_c A[r][c] x[c]   (rows x cols block, cols a multiple of 128): one wave per row, 8 rows per workgroup pass
+__global__ __launch_bounds__(256) void gemv_sub_kernel(const double* __restrict__ A, int64_t ld, int64_t rows,
+                                                       int64_t cols, const double* __restrict__ x,
+                                                       double* __restrict__ y) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const double2 v = reinterpret_cast<const double2*>(yk)[lane];
-  const int64_t rbase = ((int64_t)blockIdx.x * 4 + wave) * 8;
-  for (int q = 0; q < 8; ++q) {
-    const int64_t r = rbase + q;
-    if (r >= rows) break;
-    const double2 l = reinterpret_cast<const double2*>(L + r * ld)[lane];
-    double s = fma(l.x, v.x, l.y * v.y);
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < rows; r += (int64_t)gridDim.x * 4) {
+    const double2* ar = reinterpret_cast<const double2*>(A + r * ld);
+    const double2* xr = reinterpret_cast<const double2*>(x);
+    double s0 = 0.0, s1 = 0.0;
+    for (int64_t c = lane; c < cols / 2; c += 64) {
+      const double2 a = ar[c], b = xr[c];
+      s0 = fma(a.x, b.x, s0);
+      s1 = fma(a.y, b.y, s1);
+    }
+    double s = s0 + s1;
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if (lane == 0) y[r] -= s;
   }
 }
 
-// backward: z[j] -= sum_i L[i][j] * zk[i], i in the 128 rows of block k, j in [0, cols)
-__global__ __launch_bounds__(256) void trsv_bwd_update_kernel(const double* __restrict__ Lrow, int64_t ld,
-                                                              const double* __restrict__ zk, double* __restrict__ z,
-                                                              int64_t cols) {
-  __shared__ double zs[NB];
-  if (threadIdx.x < NB) zs[threadIdx.x] = zk[threadIdx.x];
-  __syncthreads();
-  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= cols) return;
-  double s = 0.0;
-#pragma unroll 8
-  for (int i = 0; i < NB; ++i) s = fma(Lrow[(int64_t)i * ld + j], zs[i], s);
-  z[j] -= s;
+__global__ __launch_bounds__(256) void vec_sub_kernel(double* __restrict__ y, const double* __restrict__ d, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] -= d[i];
 }
 
 __global__ __launch_bounds__(256) void logdet_kernel(const double* __restrict__ L, int64_t ld, int64_t n,
@@ -293,29 +312,54 @@ int chol_potrf_nozero(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double* in
   return potrf_rec(ctx, A, ld, n, invd, base, n_valid);
 }
 
-int chol_trsv(gpx_ctx* ctx, const double* L, int64_t ld, const double* invd, double* y, int64_t n, bool transposed) {
-  GPX_ARG(n % NB == 0, "trsv: padded length must be a multiple of 128");
-  const int64_t nblk = n / NB;
-  ProfScope ps(ctx, GPX_PROF_TRSV, (double)n * n, 4.0 * (double)n * n);
-  if (!transposed) {
-    for (int64_t k = 0; k < nblk; ++k) {
-      double* yk = y + k * NB;
-      hipLaunchKernelGGL(trsv_diag_kernel, dim3(1), dim3(128), 0, ctx->stream, invd + k * NB * NB, yk, 0);
-      const int64_t rows = n - (k + 1) * NB;
-      if (rows > 0)
-        hipLaunchKernelGGL(trsv_fwd_update_kernel, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, ctx->stream,
-                           L + (k + 1) * NB * ld + k * NB, ld, yk, y + (k + 1) * NB, rows);
-    }
-  } else {
-    for (int64_t k = nblk - 1; k >= 0; --k) {
-      double* zk = y + k * NB;
-      hipLaunchKernelGGL(trsv_diag_kernel, dim3(1), dim3(128), 0, ctx->stream, invd + k * NB * NB, zk, 1);
-      const int64_t cols = k * NB;
-      if (cols > 0)
-        hipLaunchKernelGGL(trsv_bwd_update_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, ctx->stream,
-                           L + k * NB * ld, ld, zk, y, cols);
-    }
+static int trsv_fwd_rec(gpx_ctx* ctx, const double* L, int64_t ld, const double* invd, double* y, int64_t n) {
+  if (n == NB) {
+    hipLaunchKernelGGL(trsv_leaf_fwd_kernel, dim3(1), dim3(256), 0, ctx->stream, invd, y);
+    return 0;
   }
+  const int64_t n1 = split(n), n2 = n - n1;
+  GPX_TRY(trsv_fwd_rec(ctx, L, ld, invd, y, n1));
+  int64_t wg = (n2 + 3) / 4;
+  if (wg > 4096) wg = 4096;
+  hipLaunchKernelGGL(gemv_sub_kernel, dim3((unsigned)wg), dim3(256), 0, ctx->stream, L + n1 * ld, ld, n2, n1, y, y + n1);
+  return trsv_fwd_rec(ctx, L + n1 * ld + n1, ld, invd + (n1 / NB) * NB * NB, y + n1, n2);
+}
+
+// scratch: tmp (>= n doubles) and part (>= colreduce_partial_elems(n, n) doubles) for the transposed GEMV
+static int trsv_bwd_rec(gpx_ctx* ctx, const double* L, int64_t ld, const double* invd, double* z, int64_t n,
+                        double* tmp, double* part) {
+  if (n == NB) {
+    hipLaunchKernelGGL(trsv_leaf_bwd_kernel, dim3(1), dim3(128), 0, ctx->stream, invd, z);
+    return 0;
+  }
+  const int64_t n1 = split(n), n2 = n - n1;
+  GPX_TRY(trsv_bwd_rec(ctx, L + n1 * ld + n1, ld, invd + (n1 / NB) * NB * NB, z + n1, n2, tmp, part));
+  // z1 -= L21^T z2 : deterministic column reduction of the (n2 x n1) block against z2
+  GPX_TRY(launch_colreduce(ctx, L + n1 * ld, ld, n2, n1, z + n1, tmp, part));
+  hipLaunchKernelGGL(vec_sub_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, ctx->stream, z, tmp, n1);
+  return trsv_bwd_rec(ctx, L, ld, invd, z, n1, tmp, part);
+}
+
+int chol_trsv(gpx_ctx* ctx, const double* L, int64_t ld, const double* invd, double* y, int64_t n, bool transposed) {
+  GPX_ARG(n % NB == 0 && n > 0, "trsv: padded length must be a positive multiple of 128");
+  GPX_ARG(ld % 2 == 0, "trsv: leading dimension must be even");
+  ProfScope ps(ctx, GPX_PROF_TRSV, (double)n * n, 4.0 * (double)n * n);
+  int r = 0;
+  if (!transposed) {
+    r = trsv_fwd_rec(ctx, L, ld, invd, y, n);
+  } else {
+    void *ptmp, *ppart;
+    const int64_t bt = n * 8, bp = colreduce_partial_elems(n, n) * 8 + 8;
+    GPX_TRY(gpx_dev_alloc(ctx, bt, &ptmp));
+    r = gpx_dev_alloc(ctx, bp, &ppart);
+    if (r == 0) {
+      r = trsv_bwd_rec(ctx, L, ld, invd, y, n, (double*)ptmp, (double*)ppart);
+      (void)hipStreamSynchronize(ctx->stream);
+      gpx_dev_release(ctx, ppart, bp);
+    }
+    gpx_dev_release(ctx, ptmp, bt);
+  }
+  if (r != 0) return r;
   GPX_HIP(hipGetLastError());
   return 0;
 }
