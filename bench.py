@@ -103,7 +103,17 @@ def main():
 
     if world > 1 or os.environ.get("GPX_FORCE_DIST") == "1":  # GPX_FORCE_DIST: rehearse the RCCL runner on one GPU
         from gpexp_amd import dist
-        comm = dist.init_from_env(ctx)
+        # RCCL prints its version banner on stdout during init; the contract is ONE JSON line on stdout, so point fd 1 at
+        # stderr while the communicator comes up
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            comm = dist.init_from_env(ctx)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         runner = dist.DistFitIvar(ctx, comm, spec, Xh, yh, Zh, noise, nb=int(os.environ.get("GPX_DIST_NB", "512")))
         step = runner.step
         barrier = comm.barrier
@@ -112,14 +122,22 @@ def main():
         X = dev.points(ctx, Xh)
         Z = dev.points(ctx, Zh)
         K = dev.DeviceMatrix.zeros(ctx, N, N)   # allocated once; refilled in place every step
+        y_dev = dev.padded_vector(ctx, yh)
+        alpha_dev = dev.padded_vector(ctx, np.zeros(N))
 
         def step():
             dev.kfill_into(ctx, spec, X, K, nugget=noise)
             dev.potrf(ctx, K)
-            alpha = dev.potrs(ctx, K, yh)
-            logdet = dev.logdet(ctx, K)
-            ll = -0.5 * float(yh @ alpha) - 0.5 * logdet - N / 2.0 * np.log(2 * np.pi)
+            # alpha = K^-1 y is ~1300 latency-bound micro-launches: enqueue it on the high-priority side stream so that it
+            # runs underneath the IVAR GEMMs (both only read L); the results are collected after the device-wide sync
+            ctx.stream(1)
+            dev.potrs_dev(ctx, K, y_dev, alpha_dev)
+            ctx.stream(0)
             iv = abs(dev.ivar(ctx, spec, K, X, Z))
+            logdet = dev.logdet(ctx, K)
+            ctx.sync()
+            alpha = alpha_dev.to_host()[:N, 0]
+            ll = -0.5 * float(yh @ alpha) - 0.5 * logdet - N / 2.0 * np.log(2 * np.pi)
             return ll, iv
 
         def barrier():

@@ -37,6 +37,7 @@ _SIGS = {
     "gpx_kernel_eval": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_dp, c_i64, c_dp, c_i64, c_dp]),
     "gpx_potrf": (C.c_int, [c_vp, c_vp]),
     "gpx_potrs": (C.c_int, [c_vp, c_vp, c_dp, c_dp]),
+    "gpx_potrs_dev": (C.c_int, [c_vp, c_vp, c_vp, c_vp]),
     "gpx_logdet": (C.c_int, [c_vp, c_vp, c_dp]),
     "gpx_potri": (C.c_int, [c_vp, c_vp, C.POINTER(c_vp)]),
     "gpx_posterior": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_dp, c_vp, c_dp, c_dp]),

@@ -196,6 +196,8 @@ int gpx_create(int device, gpx_ctx** out) {
   GPX_HIP(hipMemset(c->d_info, 0, 256));
   GPX_HIP(hipMalloc((void**)&c->d_counters, GPX_COUNTER_SLOTS * 8 * sizeof(int)));
   c->counter_slot = 0;
+  c->trsv_scratch = nullptr;
+  c->trsv_scratch_bytes = 0;
   *out = c;
   return 0;
 }
@@ -219,6 +221,7 @@ int gpx_destroy(gpx_ctx* ctx) {
   (void)hipFree(ctx->d_info);
   (void)hipFree(ctx->d_scal);
   (void)hipFree(ctx->d_counters);
+  if (ctx->trsv_scratch) (void)hipFree(ctx->trsv_scratch);
   for (auto ev : ctx->sync_events) (void)hipEventDestroy(ev);
   for (int i = 0; i < 3; ++i) (void)hipStreamDestroy(ctx->streams[i]);
   delete ctx;
@@ -460,6 +463,28 @@ int gpx_potrs(gpx_ctx* ctx, const gpx_mat* L, const double* y, double* alpha) {
   gpx_dev_release(ctx, dv, np * 8);
   if (r == -2) gpx_set_error("potrs: HIP copy failed");
   return r;
+}
+
+// device-vector form, asynchronous on the selected stream: alpha (>= padded N doubles) <- K^-1 y
+int gpx_potrs_dev(gpx_ctx* ctx, const gpx_mat* L, const gpx_mat* y, gpx_mat* alpha) {
+  GPX_ARG(ctx && y && alpha, "NULL argument");
+  GPX_TRY(need_factor(L));
+  const int64_t np = L->prows;
+  GPX_ARG(y->bytes >= np * 8 && alpha->bytes >= np * 8, "y / alpha must hold the padded length (zero padded)");
+  const int64_t need = chol_trsv_scratch_bytes(np);
+  if (ctx->trsv_scratch_bytes < need) {
+    GPX_HIP(hipDeviceSynchronize());  // the old scratch may still be in use on another stream
+    if (ctx->trsv_scratch) (void)hipFree(ctx->trsv_scratch);
+    ctx->trsv_scratch = nullptr;
+    ctx->trsv_scratch_bytes = 0;
+    GPX_HIP(hipMalloc((void**)&ctx->trsv_scratch, (size_t)need));
+    ctx->trsv_scratch_bytes = need;
+  }
+  if (alpha->p != y->p)
+    GPX_HIP(hipMemcpyAsync(alpha->p, y->p, (size_t)np * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  GPX_TRY(chol_trsv_with_scratch(ctx, L->p, L->ld, L->aux, alpha->p, np, false, nullptr));
+  GPX_TRY(chol_trsv_with_scratch(ctx, L->p, L->ld, L->aux, alpha->p, np, true, ctx->trsv_scratch));
+  return 0;
 }
 
 int gpx_logdet(gpx_ctx* ctx, const gpx_mat* L, double* out) {

@@ -340,28 +340,29 @@ static int trsv_bwd_rec(gpx_ctx* ctx, const double* L, int64_t ld, const double*
   return trsv_bwd_rec(ctx, L, ld, invd, z, n1, tmp, part);
 }
 
-int chol_trsv(gpx_ctx* ctx, const double* L, int64_t ld, const double* invd, double* y, int64_t n, bool transposed) {
+int64_t chol_trsv_scratch_bytes(int64_t n) { return n * 8 + colreduce_partial_elems(n, n) * 8 + 64; }
+
+// asynchronous on the selected stream; scratch (chol_trsv_scratch_bytes) is only used by the transposed sweep
+int chol_trsv_with_scratch(gpx_ctx* ctx, const double* L, int64_t ld, const double* invd, double* y, int64_t n,
+                           bool transposed, double* scratch) {
   GPX_ARG(n % NB == 0 && n > 0, "trsv: padded length must be a positive multiple of 128");
   GPX_ARG(ld % 2 == 0, "trsv: leading dimension must be even");
   ProfScope ps(ctx, GPX_PROF_TRSV, (double)n * n, 4.0 * (double)n * n);
-  int r = 0;
-  if (!transposed) {
-    r = trsv_fwd_rec(ctx, L, ld, invd, y, n);
-  } else {
-    void *ptmp, *ppart;
-    const int64_t bt = n * 8, bp = colreduce_partial_elems(n, n) * 8 + 8;
-    GPX_TRY(gpx_dev_alloc(ctx, bt, &ptmp));
-    r = gpx_dev_alloc(ctx, bp, &ppart);
-    if (r == 0) {
-      r = trsv_bwd_rec(ctx, L, ld, invd, y, n, (double*)ptmp, (double*)ppart);
-      (void)hipStreamSynchronize(ctx->stream);
-      gpx_dev_release(ctx, ppart, bp);
-    }
-    gpx_dev_release(ctx, ptmp, bt);
-  }
+  int r = transposed ? trsv_bwd_rec(ctx, L, ld, invd, y, n, scratch, scratch + n) : trsv_fwd_rec(ctx, L, ld, invd, y, n);
   if (r != 0) return r;
   GPX_HIP(hipGetLastError());
   return 0;
+}
+
+int chol_trsv(gpx_ctx* ctx, const double* L, int64_t ld, const double* invd, double* y, int64_t n, bool transposed) {
+  if (!transposed) return chol_trsv_with_scratch(ctx, L, ld, invd, y, n, false, nullptr);
+  void* p;
+  const int64_t b = chol_trsv_scratch_bytes(n);
+  GPX_TRY(gpx_dev_alloc(ctx, b, &p));
+  int r = chol_trsv_with_scratch(ctx, L, ld, invd, y, n, true, (double*)p);
+  (void)hipStreamSynchronize(ctx->stream);
+  gpx_dev_release(ctx, p, b);
+  return r;
 }
 
 int launch_logdet(gpx_ctx* ctx, const double* L, int64_t ld, int64_t n, double* d_out) {

@@ -87,6 +87,8 @@ struct gpx_ctx {
   int* d_info;      // first failing pivot (1-based), 0 = ok
   double* d_scal;   // small scalar workspace (>= 64 doubles)
   int* d_counters;  // GPX_COUNTER_SLOTS x 8 work counters (persistent GEMM)
+  double* trsv_scratch;      // grown on demand, kept until gpx_destroy (lets gpx_potrs_dev stay asynchronous)
+  int64_t trsv_scratch_bytes;
   unsigned counter_slot;
   // multi-GPU (RCCL communicator, opaque here; see dist.hip)
   void* comm;
@@ -141,6 +143,10 @@ int chol_trsm_right(gpx_ctx* ctx, const double* L, int64_t ldl, const double* in
 int chol_trsm_left(gpx_ctx* ctx, const double* L, int64_t ldl, const double* invd, double* B, int64_t ldb,
                    int64_t n, int64_t m);
 int chol_trsv(gpx_ctx* ctx, const double* L, int64_t ld, const double* invd, double* y, int64_t n, bool transposed);
+// bytes of scratch chol_trsv needs for the transposed sweep of order n
+int64_t chol_trsv_scratch_bytes(int64_t n);
+int chol_trsv_with_scratch(gpx_ctx* ctx, const double* L, int64_t ld, const double* invd, double* y, int64_t n,
+                           bool transposed, double* scratch);
 int launch_logdet(gpx_ctx* ctx, const double* L, int64_t ld, int64_t n, double* d_out);
 
 // reduce.hip

@@ -47,6 +47,16 @@ class Context:
         check(self.lib.gpx_device_info(self.h, name, 256, C.byref(cus), C.byref(mem), C.byref(clk)))
         return dict(name=name.value.decode(), cus=cus.value, hbm_bytes=mem.value, clock_mhz=clk.value)
 
+    # ---- streams / events (0 main, 1 side high-priority, 2 communication) ----
+    def stream(self, which):
+        check(self.lib.gpx_stream_select(self.h, int(which)))
+
+    def record(self, ev):
+        check(self.lib.gpx_event_record(self.h, int(ev)))
+
+    def wait(self, ev):
+        check(self.lib.gpx_event_wait(self.h, int(ev)))
+
     # ---- profiling ----
     def profile(self, on):
         check(self.lib.gpx_profile_enable(self.h, 1 if on else 0))
@@ -194,6 +204,20 @@ def potrs(ctx, L, y):
     out = np.empty_like(y)
     check(ctx.lib.gpx_potrs(ctx.h, L.h, dptr(y), dptr(out)))
     return out
+
+
+def padded_vector(ctx, v, n_padded=None):
+    """Upload a vector as an (n_padded x 1) device matrix, zero padded to a multiple of 128."""
+    v = as_f64(np.ravel(v))
+    npad = n_padded or (max(v.size, 1) + 127) // 128 * 128
+    buf = np.zeros(npad)
+    buf[:v.size] = v
+    return DeviceMatrix.from_host(ctx, buf.reshape(-1, 1), pad=False)
+
+
+def potrs_dev(ctx, L, y_dev, alpha_dev):
+    """alpha_dev <- K^-1 y_dev, asynchronous on the currently selected stream (see Context.stream)."""
+    check(ctx.lib.gpx_potrs_dev(ctx.h, L.h, y_dev.h, alpha_dev.h))
 
 
 def logdet(ctx, L):

@@ -358,6 +358,8 @@ class DistFitIvar:
         self.Zloc = _dev.points(ctx, Zh[lo:hi]) if hi > lo else None
         self.K = self.ops.alloc_matrix(self.n)
         self.P = [self.ops.alloc_panel(self.n, self.nb), self.ops.alloc_panel(self.n, self.nb)]
+        self.y_dev = _dev.padded_vector(ctx, self.yh)
+        self.alpha_dev = _dev.padded_vector(ctx, np.zeros(self.n))
 
     def step(self):
         ctx, comm = self.ctx, self.comm
@@ -366,12 +368,21 @@ class DistFitIvar:
         if info:
             from ._lib import NotPositiveDefinite
             raise NotPositiveDefinite(info)
-        alpha = _dev.potrs(ctx, self.K, self.yh)          # every rank holds L: no exchange
-        logdet = _dev.logdet(ctx, self.K)
-        ll = -0.5 * float(self.yh @ alpha) - 0.5 * logdet - self.n / 2.0 * np.log(2 * np.pi)
+        # every rank holds L: alpha / logdet need no exchange.  The sweeps are latency-bound micro-launches: rank 0 runs
+        # them on the side stream underneath its slice of the evaluation GEMMs; the other ranks skip them.
+        if comm.rank == 0:
+            ctx.stream(PANEL)
+            _dev.potrs_dev(ctx, self.K, self.y_dev, self.alpha_dev)
+            ctx.stream(MAIN)
         part = 0.0
         if self.Zloc is not None:
             _, var = _dev.posterior(ctx, self.spec, self.K, self.X, None, self.Zloc, want_mean=False)
             part = float(np.sum(var))
+        ll = 0.0
+        if comm.rank == 0:
+            logdet = _dev.logdet(ctx, self.K)
+            ctx.sync()
+            alpha = self.alpha_dev.to_host()[:self.n, 0]
+            ll = -0.5 * float(self.yh @ alpha) - 0.5 * logdet - self.n / 2.0 * np.log(2 * np.pi)
         iv = abs(ordered_sum(comm.allgather(np.array([part]))[:, 0]) / self.m)
         return ll, iv

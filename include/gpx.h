@@ -108,6 +108,9 @@ int gpx_kernel_eval(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp,
 int gpx_potrf(gpx_ctx* ctx, gpx_mat* K);
 /* alpha = K^{-1} y from the factor; y, alpha host (N)                 gp.py:101, 435 */
 int gpx_potrs(gpx_ctx* ctx, const gpx_mat* L, const double* y, double* alpha);
+/* the same on device vectors (y, alpha: at least padded-N doubles, zero padded), ASYNCHRONOUS on the selected
+ * stream -- lets the latency-bound sweeps run on the side stream underneath the evaluation GEMMs */
+int gpx_potrs_dev(gpx_ctx* ctx, const gpx_mat* L, const gpx_mat* y, gpx_mat* alpha);
 /* log det K = 2 sum log L_ii                                          gp.py:434 (slogdet) */
 int gpx_logdet(gpx_ctx* ctx, const gpx_mat* L, double* out);
 /* explicit inverse (lower triangle valid) for the lazy precisionMatrix attribute and lml_grad */

@@ -195,7 +195,8 @@ def run_gpu(args):
     ll1 = -0.5 * float(yh @ alpha) - 0.5 * dev.logdet(ctx, K1) - N / 2.0 * np.log(2 * np.pi)
     iv1 = abs(dev.ivar(ctx, spec, K1, X, dev.points(ctx, Zh)))
     assert errL < 1e-12, errL
-    assert abs(ll - ll1) <= 1e-11 * abs(ll1), (ll, ll1)
+    if comm.rank == 0:  # the log-likelihood is produced on rank 0 only (its sweeps hide under rank 0's evaluation slice)
+        assert abs(ll - ll1) <= 1e-11 * abs(ll1), (ll, ll1)
     assert abs(iv - iv1) <= 1e-11 * abs(iv1), (iv, iv1)
     errs = comm.allgather(np.array([errL]))[:, 0]
     comm.barrier()
