@@ -6,8 +6,10 @@
 //
 // HBM-bound by intent: algorithmic bytes = 8*rows*cols written + 8*(rows+cols)*d read.  What it takes to get
 // there in fp64 (no hardware exp/sqrt):
-//   * 64x64 tiles; point coordinates staged once per tile into LDS pre-multiplied by the length scale; each thread
-//     keeps its two B points in registers, A points are LDS broadcasts; 16-byte stores forming 512-byte row segments.
+//   * 64x64 tiles; point coordinates staged once per tile into LDS pre-multiplied by the length scale.  The Gram
+//     term of the distance, a.b, is a K=d GEMM and runs on the fp64 MFMA pipe (|a-b|^2 = |a|^2 + |b|^2 - 2 a.b);
+//     the VALU -- measured at ~5.4 cycles per wave64 fp64 FMA, the binding resource of the all-VALU version (71
+//     instructions per element) -- only evaluates the kernel function.  Diagonal entries keep an exact zero distance.
 //   * symmetric fill: only tiles on/below the diagonal are COMPUTED; each is also written transposed through a
 //     padded LDS image (coalesced mirror stores) -- half the exp/sqrt work for the same 8*N^2 bytes.
 //   * exp: one rndne + two-constant Cody-Waite reduction + degree-13 polynomial + v_ldexp (about 20 fp64
@@ -15,6 +17,7 @@
 //     Newton steps + residual correction.  Both stay within 2 ulp (tests: 1e-13 against the oracle / the reference).
 #include "gpx_internal.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -44,7 +47,10 @@ __device__ __forceinline__ double fast_exp(double x) {
   return ldexp(p, (int)n);
 }
 
-__device__ __forceinline__ double fast_sqrt(double x) {  // x >= 0, not subnormal (squared scaled distances)
+__device__ __forceinline__ double fast_sqrt(double xin) {  // xin >= 0 (squared scaled distances)
+  // coincident points give exactly 0: clamp instead of a compare + two selects; sqrt(1e-300) = 1e-150 leaves every
+  // kernel value bit-identical to the r = 0 result (1 + 1e-150 == 1, exp(-1e-150) == 1)
+  const double x = fmax(xin, 1e-300);
   const double y = __builtin_amdgcn_rsq(x);
   double g = x * y, h = 0.5 * y;
   double e = fma(-h, g, 0.5);
@@ -54,8 +60,7 @@ __device__ __forceinline__ double fast_sqrt(double x) {  // x >= 0, not subnorma
   g = fma(g, e, g);
   h = fma(h, e, h);
   const double d = fma(-g, g, x);
-  g = fma(d, h, g);
-  return x > 0.0 ? g : 0.0;
+  return fma(d, h, g);
 }
 
 template <int KIND>
@@ -73,16 +78,20 @@ __device__ __forceinline__ double kvalue(double acc, double sig) {
   }
 }
 
-// stage one tile of points into LDS: P[p][k] = X[g0+p][k] * s_k  (+ Mehler norm in slot d)
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// Stage one 64-point tile into LDS for the MFMA Gram product: P[p][k] = coordinate k of point p times its scale
+// (Mehler: times c2 on the A side), zero for k >= d (K is padded to a multiple of 4), and nrm[p] = the point's own
+// term of the exponent (sum of squared scaled coordinates, or sum c1 x^2 for Mehler).
 template <int KIND, bool SIDE_A>
-__device__ __forceinline__ void stage_points(const KParams& kp, int d, int dp, const double* __restrict__ X,
-                                             int64_t n, int64_t g0, double* P) {
+__device__ __forceinline__ void stage_points(const KParams& kp, int d, int dpad, int sl, const double* __restrict__ X,
+                                             int64_t n, int64_t g0, double* P, double* nrm) {
   const int t = threadIdx.x;
-  for (int idx = t; idx < TM * d; idx += 256) {
-    int p = idx / d, k = idx - p * d;
-    int64_t g = g0 + p;
+  for (int idx = t; idx < TM * dpad; idx += 256) {
+    const int p = idx / dpad, k = idx - p * dpad;
+    const int64_t g = g0 + p;
     double v = 0.0;
-    if (g < n) {
+    if (g < n && k < d) {
       v = X[g * d + k];
       if (KIND == GPX_K_MEHLER) {
         if (SIDE_A) v *= kp.c2[k];
@@ -90,34 +99,45 @@ __device__ __forceinline__ void stage_points(const KParams& kp, int d, int dp, c
         v *= kp.scale[k];
       }
     }
-    P[p * dp + k] = v;
+    P[p * sl + k] = v;
   }
-  if (KIND == GPX_K_MEHLER) {
-    if (t < TM) {
-      int64_t g = g0 + t;
-      double s = 0.0;
-      if (g < n)
-        for (int k = 0; k < d; ++k) {
-          double v = X[g * d + k];
+  if (t < TM) {
+    const int64_t g = g0 + t;
+    double s = 0.0;
+    if (g < n)
+      for (int k = 0; k < d; ++k) {
+        const double v = X[g * d + k];
+        if (KIND == GPX_K_MEHLER) {
           s = fma(kp.c1[k] * v, v, s);
+        } else {
+          const double w = v * kp.scale[k];
+          s = fma(w, w, s);
         }
-      P[t * dp + d] = s;
-    }
+      }
+    nrm[t] = s;
   }
 }
 
+// 64x64 tile per 256-thread workgroup; wave (wm, wn) owns a 32x32 quadrant = 2x2 fp64 MFMA 16x16 blocks.
+// The Gram term c = a.b comes from v_mfma_f64_16x16x4_f64 (the matrix pipe is otherwise idle here and co-issues with
+// the VALU); the exponent argument is |a|^2 + |b|^2 - 2c (SE / Matern) or pa + pb - c (Mehler).  MFMA column q of
+// block ni is mapped to tile column 2q+ni, so a lane's two blocks are ADJACENT columns: 16-byte stores, 256-byte row
+// segments per 16-lane group.
 // SYM: 1-D grid over the tiles on/below the diagonal, mirror-written; otherwise 2-D grid over all tiles.
-template <int KIND, int DT, bool SYM>
+template <int KIND, bool SYM>
 __global__ __launch_bounds__(256) void kfill_kernel(KParams kp, const double* __restrict__ A, int64_t na,
                                                     const double* __restrict__ B, int64_t nb, int symmetric,
                                                     const double* __restrict__ nugget, int64_t nugget_len,
                                                     double nugget_scalar, double* __restrict__ out, int64_t ld) {
   extern __shared__ double sm[];
-  const int d = DT > 0 ? DT : kp.d;
-  const int dp = d + (KIND == GPX_K_MEHLER ? 1 : 0);
+  const int d = kp.d;
+  const int dpad = (d + 3) & ~3;
+  const int sl = dpad + 1;  // odd stride
   double* As = sm;
-  double* Bs = sm + TM * dp;
-  double* Tr = Bs + TN * dp;  // [32][TP] transpose image (SYM only)
+  double* Bs = As + TM * sl;
+  double* pa = Bs + TN * sl;
+  double* pb = pa + TM;
+  double* Tr = pb + TN;  // [32][TP] transpose image (SYM only)
   int ti, tj;
   if (SYM) {
     const int w = blockIdx.x;
@@ -130,98 +150,93 @@ __global__ __launch_bounds__(256) void kfill_kernel(KParams kp, const double* __
     tj = blockIdx.x;
   }
   const int64_t i0 = (int64_t)ti * TM, j0 = (int64_t)tj * TN;
-  stage_points<KIND, true>(kp, d, dp, A, na, i0, As);
-  stage_points<KIND, false>(kp, d, dp, B, nb, j0, Bs);
+  stage_points<KIND, true>(kp, d, dpad, sl, A, na, i0, As, pa);
+  stage_points<KIND, false>(kp, d, dpad, sl, B, nb, j0, Bs, pb);
   __syncthreads();
 
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int c0 = 2 * tx;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int g = lane >> 4, q = lane & 15;
+
+  d4 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
+  const double* ap = As + (wm * 32 + q) * sl + g;           // A[row = mi*16 + q][k = 4s + g]
+  const double* bp = Bs + (wn * 32 + 2 * q) * sl + g;       // B[col = 2q + ni][k = 4s + g]
+  for (int ks = 0; ks < dpad; ks += 4) {
+    const double a0 = ap[ks], a1 = ap[16 * sl + ks];
+    const double b0 = bp[ks], b1 = bp[sl + ks];
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+  }
+
+  // this lane's elements: rows r(mi, v) = wm*32 + mi*16 + g + 4v, columns c0, c0+1 with c0 = wn*32 + 2q
+  const int c0 = wn * 32 + 2 * q;
+  const double pb0 = pb[c0], pb1 = pb[c0 + 1];
   const double sig = kp.sig;
   const int64_t gj0 = j0 + c0, gj1 = gj0 + 1;
-
-  constexpr int DD = DT > 0 ? DT : 1;
-  double b0[DD], b1[DD];
-  double pb0 = 0.0, pb1 = 0.0;
-  if (DT > 0) {
+  // interior tile: fully inside both point sets and (for the symmetric forms) not touching the diagonal
+  const bool interior = (i0 + TM <= na) && (j0 + TN <= nb) && (!symmetric || (i0 + TM <= j0) || (j0 + TN <= i0));
+  double2 val[2][4];
 #pragma unroll
-    for (int k = 0; k < DD; ++k) {
-      b0[k] = Bs[c0 * dp + k];
-      b1[k] = Bs[(c0 + 1) * dp + k];
-    }
-  }
-  if (KIND == GPX_K_MEHLER) {
-    pb0 = Bs[c0 * dp + d];
-    pb1 = Bs[(c0 + 1) * dp + d];
-  }
-
-  double2 val[TM / 8];  // this thread's 8 rows x 2 columns
+  for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-  for (int a = 0; a < TM / 8; ++a) {
-    const int r = ty + 8 * a;
-    double s0 = 0.0, s1 = 0.0;
-    if (DT > 0) {
-#pragma unroll
-      for (int k = 0; k < DD; ++k) {
-        const double av = As[r * dp + k];
-        if (KIND == GPX_K_MEHLER) {
-          s0 = fma(av, b0[k], s0);
-          s1 = fma(av, b1[k], s1);
-        } else {
-          const double e0 = av - b0[k], e1 = av - b1[k];
-          s0 = fma(e0, e0, s0);
-          s1 = fma(e1, e1, s1);
+    for (int v = 0; v < 4; ++v) {
+      const int r = wm * 32 + mi * 16 + g + 4 * v;
+      const double par = pa[r];
+      double s0, s1;
+      if (KIND == GPX_K_MEHLER) {
+        s0 = par + pb0 - acc[mi][0][v];
+        s1 = par + pb1 - acc[mi][1][v];
+      } else {  // squared scaled distance; tiny negative round-off is clamped
+        s0 = fmax(fma(-2.0, acc[mi][0][v], par + pb0), 0.0);
+        s1 = fmax(fma(-2.0, acc[mi][1][v], par + pb1), 0.0);
+      }
+      const int64_t gi = i0 + r;
+      if (!interior && symmetric && KIND != GPX_K_MEHLER) {  // exact zero distance on the diagonal, as the reference has it
+        if (gi == gj0) s0 = 0.0;
+        if (gi == gj1) s1 = 0.0;
+      }
+      double v0 = kvalue<KIND>(s0, sig), v1 = kvalue<KIND>(s1, sig);
+      if (!interior) {  // wave-uniform: only edge tiles (padding) and tiles crossing the diagonal (nugget) pay for this
+        const bool rin = gi < na;
+        if (!(rin && gj0 < nb)) v0 = (symmetric && gi == gj0) ? 1.0 : 0.0;
+        if (!(rin && gj1 < nb)) v1 = (symmetric && gi == gj1) ? 1.0 : 0.0;
+        if (symmetric && rin && nugget_len > 0) {
+          const double nz = nugget_len == 1 ? nugget_scalar : nugget[gi];
+          if (gi == gj0) v0 += nz;
+          if (gi == gj1) v1 += nz;
         }
       }
-    } else {
-      for (int k = 0; k < d; ++k) {
-        const double av = As[r * dp + k];
-        const double bv0 = Bs[c0 * dp + k], bv1 = Bs[(c0 + 1) * dp + k];
-        if (KIND == GPX_K_MEHLER) {
-          s0 = fma(av, bv0, s0);
-          s1 = fma(av, bv1, s1);
-        } else {
-          const double e0 = av - bv0, e1 = av - bv1;
-          s0 = fma(e0, e0, s0);
-          s1 = fma(e1, e1, s1);
-        }
-      }
+      val[mi][v].x = v0;
+      val[mi][v].y = v1;
+      *reinterpret_cast<double2*>(out + gi * ld + gj0) = val[mi][v];
     }
-    if (KIND == GPX_K_MEHLER) {
-      const double pa = As[r * dp + d];
-      s0 = pa + pb0 - s0;
-      s1 = pa + pb1 - s1;
-    }
-    const int64_t gi = i0 + r;
-    double v0 = kvalue<KIND>(s0, sig), v1 = kvalue<KIND>(s1, sig);
-    const bool rin = gi < na;
-    if (!(rin && gj0 < nb)) v0 = (symmetric && gi == gj0) ? 1.0 : 0.0;
-    if (!(rin && gj1 < nb)) v1 = (symmetric && gi == gj1) ? 1.0 : 0.0;
-    if (symmetric && rin && nugget_len > 0) {
-      const double nz = nugget_len == 1 ? nugget_scalar : nugget[gi];
-      if (gi == gj0) v0 += nz;
-      if (gi == gj1) v1 += nz;
-    }
-    val[a].x = v0;
-    val[a].y = v1;
-    *reinterpret_cast<double2*>(out + gi * ld + gj0) = val[a];
-  }
 
   if (SYM && ti != tj) {
-    // mirror: out[j0 + c][i0 + r] = V[r][c], two passes of 32 tile rows through the padded image
+    // mirror: out[j0 + c][i0 + r] = V[r][c]; the two row halves (wm = 0 / 1) go through the padded image in turn
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       __syncthreads();
+      if (wm == half) {
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {  // rows r = ty + 8*(4*half + a)  ->  image row ty + 8a
-        Tr[(ty + 8 * a) * TP + c0] = val[4 * half + a].x;
-        Tr[(ty + 8 * a) * TP + c0 + 1] = val[4 * half + a].y;
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int rl = mi * 16 + g + 4 * v;  // row inside the half
+            Tr[rl * TP + c0] = val[mi][v].x;
+            Tr[rl * TP + c0 + 1] = val[mi][v].y;
+          }
       }
       __syncthreads();
-      // thread (tx, ty): transposed rows c = ty + 8q (q = 0..7), columns r = 32*half + tx  -> 32 lanes x 8 B = 256 B
-      // segments; two 32-lane groups of a wave cover two different rows
+      const int tx = t & 31, ty = t >> 5;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int c = ty + 8 * q;
+      for (int qq = 0; qq < 8; ++qq) {
+        const int c = ty + 8 * qq;
         out[(j0 + c) * ld + i0 + 32 * half + tx] = Tr[tx * TP + c];
       }
     }
@@ -255,21 +270,10 @@ int launch_kind(gpx_ctx* ctx, const KParams& kp, const double* A, int64_t na, co
   } else {
     grid = dim3((unsigned)(pcols / TN), (unsigned)(prows / TM));
   }
-  const int dp = kp.d + (KIND == GPX_K_MEHLER ? 1 : 0);
-  size_t sh = (size_t)(2 * TM * dp + (SYM ? 32 * TP : 0)) * sizeof(double);
-#define GPX_KF(DT)                                                                                             \
-  hipLaunchKernelGGL((kfill_kernel<KIND, DT, SYM>), grid, dim3(256), sh, ctx->stream, kp, A, na, B, nb, symmetric, \
-                     d_nugget, nugget_len, nugget_scalar, out, ld)
-  switch (kp.d) {
-    case 1: GPX_KF(1); break;
-    case 2: GPX_KF(2); break;
-    case 3: GPX_KF(3); break;
-    case 4: GPX_KF(4); break;
-    case 8: GPX_KF(8); break;
-    case 10: GPX_KF(10); break;
-    default: GPX_KF(0); break;
-  }
-#undef GPX_KF
+  const int dpad = (kp.d + 3) & ~3;
+  const size_t sh = (size_t)(2 * TM * (dpad + 1) + 2 * TM + (SYM ? 32 * TP : 0)) * sizeof(double);
+  hipLaunchKernelGGL((kfill_kernel<KIND, SYM>), grid, dim3(256), sh, ctx->stream, kp, A, na, B, nb, symmetric, d_nugget,
+                     nugget_len, nugget_scalar, out, ld);
   GPX_HIP(hipGetLastError());
   return 0;
 }
