@@ -72,6 +72,8 @@ struct gpx_mat {
 struct ProfRec {
   hipEvent_t a, b;
   int cls;
+  hipStream_t stream;
+  bool open;
 };
 
 struct gpx_ctx {
