@@ -1,0 +1,130 @@
+"""GPU edge cases (-m gpu): maximum dimension, 1-D Mehler, per-point noise through loglikeParams(noiseIn=...),
+posterior covariance larger than one tile, ragged sizes around the 64/128 tile edges, heavy chunking, tiny problems."""
+import numpy as np
+import pytest
+
+from oracle import gpexp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=float)
+    b = np.asarray(b, dtype=float)
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from gpexp_amd import device
+    return device
+
+
+@pytest.fixture(scope="module")
+def ctx(dev):
+    return dev.context()
+
+
+def test_max_dimension_32(dev, ctx):
+    rng = np.random.default_rng(32)
+    d = 32
+    X = rng.uniform(-1, 1, (100, d))
+    Z = rng.uniform(-1, 1, (37, d))
+    for s, sp in [(dict(kind="se", cl=list(1.0 + 0.02 * np.arange(d)), signalSize=0.9, d=d),
+                   dev.KernelSpec(dev.K_SE, d, list(1.0 + 0.02 * np.arange(d)) + [0.9])),
+                  (dict(kind="mehler", t=list(0.1 + 0.01 * np.arange(d)), d=d),
+                   dev.KernelSpec(dev.K_MEHLER, d, list(0.1 + 0.01 * np.arange(d))))]:
+        K = dev.kfill(ctx, sp, dev.points(ctx, X), nugget=0.0).to_host()
+        assert rel(K, orc.cov_matrix(s, X, 0.0, row_loop=False)) <= 1e-12
+        Kxz = dev.kfill(ctx, sp, dev.points(ctx, X), Z=dev.points(ctx, Z)).to_host()
+        assert rel(Kxz, orc.cross_matrix(s, Z, X).T) <= 1e-12
+    with pytest.raises(Exception):
+        dev.kfill(ctx, dev.KernelSpec(dev.K_SE, 33, [1.0] * 34), dev.points(ctx, np.zeros((4, 33))))
+
+
+@pytest.mark.parametrize("n", [63, 64, 65, 127, 128, 129, 191, 257])
+def test_symmetric_fill_and_fit_at_tile_edges(dev, ctx, n):
+    """sizes straddling the 64-point fill tile and the 128 padding: K is exactly symmetric, diagonal exact, fit agrees"""
+    rng = np.random.default_rng(n)
+    X = rng.uniform(-1, 1, (n, 3))
+    s = dict(kind="matern52", rho=0.7, signalSize=1.3, d=3)
+    sp = dev.KernelSpec(dev.K_MATERN52, 3, [0.7, 1.3])
+    K = dev.kfill(ctx, sp, dev.points(ctx, X), nugget=0.05).to_host()
+    np.testing.assert_array_equal(K, K.T)                      # mirror-written tiles
+    np.testing.assert_array_equal(np.diag(K), np.full(n, 1.3 + 0.05))  # exact zero distance on the diagonal
+    assert rel(K, orc.cov_matrix(s, X, 0.05, row_loop=False)) <= 1e-13
+    y = rng.standard_normal(n)
+    L = dev.potrf(ctx, dev.kfill(ctx, sp, dev.points(ctx, X), nugget=0.05))
+    assert rel(dev.potrs(ctx, L, y), np.linalg.solve(orc.cov_matrix(s, X, 0.05, row_loop=False), y)) <= 1e-10
+
+
+def test_mehler_1d_kernel_class(golden):
+    from gpExp.kernels import KernelMehler1D, KernelMehlerND
+    rng = np.random.default_rng(1)
+    a, b = rng.uniform(-1, 1, (20, 1)), rng.uniform(-1, 1, (20, 1))
+    k1 = KernelMehler1D(0.4, 1)
+    want = orc.kernel_eval(dict(kind="mehler", t=[0.4], d=1), a, b)
+    assert rel(k1.evaluate(a, b), want) <= 1e-13
+    assert rel(KernelMehlerND([0.4], 1).evaluate(a, b[:1]), orc.kernel_eval(dict(kind="mehler", t=[0.4], d=1), a, b[:1])) <= 1e-13
+    with pytest.raises(AssertionError):
+        k1.evaluate(np.zeros((3, 2)), np.zeros((3, 2)))
+
+
+def test_loglike_with_per_point_noise():
+    """loglikeParams(noiseIn=array): broken in the reference (gp.py:429-430 passes an unknown keyword); implemented with the
+    per-point nugget semantics of calculateCovarianceMatrix (gp_kernel_utilities.py:64-65) and checked against the oracle."""
+    from gpExp.kernels import KernelSquaredExponential
+    from gpExp.gp import GP
+    rng = np.random.default_rng(7)
+    X = rng.uniform(-1, 1, (90, 2))
+    y = rng.standard_normal(90)
+    nz = 0.02 * (1 + rng.uniform(0, 1, 90))
+    g = GP(KernelSquaredExponential([0.4, 0.9], 2.0, 2), 0.5)
+    s = dict(kind="se", cl=[0.4, 0.9], signalSize=2.0, d=2)
+    assert g.loglikeParams(X, y, noiseIn=nz) == pytest.approx(orc.loglike(s, X, y, nz), rel=1e-10)
+    assert g.pts is None  # loglikeParams does not touch the trained state
+
+
+def test_posterior_cov_larger_than_a_tile(dev, ctx):
+    rng = np.random.default_rng(8)
+    s = dict(kind="se", cl=[0.5, 0.6, 0.7], signalSize=1.1, d=3)
+    sp = dev.KernelSpec(dev.K_SE, 3, [0.5, 0.6, 0.7, 1.1])
+    Xh, Zh = rng.uniform(-1, 1, (210, 3)), rng.uniform(-1, 1, (150, 3))
+    X = dev.points(ctx, Xh)
+    L = dev.potrf(ctx, dev.kfill(ctx, sp, X, nugget=0.05))
+    cov = dev.posterior_cov(ctx, sp, L, X, dev.points(ctx, Zh))
+    model = orc.fit(s, Xh, None, 0.05)
+    _, want = orc.posterior(s, model, Zh, compvar=2)
+    assert cov.shape == (150, 150) and rel(cov, want) <= 1e-10
+    _, var = dev.posterior(ctx, sp, L, X, None, dev.points(ctx, Zh), want_mean=False)
+    assert rel(np.diag(cov), var) <= 1e-12
+
+
+def test_many_small_chunks_and_tiny_training_set(dev, ctx, monkeypatch):
+    rng = np.random.default_rng(9)
+    s = dict(kind="matern32", rho=0.8, signalSize=1.0, d=2)
+    sp = dev.KernelSpec(dev.K_MATERN32, 2, [0.8, 1.0])
+    Xh = rng.uniform(-1, 1, (3, 2))      # 3 training points
+    y = rng.standard_normal(3)
+    Zh = rng.uniform(-1, 1, (1000, 2))
+    X, Z = dev.points(ctx, Xh), dev.points(ctx, Zh)
+    L = dev.potrf(ctx, dev.kfill(ctx, sp, X, nugget=0.01))
+    alpha = dev.potrs(ctx, L, y)
+    monkeypatch.setenv("GPX_CROSS_BYTES", "1")  # smallest possible chunk: 128 evaluation points at a time (8 chunks)
+    m, v = dev.posterior(ctx, sp, L, X, alpha, Z)
+    model = orc.fit(s, Xh, y, 0.01)
+    mo, vo = orc.posterior(s, model, Zh)
+    assert rel(m, mo) <= 1e-10 and rel(v, vo) <= 1e-10
+    iv = dev.ivar(ctx, sp, L, X, Z)
+    assert iv == pytest.approx(vo.mean(), rel=1e-10)
+    best, costs = dev.greedy_ivar_step(ctx, sp, L, X, dev.points(ctx, Zh[:300]), dev.points(ctx, Zh[300:]), 0.01)
+    want = [orc.ivar(s, np.vstack((Xh, Zh[j:j + 1])), Zh[300:], 0.01) for j in range(0, 300, 37)]
+    assert rel(costs[0:300:37], want) <= 1e-10
+
+
+def test_single_candidate_and_single_selection(dev, ctx):
+    sp = dev.KernelSpec(dev.K_SE, 1, [0.3, 1.0])
+    C = dev.points(ctx, np.array([[0.25]]))
+    assert list(dev.greedy_var(ctx, sp, C, 1)) == [0]
+    idx, ratios = dev.mi_greedy(ctx, sp, dev.points(ctx, np.array([[0.1], [0.5], [-0.7]])), 0.1, 1, 2)
+    assert list(idx) == [2] and ratios.size == 0
