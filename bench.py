@@ -93,7 +93,8 @@ def main():
         args.gpus = world
 
     from gpexp_amd import device as dev
-    ctx = dev.Context(local_rank)
+    # GPX_FORCE_DEVICE: rehearsal of the multi-rank flow on a box with fewer GPUs than ranks (with GPX_COMM=host)
+    ctx = dev.Context(int(os.environ.get("GPX_FORCE_DEVICE", local_rank)))
     dev._ctx = ctx
     info = ctx.info()
 

@@ -25,26 +25,23 @@ constexpr int TM = 64;  // tile rows
 constexpr int TN = 64;  // tile cols
 constexpr int TP = TN + 1;  // padded stride of the transpose image
 
-__device__ __forceinline__ double fast_exp(double x) {
-  // exp(x) = 2^n * exp(r), n = rint(x/ln2), |r| <= ln2/2; Taylor to r^13 (truncation 4e-18 relative)
-  const double n = rint(x * 1.4426950408889634074);
-  double r = fma(n, -6.93147180369123816490e-01, x);
-  r = fma(n, -1.90821492927058770002e-10, r);
-  double p = 1.6059043836821614599e-10;             // 1/13!
-  p = fma(p, r, 2.0876756987868098979e-09);          // 1/12!
-  p = fma(p, r, 2.5052108385441718775e-08);          // 1/11!
-  p = fma(p, r, 2.7557319223985890653e-07);          // 1/10!
-  p = fma(p, r, 2.7557319223985892511e-06);          // 1/9!
-  p = fma(p, r, 2.4801587301587301566e-05);          // 1/8!
-  p = fma(p, r, 1.9841269841269841253e-04);          // 1/7!
-  p = fma(p, r, 1.3888888888888889419e-03);          // 1/6!
-  p = fma(p, r, 8.3333333333333332177e-03);          // 1/5!
-  p = fma(p, r, 4.1666666666666664354e-02);          // 1/4!
-  p = fma(p, r, 1.6666666666666665741e-01);          // 1/3!
+// exp(x) = 2^n * 2^(j/32) * exp(r):  m = rint(x * 32/ln2), n = m >> 5, j = m & 31, r = x - m*ln2/32 (two-constant
+// Cody-Waite), |r| <= ln2/64, so a degree-6 polynomial is exact to 3.5e-18; tab[j] = 2^(j/32) sits in LDS (32 entries
+// = 32 distinct bank pairs: gathers are conflict-free).  11 fp64 ops + 5 integer ops instead of 19 fp64 ops.
+__device__ __forceinline__ double fast_exp(double x, const double* __restrict__ tab) {
+  const double m = rint(x * 46.166241308446828384);           // 32 / ln 2
+  double r = fma(m, -2.16608493865351192653e-02, x);          // ln2/32, high part
+  r = fma(m, -5.96317165397058692545e-12, r);                 // ln2/32, low part
+  const int mi = (int)m;
+  const double tj = tab[mi & 31];
+  double p = 1.3888888888888889419e-03;                       // 1/720
+  p = fma(p, r, 8.3333333333333332177e-03);                   // 1/120
+  p = fma(p, r, 4.1666666666666664354e-02);                   // 1/24
+  p = fma(p, r, 1.6666666666666665741e-01);                   // 1/6
   p = fma(p, r, 0.5);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
-  return ldexp(p, (int)n);
+  return ldexp(tj * p, mi >> 5);
 }
 
 __device__ __forceinline__ double fast_sqrt(double xin) {  // xin >= 0 (squared scaled distances)
@@ -64,19 +61,29 @@ __device__ __forceinline__ double fast_sqrt(double xin) {  // xin >= 0 (squared 
 }
 
 template <int KIND>
-__device__ __forceinline__ double kvalue(double acc, double sig) {
+__device__ __forceinline__ double kvalue(double acc, double sig, const double* __restrict__ tab) {
   if (KIND == GPX_K_SE) {
-    return sig * fast_exp(-0.5 * acc);
+    return sig * fast_exp(-0.5 * acc, tab);
   } else if (KIND == GPX_K_MATERN32) {
     const double t = fast_sqrt(acc);
-    return sig * (1.0 + t) * fast_exp(-t);
+    return sig * (1.0 + t) * fast_exp(-t, tab);
   } else if (KIND == GPX_K_MATERN52) {
     const double t = fast_sqrt(acc);
-    return sig * (1.0 + t + acc * (1.0 / 3.0)) * fast_exp(-t);
+    return sig * (1.0 + t + acc * (1.0 / 3.0)) * fast_exp(-t, tab);
   } else {  // Mehler: acc = pa + pb - cross
-    return sig * fast_exp(-acc);
+    return sig * fast_exp(-acc, tab);
   }
 }
+
+// 2^(j/32), j = 0..31 (correctly rounded)
+__device__ const double kExp2Tab[32] = {
+    1.0, 1.0218971486541166, 1.0442737824274138, 1.0671404006768237, 1.0905077326652577, 1.1143867425958924,
+    1.1387886347566916, 1.1637248587775775, 1.189207115002721, 1.215247359980469, 1.241857812073484,
+    1.2690509571917332, 1.2968395546510096, 1.3252366431597413, 1.3542555469368927, 1.383909881963832,
+    1.4142135623730951, 1.4451808069770467, 1.4768261459394993, 1.5091644275934228, 1.5422108254079407,
+    1.5759808451078865, 1.6104903319492543, 1.645755478153965, 1.681792830507429, 1.718619298122478,
+    1.7562521603732995, 1.7947090750031072, 1.8340080864093424, 1.8741676341103, 1.9152065613971474,
+    1.9571441241754002};
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -137,7 +144,8 @@ __global__ __launch_bounds__(256) void kfill_kernel(KParams kp, const double* __
   double* Bs = As + TM * sl;
   double* pa = Bs + TN * sl;
   double* pb = pa + TM;
-  double* Tr = pb + TN;  // [32][TP] transpose image (SYM only)
+  double* tab = pb + TN;   // 2^(j/32) table
+  double* Tr = tab + 32;   // [32][TP] transpose image (SYM only)
   int ti, tj;
   if (SYM) {
     const int w = blockIdx.x;
@@ -152,6 +160,7 @@ __global__ __launch_bounds__(256) void kfill_kernel(KParams kp, const double* __
   const int64_t i0 = (int64_t)ti * TM, j0 = (int64_t)tj * TN;
   stage_points<KIND, true>(kp, d, dpad, sl, A, na, i0, As, pa);
   stage_points<KIND, false>(kp, d, dpad, sl, B, nb, j0, Bs, pb);
+  if (threadIdx.x < 32) tab[threadIdx.x] = kExp2Tab[threadIdx.x];
   __syncthreads();
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -181,6 +190,8 @@ __global__ __launch_bounds__(256) void kfill_kernel(KParams kp, const double* __
   const int64_t gj0 = j0 + c0, gj1 = gj0 + 1;
   // interior tile: fully inside both point sets and (for the symmetric forms) not touching the diagonal
   const bool interior = (i0 + TM <= na) && (j0 + TN <= nb) && (!symmetric || (i0 + TM <= j0) || (j0 + TN <= i0));
+  char* const otile = reinterpret_cast<char*>(out + i0 * ld + j0);
+  const unsigned ooff = (unsigned)(((wm * 32 + g) * ld + c0) * 8);
   double2 val[2][4];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
@@ -201,7 +212,7 @@ __global__ __launch_bounds__(256) void kfill_kernel(KParams kp, const double* __
         if (gi == gj0) s0 = 0.0;
         if (gi == gj1) s1 = 0.0;
       }
-      double v0 = kvalue<KIND>(s0, sig), v1 = kvalue<KIND>(s1, sig);
+      double v0 = kvalue<KIND>(s0, sig, tab), v1 = kvalue<KIND>(s1, sig, tab);
       if (!interior) {  // wave-uniform: only edge tiles (padding) and tiles crossing the diagonal (nugget) pay for this
         const bool rin = gi < na;
         if (!(rin && gj0 < nb)) v0 = (symmetric && gi == gj0) ? 1.0 : 0.0;
@@ -214,7 +225,8 @@ __global__ __launch_bounds__(256) void kfill_kernel(KParams kp, const double* __
       }
       val[mi][v].x = v0;
       val[mi][v].y = v1;
-      *reinterpret_cast<double2*>(out + gi * ld + gj0) = val[mi][v];
+      // address = (wave-uniform row-group base, SGPRs) + (per-lane 32-bit byte offset): no 64-bit VALU address math
+      *reinterpret_cast<double2*>(otile + (int64_t)(mi * 16 + 4 * v) * ld * 8 + ooff) = val[mi][v];
     }
 
   if (SYM && ti != tj) {
@@ -256,7 +268,7 @@ __global__ __launch_bounds__(256) void kdiag_kernel(KParams kp, const double* __
       acc += 2.0 * (kp.c1[k] * z) * z - (kp.c2[k] * z) * z;
     }
   }
-  out[j] = kvalue<KIND>(acc, kp.sig);
+  out[j] = kvalue<KIND>(acc, kp.sig, kExp2Tab);
 }
 
 template <int KIND, bool SYM>
@@ -271,7 +283,7 @@ int launch_kind(gpx_ctx* ctx, const KParams& kp, const double* A, int64_t na, co
     grid = dim3((unsigned)(pcols / TN), (unsigned)(prows / TM));
   }
   const int dpad = (kp.d + 3) & ~3;
-  const size_t sh = (size_t)(2 * TM * (dpad + 1) + 2 * TM + (SYM ? 32 * TP : 0)) * sizeof(double);
+  const size_t sh = (size_t)(2 * TM * (dpad + 1) + 2 * TM + 32 + (SYM ? 32 * TP : 0)) * sizeof(double);
   hipLaunchKernelGGL((kfill_kernel<KIND, SYM>), grid, dim3(256), sh, ctx->stream, kp, A, na, B, nb, symmetric, d_nugget,
                      nugget_len, nugget_scalar, out, ld);
   GPX_HIP(hipGetLastError());
