@@ -67,6 +67,7 @@ _SIGS = {
     "gpx_event_record": (C.c_int, [c_vp, C.c_int]),
     "gpx_event_wait": (C.c_int, [c_vp, C.c_int]),
     "gpx_dist_finish": (C.c_int, [c_vp, c_vp]),
+    "gpx_ivar_grad": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_dp]),
     "gpx_profile_enable": (C.c_int, [c_vp, C.c_int]),
     "gpx_profile_reset": (C.c_int, [c_vp]),
     "gpx_profile_get": (C.c_int, [c_vp, C.c_int, c_ip, c_dp, c_dp, c_dp]),

@@ -279,6 +279,18 @@ int chol_trsm_right(gpx_ctx* ctx, const double* L, int64_t ldl, const double* in
   return chol_trsm_right(ctx, L + n1 * ldl + n1, ldl, invd + (n1 / NB) * NB * NB, X + n1, ldx, m, n2);
 }
 
+// X (m x n) <- X * L^-1  (right side, lower, NOT transposed): [X1 X2][L11 0; L21 L22] = [A1 A2]
+//   X2 = A2 L22^-1;  A1 -= X2 L21;  X1 = A1 L11^-1.   Leaf: X <- X * inv (in place, one 128-wide tile per workgroup)
+int chol_trsm_right_n(gpx_ctx* ctx, const double* L, int64_t ldl, const double* invd, double* X, int64_t ldx,
+                      int64_t m, int64_t n) {
+  if (m == 0 || n == 0) return 0;
+  if (n == NB) return launch_gemm(ctx, X, ldx, invd, NB, X, ldx, m, NB, NB, false, false, false);
+  const int64_t n1 = split(n), n2 = n - n1;
+  GPX_TRY(chol_trsm_right_n(ctx, L + n1 * ldl + n1, ldl, invd + (n1 / NB) * NB * NB, X + n1, ldx, m, n2));
+  GPX_TRY(launch_gemm(ctx, X + n1, ldx, L + n1 * ldl, ldl, X, ldx, m, n1, n2, false, true, false));
+  return chol_trsm_right_n(ctx, L, ldl, invd, X, ldx, m, n1);
+}
+
 // B (n x m) <- L^-1 B
 int chol_trsm_left(gpx_ctx* ctx, const double* L, int64_t ldl, const double* invd, double* B, int64_t ldb,
                    int64_t n, int64_t m) {

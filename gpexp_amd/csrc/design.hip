@@ -26,14 +26,6 @@ __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict
   for (int r = ty; r < 32; r += 8) out[(j0 + r) * ldo + i0 + tx] = tile[tx][r];
 }
 
-int launch_transpose(gpx_ctx* ctx, const double* in, int64_t rows, int64_t cols, int64_t ldi, double* out,
-                     int64_t ldo) {
-  dim3 grid((unsigned)(cols / 32), (unsigned)(rows / 32));
-  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, ctx->stream, in, ldi, out, ldo);
-  GPX_HIP(hipGetLastError());
-  return 0;
-}
-
 __global__ __launch_bounds__(256) void set_identity_kernel(double* __restrict__ A, int64_t n, int64_t ld) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx < n) A[idx * ld + idx] = 1.0;
@@ -195,6 +187,14 @@ double pairwise_sum(std::vector<double>& v, int64_t m) {
 }
 
 }  // namespace
+
+int launch_transpose(gpx_ctx* ctx, const double* in, int64_t rows, int64_t cols, int64_t ldi, double* out,
+                     int64_t ldo) {
+  dim3 grid((unsigned)(cols / 32), (unsigned)(rows / 32));
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, ctx->stream, in, ldi, out, ldo);
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
 
 extern "C" {
 

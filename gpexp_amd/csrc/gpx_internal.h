@@ -141,6 +141,9 @@ int chol_potrf_nozero(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double* in
 // X <- X * L^-T (right, lower, transposed): X is m x n (ld ldx), L n x n lower with leaf inverses invd
 int chol_trsm_right(gpx_ctx* ctx, const double* L, int64_t ldl, const double* invd, double* X, int64_t ldx,
                     int64_t m, int64_t n);
+// X <- X * L^-1 (right, lower, not transposed)
+int chol_trsm_right_n(gpx_ctx* ctx, const double* L, int64_t ldl, const double* invd, double* X, int64_t ldx,
+                      int64_t m, int64_t n);
 // B <- L^-1 B (left, lower): B is n x m
 int chol_trsm_left(gpx_ctx* ctx, const double* L, int64_t ldl, const double* invd, double* B, int64_t ldb,
                    int64_t n, int64_t m);
@@ -157,3 +160,6 @@ int launch_colreduce(gpx_ctx* ctx, const double* B, int64_t ld, int64_t rows, in
                      double* out, double* d_partial);
 int64_t colreduce_partial_elems(int64_t rows, int64_t pcols);
 int launch_sum(gpx_ctx* ctx, const double* x, int64_t n, double* d_out);
+
+// design.hip
+int launch_transpose(gpx_ctx* ctx, const double* in, int64_t rows, int64_t cols, int64_t ldi, double* out, int64_t ldo);

@@ -289,5 +289,12 @@ def lml_grad(ctx, spec, L, X, alpha):
     return out
 
 
+def ivar_grad(ctx, spec, L, X, Z):
+    """d IVAR / d design coordinates, flattened (N*d) in the reference's row order (point-major)."""
+    out = np.empty(X.shape[0] * spec.d)
+    check(ctx.lib.gpx_ivar_grad(ctx.h, *spec.args(), L.h, X.h, Z.h, dptr(out)))
+    return out
+
+
 def dbg_gemm(ctx, A, B, Cm, bt, accumulate, lower=False):
     check(ctx.lib.gpx_dbg_gemm(ctx.h, A.h, B.h, Cm.h, int(bt), int(accumulate), int(lower)))

@@ -80,10 +80,17 @@ class costFunctionGP_IVAR(costFunctionBase):
         return np.abs(cost)
 
     def derivative(self, inputPoints):
-        """d IVAR / d design coordinates, flattened (experimentalDesign.py:168-179)."""
+        """d IVAR / d design coordinates, flattened (experimentalDesign.py:168-179).
+
+        Squared-exponential kernel with homoscedastic noise: computed on the GPU (gpx_ivar_grad: two triangular solves,
+        one MFMA GEMM and a fused row reduction instead of the reference's (N*d x M) matrix).  Other kernels /
+        a heteroscedastic `space.noiseFunc`: the host restatement of gp.py:282-341 in GP.evaluateVarianceDerivative."""
+        from .kernels import KernelSquaredExponential
         gp = self.gaussianProcess
         if self.space.noiseFunc is None:
             gp.addNodesAndComputeCovariance(inputPoints)
+            if isinstance(gp.kernel, KernelSquaredExponential):
+                return _dev.ivar_grad(_dev.context(), gp.kernel._spec(), gp._L, gp._X, self._mc())
             out = gp.evaluateVarianceDerivative(self.mcPoints)
         else:
             gp.addNodesAndComputeCovariance(inputPoints, noiseIn=self.space.noiseFunc(inputPoints))

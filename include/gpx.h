@@ -156,6 +156,13 @@ int gpx_mi_greedy(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, co
 int gpx_lml_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
                  const double* alpha, double* grad);
 
+/* ---- design-point gradient -------------------------------------------------------------
+ * grad[a*d + l] = d IVAR / d X[a][l] = (1/M) sum_j d var(z_j) / d X[a][l]  for the GP factored on X (L), in the
+ * reference's convention (costFunctionGP_IVAR.derivative, experimentalDesign.py:168-172 -> gp.py:282-341, including the
+ * doubled signalSize of kernels.py:177).  Squared-exponential kernel, homoscedastic noise.  grad: host, N*d. */
+int gpx_ivar_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
+                  const gpx_mat* Z, double* grad);
+
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ------------------------------------------------
  * Replaces the reference's only parallel backend, the fork + mp.Queue row-sharding helper
  * (parallel_utilities.py:26-80; used at gp.py:258).  The covariance matrix is distributed by block columns

@@ -309,3 +309,50 @@ def test_demo_flow_config1(golden, capsys):
     np.testing.assert_allclose(design[:4], xTrain, atol=1e-12)
     assert cf.evaluate(design) == pytest.approx(float(golden(c, "design_cost")), rel=1e-3)
     np.testing.assert_allclose(np.sort(design[:, 0]), np.sort(golden(c, "design")[:, 0]), atol=2e-3)
+
+
+def test_ivar_gradient_on_device_f1(golden):
+    """SURVEY 8 f1 on the GPU: d IVAR / d design points (gpx_ivar_grad) against (a) the reference's own vectors
+    (evaluateVarianceDerivative summed over the evaluation points; the SLSQP gradient of the demo flow) and (b) central
+    differences of the GPU IVAR itself (signalSize = 1, where the reference's doubled-signalSize convention is exact)."""
+    from gpexp_amd import device as dev
+    from gpExp.gp import GP
+    from gpExp.kernels import KernelSquaredExponential
+    ctx = dev.context()
+    c = "varderiv"
+    k = make_kernel(golden.index[c]["kernel"])
+    Xh, Zh = golden(c, "X"), golden(c, "Z")
+    X, Z = dev.points(ctx, Xh), dev.points(ctx, Zh)
+    L = dev.potrf(ctx, dev.kfill(ctx, k._spec(), X, nugget=1e-2))
+    g = dev.ivar_grad(ctx, k._spec(), L, X, Z)
+    want = golden(c, "dvar_dpts").sum(axis=1) / len(Zh)
+    assert rel(g, want) <= 1e-9
+    # demo flow: gradient SLSQP starts from (8 design points, 10000 MC points, noise 1e-12)
+    c = "demo_flow"
+    gp = GP(KernelSquaredExponential([float(golden(c, "opt_cl0"))], float(golden(c, "opt_signalSize")), 1),
+            float(golden(c, "opt_noise")))
+    mc = golden(c, "mc")
+    start = np.concatenate((golden(c, "xTrain"), mc), axis=0)[list(golden(c, "greedy_start_idx"))]
+    gp.addNodesAndComputeCovariance(start)
+    gd = dev.ivar_grad(ctx, gp.kernel._spec(), gp._L, gp._X, dev.points(ctx, mc))
+    assert rel(gd, golden(c, "greedy_start_grad")) <= 1e-5
+    # finite differences at a larger size
+    rng = np.random.default_rng(77)
+    n, d, m = 40, 3, 500
+    Xh = rng.uniform(-1, 1, (n, d))
+    Zh = rng.uniform(-1, 1, (m, d))
+    sp = dev.KernelSpec(dev.K_SE, d, [0.5, 0.7, 0.9, 1.0])
+    Z = dev.points(ctx, Zh)
+
+    def ivar_at(P):
+        Xd = dev.points(ctx, P)
+        return dev.ivar(ctx, sp, dev.potrf(ctx, dev.kfill(ctx, sp, Xd, nugget=0.05)), Xd, Z)
+
+    Xd = dev.points(ctx, Xh)
+    g = dev.ivar_grad(ctx, sp, dev.potrf(ctx, dev.kfill(ctx, sp, Xd, nugget=0.05)), Xd, Z).reshape(n, d)
+    for a, l in [(0, 0), (7, 2), (39, 1), (20, 0)]:
+        Pp, Pm = Xh.copy(), Xh.copy()
+        Pp[a, l] += 1e-6
+        Pm[a, l] -= 1e-6
+        fd = (ivar_at(Pp) - ivar_at(Pm)) / 2e-6
+        assert g[a, l] == pytest.approx(fd, rel=1e-5, abs=1e-10)
