@@ -386,3 +386,26 @@ class DistFitIvar:
             ll = -0.5 * float(self.yh @ alpha) - 0.5 * logdet - self.n / 2.0 * np.log(2 * np.pi)
         iv = abs(ordered_sum(comm.allgather(np.array([part]))[:, 0]) / self.m)
         return ll, iv
+
+
+def dist_greedy_ivar_step(ctx, comm, spec, L, X, cand_host, Z, noise):
+    """Greedy-IVAR step with the CANDIDATES sharded over the ranks: every rank already holds the
+    complete factor, scores its contiguous slice of candidates with gpx_greedy_ivar_step, and the ranks exchange one
+    (cost, global index) pair each; the winner follows np.argmin's rule -- lowest cost, ties to the lowest global index
+    -- so the selection is identical to the single-GPU one.  Returns (global best index, its cost)."""
+    m = cand_host.shape[0]
+    lo, hi = eval_slice(m, comm.rank, comm.world)
+    if hi > lo:
+        best, costs = _dev.greedy_ivar_step(ctx, spec, L, X, _dev.points(ctx, cand_host[lo:hi]), Z, noise)
+        mine = np.array([costs[best], float(lo + best)])
+    else:
+        mine = np.array([np.inf, float(m)])
+    pairs = comm.allgather(mine)
+    cost, idx = merge_argmin(pairs[:, 0], pairs[:, 1].astype(np.int64))
+    return idx, cost
+
+
+def dist_greedy_var(ctx, comm, spec, cand_host, nsel, keep=()):
+    """Greedy maximum-variance design is O(M*n) per step and sequential in the steps: every rank runs the identical
+    deterministic selection on the full candidate set (no exchange) -- "replicas" for this sub-path, by design."""
+    return _dev.greedy_var(ctx, spec, _dev.points(ctx, cand_host), nsel, keep=keep)

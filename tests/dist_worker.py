@@ -198,6 +198,18 @@ def run_gpu(args):
     if comm.rank == 0:  # the log-likelihood is produced on rank 0 only (its sweeps hide under rank 0's evaluation slice)
         assert abs(ll - ll1) <= 1e-11 * abs(ll1), (ll, ll1)
     assert abs(iv - iv1) <= 1e-11 * abs(iv1), (iv, iv1)
+    # sharded design search: candidates split over the ranks, first-minimum merge == single-GPU selection
+    Ch = rng.uniform(-1, 1, (517, d))
+    Zd = dev.points(ctx, Zh)
+    gidx, gcost = dist.dist_greedy_ivar_step(ctx, comm, spec, runner.K, runner.X, Ch, Zd, 0.1)
+    sbest, scosts = dev.greedy_ivar_step(ctx, spec, K1, X, dev.points(ctx, Ch), Zd, 0.1)
+    assert gidx == sbest and abs(gcost - scosts[sbest]) <= 1e-12 * abs(gcost), (gidx, sbest, gcost, scosts[sbest])
+    # exact tie between two candidates living on different ranks: the lower global index must win
+    Ct = Ch.copy()
+    Ct[-1] = Ct[sbest]
+    if sbest != len(Ct) - 1:
+        tidx, _ = dist.dist_greedy_ivar_step(ctx, comm, spec, runner.K, runner.X, Ct, Zd, 0.1)
+        assert tidx == sbest, (tidx, sbest)
     errs = comm.allgather(np.array([errL]))[:, 0]
     comm.barrier()
     if comm.rank == 0:

@@ -49,6 +49,7 @@ def test_index_logic():
     assert dist.ordered_sum([0.1, 0.2, 0.3]) == (0.1 + 0.2) + 0.3
     # first-minimum rule across ranks (np.argmin semantics: ties -> lowest global index)
     assert dist.merge_argmin([0.5, 0.2, 0.2], [7, 40, 12]) == (0.2, 12)
+    assert dist.merge_argmin([np.inf, 0.3], [99, 5]) == (0.3, 5)  # a rank with an empty slice reports +inf
 
 
 @pytest.mark.parametrize("world,n,nb", [(2, 700, 256), (3, 1000, 128), (2, 300, 512)])
