@@ -4,17 +4,20 @@
 // Kernel.evaluate + np.tile per row) and the column loops that build kernelvals
 // (gp.py:132-135, 246-249; experimentalDesign.py:829-831).
 //
-// HBM-bound by intent: algorithmic bytes = 8*rows*cols written + 8*(rows+cols)*d read.  What it takes to get
-// there in fp64 (no hardware exp/sqrt):
-//   * 64x64 tiles; point coordinates staged once per tile into LDS pre-multiplied by the length scale.  The Gram
-//     term of the distance, a.b, is a K=d GEMM and runs on the fp64 MFMA pipe (|a-b|^2 = |a|^2 + |b|^2 - 2 a.b);
-//     the VALU -- measured at ~5.4 cycles per wave64 fp64 FMA, the binding resource of the all-VALU version (71
-//     instructions per element) -- only evaluates the kernel function.  Diagonal entries keep an exact zero distance.
+// HBM-bound by intent: algorithmic bytes = 8*rows*cols written + 8*(rows+cols)*d read.  A pure store kernel with this
+// tile pattern reaches 5.6 TB/s on MI355X (scripts/store_peak.hip; hipMemset 6.3 TB/s).  What it takes to get near
+// that in fp64 (no hardware exp/sqrt):
+//   * 64x64 tiles.  The whole exponent argument comes out of the fp64 MFMA pipe: the staged operands are augmented,
+//     A' = [a*scale, |a|^2, 1], B' = [-2 b*scale, 1, |b|^2], so A'.B' = |a-b|^2 (Mehler: [c2 a, pa, 1].[-b, 1, pb] =
+//     pa + pb - cross).  The VALU only evaluates the kernel function.  Diagonal entries keep an exact zero distance.
+//   * staging is ONE global round trip per tile (4 threads per point, norms reduced with DPP shuffles): under a
+//     saturated store queue every dependent load costs microseconds of workgroup lifetime, i.e. occupancy.
 //   * symmetric fill: only tiles on/below the diagonal are COMPUTED; each is also written transposed through a
 //     padded LDS image (coalesced mirror stores) -- half the exp/sqrt work for the same 8*N^2 bytes.
-//   * exp: one rndne + two-constant Cody-Waite reduction + degree-13 polynomial + v_ldexp (about 20 fp64
-//     instructions, no special-case branches: arguments here are finite and <= ~1); sqrt: v_rsq_f64 + two coupled
-//     Newton steps + residual correction.  Both stay within 2 ulp (tests: 1e-13 against the oracle / the reference).
+//   * interior tiles (no padding, no diagonal) take a branch-free path selected by a scalar branch.
+//   * exp: rndne + two-constant Cody-Waite reduction to |r| <= ln2/64 + 32-entry 2^(j/32) table in LDS + degree-6
+//     polynomial + v_ldexp; sqrt: v_rsq_f64 (2^-23) + one coupled Newton step + residual correction.  Both stay within
+//     2 ulp (tests: 1e-13 against the oracle / the reference).
 #include "gpx_internal.h"
 #include <math.h>
 #include <stdlib.h>
@@ -24,15 +27,22 @@ namespace {
 constexpr int TM = 64;  // tile rows
 constexpr int TN = 64;  // tile cols
 constexpr int TP = TN + 1;  // padded stride of the transpose image
+#ifndef WAVES_PER_EU
+#define WAVES_PER_EU 5
+#endif
 
 // exp(x) = 2^n * 2^(j/32) * exp(r):  m = rint(x * 32/ln2), n = m >> 5, j = m & 31, r = x - m*ln2/32 (two-constant
 // Cody-Waite), |r| <= ln2/64, so a degree-6 polynomial is exact to 3.5e-18; tab[j] = 2^(j/32) sits in LDS (32 entries
-// = 32 distinct bank pairs: gathers are conflict-free).  11 fp64 ops + 5 integer ops instead of 19 fp64 ops.
+// = 32 distinct bank pairs: gathers are conflict-free).  m comes from the add-and-subtract-1.5*2^52 trick: the rounded
+// integer is also the low dword of the shifted sum, so there is no v_rndne / v_cvt.  Valid for |x| < 2^31 * ln2/32
+// (arguments here are <= 0 and far above -4.6e7).  12 fp64 ops + 4 integer ops.
 __device__ __forceinline__ double fast_exp(double x, const double* __restrict__ tab) {
-  const double m = rint(x * 46.166241308446828384);           // 32 / ln 2
+  const double SHIFT = 6755399441055744.0;                    // 1.5 * 2^52
+  const double sh = fma(x, 46.166241308446828384, SHIFT);     // 32 / ln 2
+  const int mi = __double2loint(sh);
+  const double m = sh - SHIFT;
   double r = fma(m, -2.16608493865351192653e-02, x);          // ln2/32, high part
   r = fma(m, -5.96317165397058692545e-12, r);                 // ln2/32, low part
-  const int mi = (int)m;
   const double tj = tab[mi & 31];
   double p = 1.3888888888888889419e-03;                       // 1/720
   p = fma(p, r, 8.3333333333333332177e-03);                   // 1/120
@@ -46,31 +56,31 @@ __device__ __forceinline__ double fast_exp(double x, const double* __restrict__ 
 
 __device__ __forceinline__ double fast_sqrt(double xin) {  // xin >= 0 (squared scaled distances)
   // coincident points give exactly 0: clamp instead of a compare + two selects; sqrt(1e-300) = 1e-150 leaves every
-  // kernel value bit-identical to the r = 0 result (1 + 1e-150 == 1, exp(-1e-150) == 1)
+  // kernel value bit-identical to the r = 0 result (1 + 1e-150 == 1, exp(-1e-150) == 1).
+  // v_rsq_f64 is good to 2^-23; one coupled (Goldschmidt) step squares that to ~2^-45 and the residual correction
+  // g += (x - g*g) * h is a further Newton step for the root itself: < 1 ulp.
   const double x = fmax(xin, 1e-300);
   const double y = __builtin_amdgcn_rsq(x);
   double g = x * y, h = 0.5 * y;
-  double e = fma(-h, g, 0.5);
-  g = fma(g, e, g);
-  h = fma(h, e, h);
-  e = fma(-h, g, 0.5);
+  const double e = fma(-h, g, 0.5);
   g = fma(g, e, g);
   h = fma(h, e, h);
   const double d = fma(-g, g, x);
   return fma(d, h, g);
 }
 
+// acc = the exponent argument straight from the MFMA (squared scaled distance, or the Mehler exponent); sig3 = sig/3
 template <int KIND>
-__device__ __forceinline__ double kvalue(double acc, double sig, const double* __restrict__ tab) {
+__device__ __forceinline__ double kvalue(double acc, double sig, double sig3, const double* __restrict__ tab) {
   if (KIND == GPX_K_SE) {
     return sig * fast_exp(-0.5 * acc, tab);
   } else if (KIND == GPX_K_MATERN32) {
     const double t = fast_sqrt(acc);
-    return sig * (1.0 + t) * fast_exp(-t, tab);
+    return fma(t, sig, sig) * fast_exp(-t, tab);
   } else if (KIND == GPX_K_MATERN52) {
     const double t = fast_sqrt(acc);
-    return sig * (1.0 + t + acc * (1.0 / 3.0)) * fast_exp(-t, tab);
-  } else {  // Mehler: acc = pa + pb - cross
+    return fma(acc, sig3, fma(t, sig, sig)) * fast_exp(-t, tab);
+  } else {  // Mehler
     return sig * fast_exp(-acc, tab);
   }
 }
@@ -87,133 +97,81 @@ __device__ const double kExp2Tab[32] = {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-// Stage one 64-point tile into LDS for the MFMA Gram product: P[p][k] = coordinate k of point p times its scale
-// (Mehler: times c2 on the A side), zero for k >= d (K is padded to a multiple of 4), and nrm[p] = the point's own
-// term of the exponent (sum of squared scaled coordinates, or sum c1 x^2 for Mehler).
-template <int KIND, bool SIDE_A>
+constexpr int MAXK4 = (GPX_MAXD + 2 + 3) / 4;  // most k slots a staging thread can own
+
+// Stage one 64-point tile into LDS as the augmented MFMA operand (see the header): 4 threads per point, thread c takes
+// coordinates c, c+4, ...; every global load of the tile is issued before the first use, the point's own exponent term
+// is reduced over the 4 threads with shuffles and lands in slot d (A side) / d+1 (B side), the other slot holds 1.
+template <int KIND, bool SIDE_A, int K4>
 __device__ __forceinline__ void stage_points(const KParams& kp, int d, int dpad, int sl, const double* __restrict__ X,
-                                             int64_t n, int64_t g0, double* P, double* nrm) {
-  const int t = threadIdx.x;
-  for (int idx = t; idx < TM * dpad; idx += 256) {
-    const int p = idx / dpad, k = idx - p * dpad;
-    const int64_t g = g0 + p;
-    double v = 0.0;
-    if (g < n && k < d) {
-      v = X[g * d + k];
+                                             int64_t n, int64_t g0, double* P) {
+  const int t = threadIdx.x, p = t >> 2, c = t & 3;
+  const int64_t g = g0 + p;
+  const bool inb = g < n;
+  const double* xp = X + g * d;
+  double x[K4];
+#pragma unroll
+  for (int i = 0; i < K4; ++i) {
+    const int k = c + 4 * i;
+    x[i] = (inb && k < d) ? xp[k] : 0.0;
+  }
+  double part = 0.0;
+#pragma unroll
+  for (int i = 0; i < K4; ++i) {
+    const int k = c + 4 * i;
+    if (k < d) {
       if (KIND == GPX_K_MEHLER) {
-        if (SIDE_A) v *= kp.c2[k];
+        part = fma(kp.c1[k] * x[i], x[i], part);
+        x[i] = SIDE_A ? kp.c2[k] * x[i] : -x[i];
       } else {
-        v *= kp.scale[k];
+        const double w = x[i] * kp.scale[k];
+        part = fma(w, w, part);
+        x[i] = SIDE_A ? w : -2.0 * w;
       }
     }
-    P[p * sl + k] = v;
   }
-  if (t < TM) {
-    const int64_t g = g0 + t;
-    double s = 0.0;
-    if (g < n)
-      for (int k = 0; k < d; ++k) {
-        const double v = X[g * d + k];
-        if (KIND == GPX_K_MEHLER) {
-          s = fma(kp.c1[k] * v, v, s);
-        } else {
-          const double w = v * kp.scale[k];
-          s = fma(w, w, s);
-        }
-      }
-    nrm[t] = s;
+  part += __shfl_xor(part, 1);
+  part += __shfl_xor(part, 2);
+  const double own = inb ? part : 0.0, one = 1.0;
+#pragma unroll
+  for (int i = 0; i < K4; ++i) {
+    const int k = c + 4 * i;
+    if (k < dpad) {
+      double v = x[i];
+      if (k == d) v = SIDE_A ? own : one;
+      if (k == d + 1) v = SIDE_A ? one : own;
+      P[p * sl + k] = v;
+    }
   }
 }
 
-// 64x64 tile per 256-thread workgroup; wave (wm, wn) owns a 32x32 quadrant = 2x2 fp64 MFMA 16x16 blocks.
-// The Gram term c = a.b comes from v_mfma_f64_16x16x4_f64 (the matrix pipe is otherwise idle here and co-issues with
-// the VALU); the exponent argument is |a|^2 + |b|^2 - 2c (SE / Matern) or pa + pb - c (Mehler).  MFMA column q of
-// block ni is mapped to tile column 2q+ni, so a lane's two blocks are ADJACENT columns: 16-byte stores, 256-byte row
-// segments per 16-lane group.
-// SYM: 1-D grid over the tiles on/below the diagonal, mirror-written; otherwise 2-D grid over all tiles.
-template <int KIND, bool SYM>
-__global__ __launch_bounds__(256) void kfill_kernel(KParams kp, const double* __restrict__ A, int64_t na,
-                                                    const double* __restrict__ B, int64_t nb, int symmetric,
-                                                    const double* __restrict__ nugget, int64_t nugget_len,
-                                                    double nugget_scalar, double* __restrict__ out, int64_t ld) {
-  extern __shared__ double sm[];
-  const int d = kp.d;
-  const int dpad = (d + 3) & ~3;
-  const int sl = dpad + 1;  // odd stride
-  double* As = sm;
-  double* Bs = As + TM * sl;
-  double* pa = Bs + TN * sl;
-  double* pb = pa + TM;
-  double* tab = pb + TN;   // 2^(j/32) table
-  double* Tr = tab + 32;   // [32][TP] transpose image (SYM only)
-  int ti, tj;
-  if (SYM) {
-    const int w = blockIdx.x;
-    ti = (int)((sqrtf(8.0f * (float)w + 1.0f) - 1.0f) * 0.5f);
-    while ((ti + 1) * (ti + 2) / 2 <= w) ++ti;
-    while (ti * (ti + 1) / 2 > w) --ti;
-    tj = w - ti * (ti + 1) / 2;
-  } else {
-    ti = blockIdx.y;
-    tj = blockIdx.x;
-  }
-  const int64_t i0 = (int64_t)ti * TM, j0 = (int64_t)tj * TN;
-  stage_points<KIND, true>(kp, d, dpad, sl, A, na, i0, As, pa);
-  stage_points<KIND, false>(kp, d, dpad, sl, B, nb, j0, Bs, pb);
-  if (threadIdx.x < 32) tab[threadIdx.x] = kExp2Tab[threadIdx.x];
-  __syncthreads();
-
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int g = lane >> 4, q = lane & 15;
-
-  d4 acc[2][2];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
-  const double* ap = As + (wm * 32 + q) * sl + g;           // A[row = mi*16 + q][k = 4s + g]
-  const double* bp = Bs + (wn * 32 + 2 * q) * sl + g;       // B[col = 2q + ni][k = 4s + g]
-  for (int ks = 0; ks < dpad; ks += 4) {
-    const double a0 = ap[ks], a1 = ap[16 * sl + ks];
-    const double b0 = bp[ks], b1 = bp[sl + ks];
-    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-  }
-
-  // this lane's elements: rows r(mi, v) = wm*32 + mi*16 + g + 4v, columns c0, c0+1 with c0 = wn*32 + 2q
-  const int c0 = wn * 32 + 2 * q;
-  const double pb0 = pb[c0], pb1 = pb[c0 + 1];
-  const double sig = kp.sig;
+// The 16 kernel values of one lane (rows r(mi, v) = wm*32 + mi*16 + g + 4v, columns c0, c0+1) from the MFMA
+// accumulators, stored straight to the tile.  INTERIOR = the tile lies fully inside both point sets and does not touch
+// the diagonal: no padding, nugget or exact-zero handling.
+template <int KIND, bool INTERIOR>
+__device__ __forceinline__ void finish_tile(const d4 (&acc)[2][2], double2 (&val)[2][4], double sig,
+                                            const double* __restrict__ tab, int64_t i0, int64_t j0, int64_t na,
+                                            int64_t nb, int symmetric, const double* __restrict__ nugget,
+                                            int64_t nugget_len, double nugget_scalar, char* otile, unsigned ooff,
+                                            int64_t ld, int rbase, int c0, bool diag_tile) {
+  const double sig3 = sig * (1.0 / 3.0);
   const int64_t gj0 = j0 + c0, gj1 = gj0 + 1;
-  // interior tile: fully inside both point sets and (for the symmetric forms) not touching the diagonal
-  const bool interior = (i0 + TM <= na) && (j0 + TN <= nb) && (!symmetric || (i0 + TM <= j0) || (j0 + TN <= i0));
-  char* const otile = reinterpret_cast<char*>(out + i0 * ld + j0);
-  const unsigned ooff = (unsigned)(((wm * 32 + g) * ld + c0) * 8);
-  double2 val[2][4];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const int r = wm * 32 + mi * 16 + g + 4 * v;
-      const double par = pa[r];
-      double s0, s1;
-      if (KIND == GPX_K_MEHLER) {
-        s0 = par + pb0 - acc[mi][0][v];
-        s1 = par + pb1 - acc[mi][1][v];
-      } else {  // squared scaled distance; tiny negative round-off is clamped
-        s0 = fmax(fma(-2.0, acc[mi][0][v], par + pb0), 0.0);
-        s1 = fmax(fma(-2.0, acc[mi][1][v], par + pb1), 0.0);
+      double s0 = acc[mi][0][v], s1 = acc[mi][1][v];
+      if (KIND != GPX_K_MEHLER) {  // squared scaled distance; tiny negative round-off is clamped
+        s0 = fmax(s0, 0.0);
+        s1 = fmax(s1, 0.0);
       }
-      const int64_t gi = i0 + r;
-      if (!interior && symmetric && KIND != GPX_K_MEHLER) {  // exact zero distance on the diagonal, as the reference has it
+      const int64_t gi = i0 + rbase + mi * 16 + 4 * v;
+      if (!INTERIOR && symmetric && KIND != GPX_K_MEHLER) {  // exact zero distance on the diagonal, as the reference has it
         if (gi == gj0) s0 = 0.0;
         if (gi == gj1) s1 = 0.0;
       }
-      double v0 = kvalue<KIND>(s0, sig, tab), v1 = kvalue<KIND>(s1, sig, tab);
-      if (!interior) {  // wave-uniform: only edge tiles (padding) and tiles crossing the diagonal (nugget) pay for this
+      double v0 = kvalue<KIND>(s0, sig, sig3, tab), v1 = kvalue<KIND>(s1, sig, sig3, tab);
+      if (!INTERIOR) {  // edge tiles (padding) and tiles crossing the diagonal (nugget)
         const bool rin = gi < na;
         if (!(rin && gj0 < nb)) v0 = (symmetric && gi == gj0) ? 1.0 : 0.0;
         if (!(rin && gj1 < nb)) v1 = (symmetric && gi == gj1) ? 1.0 : 0.0;
@@ -226,11 +184,92 @@ __global__ __launch_bounds__(256) void kfill_kernel(KParams kp, const double* __
       val[mi][v].x = v0;
       val[mi][v].y = v1;
       // address = (wave-uniform row-group base, SGPRs) + (per-lane 32-bit byte offset): no 64-bit VALU address math
-      *reinterpret_cast<double2*>(otile + (int64_t)(mi * 16 + 4 * v) * ld * 8 + ooff) = val[mi][v];
+      double* const dst = reinterpret_cast<double*>(otile + (int64_t)(mi * 16 + 4 * v) * ld * 8 + ooff);
+      if (!INTERIOR && diag_tile) {
+        // the augmented dot product adds |a|^2 and |b|^2 in operand order, so V[r][c] and V[c][r] can differ in the
+        // last bit: the diagonal tile of the mirrored fill stores its lower half here and mirrors it like any other
+        if (gi >= gj0) dst[0] = v0;
+        if (gi >= gj1) dst[1] = v1;
+      } else {
+        *reinterpret_cast<double2*>(dst) = val[mi][v];
+      }
     }
+}
 
-  if (SYM && ti != tj) {
+// 64x64 tile per 256-thread workgroup; wave (wm, wn) owns a 32x32 quadrant = 2x2 fp64 MFMA 16x16 blocks.
+// MFMA column q of block ni is mapped to tile column 2q+ni, so a lane's two blocks are ADJACENT columns: 16-byte
+// stores, 256-byte row segments per 16-lane group.
+// SYM: 1-D grid over the tiles on/below the diagonal, mirror-written; otherwise 2-D grid over all tiles.
+// K4 = augmented K (d + 2) rounded up to the MFMA step, in units of 4: compile-time so staging holds K4 registers a side.
+template <int KIND, bool SYM, int K4>
+__global__ __launch_bounds__(256, WAVES_PER_EU) void kfill_kernel(KParams kp, const double* __restrict__ A, int64_t na,
+                                                    const double* __restrict__ B, int64_t nb, int symmetric,
+                                                    const double* __restrict__ nugget, int64_t nugget_len,
+                                                    double nugget_scalar, double* __restrict__ out, int64_t ld) {
+  extern __shared__ double sm[];
+  const int d = kp.d;
+  constexpr int dpad = 4 * K4;  // coordinates + the two augmentation slots, padded to the MFMA K step
+  constexpr int sl = dpad + 1;  // odd stride
+  double* As = sm;
+  double* Bs = As + TM * sl;
+  double* tab = Bs + TN * sl;  // 2^(j/32) table
+  double* Tr = tab + 32;       // [32][TP] transpose image (SYM only)
+  int ti, tj;
+  if (SYM) {
+    const int w = blockIdx.x;
+    ti = (int)((sqrtf(8.0f * (float)w + 1.0f) - 1.0f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= w) ++ti;
+    while (ti * (ti + 1) / 2 > w) --ti;
+    tj = w - ti * (ti + 1) / 2;
+  } else {
+    ti = blockIdx.y;
+    tj = blockIdx.x;
+  }
+  const int64_t i0 = (int64_t)ti * TM, j0 = (int64_t)tj * TN;
+  stage_points<KIND, true, K4>(kp, d, dpad, sl, A, na, i0, As);
+  stage_points<KIND, false, K4>(kp, d, dpad, sl, B, nb, j0, Bs);
+  if (threadIdx.x < 32) tab[threadIdx.x] = kExp2Tab[threadIdx.x];
+  __syncthreads();
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int g = lane >> 4, q = lane & 15;
+
+  d4 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
+  const double* ap = As + (wm * 32 + q) * sl + g;           // A'[row = mi*16 + q][k = 4s + g]
+  const double* bp = Bs + (wn * 32 + 2 * q) * sl + g;       // B'[col = 2q + ni][k = 4s + g]
+#pragma unroll
+  for (int ks = 0; ks < dpad; ks += 4) {
+    const double a0 = ap[ks], a1 = ap[16 * sl + ks];
+    const double b0 = bp[ks], b1 = bp[sl + ks];
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+  }
+
+  const int c0 = wn * 32 + 2 * q;
+  const bool interior = (i0 + TM <= na) && (j0 + TN <= nb) && (!symmetric || (i0 + TM <= j0) || (j0 + TN <= i0));
+  char* const otile = reinterpret_cast<char*>(out + i0 * ld + j0);
+  const unsigned ooff = (unsigned)(((wm * 32 + g) * ld + c0) * 8);
+  double2 val[2][4];
+  if (__builtin_amdgcn_readfirstlane((int)interior))
+    finish_tile<KIND, true>(acc, val, kp.sig, tab, i0, j0, na, nb, symmetric, nugget, nugget_len, nugget_scalar, otile,
+                            ooff, ld, wm * 32 + g, c0, false);
+  else
+    finish_tile<KIND, false>(acc, val, kp.sig, tab, i0, j0, na, nb, symmetric, nugget, nugget_len, nugget_scalar, otile,
+                             ooff, ld, wm * 32 + g, c0, SYM && ti == tj);
+
+  if (SYM) {
     // mirror: out[j0 + c][i0 + r] = V[r][c]; the two row halves (wm = 0 / 1) go through the padded image in turn
+    // (the diagonal tile mirrors its strictly-lower part only)
+    const int tx = t & 31, ty = t >> 5;
+    char* const mbase = reinterpret_cast<char*>(out + j0 * ld + i0);
+    const unsigned moff = (unsigned)((ty * ld + tx) * 8);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       __syncthreads();
@@ -245,11 +284,16 @@ __global__ __launch_bounds__(256) void kfill_kernel(KParams kp, const double* __
           }
       }
       __syncthreads();
-      const int tx = t & 31, ty = t >> 5;
+      if (ti != tj) {
 #pragma unroll
-      for (int qq = 0; qq < 8; ++qq) {
-        const int c = ty + 8 * qq;
-        out[(j0 + c) * ld + i0 + 32 * half + tx] = Tr[tx * TP + c];
+        for (int qq = 0; qq < 8; ++qq)
+          *reinterpret_cast<double*>(mbase + (int64_t)(8 * qq) * ld * 8 + moff + 256 * half) = Tr[tx * TP + ty + 8 * qq];
+      } else {
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) {
+          const int c = ty + 8 * qq;
+          if (32 * half + tx > c) out[(j0 + c) * ld + i0 + 32 * half + tx] = Tr[tx * TP + c];
+        }
       }
     }
   }
@@ -268,13 +312,13 @@ __global__ __launch_bounds__(256) void kdiag_kernel(KParams kp, const double* __
       acc += 2.0 * (kp.c1[k] * z) * z - (kp.c2[k] * z) * z;
     }
   }
-  out[j] = kvalue<KIND>(acc, kp.sig, kExp2Tab);
+  out[j] = kvalue<KIND>(acc, kp.sig, kp.sig * (1.0 / 3.0), kExp2Tab);
 }
 
-template <int KIND, bool SYM>
-int launch_kind(gpx_ctx* ctx, const KParams& kp, const double* A, int64_t na, const double* B, int64_t nb,
-                int symmetric, const double* d_nugget, int64_t nugget_len, double nugget_scalar, double* out,
-                int64_t prows, int64_t pcols, int64_t ld) {
+template <int KIND, bool SYM, int K4>
+int launch_k4(gpx_ctx* ctx, const KParams& kp, const double* A, int64_t na, const double* B, int64_t nb, int symmetric,
+              const double* d_nugget, int64_t nugget_len, double nugget_scalar, double* out, int64_t prows,
+              int64_t pcols, int64_t ld) {
   dim3 grid;
   if (SYM) {
     const int64_t t = prows / TM;
@@ -282,12 +326,25 @@ int launch_kind(gpx_ctx* ctx, const KParams& kp, const double* A, int64_t na, co
   } else {
     grid = dim3((unsigned)(pcols / TN), (unsigned)(prows / TM));
   }
-  const int dpad = (kp.d + 3) & ~3;
-  const size_t sh = (size_t)(2 * TM * (dpad + 1) + 2 * TM + 32 + (SYM ? 32 * TP : 0)) * sizeof(double);
-  hipLaunchKernelGGL((kfill_kernel<KIND, SYM>), grid, dim3(256), sh, ctx->stream, kp, A, na, B, nb, symmetric, d_nugget,
-                     nugget_len, nugget_scalar, out, ld);
+  const size_t sh = (size_t)(2 * TM * (4 * K4 + 1) + 32 + (SYM ? 32 * TP : 0)) * sizeof(double);
+  hipLaunchKernelGGL((kfill_kernel<KIND, SYM, K4>), grid, dim3(256), sh, ctx->stream, kp, A, na, B, nb, symmetric,
+                     d_nugget, nugget_len, nugget_scalar, out, ld);
   GPX_HIP(hipGetLastError());
   return 0;
+}
+
+template <int KIND, bool SYM>
+int launch_kind(gpx_ctx* ctx, const KParams& kp, const double* A, int64_t na, const double* B, int64_t nb,
+                int symmetric, const double* d_nugget, int64_t nugget_len, double nugget_scalar, double* out,
+                int64_t prows, int64_t pcols, int64_t ld) {
+#define GPX_K4(N_) \
+  launch_k4<KIND, SYM, N_>(ctx, kp, A, na, B, nb, symmetric, d_nugget, nugget_len, nugget_scalar, out, prows, pcols, ld)
+  const int k4 = (kp.d + 2 + 3) / 4;
+  if (k4 <= 2) return GPX_K4(2);   // d <= 6
+  if (k4 <= 3) return GPX_K4(3);   // d <= 10
+  if (k4 <= 5) return GPX_K4(5);   // d <= 18
+  return GPX_K4(MAXK4);
+#undef GPX_K4
 }
 
 }  // namespace
