@@ -15,7 +15,7 @@
 //   * symmetric fill: only tiles on/below the diagonal are COMPUTED; each is also written transposed through a
 //     padded LDS image (coalesced mirror stores) -- half the exp/sqrt work for the same 8*N^2 bytes.
 //   * interior tiles (no padding, no diagonal) take a branch-free path selected by a scalar branch.
-//   * exp: rndne + two-constant Cody-Waite reduction to |r| <= ln2/64 + 32-entry 2^(j/32) table in LDS + degree-6
+//   * exp: shifter-trick rounding + one-constant reduction to |r| <= ln2/128 + 64-entry 2^(j/64) table in LDS + degree-5
 //     polynomial + v_ldexp; sqrt: v_rsq_f64 (2^-23) + one coupled Newton step + residual correction.  Both stay within
 //     2 ulp (tests: 1e-13 against the oracle / the reference).
 #include "gpx_internal.h"
@@ -31,27 +31,27 @@ constexpr int TP = TN + 1;  // padded stride of the transpose image
 #define WAVES_PER_EU 5
 #endif
 
-// exp(x) = 2^n * 2^(j/32) * exp(r):  m = rint(x * 32/ln2), n = m >> 5, j = m & 31, r = x - m*ln2/32 (two-constant
-// Cody-Waite), |r| <= ln2/64, so a degree-6 polynomial is exact to 3.5e-18; tab[j] = 2^(j/32) sits in LDS (32 entries
-// = 32 distinct bank pairs: gathers are conflict-free).  m comes from the add-and-subtract-1.5*2^52 trick: the rounded
-// integer is also the low dword of the shifted sum, so there is no v_rndne / v_cvt.  Valid for |x| < 2^31 * ln2/32
-// (arguments here are <= 0 and far above -4.6e7).  12 fp64 ops + 4 integer ops.
+// exp(x) = 2^n * 2^(j/64) * exp(r):  m = rint(x * 64/ln2), n = m >> 6, j = m & 63, r = x - m*ln2/64, |r| <= ln2/128, so
+// a degree-5 polynomial is exact to 3.5e-17; tab[j] = 2^(j/64) sits in LDS.  m comes from the add-and-subtract-1.5*2^52
+// trick: the rounded integer is also the low dword of the shifted sum, so there is no v_rndne / v_cvt.  The reduction
+// uses ONE constant: the fma forms m*C exactly, so the only error is m * (C - ln2/64) <= |x| * 8e-17, below the
+// rounding of the argument itself.  Valid for |x| < 2^31 * ln2/64 (arguments here are <= 0 and far above -2e7).
+// 10 fp64 ops + 4 integer ops.
+constexpr int EXP_TAB = 64;
 __device__ __forceinline__ double fast_exp(double x, const double* __restrict__ tab) {
   const double SHIFT = 6755399441055744.0;                    // 1.5 * 2^52
-  const double sh = fma(x, 46.166241308446828384, SHIFT);     // 32 / ln 2
+  const double sh = fma(x, 92.33248261689366, SHIFT);         // 64 / ln 2
   const int mi = __double2loint(sh);
   const double m = sh - SHIFT;
-  double r = fma(m, -2.16608493865351192653e-02, x);          // ln2/32, high part
-  r = fma(m, -5.96317165397058692545e-12, r);                 // ln2/32, low part
-  const double tj = tab[mi & 31];
-  double p = 1.3888888888888889419e-03;                       // 1/720
-  p = fma(p, r, 8.3333333333333332177e-03);                   // 1/120
+  const double r = fma(m, -0.010830424696249145, x);          // ln2 / 64
+  const double tj = tab[mi & (EXP_TAB - 1)];
+  double p = 8.3333333333333332177e-03;                       // 1/120
   p = fma(p, r, 4.1666666666666664354e-02);                   // 1/24
   p = fma(p, r, 1.6666666666666665741e-01);                   // 1/6
   p = fma(p, r, 0.5);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
-  return ldexp(tj * p, mi >> 5);
+  return ldexp(tj * p, mi >> 6);
 }
 
 __device__ __forceinline__ double fast_sqrt(double xin) {  // xin >= 0 (squared scaled distances)
@@ -64,8 +64,7 @@ __device__ __forceinline__ double fast_sqrt(double xin) {  // xin >= 0 (squared 
   double g = x * y, h = 0.5 * y;
   const double e = fma(-h, g, 0.5);
   g = fma(g, e, g);
-  h = fma(h, e, h);
-  const double d = fma(-g, g, x);
+  const double d = fma(-g, g, x);  // the correction below is second order: h at 2^-23 is plenty
   return fma(d, h, g);
 }
 
@@ -85,15 +84,21 @@ __device__ __forceinline__ double kvalue(double acc, double sig, double sig3, co
   }
 }
 
-// 2^(j/32), j = 0..31 (correctly rounded)
-__device__ const double kExp2Tab[32] = {
-    1.0, 1.0218971486541166, 1.0442737824274138, 1.0671404006768237, 1.0905077326652577, 1.1143867425958924,
-    1.1387886347566916, 1.1637248587775775, 1.189207115002721, 1.215247359980469, 1.241857812073484,
-    1.2690509571917332, 1.2968395546510096, 1.3252366431597413, 1.3542555469368927, 1.383909881963832,
-    1.4142135623730951, 1.4451808069770467, 1.4768261459394993, 1.5091644275934228, 1.5422108254079407,
-    1.5759808451078865, 1.6104903319492543, 1.645755478153965, 1.681792830507429, 1.718619298122478,
-    1.7562521603732995, 1.7947090750031072, 1.8340080864093424, 1.8741676341103, 1.9152065613971474,
-    1.9571441241754002};
+// 2^(j/64), j = 0..63 (correctly rounded)
+__device__ const double kExp2Tab[EXP_TAB] = {
+    1.0, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284, 1.0442737824274138, 1.0556451783605572,
+    1.0671404006768237, 1.0787607977571199, 1.0905077326652577, 1.102382583307841, 1.1143867425958924,
+    1.1265216186082418, 1.1387886347566916, 1.1511892299529827, 1.1637248587775775, 1.1763969916502812,
+    1.189207115002721, 1.202156731452703, 1.215247359980469, 1.22848053610687, 1.241857812073484, 1.255380757024691,
+    1.2690509571917332, 1.2828700160787783, 1.2968395546510096, 1.3109612115247644, 1.3252366431597413,
+    1.339667524053303, 1.3542555469368927, 1.3690024229745905, 1.383909881963832, 1.3989796725383112,
+    1.4142135623730951, 1.42961333839197, 1.4451808069770467, 1.460917794180647, 1.4768261459394993,
+    1.4929077282912648, 1.5091644275934228, 1.5255981507445384, 1.5422108254079407, 1.559004400237837,
+    1.5759808451078865, 1.593142151342267, 1.6104903319492543, 1.6280274218573478, 1.645755478153965,
+    1.6636765803267364, 1.681792830507429, 1.7001063537185235, 1.718619298122478, 1.7373338352737062,
+    1.7562521603732995, 1.7753764925265212, 1.7947090750031072, 1.8142521755003989, 1.8340080864093424,
+    1.8539791250833855, 1.8741676341103, 1.8945759815869656, 1.9152065613971474, 1.9360617934922943,
+    1.9571441241754002, 1.978456026387951};
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -212,8 +217,8 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void kfill_kernel(KParams kp, co
   constexpr int sl = dpad + 1;  // odd stride
   double* As = sm;
   double* Bs = As + TM * sl;
-  double* tab = Bs + TN * sl;  // 2^(j/32) table
-  double* Tr = tab + 32;       // [32][TP] transpose image (SYM only)
+  double* tab = Bs + TN * sl;  // 2^(j/64) table
+  double* Tr = tab + EXP_TAB;  // [32][TP] transpose image (SYM only)
   int ti, tj;
   if (SYM) {
     const int w = blockIdx.x;
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void kfill_kernel(KParams kp, co
   const int64_t i0 = (int64_t)ti * TM, j0 = (int64_t)tj * TN;
   stage_points<KIND, true, K4>(kp, d, dpad, sl, A, na, i0, As);
   stage_points<KIND, false, K4>(kp, d, dpad, sl, B, nb, j0, Bs);
-  if (threadIdx.x < 32) tab[threadIdx.x] = kExp2Tab[threadIdx.x];
+  if (threadIdx.x < EXP_TAB) tab[threadIdx.x] = kExp2Tab[threadIdx.x];
   __syncthreads();
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -326,7 +331,7 @@ int launch_k4(gpx_ctx* ctx, const KParams& kp, const double* A, int64_t na, cons
   } else {
     grid = dim3((unsigned)(pcols / TN), (unsigned)(prows / TM));
   }
-  const size_t sh = (size_t)(2 * TM * (4 * K4 + 1) + 32 + (SYM ? 32 * TP : 0)) * sizeof(double);
+  const size_t sh = (size_t)(2 * TM * (4 * K4 + 1) + EXP_TAB + (SYM ? 32 * TP : 0)) * sizeof(double);
   hipLaunchKernelGGL((kfill_kernel<KIND, SYM, K4>), grid, dim3(256), sh, ctx->stream, kp, A, na, B, nb, symmetric,
                      d_nugget, nugget_len, nugget_scalar, out, ld);
   GPX_HIP(hipGetLastError());
