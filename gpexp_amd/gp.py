@@ -247,9 +247,13 @@ class GP:
 
     # ---- hyper-parameter fit: host driver around loglikeParams -----------------------------------
     def findOptParamsLogLike(self, pts, evals, paramsStart=None, paramLowerBounds=None, paramUpperBounds=None,
-                             useNoise=None, maxiter=40, useLastParams=True):
+                             useNoise=None, maxiter=40, useLastParams=True, analyticGradient=False):
         """Maximise the marginal likelihood over the kernel hyper-parameters (+ noise unless `useNoise` is given);
-        bounds default to [max(v/10, 1e-3), min(10 v, 10)], noise to [1e-12, 1] from 1e-5 (gp.py:498-590)."""
+        bounds default to [max(v/10, 1e-3), min(10 v, 10)], noise to [1e-12, 1] from 1e-5 (gp.py:498-590).
+
+        `analyticGradient=True` (opt-in; squared-exponential kernel) hands L-BFGS-B the gradient from
+        gpx_lml_grad instead of letting it difference the objective (gp.py:635, approx_grad=True): one factorisation per
+        iterate instead of nparams+1.  The default reproduces the reference's numerical-gradient search."""
         if paramsStart is None:
             paramsStart = copy.deepcopy(self.kernel.hyperParam)
         if paramLowerBounds is None:
@@ -270,6 +274,10 @@ class GP:
             self.updateKernelParams(dict(zip(keys, in0)))
             if gradIn.size > 0:
                 margLogLike, derivs = self.loglikeParams(pts, evals, returnDeriv=1)
+                if analyticGradient and 'noise' in derivs and 'noise' in keys:
+                    # loglikeParams scales the noise entry by 2*noise (gp.py:463-464, a derivative w.r.t. sqrt(noise));
+                    # the search variable is the noise VARIANCE, so the optimiser gets the unscaled trace term
+                    derivs['noise'] /= 2.0 * self.noise
                 gradIn[:] = -np.array([derivs[k] for k in keys])
             else:
                 margLogLike = self.loglikeParams(pts, evals, returnDeriv=0)
@@ -277,18 +285,28 @@ class GP:
             objFunc.last_f_value = -margLogLike
             return -margLogLike
 
-        paramsOut, optValue = self.chooseParams(lbs, ubs, vals, objFunc, maxiter=maxiter, useLastParams=useLastParams)
+        paramsOut, optValue = self.chooseParams(lbs, ubs, vals, objFunc, maxiter=maxiter, useLastParams=useLastParams,
+                                                analyticGradient=analyticGradient)
         params = dict(zip(keys, paramsOut))
         self.updateKernelParams(params)
         return params, optValue
 
     def chooseParams(self, paramLowerBounds, paramUpperBounds, startValues, costFunction, maxiter=40,
-                     useLastParams=True):
-        """SciPy L-BFGS-B with numerical gradients, factr=1e10, maxfun=maxiter (gp.py:615-639)."""
+                     useLastParams=True, analyticGradient=False):
+        """SciPy L-BFGS-B, factr=1e10, maxfun=maxiter (gp.py:615-639): numerical gradients as in the reference, or the
+        cost function's own gradient when `analyticGradient` is set."""
         bounds = list(zip(paramLowerBounds, paramUpperBounds))
 
         def objFunc(x):
             return costFunction(x, np.empty(0))
 
-        sol = bfgs(objFunc, np.array(startValues), bounds=bounds, approx_grad=True, factr=1e10, maxfun=maxiter)[0]
+        def objFuncWithGrad(x):
+            g = np.empty(len(x))
+            f = costFunction(x, g)
+            return f, g
+
+        if analyticGradient:
+            sol = bfgs(objFuncWithGrad, np.array(startValues), bounds=bounds, factr=1e10, maxfun=maxiter)[0]
+        else:
+            sol = bfgs(objFunc, np.array(startValues), bounds=bounds, approx_grad=True, factr=1e10, maxfun=maxiter)[0]
         return sol, objFunc(sol)

@@ -356,3 +356,42 @@ def test_ivar_gradient_on_device_f1(golden):
         Pm[a, l] -= 1e-6
         fd = (ivar_at(Pp) - ivar_at(Pm)) / 2e-6
         assert g[a, l] == pytest.approx(fd, rel=1e-5, abs=1e-10)
+
+
+def test_hyperparameter_fit_with_analytic_gradient_f3():
+    """L-BFGS-B driven by gpx_lml_grad.  The gradient handed to the optimiser must be the gradient
+    of the objective it is handed (central differences of loglikeParams, noise as a variance), and the search must end
+    at a likelihood at least as high as the reference-style numerical-gradient search from the same start."""
+    from gpExp.kernels import KernelSquaredExponential
+    from gpExp.gp import GP
+    rng = np.random.default_rng(33)
+    n, d = 300, 2
+    X = rng.uniform(-1, 1, (n, d))
+    y = np.sin(3.0 * X[:, 0]) * np.cos(2.0 * X[:, 1]) + 0.1 * rng.standard_normal(n)
+    start = dict(cl0=0.8, cl1=0.8, signalSize=1.0)
+
+    def fresh():
+        return GP(KernelSquaredExponential([0.8, 0.8], 1.0, d), 1e-2)
+
+    # gradient consistency at a generic point
+    g = fresh()
+    x0 = dict(cl0=0.55, cl1=0.7, signalSize=1.3, noise=0.02)
+    g.updateKernelParams(dict(x0))
+    _, derivs = g.loglikeParams(X, y, returnDeriv=1)
+    derivs["noise"] /= 2.0 * g.noise  # undo gp.py:463-464: compare as d/d(noise variance)
+    for k, v in x0.items():
+        h = 1e-5 * v
+        up, dn = dict(x0), dict(x0)
+        up[k], dn[k] = v + h, v - h
+        g.updateKernelParams(up)
+        fp = g.loglikeParams(X, y)
+        g.updateKernelParams(dn)
+        fm = g.loglikeParams(X, y)
+        assert derivs[k] == pytest.approx((fp - fm) / (2 * h), rel=2e-6), k
+
+    ga, gn = fresh(), fresh()
+    pa, va = ga.findOptParamsLogLike(X, y, paramsStart=dict(start), analyticGradient=True)
+    pn, vn = gn.findOptParamsLogLike(X, y, paramsStart=dict(start))
+    assert va <= vn + 1e-6 * abs(vn)           # values are NEGATIVE log-likelihoods
+    assert 0.3 < pa["cl0"] < 1.2 and 0.4 < pa["cl1"] < 2.0 and 1e-3 < pa["noise"] < 5e-2
+    assert ga.noise == pytest.approx(pa["noise"])
