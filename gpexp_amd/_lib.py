@@ -82,11 +82,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("GPX_LIB_PATH", LIB_PATH)  # developer knob: A/B-test an alternative build of the same ABI
+    if not os.path.exists(path):
         raise ImportError(
             "gpexp_amd: %s not found - the HIP library is required (no CPU fallback). "
-            "Build it with `make -C gpexp_amd/csrc` or __graft_entry__.build()." % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+            "Build it with `make -C gpexp_amd/csrc` or __graft_entry__.build()." % path)
+    lib = C.CDLL(path)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res

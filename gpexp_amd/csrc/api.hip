@@ -212,8 +212,6 @@ int gpx_create(int device, gpx_ctx** out) {
   GPX_HIP(hipMalloc((void**)&c->d_info, 256));
   GPX_HIP(hipMalloc((void**)&c->d_scal, 64 * sizeof(double)));
   GPX_HIP(hipMemset(c->d_info, 0, 256));
-  GPX_HIP(hipMalloc((void**)&c->d_counters, GPX_COUNTER_SLOTS * 8 * sizeof(int)));
-  c->counter_slot = 0;
   c->trsv_scratch = nullptr;
   c->trsv_scratch_bytes = 0;
   *out = c;
@@ -238,7 +236,6 @@ int gpx_destroy(gpx_ctx* ctx) {
   for (auto ev : ctx->ev_free) (void)hipEventDestroy(ev);
   (void)hipFree(ctx->d_info);
   (void)hipFree(ctx->d_scal);
-  (void)hipFree(ctx->d_counters);
   if (ctx->trsv_scratch) (void)hipFree(ctx->trsv_scratch);
   for (auto ev : ctx->sync_events) (void)hipEventDestroy(ev);
   for (int i = 0; i < 3; ++i) (void)hipStreamDestroy(ctx->streams[i]);

@@ -99,27 +99,25 @@ __device__ __forceinline__ void gemm_tile(Smem<BT, TE>& sm, const double* A, int
 
   // Staging registers.  For the 128-tile they are NAMED scalars with the address chain written out: the equivalent
   // array form compiles to a measurably slower NN loop (IVAR 551 vs 534 ms at C4) -- hipcc scheduling lottery.
-  struct Stage {
-    double2 a0, a1, a2, a3, b0, b1, b2, b3;
-  };
-  Stage P, Q;  // Q only used by PF == 2
+  double2 Pa0, Pa1, Pa2, Pa3, Pb0, Pb1, Pb2, Pb3;
+  double2 Qa0, Qa1, Qa2, Qa3, Qb0, Qb1, Qb2, Qb3;  // only used by PF == 2
   const int64_t b_rs2 = 2 * b_rs, b_rs3 = 3 * b_rs, a_rs2 = 2 * a_rs, a_rs3 = 3 * a_rs;
 #define GPX_LD16(base_, voff_) (*reinterpret_cast<const double2*>((base_) + (voff_)))
 #define GPX_GLOAD(S_, kt_)                                                                            \
   do {                                                                                                \
     const char* ap_ = Abase + (int64_t)(kt_) * a_ks;                                                  \
     const char* bp_ = Bbase + (int64_t)(kt_) * b_ks;                                                  \
-    S_.a0 = GPX_LD16(ap_, voff_a);                                                                    \
-    S_.a1 = GPX_LD16(ap_ + a_rs, voff_a);                                                             \
+    S_##a0 = GPX_LD16(ap_, voff_a);                                                                    \
+    S_##a1 = GPX_LD16(ap_ + a_rs, voff_a);                                                             \
     if (NL == 4) {                                                                                    \
-      S_.a2 = GPX_LD16(ap_ + a_rs2, voff_a);                                                          \
-      S_.a3 = GPX_LD16(ap_ + a_rs3, voff_a);                                                          \
+      S_##a2 = GPX_LD16(ap_ + a_rs2, voff_a);                                                          \
+      S_##a3 = GPX_LD16(ap_ + a_rs3, voff_a);                                                          \
     }                                                                                                 \
-    S_.b0 = GPX_LD16(bp_, voff_b);                                                                    \
-    S_.b1 = GPX_LD16(bp_ + b_rs, voff_b);                                                             \
+    S_##b0 = GPX_LD16(bp_, voff_b);                                                                    \
+    S_##b1 = GPX_LD16(bp_ + b_rs, voff_b);                                                             \
     if (NL == 4) {                                                                                    \
-      S_.b2 = GPX_LD16(bp_ + b_rs2, voff_b);                                                          \
-      S_.b3 = GPX_LD16(bp_ + b_rs3, voff_b);                                                          \
+      S_##b2 = GPX_LD16(bp_ + b_rs2, voff_b);                                                          \
+      S_##b3 = GPX_LD16(bp_ + b_rs3, voff_b);                                                          \
     }                                                                                                 \
   } while (0)
 
@@ -144,17 +142,17 @@ __device__ __forceinline__ void gemm_tile(Smem<BT, TE>& sm, const double* A, int
   do {                                                                                                \
     double* aw_ = sa_w + (buf_) * A_BUF;                                                              \
     double* bw_ = sb_w + (buf_) * B_BUF;                                                              \
-    GPX_ST2(aw_, S_.a0);                                                                              \
-    GPX_ST2(aw_ + 32 * SA, S_.a1);                                                                    \
+    GPX_ST2(aw_, S_##a0);                                                                              \
+    GPX_ST2(aw_ + 32 * SA, S_##a1);                                                                    \
     if (NL == 4) {                                                                                    \
-      GPX_ST2(aw_ + 64 * SA, S_.a2);                                                                  \
-      GPX_ST2(aw_ + 96 * SA, S_.a3);                                                                  \
+      GPX_ST2(aw_ + 64 * SA, S_##a2);                                                                  \
+      GPX_ST2(aw_ + 96 * SA, S_##a3);                                                                  \
     }                                                                                                 \
-    GPX_STB(bw_, S_.b0);                                                                              \
-    GPX_STB(bw_ + B_WS, S_.b1);                                                                       \
+    GPX_STB(bw_, S_##b0);                                                                              \
+    GPX_STB(bw_ + B_WS, S_##b1);                                                                       \
     if (NL == 4) {                                                                                    \
-      GPX_STB(bw_ + 2 * B_WS, S_.b2);                                                                 \
-      GPX_STB(bw_ + 3 * B_WS, S_.b3);                                                                 \
+      GPX_STB(bw_ + 2 * B_WS, S_##b2);                                                                 \
+      GPX_STB(bw_ + 3 * B_WS, S_##b3);                                                                 \
     }                                                                                                 \
   } while (0)
 
@@ -215,18 +213,119 @@ __device__ __forceinline__ void gemm_tile(Smem<BT, TE>& sm, const double* A, int
       }
     }
   } else {
+    // Steady state, scheduled by hand (GPX_PIN pins it): the global loads of step kt+1 are issued first and are
+    // only waited for after three quarters of this step's MFMAs (left alone, hipcc hoists the LDS store + barrier to
+    // after the first 20 MFMAs, ~1 us after the loads were issued: a vmcnt stall on every step -- 13 % of the MFMA
+    // pipe idle in SQ_VALU_MFMA_BUSY_CYCLES); the last quarter runs after the barrier from fragments already in
+    // registers, so the barrier skew is covered too.  Every fragment read of a step precedes its barrier.
+#define GPX_FRAGS(buf_, kk_, slot_)                                                                   \
+  do {                                                                                                \
+    const double* as = as0 + (buf_) * A_BUF;                                                          \
+    const double* bs = bs0 + (buf_) * B_BUF;                                                          \
+    _Pragma("unroll") for (int i = 0; i < FI; ++i) fa##slot_[i] = as[(i * 16) * SA + (kk_) * 4];      \
+    _Pragma("unroll") for (int j = 0; j < FI; ++j)                                                    \
+        fb##slot_[j] = BT ? bs[(j * 16) * SA + (kk_) * 4] : bs[((kk_) * 4) * SBN + j * 16];           \
+  } while (0)
+#define GPX_MFMAS(slot_)                                                                              \
+  do {                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < FI; ++i) _Pragma("unroll") for (int j = 0; j < FI; ++j)     \
+        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa##slot_[i], fb##slot_[j], acc[i][j], 0, 0, 0); \
+  } while (0)
+    // memory operations cannot cross this, and it consumes the accumulator every k-substep updates last: the LDS store
+    // and the barrier stay behind the third substep's MFMAs, the fourth substep stays behind the barrier
+#define GPX_PIN() asm volatile("" : "+v"(acc[FI - 1][FI - 1]) : : "memory")
+    static_assert(KB == 16, "the hand schedule below is written for four k-substeps");
+    double fa0[FI], fa1[FI], fa2[FI], fa3[FI], fb0[FI], fb1[FI], fb2[FI], fb3[FI];  // slots 2, 3 only used by KU == 4
     GPX_GLOAD(P, 0);
     GPX_SSTORE(P, 0);
     __syncthreads();
+    // The loop is rotated: on entry to a step its first fragments are already in registers -- they were read right after
+    // the previous barrier, underneath that step's last 16 MFMAs -- so no LDS latency is exposed at the top.
+#ifndef GPX_GEMM_ROT
+#define GPX_GEMM_ROT 1
+#endif
+    if (GPX_GEMM_ROT) {
+      GPX_FRAGS(0, 0, 0);
+      GPX_FRAGS(0, 1, 1);
+      if (KU == 4) {
+        GPX_FRAGS(0, 2, 2);
+        GPX_FRAGS(0, 3, 3);
+      }
+    }
     int kt = 0;
-    for (; kt + 1 < nk; ++kt) {  // prefetch step kt+1 while the MFMAs of step kt run
+    for (; kt + 1 < nk; ++kt) {
       const int buf = kt & 1;
       GPX_GLOAD(P, kt + 1);
-      GPX_COMPUTE(buf);
+      if (!GPX_GEMM_ROT) {
+        GPX_FRAGS(buf, 0, 0);
+        GPX_FRAGS(buf, 1, 1);
+        if (KU == 4) {
+          GPX_FRAGS(buf, 2, 2);
+          GPX_FRAGS(buf, 3, 3);
+        }
+      }
+      if (KU == 4) {
+        GPX_MFMAS(0);
+        GPX_MFMAS(1);
+        GPX_MFMAS(2);
+      } else {
+        GPX_MFMAS(0);
+        GPX_FRAGS(buf, 2, 0);
+        GPX_MFMAS(1);
+        GPX_FRAGS(buf, 3, 1);
+        GPX_MFMAS(0);
+      }
+      GPX_PIN();
       GPX_SSTORE(P, buf ^ 1);
       __syncthreads();
+      GPX_PIN();
+      if (!GPX_GEMM_ROT) {
+        if (KU == 4) {
+          GPX_MFMAS(3);
+        } else {
+          GPX_MFMAS(1);
+        }
+      } else if (KU == 4) {
+        GPX_FRAGS(buf ^ 1, 0, 0);
+        GPX_FRAGS(buf ^ 1, 1, 1);
+        GPX_FRAGS(buf ^ 1, 2, 2);
+        GPX_PIN();  // the reads above are issued BEFORE the last 16 MFMAs (hipcc would sink most of them below)
+        GPX_MFMAS(3);
+        GPX_FRAGS(buf ^ 1, 3, 3);
+      } else {
+        GPX_FRAGS(buf ^ 1, 0, 0);
+        GPX_PIN();
+        GPX_MFMAS(1);
+        GPX_FRAGS(buf ^ 1, 1, 1);
+      }
     }
-    GPX_COMPUTE(kt & 1);
+    {  // last step: fragments 0, 1 (KU == 4: all four) are loaded
+      const int buf = kt & 1;
+      if (!GPX_GEMM_ROT) {
+        GPX_FRAGS(buf, 0, 0);
+        GPX_FRAGS(buf, 1, 1);
+        if (KU == 4) {
+          GPX_FRAGS(buf, 2, 2);
+          GPX_FRAGS(buf, 3, 3);
+        }
+      }
+      if (KU == 4) {
+        GPX_MFMAS(0);
+        GPX_MFMAS(1);
+        GPX_MFMAS(2);
+        GPX_MFMAS(3);
+      } else {
+        GPX_MFMAS(0);
+        GPX_FRAGS(buf, 2, 0);
+        GPX_MFMAS(1);
+        GPX_FRAGS(buf, 3, 1);
+        GPX_MFMAS(0);
+        GPX_MFMAS(1);
+      }
+    }
+#undef GPX_FRAGS
+#undef GPX_MFMAS
+#undef GPX_PIN
   }
 #undef GPX_GLOAD
 #undef GPX_LD16
@@ -270,36 +369,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64
   gemm_tile<BT, ACC, PF, KU, TE>(sm, A, lda, B, ldb, C, ldc, nk, by, bx);
 }
 
-// Persistent variant for large grids: 2 workgroups per CU stay resident; each reads the XCD it really runs on
-// (HW_REG_XCC_ID) and pulls (super-block, tile) slots of THAT XCD from a per-XCD atomic counter.  After the first wave
-// the dispatcher hands workgroup ids to whichever XCD frees a slot, which smears a super-block over several L2s.
-// Every workgroup leaves the loop as soon as its XCD's slots are exhausted: no spinning, no inter-workgroup waits.
-// STATUS (round 1): correct, but opt-in (GPX_GEMM_PERSIST_MIN=<tiles>).  PMC FETCH_SIZE showed the hit rate does not
-// recover with exact XCD placement alone (4096x8192x16384: 51 GB fetched with or without it, 69 GB requested): the
-// first wave of a launch shares panels because it starts in lock-step (70-81 % L2 hit); later tiles start whenever a
-// slot frees and the workgroups drift apart by more than the ~16 k-steps a 4 MiB L2 can bridge (18-31 %).  Next step:
-// a bounded (performance-only) per-XCD re-synchronisation every few hundred k-steps on top of this kernel.
-template <bool BT, bool ACC, bool LOWER, int PF, int KU>
-__global__ __launch_bounds__(256, 2) void gemm_f64_persistent(const double* A, int64_t lda, const double* B,
-                                                              int64_t ldb, double* C, int64_t ldc, int nk,
-                                                              int tiles_m, int tiles_n, int sb_cols, int sb_shift,
-                                                              int nsb, int* __restrict__ counters) {
-  __shared__ Smem<BT, 128> sm;
-  __shared__ int s_slot;
-  const int xcd = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;  // HW_REG_XCC_ID[3:0]
-  const int sbs2 = 2 * sb_shift;
-  for (;;) {
-    if (threadIdx.x == 0) s_slot = atomicAdd(&counters[xcd], 1);
-    __syncthreads();
-    const int slot = s_slot;
-    __syncthreads();  // everyone has read the slot (and finished the previous tile's LDS reads) before it is reused
-    const int sblk = (slot >> sbs2) * 8 + xcd;
-    if (sblk >= nsb) break;
-    int by, bx;
-    if (!tile_of<LOWER>(sblk, slot & ((1 << sbs2) - 1), tiles_m, tiles_n, sb_cols, sb_shift, &by, &bx)) continue;
-    gemm_tile<BT, ACC, PF, KU, 128>(sm, A, lda, B, ldb, C, ldc, nk, by, bx);
-  }
-}
+// (A persistent per-XCD work-queue variant of this kernel was measured in round 1 and removed: exact XCD placement
+// alone does not bring the L2 hit rate back -- 4096x8192x16384: 51 GB fetched with or without it, 69 GB requested; the
+// first wave of a launch shares panels because it starts in lock-step (70-81 % hit), later tiles drift apart by more
+// than the ~16 k-steps a 4 MiB L2 can bridge (18-31 %) -- and the kernel is MFMA-bound either way.)
 
 struct Plan {
   int te, tm, tn, sb_shift, sbc;
@@ -332,12 +405,10 @@ int launch_gemm(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int
   GPX_ARG(m % 128 == 0 && n % 128 == 0 && k % KB == 0 && k > 0, "gemm: m,n must be multiples of 128 and k of 16");
   GPX_ARG((lda % 2) == 0 && (ldb % 2) == 0, "gemm: leading dimensions must be even (16-byte loads)");
   GPX_ARG(!lower || m == n, "gemm: lower-only update needs a square C");
-  static int pf = -1, persist_min = -1, small_max = -1;
+  static int pf = -1, small_max = -1;
   if (pf < 0) {
     const char* e = getenv("GPX_GEMM_PF");
     pf = e ? atoi(e) : 0;  // 0: default (per-variant best); 2: depth-2 prefetch; 12/14: depth-1 + inner unroll 2/4
-    const char* e2 = getenv("GPX_GEMM_PERSIST_MIN");  // tiles from which the persistent kernel is used (0 = never)
-    persist_min = e2 ? atoi(e2) : 0;   // opt-in: measured neutral/slightly slower, see the kernel's comment
     const char* e3 = getenv("GPX_GEMM_SMALL_MAX");    // use 64x64 tiles while the 128-tile count is below this
     small_max = e3 ? atoi(e3) : 1024;  // C4 potrf: 270 ms without, 251 ms at 256, 247 ms at 1024
   }
@@ -352,13 +423,6 @@ int launch_gemm(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int
   dim3 grid((unsigned)p.wgs);
   const int nk = (int)(k / KB);
   ProfScope ps(ctx, GPX_PROF_GEMM, 2.0 * tiles128 * 128.0 * 128.0 * (double)k, 0.0);
-  const bool persist = te == 128 && persist_min > 0 && tiles128 >= (double)persist_min && p.nsb >= 16;
-  int* counters = nullptr;
-  if (persist) {
-    counters = ctx->d_counters + 8 * (ctx->counter_slot++ % GPX_COUNTER_SLOTS);
-    GPX_HIP(hipMemsetAsync(counters, 0, 8 * sizeof(int), ctx->stream));
-    grid = dim3((unsigned)(2 * ctx->cus));
-  }
 #define GPX_K(BT_, ACC_, LOW_, PF_, KU_, TE_)                                                                       \
   hipLaunchKernelGGL((gemm_f64_kernel<BT_, ACC_, LOW_, PF_, KU_, TE_>), grid, dim3(256), 0, ctx->stream, A, lda, B, \
                      ldb, C, ldc, nk, p.tm, p.tn, p.sbc, p.sb_shift)
@@ -366,9 +430,6 @@ int launch_gemm(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int
   do {                                                                                                               \
     if (te == 64)                                                                                                    \
       GPX_K(BT_, ACC_, LOW_, 1, 4, 64);                                                                              \
-    else if (persist)                                                                                                \
-      hipLaunchKernelGGL((gemm_f64_persistent<BT_, ACC_, LOW_, 1, 4>), grid, dim3(256), 0, ctx->stream, A, lda, B,   \
-                         ldb, C, ldc, nk, p.tm, p.tn, p.sbc, p.sb_shift, (int)p.nsb, counters);                      \
     else if (pf == 2)                                                                                                \
       GPX_K(BT_, ACC_, LOW_, 2, 2, 128);                                                                             \
     else if (pf == 12)                                                                                               \

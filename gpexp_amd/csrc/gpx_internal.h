@@ -9,7 +9,6 @@
 
 #define GPX_TILE 128          // padding / GEMM tile / Cholesky leaf size
 #define GPX_MAXD GPX_MAX_DIM
-#define GPX_COUNTER_SLOTS 64     // ring of per-XCD work counters for the persistent GEMM (8 ints each)
 
 // ---- error plumbing ---------------------------------------------------------------------------
 void gpx_set_error(const char* fmt, ...);
@@ -88,10 +87,8 @@ struct gpx_ctx {
   // scalars
   int* d_info;      // first failing pivot (1-based), 0 = ok
   double* d_scal;   // small scalar workspace (>= 64 doubles)
-  int* d_counters;  // GPX_COUNTER_SLOTS x 8 work counters (persistent GEMM)
   double* trsv_scratch;      // grown on demand, kept until gpx_destroy (lets gpx_potrs_dev stay asynchronous)
   int64_t trsv_scratch_bytes;
-  unsigned counter_slot;
   // multi-GPU (RCCL communicator, opaque here; see dist.hip)
   void* comm;
   int rank, world;
