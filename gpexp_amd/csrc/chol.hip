@@ -9,6 +9,7 @@
 // also inverts it, so that all triangular solves against a leaf are GEMMs with the inverse.
 #include "gpx_internal.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -69,71 +70,121 @@ __device__ __forceinline__ void leaf_inverse_column(const double* S, const doubl
   }
 }
 
-__global__ __launch_bounds__(256) void leaf_kernel(double* __restrict__ A, int64_t ld, double* __restrict__ inv,
-                                                   int64_t base_index, int64_t n_valid, int* __restrict__ info) {
-  __shared__ double S[NB * LS];
-  __shared__ double T[8][LB * TS17];
-  const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
-  const int g = lane >> 4, q = lane & 15;
-  for (int idx = t; idx < NB * NB; idx += 256) {
-    const int i = idx >> 7, j = idx & 127;
-    if (j <= i) S[i * LS + j] = A[(int64_t)i * ld + j];
-    if ((j >> 4) > (i >> 4)) inv[idx] = 0.0;  // upper blocks of the inverse are zero; the others are written below
+// lane N of the caller's 16-lane row, broadcast to the row (64-bit DPP supports exactly this: row_newbcast)
+template <int N>
+__device__ __forceinline__ double row_bcast(double v) {
+  return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + N, 0xf, 0xf, false);
+}
+__device__ __forceinline__ double row_bcast_n(double v, int n) {  // n is a constant after unrolling
+  switch (n) {
+    case 0: return row_bcast<0>(v);
+    case 1: return row_bcast<1>(v);
+    case 2: return row_bcast<2>(v);
+    case 3: return row_bcast<3>(v);
+    case 4: return row_bcast<4>(v);
+    case 5: return row_bcast<5>(v);
+    case 6: return row_bcast<6>(v);
+    case 7: return row_bcast<7>(v);
+    case 8: return row_bcast<8>(v);
+    case 9: return row_bcast<9>(v);
+    case 10: return row_bcast<10>(v);
+    case 11: return row_bcast<11>(v);
+    case 12: return row_bcast<12>(v);
+    case 13: return row_bcast<13>(v);
+    case 14: return row_bcast<14>(v);
+    default: return row_bcast<15>(v);
   }
-  __syncthreads();
+}
 
+// (1) of the leaf: factor the 16x16 diagonal block at (c0, c0) of S and invert the factor, one wave, in registers.
+// Lane q of every 16-lane row owns row q of the block and column q of the inverse (the four rows of the wave work
+// redundantly); L[c][j] reaches the other lanes through a DPP row broadcast, and one broadcast feeds both the
+// right-looking update of the factor and the forward substitution of the inverse.  sqrt and 1/sqrt of the pivot come from
+// v_rsq_f64 + two coupled Goldschmidt steps + a residual correction: 8 dependent fp64 ops instead of sqrt + division.
+__device__ __forceinline__ void leaf_diag(double* __restrict__ S, double* __restrict__ Tp, int c0, int q, int lane,
+                                          int64_t base_index, int64_t n_valid, int* __restrict__ info) {
+  double a[LB], sacc[LB], x[LB];
+#pragma unroll
+  for (int c = 0; c < LB; ++c) {
+    a[c] = (c <= q) ? S[(c0 + q) * LS + c0 + c] : 0.0;
+    sacc[c] = (c == q) ? 1.0 : 0.0;
+  }
+#pragma unroll
+  for (int j = 0; j < LB; ++j) {
+    double piv = row_bcast_n(a[j], j);
+    if (!(piv > 0.0)) {  // non-positive or NaN pivot: record the first one, continue with 1.0
+      if (lane == 0 && base_index + c0 + j < n_valid) atomicCAS(info, 0, (int)(base_index + c0 + j + 1));
+      piv = 1.0;
+    }
+    const double y = __builtin_amdgcn_rsq(piv);
+    double g = piv * y, h = 0.5 * y;
+    double r = fma(-g, h, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    r = fma(-g, h, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    g = fma(fma(-g, g, piv), h, g);  // sqrt(piv)
+    const double rs = h + h;         // 1/sqrt(piv)
+    a[j] = (q == j) ? g : a[j] * rs;
+    x[j] = sacc[j] * rs;
+    const double naj = -a[j], nxj = -x[j];
+#pragma unroll
+    for (int c = j + 1; c < LB; ++c) {
+      const double l = row_bcast_n(a[j], c);  // L[c][j]
+      a[c] = fma(l, naj, a[c]);
+      sacc[c] = fma(l, nxj, sacc[c]);
+    }
+  }
+  if (lane < LB) {
+#pragma unroll
+    for (int c = 0; c < LB; ++c) S[(c0 + q) * LS + c0 + c] = (c <= q) ? a[c] : 0.0;
+#pragma unroll
+    for (int r = 0; r < LB; ++r) Tp[r * TS17 + q] = x[r];
+  }
+}
+
+// The 28 blocks (I,K), 1 <= K <= I <= 7, of the trailing matrix live in REGISTERS (MFMA accumulator layout) from the
+// first step to the step that makes their block column current: wave W owns blocks 4s+W of the column-major
+// enumeration, s = 0..6, so the block column of a wave's slots never decreases with s.
+struct LeafBlk { int I, K; };
+__device__ constexpr int kLeafI[28] = {1, 2, 3, 4, 5, 6, 7, 2, 3, 4, 5, 6, 7, 3, 4, 5, 6, 7, 4, 5, 6, 7, 5, 6, 7, 6, 7, 7};
+__device__ constexpr int kLeafK[28] = {1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 6, 6, 7};
+__device__ __forceinline__ constexpr LeafBlk leaf_blk(int b) {  // b-th block, columns K = 1..7 holding rows I = K..7
+  return LeafBlk{kLeafI[b], kLeafK[b]};
+}
+
+// C(slot) -= B_I B_K^T for slots S0..6 of wave W, from the scaled block column at c0; the MFMAs of different slots interleave
+template <int W, int S0>
+__device__ __forceinline__ void leaf_update(const double* __restrict__ S, d4 (&blk)[7], int c0, int g, int q) {
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+    for (int s = S0; s < 7; ++s) {
+      const LeafBlk bk = leaf_blk(4 * s + W);
+      const double a = -S[(LB * bk.I + q) * LS + c0 + 4 * s4 + g];
+      const double b = S[(LB * bk.K + q) * LS + c0 + 4 * s4 + g];
+      blk[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, blk[s], 0, 0, 0);
+    }
+  }
+}
+
+template <int W>
+__device__ __forceinline__ void leaf_factor(double* __restrict__ S, double (*T)[LB * TS17], int g, int q, int lane,
+                                            int64_t base_index, int64_t n_valid, int* __restrict__ info) {
+  d4 blk[7];
+#pragma unroll
+  for (int s = 0; s < 7; ++s) {
+    const LeafBlk bk = leaf_blk(4 * s + W);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) blk[s][v] = S[(LB * bk.I + g + 4 * v) * LS + LB * bk.K + q];
+  }
   for (int p = 0; p < 8; ++p) {
     const int c0 = LB * p;
-    if (wave == 0) {
-      // (1) diagonal block: lane q (all four 16-lane groups redundantly) owns row q
-      double a[LB], rinv[LB], x[LB];
-#pragma unroll
-      for (int c = 0; c < LB; ++c) a[c] = (c <= q) ? S[(c0 + q) * LS + c0 + c] : 0.0;
-#pragma unroll
-      for (int j = 0; j < LB; ++j) {
-        double piv = readlane_d(a[j], j);
-        if (!(piv > 0.0)) {  // non-positive or NaN pivot: record the first one, continue with 1.0
-          if (lane == 0 && base_index + c0 + j < n_valid) atomicCAS(info, 0, (int)(base_index + c0 + j + 1));
-          piv = 1.0;
-        }
-        // 1/sqrt(piv) from v_rsq_f64 + two Newton steps, sqrt(piv) = piv*rs with one residual correction: ~15 dependent
-        // fp64 ops instead of a full-precision sqrt followed by a division (~100) on the serial pivot chain
-        double rs = __builtin_amdgcn_rsq(piv);
-        const double hp = 0.5 * piv;
-        rs = rs * fma(-hp * rs, rs, 1.5);
-        rs = rs * fma(-hp * rs, rs, 1.5);
-        double sq = piv * rs;
-        sq = fma(fma(-sq, sq, piv), 0.5 * rs, sq);
-        rinv[j] = rs;
-        a[j] = (q == j) ? sq : a[j] * rs;
-#pragma unroll
-        for (int c = j + 1; c < LB; ++c) {
-          const double lc = readlane_d(a[j], c);
-          a[c] = fma(-a[j], lc, a[c]);
-        }
-      }
-      // inverse of the 16x16 factor: lane q owns column q
-#pragma unroll
-      for (int r = 0; r < LB; ++r) {
-        double sacc = (r == q) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < r; ++k) {
-          const double lrk = readlane_d(a[k], r);
-          sacc = fma(-lrk, x[k], sacc);
-        }
-        x[r] = sacc * rinv[r];
-      }
-      if (lane < LB) {
-#pragma unroll
-        for (int c = 0; c < LB; ++c) S[(c0 + q) * LS + c0 + c] = (c <= q) ? a[c] : 0.0;
-#pragma unroll
-        for (int r = 0; r < LB; ++r) T[p][r * TS17 + q] = x[r];
-      }
-    }
+    if (W == 0) leaf_diag(S, T[p], c0, q, lane, base_index, n_valid, info);
     __syncthreads();
     // (2) blocks below the diagonal: B <- B * T^T
-    for (int I = p + 1 + wave; I < 8; I += 4) {
+    for (int I = p + 1 + W; I < 8; I += 4) {
       double af[4];
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) af[s4] = S[(LB * I + q) * LS + c0 + 4 * s4 + g];
@@ -145,31 +196,86 @@ __global__ __launch_bounds__(256) void leaf_kernel(double* __restrict__ A, int64
       for (int v = 0; v < 4; ++v) S[(LB * I + g + 4 * v) * LS + c0 + q] = acc[v];
     }
     __syncthreads();
-    // (3) trailing blocks (I,K), p < K <= I: C -= B_I B_K^T
-    const int m = 7 - p;
-    for (int idx = wave; idx < m * (m + 1) / 2; idx += 4) {
-      int ii = 0;
-      while ((ii + 1) * (ii + 2) / 2 <= idx) ++ii;
-      const int kk = idx - ii * (ii + 1) / 2;
-      const int I = p + 1 + ii, K = p + 1 + kk;
-      d4 acc;
+    if (p == 7) break;
+    // (3) trailing blocks in registers.  Slots whose column is <= p are finished (already back in LDS): skipped.
+    int s0 = 0;
 #pragma unroll
-      for (int v = 0; v < 4; ++v) acc[v] = S[(LB * I + g + 4 * v) * LS + LB * K + q];
+    for (int s = 0; s < 7; ++s)
+      if (leaf_blk(4 * s + W).K <= p) s0 = s + 1;
+    switch (s0) {
+      case 0: leaf_update<W, 0>(S, blk, c0, g, q); break;
+      case 1: leaf_update<W, 1>(S, blk, c0, g, q); break;
+      case 2: leaf_update<W, 2>(S, blk, c0, g, q); break;
+      case 3: leaf_update<W, 3>(S, blk, c0, g, q); break;
+      case 4: leaf_update<W, 4>(S, blk, c0, g, q); break;
+      case 5: leaf_update<W, 5>(S, blk, c0, g, q); break;
+      case 6: leaf_update<W, 6>(S, blk, c0, g, q); break;
+      default: break;
+    }
+    // the next block column becomes current: its blocks go back to LDS for the diagonal factor and the scaling
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const double a = -S[(LB * I + q) * LS + c0 + 4 * s4 + g];
-        const double b = S[(LB * K + q) * LS + c0 + 4 * s4 + g];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    for (int s = 0; s < 7; ++s) {
+      const LeafBlk bk = leaf_blk(4 * s + W);
+      if (bk.K == p + 1) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) S[(LB * bk.I + g + 4 * v) * LS + LB * bk.K + q] = blk[s][v];
       }
-#pragma unroll
-      for (int v = 0; v < 4; ++v) S[(LB * I + g + 4 * v) * LS + LB * K + q] = acc[v];
     }
     __syncthreads();
   }
-  // write L back (zero the strict upper part of the diagonal block)
-  for (int idx = t; idx < NB * NB; idx += 256) {
-    const int i = idx >> 7, j = idx & 127;
-    A[(int64_t)i * ld + j] = (j <= i) ? S[i * LS + j] : 0.0;
+}
+
+__global__ __launch_bounds__(256) void leaf_kernel(double* __restrict__ A, int64_t ld, double* __restrict__ inv,
+                                                   int64_t base_index, int64_t n_valid, int* __restrict__ info) {
+  __shared__ double S[NB * LS];
+  __shared__ double T[8][LB * TS17];
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int g = lane >> 4, q = lane & 15;
+  // global -> LDS in two batches of 16 loads per thread: two round trips to memory instead of 64
+  {
+    const int r0 = t >> 6, c = 2 * (t & 63);
+    const double* ap = A + (int64_t)r0 * ld + c;
+    double* sp = S + r0 * LS + c;
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+      double2 v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = *reinterpret_cast<const double2*>(ap + (int64_t)(4 * i) * ld);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        sp[(4 * i) * LS] = v[i].x;
+        sp[(4 * i) * LS + 1] = v[i].y;
+      }
+      ap += 64 * ld;
+      sp += 64 * LS;
+    }
+  }
+  __syncthreads();
+  switch (wave) {
+    case 0: leaf_factor<0>(S, T, g, q, lane, base_index, n_valid, info); break;
+    case 1: leaf_factor<1>(S, T, g, q, lane, base_index, n_valid, info); break;
+    case 2: leaf_factor<2>(S, T, g, q, lane, base_index, n_valid, info); break;
+    default: leaf_factor<3>(S, T, g, q, lane, base_index, n_valid, info); break;
+  }
+  // write L back (zero above the diagonal) and zero the upper blocks of the inverse; the other blocks are written below
+  {
+    const int r0 = t >> 6, c = 2 * (t & 63);
+    double* ap = A + (int64_t)r0 * ld + c;
+    double* ip = inv + r0 * NB + c;
+    const double* sp = S + r0 * LS + c;
+#pragma unroll 4
+    for (int i = 0; i < 32; ++i) {
+      const int r = r0 + 4 * i;
+      double2 o;
+      o.x = (c <= r) ? sp[0] : 0.0;
+      o.y = (c + 1 <= r) ? sp[1] : 0.0;
+      *reinterpret_cast<double2*>(ap) = o;
+      if ((c >> 4) > (r >> 4)) *reinterpret_cast<double2*>(ip) = double2{0.0, 0.0};
+      ap += 4 * ld;
+      ip += 4 * NB;
+      sp += 4 * LS;
+    }
   }
   // inverse: wave w builds block columns w and 7-w (balanced: 140+4 / 108+12 / 80+24 / 56+40 MFMAs)
   switch (wave) {
