@@ -286,6 +286,158 @@ __global__ __launch_bounds__(256) void leaf_kernel(double* __restrict__ A, int64
   }
 }
 
+// ---- leaf multiplies: X <- X * inv^T (right) and B <- inv * B (left), in place -----------------------------------
+// The triangular solves against a 128x128 diagonal block are products with its inverse.  As 128x128x128 GEMM tiles they
+// are bound by the serial MFMA chain and eight k-steps of load latency (21 us however few rows there are, 1024 of them in
+// a C4 factorisation).  Here a workgroup owns a strip of ST rows (right) / ST columns (left) over the WHOLE 128-wide
+// leaf -- so the in-place update is race-free by construction --, brings the strip and the block-lower part of the
+// inverse into LDS in ONE round trip, and each wave multiplies the block pair (w, 7-w) of the inverse's block rows, whose
+// k-extents 16(w+1) + 16(8-w) always add up to 144: the zero upper blocks are never multiplied (36/64 of the MFMAs).
+constexpr int kInvRowOff(int cb) { return 16 * (8 * cb * (cb + 1) + cb); }  // doubles before block row cb: 16 rows x (16(b+1)+1)
+constexpr int INV_LDS = kInvRowOff(8);                                      // 9344 doubles (73 KiB)
+
+// inverse (row-major 128x128, ld 128) -> LDS, block row cb stored with row stride 16(cb+1)+1 (odd: conflict-free)
+__device__ __forceinline__ void leaf_stage_inverse(const double* __restrict__ inv, double* __restrict__ Is) {
+  const int t = threadIdx.x;
+  double2 v[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const int idx = t + 256 * i, r = idx >> 6, c = 2 * (idx & 63);
+    v[i] = double2{0.0, 0.0};
+    if (c < 16 * ((r >> 4) + 1)) v[i] = *reinterpret_cast<const double2*>(inv + r * NB + c);
+  }
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const int idx = t + 256 * i, r = idx >> 6, c = 2 * (idx & 63);
+    const int cb = r >> 4, len = 16 * (cb + 1);
+    if (c < len) {
+      double* d = Is + 16 * (8 * cb * (cb + 1) + cb) + (r & 15) * (len + 1) + c;
+      d[0] = v[i].x;
+      d[1] = v[i].y;
+    }
+  }
+}
+
+// X (m x 128, ld ldx) <- X * inv^T.  grid = m / ST workgroups.
+template <int ST>
+__global__ __launch_bounds__(256) void leaf_mul_right_kernel(double* __restrict__ X, int64_t ldx,
+                                                             const double* __restrict__ inv) {
+  extern __shared__ double lsm[];
+  double* Is = lsm;
+  double* Xs = lsm + INV_LDS;  // [ST][129]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, q = lane & 15;
+  double* Xg = X + (int64_t)blockIdx.x * ST * ldx;
+  constexpr int NX = ST * 64 / 256;  // 16-byte loads per thread for the strip
+  double2 xv[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int idx = t + 256 * i, r = idx >> 6, c = 2 * (idx & 63);
+    xv[i] = *reinterpret_cast<const double2*>(Xg + (int64_t)r * ldx + c);
+  }
+  leaf_stage_inverse(inv, Is);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int idx = t + 256 * i, r = idx >> 6, c = 2 * (idx & 63);
+    Xs[r * LS + c] = xv[i].x;
+    Xs[r * LS + c + 1] = xv[i].y;
+  }
+  __syncthreads();  // every read of the strip is done: the stores below cannot race with another workgroup's rows
+  constexpr int RB = ST / 16;
+  const int cbA = wave, cbB = 7 - wave;
+  const int lenA = 16 * (cbA + 1), lenB = 16 * (cbB + 1);
+  const double* ia = Is + 16 * (8 * cbA * (cbA + 1) + cbA) + q * (lenA + 1) + g;  // inv[16cbA + q][4s + g]
+  const double* ib = Is + 16 * (8 * cbB * (cbB + 1) + cbB) + q * (lenB + 1) + g;
+  d4 accA[RB], accB[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) accA[rb] = accB[rb] = (d4){0.0, 0.0, 0.0, 0.0};
+  const double* xs = Xs + q * LS + g;  // X[16rb + q][4s + g]
+  // both column blocks share the strip's A fragments while s is inside the shorter extent
+  const int sA = lenA / 4, sB = lenB / 4;  // sA <= sB (cbA = wave <= 3)
+  for (int s = 0; s < sA; ++s) {
+    const double ba = ia[4 * s], bb = ib[4 * s];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const double a = xs[(16 * rb) * LS + 4 * s];
+      accA[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, ba, accA[rb], 0, 0, 0);
+      accB[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, accB[rb], 0, 0, 0);
+    }
+  }
+  for (int s = sA; s < sB; ++s) {
+    const double bb = ib[4 * s];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+      accB[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(xs[(16 * rb) * LS + 4 * s], bb, accB[rb], 0, 0, 0);
+  }
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      double* row = Xg + (int64_t)(16 * rb + g + 4 * v) * ldx + q;
+      row[16 * cbA] = accA[rb][v];
+      row[16 * cbB] = accB[rb][v];
+    }
+}
+
+// B (128 x m, ld ldb) <- inv * B.  grid = m / ST workgroups (ST columns each).
+template <int ST>
+__global__ __launch_bounds__(256) void leaf_mul_left_kernel(double* __restrict__ B, int64_t ldb,
+                                                            const double* __restrict__ inv) {
+  extern __shared__ double lsm[];
+  double* Is = lsm;
+  double* Bs = lsm + INV_LDS;  // [128][ST + 1]
+  constexpr int SB = ST + 1;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, q = lane & 15;
+  double* Bg = B + (int64_t)blockIdx.x * ST;
+  constexpr int NBV = 128 * ST / 2 / 256;  // 16-byte loads per thread for the strip
+  constexpr int CPR = ST / 2;              // 16-byte chunks per strip row
+  double2 bv[NBV];
+#pragma unroll
+  for (int i = 0; i < NBV; ++i) {
+    const int idx = t + 256 * i, r = idx / CPR, c = 2 * (idx % CPR);
+    bv[i] = *reinterpret_cast<const double2*>(Bg + (int64_t)r * ldb + c);
+  }
+  leaf_stage_inverse(inv, Is);
+#pragma unroll
+  for (int i = 0; i < NBV; ++i) {
+    const int idx = t + 256 * i, r = idx / CPR, c = 2 * (idx % CPR);
+    Bs[r * SB + c] = bv[i].x;
+    Bs[r * SB + c + 1] = bv[i].y;
+  }
+  __syncthreads();
+  constexpr int CB = ST / 16;
+  const int rbA = wave, rbB = 7 - wave;
+  const int lenA = 16 * (rbA + 1), lenB = 16 * (rbB + 1);
+  const double* ia = Is + 16 * (8 * rbA * (rbA + 1) + rbA) + q * (lenA + 1) + g;  // A operand: inv[16rb + q][4s + g]
+  const double* ib = Is + 16 * (8 * rbB * (rbB + 1) + rbB) + q * (lenB + 1) + g;
+  d4 accA[CB], accB[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) accA[cb] = accB[cb] = (d4){0.0, 0.0, 0.0, 0.0};
+  const double* bs = Bs + g * SB + q;  // B operand: strip[4s + g][16cb + q]
+  const int sA = lenA / 4, sB = lenB / 4;
+  for (int s = 0; s < sA; ++s) {
+    const double aa = ia[4 * s], ab = ib[4 * s];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      const double b = bs[(4 * s) * SB + 16 * cb];
+      accA[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aa, b, accA[cb], 0, 0, 0);
+      accB[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ab, b, accB[cb], 0, 0, 0);
+    }
+  }
+  for (int s = sA; s < sB; ++s) {
+    const double ab = ib[4 * s];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+      accB[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ab, bs[(4 * s) * SB + 16 * cb], accB[cb], 0, 0, 0);
+  }
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      Bg[(int64_t)(16 * rbA + g + 4 * v) * ldb + 16 * cb + q] = accA[cb][v];
+      Bg[(int64_t)(16 * rbB + g + 4 * v) * ldb + 16 * cb + q] = accB[cb][v];
+    }
+}
+
 // ---- TRSV pieces (potrs) ---------------------------------------------------------------------------
 // The sweeps follow the same recursion as the factorisation: solve the first half, subtract the off-diagonal block
 // times that solution from the second half as ONE bandwidth-bound GEMV over the whole block, solve the second half
@@ -366,6 +518,56 @@ inline int64_t split(int64_t n) { return (n / NB / 2) * NB; }  // n multiple of 
 
 }  // namespace
 
+// the strips + the staged inverse need more than the default 64 KiB of dynamic LDS
+template <class K>
+static int leaf_mul_allow_lds(K kernel, size_t bytes) {
+  GPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return 0;
+}
+
+// X (m x 128) <- X * inv^T in place; m a multiple of 128
+static int launch_leaf_mul_right(gpx_ctx* ctx, double* X, int64_t ldx, const double* inv, int64_t m) {
+  GPX_ARG(m % NB == 0 && (ldx % 2) == 0, "leaf multiply: rows must be a multiple of 128 and ld even");
+  ProfScope ps(ctx, GPX_PROF_GEMM, 2.0 * (double)m * NB * NB, 0.0);
+  // 32-row strips while they fill the chip once, 64-row strips (half the copies of the inverse) beyond that
+  if (m <= 32 * (int64_t)ctx->cus) {
+    constexpr int ST = 32;
+    const size_t sh = (size_t)(INV_LDS + ST * LS) * sizeof(double);
+    static bool once = false;
+    if (!once) { GPX_TRY(leaf_mul_allow_lds(leaf_mul_right_kernel<ST>, sh)); once = true; }
+    hipLaunchKernelGGL(leaf_mul_right_kernel<ST>, dim3((unsigned)(m / ST)), dim3(256), sh, ctx->stream, X, ldx, inv);
+  } else {
+    constexpr int ST = 64;
+    const size_t sh = (size_t)(INV_LDS + ST * LS) * sizeof(double);
+    static bool once = false;
+    if (!once) { GPX_TRY(leaf_mul_allow_lds(leaf_mul_right_kernel<ST>, sh)); once = true; }
+    hipLaunchKernelGGL(leaf_mul_right_kernel<ST>, dim3((unsigned)(m / ST)), dim3(256), sh, ctx->stream, X, ldx, inv);
+  }
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
+
+// B (128 x m) <- inv * B in place; m a multiple of 128
+static int launch_leaf_mul_left(gpx_ctx* ctx, double* B, int64_t ldb, const double* inv, int64_t m) {
+  GPX_ARG(m % NB == 0 && (ldb % 2) == 0, "leaf multiply: columns must be a multiple of 128 and ld even");
+  ProfScope ps(ctx, GPX_PROF_GEMM, 2.0 * (double)m * NB * NB, 0.0);
+  if (m <= 32 * (int64_t)ctx->cus) {
+    constexpr int ST = 32;
+    const size_t sh = (size_t)(INV_LDS + NB * (ST + 1)) * sizeof(double);
+    static bool once = false;
+    if (!once) { GPX_TRY(leaf_mul_allow_lds(leaf_mul_left_kernel<ST>, sh)); once = true; }
+    hipLaunchKernelGGL(leaf_mul_left_kernel<ST>, dim3((unsigned)(m / ST)), dim3(256), sh, ctx->stream, B, ldb, inv);
+  } else {
+    constexpr int ST = 64;
+    const size_t sh = (size_t)(INV_LDS + NB * (ST + 1)) * sizeof(double);
+    static bool once = false;
+    if (!once) { GPX_TRY(leaf_mul_allow_lds(leaf_mul_left_kernel<ST>, sh)); once = true; }
+    hipLaunchKernelGGL(leaf_mul_left_kernel<ST>, dim3((unsigned)(m / ST)), dim3(256), sh, ctx->stream, B, ldb, inv);
+  }
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_leaf(gpx_ctx* ctx, double* A, int64_t ld, double* inv, int64_t base_index, int64_t n_valid) {
   ProfScope ps(ctx, GPX_PROF_LEAF, 2.0 * NB * NB * NB / 3.0, 0.0);
   hipLaunchKernelGGL(leaf_kernel, dim3(1), dim3(256), 0, ctx->stream, A, ld, inv, base_index, n_valid, ctx->d_info);
@@ -377,7 +579,7 @@ int launch_leaf(gpx_ctx* ctx, double* A, int64_t ld, double* inv, int64_t base_i
 int chol_trsm_right(gpx_ctx* ctx, const double* L, int64_t ldl, const double* invd, double* X, int64_t ldx,
                     int64_t m, int64_t n) {
   if (m == 0 || n == 0) return 0;
-  if (n == NB) return launch_gemm(ctx, X, ldx, invd, NB, X, ldx, m, NB, NB, true, false, false);
+  if (n == NB) return launch_leaf_mul_right(ctx, X, ldx, invd, m);
   const int64_t n1 = split(n), n2 = n - n1;
   GPX_TRY(chol_trsm_right(ctx, L, ldl, invd, X, ldx, m, n1));
   // X2 -= X1 * L21^T
@@ -401,7 +603,7 @@ int chol_trsm_right_n(gpx_ctx* ctx, const double* L, int64_t ldl, const double* 
 int chol_trsm_left(gpx_ctx* ctx, const double* L, int64_t ldl, const double* invd, double* B, int64_t ldb,
                    int64_t n, int64_t m) {
   if (m == 0 || n == 0) return 0;
-  if (n == NB) return launch_gemm(ctx, invd, NB, B, ldb, B, ldb, NB, m, NB, false, false, false);
+  if (n == NB) return launch_leaf_mul_left(ctx, B, ldb, invd, m);
   const int64_t n1 = split(n), n2 = n - n1;
   GPX_TRY(chol_trsm_left(ctx, L, ldl, invd, B, ldb, n1, m));
   // B2 -= L21 * W1

@@ -16,7 +16,7 @@ trsm_left(N, M)
 rows = []
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
-        if "gemm_f64" in r["Kernel_Name"]:
+        if "gemm_f64" in r["Kernel_Name"] or "leaf_mul" in r["Kernel_Name"]:
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
 rows.sort()
 rows = rows[-len(calls):]   # the last ivar call

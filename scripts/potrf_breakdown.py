@@ -45,7 +45,7 @@ rows = []
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         nm = r["Kernel_Name"]
-        if "gemm_f64" in nm or "leaf_kernel" in nm:
+        if "gemm_f64" in nm or "leaf_kernel" in nm or "leaf_mul" in nm:
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "leaf" if "leaf_kernel" in nm else "gemm"))
 rows.sort()
 reps = len(rows) // len(calls)
