@@ -658,7 +658,9 @@ int gpx_dbg_gemm(gpx_ctx* ctx, const gpx_mat* A, const gpx_mat* B, gpx_mat* C, i
   GPX_ARG(bt ? (B->prows == n && B->pcols == k) : (B->prows == k && B->pcols == n), "B shape");
   GPX_TRY(launch_gemm(ctx, A->p, A->ld, B->p, B->ld, C->p, C->ld, m, n, k, bt != 0, accumulate != 0,
                       lower != 0));
-  GPX_HIP(hipStreamSynchronize(ctx->stream));
+  static int nosync = -1;  // GPX_DBG_NOSYNC=1: leave the launch in flight (back-to-back timing experiments)
+  if (nosync < 0) nosync = getenv("GPX_DBG_NOSYNC") ? 1 : 0;
+  if (!nosync) GPX_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
 }
 

@@ -354,13 +354,26 @@ __device__ __forceinline__ void gemm_tile(Smem<BT, TE>& sm, const double* A, int
     }
 }
 
-// one workgroup per tile; ids congruent mod 8 are assumed to share an XCD (true for the first wave of workgroups)
+// one workgroup per tile; ids congruent mod 8 are assumed to share an XCD (true for the first wave of workgroups).
+// TE == 128 launches may carry a TAIL: the last rows of C (from element row tail_m0) are cut into 64x64 tiles handled by
+// the workgroups with the highest ids, i.e. the ones dispatched last.  All tiles of a launch take the same time, so a
+// launch whose tile count is not a multiple of the resident workgroups ends with a mostly idle round; tiles with a
+// quarter of the work shorten it.
 template <bool BT, bool ACC, bool LOWER, int PF, int KU, int TE>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64_t lda, const double* B, int64_t ldb,
                                                           double* C, int64_t ldc, int nk, int tiles_m, int tiles_n,
-                                                          int sb_cols, int sb_shift) {
+                                                          int sb_cols, int sb_shift, int main_wgs, int tail_m0,
+                                                          int tail_tn) {
   __shared__ Smem<BT, TE> sm;
   const int w = blockIdx.x;
+  if (TE == 128 && w >= main_wgs) {
+    const int wt = w - main_wgs;
+    const int by = wt / tail_tn, bx = wt - by * tail_tn;
+    if (LOWER && 64 * bx > tail_m0 + 64 * by + 63) return;  // tile entirely above the diagonal
+    gemm_tile<BT, ACC, 1, 4, 64>(reinterpret_cast<Smem<BT, 64>&>(sm), A + (int64_t)tail_m0 * lda, lda, B, ldb,
+                                 C + (int64_t)tail_m0 * ldc, ldc, nk, by, bx);
+    return;
+  }
   const int xcd = w & 7, q = w >> 3;
   const int sbs2 = 2 * sb_shift;
   int by, bx;
@@ -418,14 +431,37 @@ int launch_gemm(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int
   // whole 128-wide leaf: every read of the aliased operand then precedes that workgroup's own stores.
   const bool aliased = (C == A) || (C == B);
   const int te = (!aliased && tiles128 < (double)small_max) ? 64 : 128;
-  const Plan p = make_plan(m, n, lower, te);
-  GPX_ARG(p.wgs < ((int64_t)1 << 31), "gemm: grid too large");
-  dim3 grid((unsigned)p.wgs);
+  // tail: the last `tr` 128-row bands of C as 64x64 tiles (see the kernel), about one chip-load of them.  Used for the
+  // triangular (SYRK) launches only: their tile counts are never a multiple of the 512 resident workgroups (8192^2: 2080
+  // tiles = 4.06 rounds, 53 -> 55 TF/s with the tail; 16384^2: 65.2 -> 66.2).  Rectangular launches measured 1-4 % SLOWER
+  // with it: their tile counts divide evenly, and what looks like a drain there is the clock/fabric ramp after a stretch
+  // of small kernels (the same launch repeated back to back goes 4.86 -> 3.84 ms over ~30 ms, scripts/probe_b2b.py).
+  static int tail_target = -1;
+  if (tail_target < 0) {
+    const char* e4 = getenv("GPX_GEMM_TAIL");  // 64-tiles wanted in the tail; 0 switches the tail off
+    tail_target = e4 ? atoi(e4) : 512;
+  }
+  int64_t tr = 0;
+  if (te == 128 && lower && !aliased && tail_target > 0 && m >= 512) {
+    const int64_t tm = m / 128, tn = n / 128;
+    int64_t t64 = 0;
+    while (tr < tm / 2 && t64 < tail_target) {
+      ++tr;
+      const int64_t band = tm - tr;  // 0-based index of the band added: 2 rows of 64-tiles
+      t64 += lower ? (2 * band + 1) + (2 * band + 2) : 4 * tn;
+    }
+  }
+  const int64_t m_main = m - 128 * tr;
+  const Plan p = make_plan(m_main, n, lower, te);
+  const int64_t tail_tn = lower ? m / 64 : n / 64;
+  const int64_t tail_wgs = 2 * tr * tail_tn;
+  GPX_ARG(p.wgs + tail_wgs < ((int64_t)1 << 31), "gemm: grid too large");
+  dim3 grid((unsigned)(p.wgs + tail_wgs));
   const int nk = (int)(k / KB);
   ProfScope ps(ctx, GPX_PROF_GEMM, 2.0 * tiles128 * 128.0 * 128.0 * (double)k, 0.0);
 #define GPX_K(BT_, ACC_, LOW_, PF_, KU_, TE_)                                                                       \
   hipLaunchKernelGGL((gemm_f64_kernel<BT_, ACC_, LOW_, PF_, KU_, TE_>), grid, dim3(256), 0, ctx->stream, A, lda, B, \
-                     ldb, C, ldc, nk, p.tm, p.tn, p.sbc, p.sb_shift)
+                     ldb, C, ldc, nk, p.tm, p.tn, p.sbc, p.sb_shift, (int)p.wgs, (int)m_main, (int)tail_tn)
 #define GPX_G(BT_, ACC_, LOW_)                                                                                       \
   do {                                                                                                               \
     if (te == 64)                                                                                                    \
