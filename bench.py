@@ -215,6 +215,8 @@ def main():
                       "frac": (kf["bytes"] / (kf["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS) if kf["ms"] > 0 else 0.0,
                       "note": "all kfill launches of the step (square K + N x M cross matrix)"},
             "phases_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items() if v["launches"]},
+            "phases_note": "HIP-event spans per kernel class; trsv and reduce run on a side stream UNDERNEATH the IVAR GEMMs, "
+                           "so their spans include waiting and the classes do not add up to ms_per_step",
             "results": {"loglike": ll, "ivar": iv},
             "device": info["name"],
         }
