@@ -453,6 +453,84 @@ int gpx_potrf(gpx_ctx* ctx, gpx_mat* K) {
   return info;
 }
 
+static int need_factor(const gpx_mat* L);
+
+// f2: refit when only the trailing points of the design changed.  The leading `keep` rows/columns of
+// K(X)+nugget equal the matrix `Lold` factors, so its leading keep x keep factor block and leaf inverses are copied, the
+// rows >= keep are assembled, and the factorisation is completed: A21 <- A21 L11^-T, A22 <- A22 - A21 A21^T, potrf(A22).
+// O(N^2 b) instead of O(N^3/3) for b new points.
+int gpx_refit_rows(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* X, const double* nugget,
+                   int64_t nugget_len, const gpx_mat* Lold, int64_t keep, gpx_mat** outL) {
+  GPX_ARG(ctx && X && outL, "NULL argument");
+  KParams kp;
+  GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
+  GPX_ARG(X->cols == d && X->pcols == d, "X must be an unpadded (N x d) point set");
+  const int64_t n = X->rows;
+  GPX_ARG(nugget_len == 0 || nugget_len == 1 || nugget_len == n, "nugget_len must be 0, 1 or N");
+  GPX_ARG(nugget_len == 0 || nugget != nullptr, "nugget is NULL");
+  GPX_ARG(keep >= 0 && keep % GPX_TILE == 0, "keep must be a non-negative multiple of 128");
+  if (keep > 0) {
+    GPX_TRY(need_factor(Lold));
+    GPX_ARG(keep <= Lold->rows && keep <= n, "keep exceeds the old factor or the new point set");
+  }
+  gpx_mat* K = nullptr;
+  GPX_TRY(gpx_mat_new(ctx, n, n, 1, &K));
+  const int64_t np = K->prows;
+  int r = 0;
+  double* d_nug = nullptr;
+  int64_t nug_bytes = 0;
+  do {
+    K->aux_bytes = np * GPX_TILE * 8;
+    void* pa;
+    if ((r = gpx_dev_alloc(ctx, K->aux_bytes, &pa)) != 0) break;
+    K->aux = (double*)pa;
+    if (keep > 0) {
+      if ((r = gpx_copy2d(ctx, Lold->p, Lold->ld, K->p, K->ld, keep, keep)) != 0) break;
+      if (hipMemcpyAsync(K->aux, Lold->aux, (size_t)keep * GPX_TILE * 8, hipMemcpyDeviceToDevice, ctx->stream) !=
+          hipSuccess) { r = -2; gpx_set_error("refit_rows: copy of the leaf inverses failed"); break; }
+    }
+    double nscal = 0.0;
+    if (nugget_len == 1) nscal = nugget[0];
+    if (nugget_len > 1) {
+      nug_bytes = nugget_len * 8;
+      void* pn;
+      if ((r = gpx_dev_alloc(ctx, nug_bytes, &pn)) != 0) break;
+      d_nug = (double*)pn;
+      if (hipMemcpyAsync(d_nug, nugget, (size_t)nug_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        r = -2; gpx_set_error("refit_rows: nugget upload failed"); break;
+      }
+    }
+    if (hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream) != hipSuccess) { r = -2; break; }
+    const int64_t n2 = np - keep;
+    if (n2 > 0) {
+      double* A21 = K->p + keep * K->ld;
+      if ((r = launch_kfill_rows(ctx, kp, X->p, n, keep, d_nug, nugget_len, nscal, A21, n2, np, K->ld)) != 0) break;
+      if (keep > 0) {
+        if ((r = chol_trsm_right(ctx, K->p, K->ld, K->aux, A21, K->ld, n2, keep)) != 0) break;
+        if ((r = launch_gemm(ctx, A21, K->ld, A21, K->ld, A21 + keep, K->ld, n2, n2, keep, true, true, true)) != 0) break;
+      }
+      if ((r = chol_potrf_nozero(ctx, A21 + keep, K->ld, n2, K->aux + (keep / GPX_TILE) * GPX_TILE * GPX_TILE, keep, n)) != 0)
+        break;
+    }
+    int info = 0;
+    if (hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { r = -2; break; }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { r = -2; break; }
+    K->factored = (info == 0);
+    if (info != 0) {
+      gpx_set_error("refit_rows: matrix is not positive definite (pivot %d <= 0)", info);
+      r = info;
+    }
+  } while (0);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (d_nug) gpx_dev_release(ctx, d_nug, nug_bytes);
+  if (r != 0) {
+    gpx_mat_free(ctx, K);
+    return r;
+  }
+  *outL = K;
+  return 0;
+}
+
 static int need_factor(const gpx_mat* L) {
   GPX_ARG(L != nullptr, "factor is NULL");
   GPX_ARG(L->factored && L->aux, "matrix has not been factored by gpx_potrf");

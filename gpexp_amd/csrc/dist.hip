@@ -83,7 +83,9 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const double* __restrict__ 
   *reinterpret_cast<double2*>(dst + r * ldd + c2) = *reinterpret_cast<const double2*>(src + r * lds_ + c2);
 }
 
-int copy2d(gpx_ctx* ctx, const double* src, int64_t lds_, double* dst, int64_t ldd, int64_t rows, int64_t cols) {
+}  // namespace
+
+int gpx_copy2d(gpx_ctx* ctx, const double* src, int64_t lds_, double* dst, int64_t ldd, int64_t rows, int64_t cols) {
   if (rows <= 0 || cols <= 0) return 0;
   // grid.y is limited to 65535 rows per launch
   for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
@@ -96,7 +98,7 @@ int copy2d(gpx_ctx* ctx, const double* src, int64_t lds_, double* dst, int64_t l
   return 0;
 }
 
-}  // namespace
+
 
 extern "C" {
 
@@ -229,7 +231,7 @@ int gpx_dist_panel_factor(gpx_ctx* ctx, gpx_mat* K, int64_t k, int64_t nb, gpx_m
   GPX_ARG(P->bytes >= gpx_dist_panel_elems(np, nb) * 8, "panel buffer too small");
   double* pb = P->p;
   double* pinv = P->p + rows * nb;  // leaf inverses of this panel
-  GPX_TRY(copy2d(ctx, K->p + r0 * K->ld + r0, K->ld, pb, nb, rows, w));
+  GPX_TRY(gpx_copy2d(ctx, K->p + r0 * K->ld + r0, K->ld, pb, nb, rows, w));
   GPX_TRY(chol_potrf_nozero(ctx, pb, nb, w, pinv, r0, K->rows));
   if (rows > w) GPX_TRY(chol_trsm_right(ctx, pb, nb, pinv, pb + w * nb, nb, rows - w, w));
   return 0;
@@ -247,7 +249,7 @@ int gpx_dist_panel_store(gpx_ctx* ctx, gpx_mat* K, int64_t k, int64_t nb, const 
     GPX_TRY(gpx_dev_alloc(ctx, K->aux_bytes, &p));
     K->aux = (double*)p;
   }
-  GPX_TRY(copy2d(ctx, P->p, nb, K->p + r0 * K->ld + r0, K->ld, rows, w));
+  GPX_TRY(gpx_copy2d(ctx, P->p, nb, K->p + r0 * K->ld + r0, K->ld, rows, w));
   GPX_HIP(hipMemcpyAsync(K->aux + (r0 / GPX_TILE) * GPX_TILE * GPX_TILE, P->p + rows * nb,
                          (size_t)((w / GPX_TILE) * GPX_TILE * GPX_TILE * 8), hipMemcpyDeviceToDevice, ctx->stream));
   return 0;

@@ -125,6 +125,10 @@ int launch_kfill_offset(gpx_ctx* ctx, const KParams& kp, const double* X, int64_
                         const double* d_nugget, int64_t nugget_len, double nugget_scalar, double* out, int64_t prows,
                         int64_t pcols, int64_t ld);
 int launch_kdiag(gpx_ctx* ctx, const KParams& kp, const double* Z, int64_t m, double* out);
+int gpx_copy2d(gpx_ctx* ctx, const double* src, int64_t lds_, double* dst, int64_t ldd, int64_t rows, int64_t cols);
+int launch_kfill_rows(gpx_ctx* ctx, const KParams& kp, const double* X, int64_t n, int64_t row0, const double* d_nugget,
+                      int64_t nugget_len, double nugget_scalar, double* out, int64_t prows_band, int64_t pcols,
+                      int64_t ld);
 
 // gemm_f64.hip:  C[m x n] = (accumulate ? C - A*op(B) : A*op(B)),  m,n multiples of 128, k multiple of 16
 int launch_gemm(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,

@@ -158,7 +158,7 @@ __device__ __forceinline__ void finish_tile(const d4 (&acc)[2][2], double2 (&val
                                             const double* __restrict__ tab, int64_t i0, int64_t j0, int64_t na,
                                             int64_t nb, int symmetric, const double* __restrict__ nugget,
                                             int64_t nugget_len, double nugget_scalar, char* otile, unsigned ooff,
-                                            int64_t ld, int rbase, int c0, bool diag_tile) {
+                                            int64_t ld, int rbase, int c0, bool diag_tile, int64_t row_shift) {
   const double sig3 = sig * (1.0 / 3.0);
   const int64_t gj0 = j0 + c0, gj1 = gj0 + 1;
 #pragma unroll
@@ -171,19 +171,20 @@ __device__ __forceinline__ void finish_tile(const d4 (&acc)[2][2], double2 (&val
         s1 = fmax(s1, 0.0);
       }
       const int64_t gi = i0 + rbase + mi * 16 + 4 * v;
+      const int64_t gd = gi + row_shift;  // this row's diagonal column
       if (!INTERIOR && symmetric && KIND != GPX_K_MEHLER) {  // exact zero distance on the diagonal, as the reference has it
-        if (gi == gj0) s0 = 0.0;
-        if (gi == gj1) s1 = 0.0;
+        if (gd == gj0) s0 = 0.0;
+        if (gd == gj1) s1 = 0.0;
       }
       double v0 = kvalue<KIND>(s0, sig, sig3, tab), v1 = kvalue<KIND>(s1, sig, sig3, tab);
       if (!INTERIOR) {  // edge tiles (padding) and tiles crossing the diagonal (nugget)
         const bool rin = gi < na;
-        if (!(rin && gj0 < nb)) v0 = (symmetric && gi == gj0) ? 1.0 : 0.0;
-        if (!(rin && gj1 < nb)) v1 = (symmetric && gi == gj1) ? 1.0 : 0.0;
+        if (!(rin && gj0 < nb)) v0 = (symmetric && gd == gj0) ? 1.0 : 0.0;
+        if (!(rin && gj1 < nb)) v1 = (symmetric && gd == gj1) ? 1.0 : 0.0;
         if (symmetric && rin && nugget_len > 0) {
-          const double nz = nugget_len == 1 ? nugget_scalar : nugget[gi];
-          if (gi == gj0) v0 += nz;
-          if (gi == gj1) v1 += nz;
+          const double nz = nugget_len == 1 ? nugget_scalar : nugget[gd];
+          if (gd == gj0) v0 += nz;
+          if (gd == gj1) v1 += nz;
         }
       }
       val[mi][v].x = v0;
@@ -193,8 +194,8 @@ __device__ __forceinline__ void finish_tile(const d4 (&acc)[2][2], double2 (&val
       if (!INTERIOR && diag_tile) {
         // the augmented dot product adds |a|^2 and |b|^2 in operand order, so V[r][c] and V[c][r] can differ in the
         // last bit: the diagonal tile of the mirrored fill stores its lower half here and mirrors it like any other
-        if (gi >= gj0) dst[0] = v0;
-        if (gi >= gj1) dst[1] = v1;
+        if (gd >= gj0) dst[0] = v0;
+        if (gd >= gj1) dst[1] = v1;
       } else {
         *reinterpret_cast<double2*>(dst) = val[mi][v];
       }
@@ -210,7 +211,8 @@ template <int KIND, bool SYM, int K4>
 __global__ __launch_bounds__(256, WAVES_PER_EU) void kfill_kernel(KParams kp, const double* __restrict__ A, int64_t na,
                                                     const double* __restrict__ B, int64_t nb, int symmetric,
                                                     const double* __restrict__ nugget, int64_t nugget_len,
-                                                    double nugget_scalar, double* __restrict__ out, int64_t ld) {
+                                                    double nugget_scalar, double* __restrict__ out, int64_t ld,
+                                                    int64_t row_shift) {
   extern __shared__ double sm[];
   const int d = kp.d;
   constexpr int dpad = 4 * K4;  // coordinates + the two augmentation slots, padded to the MFMA K step
@@ -258,16 +260,18 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void kfill_kernel(KParams kp, co
   }
 
   const int c0 = wn * 32 + 2 * q;
-  const bool interior = (i0 + TM <= na) && (j0 + TN <= nb) && (!symmetric || (i0 + TM <= j0) || (j0 + TN <= i0));
+  // row_shift: the row set starts `row_shift` entries into the column set (row-band refill): diagonal at gj == gi + shift
+  const int64_t is0 = i0 + row_shift;
+  const bool interior = (i0 + TM <= na) && (j0 + TN <= nb) && (!symmetric || (is0 + TM <= j0) || (j0 + TN <= is0));
   char* const otile = reinterpret_cast<char*>(out + i0 * ld + j0);
   const unsigned ooff = (unsigned)(((wm * 32 + g) * ld + c0) * 8);
   double2 val[2][4];
   if (__builtin_amdgcn_readfirstlane((int)interior))
     finish_tile<KIND, true>(acc, val, kp.sig, tab, i0, j0, na, nb, symmetric, nugget, nugget_len, nugget_scalar, otile,
-                            ooff, ld, wm * 32 + g, c0, false);
+                            ooff, ld, wm * 32 + g, c0, false, row_shift);
   else
     finish_tile<KIND, false>(acc, val, kp.sig, tab, i0, j0, na, nb, symmetric, nugget, nugget_len, nugget_scalar, otile,
-                             ooff, ld, wm * 32 + g, c0, SYM && ti == tj);
+                             ooff, ld, wm * 32 + g, c0, SYM && ti == tj, row_shift);
 
   if (SYM) {
     // mirror: out[j0 + c][i0 + r] = V[r][c]; the two row halves (wm = 0 / 1) go through the padded image in turn
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(256) void kdiag_kernel(KParams kp, const double* __
 template <int KIND, bool SYM, int K4>
 int launch_k4(gpx_ctx* ctx, const KParams& kp, const double* A, int64_t na, const double* B, int64_t nb, int symmetric,
               const double* d_nugget, int64_t nugget_len, double nugget_scalar, double* out, int64_t prows,
-              int64_t pcols, int64_t ld) {
+              int64_t pcols, int64_t ld, int64_t row_shift) {
   dim3 grid;
   if (SYM) {
     const int64_t t = prows / TM;
@@ -333,7 +337,7 @@ int launch_k4(gpx_ctx* ctx, const KParams& kp, const double* A, int64_t na, cons
   }
   const size_t sh = (size_t)(2 * TM * (4 * K4 + 1) + EXP_TAB + (SYM ? 32 * TP : 0)) * sizeof(double);
   hipLaunchKernelGGL((kfill_kernel<KIND, SYM, K4>), grid, dim3(256), sh, ctx->stream, kp, A, na, B, nb, symmetric,
-                     d_nugget, nugget_len, nugget_scalar, out, ld);
+                     d_nugget, nugget_len, nugget_scalar, out, ld, row_shift);
   GPX_HIP(hipGetLastError());
   return 0;
 }
@@ -341,9 +345,10 @@ int launch_k4(gpx_ctx* ctx, const KParams& kp, const double* A, int64_t na, cons
 template <int KIND, bool SYM>
 int launch_kind(gpx_ctx* ctx, const KParams& kp, const double* A, int64_t na, const double* B, int64_t nb,
                 int symmetric, const double* d_nugget, int64_t nugget_len, double nugget_scalar, double* out,
-                int64_t prows, int64_t pcols, int64_t ld) {
-#define GPX_K4(N_) \
-  launch_k4<KIND, SYM, N_>(ctx, kp, A, na, B, nb, symmetric, d_nugget, nugget_len, nugget_scalar, out, prows, pcols, ld)
+                int64_t prows, int64_t pcols, int64_t ld, int64_t row_shift = 0) {
+#define GPX_K4(N_)                                                                                                      \
+  launch_k4<KIND, SYM, N_>(ctx, kp, A, na, B, nb, symmetric, d_nugget, nugget_len, nugget_scalar, out, prows, pcols, ld, \
+                           row_shift)
   const int k4 = (kp.d + 2 + 3) / 4;
   if (k4 <= 2) return GPX_K4(2);   // d <= 6
   if (k4 <= 3) return GPX_K4(3);   // d <= 10
@@ -366,6 +371,30 @@ int launch_kfill(gpx_ctx* ctx, const KParams& kp, const double* A, int64_t na, c
   (sym ? launch_kind<K_, true>(ctx, kp, A, na, B, nb, 1, d_nugget, nugget_len, nugget_scalar, out, prows, pcols, ld) \
        : launch_kind<K_, false>(ctx, kp, A, na, B, nb, symmetric, d_nugget, nugget_len, nugget_scalar, out, prows,  \
                                 pcols, ld))
+  switch (kp.kind) {
+    case GPX_K_SE: return GPX_KIND(GPX_K_SE);
+    case GPX_K_MATERN32: return GPX_KIND(GPX_K_MATERN32);
+    case GPX_K_MATERN52: return GPX_KIND(GPX_K_MATERN52);
+    case GPX_K_MEHLER: return GPX_KIND(GPX_K_MEHLER);
+  }
+#undef GPX_KIND
+  gpx_set_error("kfill: unknown kernel kind %d", kp.kind);
+  return -1;
+}
+
+// rows [row0, prows_total) of the symmetric covariance of X (all columns; diagonal, nugget and identity padding included):
+// what a refit needs when only the trailing points changed.  `out` points at row row0 of the padded matrix.
+int launch_kfill_rows(gpx_ctx* ctx, const KParams& kp, const double* X, int64_t n, int64_t row0, const double* d_nugget,
+                      int64_t nugget_len, double nugget_scalar, double* out, int64_t prows_band, int64_t pcols,
+                      int64_t ld) {
+  GPX_ARG(row0 % TM == 0 && prows_band % TM == 0 && pcols % TN == 0, "kfill_rows: band must be tile aligned");
+  GPX_ARG(prows_band / TM <= 65535, "kfill: too many row tiles");
+  int64_t na = n - row0;
+  if (na < 0) na = 0;
+  ProfScope ps(ctx, GPX_PROF_KFILL, 0.0, 8.0 * (double)prows_band * (double)pcols + 8.0 * (double)(na + n) * kp.d);
+  const double* A = X + row0 * kp.d;
+#define GPX_KIND(K_) \
+  launch_kind<K_, false>(ctx, kp, A, na, X, n, 1, d_nugget, nugget_len, nugget_scalar, out, prows_band, pcols, ld, row0)
   switch (kp.kind) {
     case GPX_K_SE: return GPX_KIND(GPX_K_SE);
     case GPX_K_MATERN32: return GPX_KIND(GPX_K_MATERN32);

@@ -199,6 +199,15 @@ def potrf(ctx, K):
     return K
 
 
+def refit_rows(ctx, spec, X, nugget, L_old, keep):
+    """Cholesky factor of K(X,X)+diag(nugget) re-using the leading `keep` (multiple of 128) rows of the factor `L_old`."""
+    nug, nlen = _nugget_args(nugget, X.shape[0])
+    h = c_vp()
+    check(ctx.lib.gpx_refit_rows(ctx.h, *spec.args(), X.h, dptr(nug), nlen, L_old.h if keep > 0 else None, int(keep),
+                                 C.byref(h)))
+    return DeviceMatrix(ctx, h)
+
+
 def potrs(ctx, L, y):
     y = as_f64(y)
     out = np.empty_like(y)

@@ -236,6 +236,44 @@ class ExperimentalDesignDerivative(ExperimentalDesign):
         return np.reshape(best, (int(len(best) / self.nDims), self.nDims))
 
 
+class ExperimentalDesignGreedyWithDerivatives(ExperimentalDesignDerivative):
+    """Batch-greedy continuous design (experimentalDesign.py:694-751, the branch without continuation): points are added
+    `nPointsBatch` at a time; every batch is an SLSQP run over ALL points so far in which the earlier ones are pinned by
+    equal lower/upper bounds (:719-724) and the new ones start from a greedy maximum-variance pick.
+
+    SURVEY.md 8 f2: because the pinned points lead every trial design, each cost/gradient evaluation of a batch re-uses
+    the factor of their covariance block (gpx_refit_rows, O(N^2 b) instead of O(N^3/3)) -- GP._factor does that
+    transparently for the GP copy the cost function owns."""
+
+    def __init__(self, costFunction, nPoints, nPointsBatch, nDims, **kwargs):
+        super(ExperimentalDesignGreedyWithDerivatives, self).__init__(costFunction, nPoints, nDims)
+        self.nPointsBatch = nPointsBatch
+        if kwargs.get('useCont', 0) != 0:
+            raise NotImplementedError("hyper-parameter continuation (experimentalDesign.py:500-692) is outside the GPU "
+                                      "hot path")
+
+    def begin(self, startValues=np.array([])):
+        nPointsAdded = len(startValues)
+        points = startValues.copy() if len(startValues) > 0 else np.zeros((0, self.nDims))
+        tol = 1e-16
+        err = 10000
+        cf = self.costFunction
+        while (nPointsAdded < self.nPoints) and (err > tol):
+            print("Number of points so far ", nPointsAdded)
+            nPointsAdded = nPointsAdded + self.nPointsBatch
+            lbounds = -100.0 * np.ones((nPointsAdded * self.nDims))
+            rbounds = 100.0 * np.ones((nPointsAdded * self.nDims))
+            nPointsPrev = nPointsAdded - self.nPointsBatch
+            lbounds[0:nPointsPrev * self.nDims] = points.reshape((nPointsPrev * self.nDims))
+            rbounds[0:nPointsPrev * self.nDims] = points.reshape((nPointsPrev * self.nDims))
+            currCost = costFunctionGP_IVAR(cf.gaussianProcess, nPointsAdded, cf.space, cf.version, mcPoints=cf.mcPoints)
+            expCurr = ExperimentalDesignDerivative(currCost, nPointsAdded, self.nDims)
+            points = expCurr.beginWithVarGreedy(nodesKeep=points, lbounds=lbounds, rbounds=rbounds)
+            err = currCost.evaluate(points)
+            print("Current Error ", err)
+        return points
+
+
 def performGreedyMIExperimentalDesign(costFuncMI, nPoints, start=0):
     """Greedy mutual-information design among costFuncMI.mcPoints, seeded with [start] (:753-785).
 

@@ -59,6 +59,11 @@ class GP:
         self._K_host = None
         self._P_host = None
         self.jitter = 0.0
+        # f2: the last factorisation, kept so that a refit whose leading points (and hyper-parameters) did
+        # not change -- the design loop pins earlier points by bounds, experimentalDesign.py:722-724 -- only assembles and
+        # factors the trailing rows.  (host copy of the points, nugget, hyper-parameter key, device factor)
+        self._fcache = None
+        self.reuseFactor = True
 
     # shallow copies (costFunctionGP_IVAR does copy.copy(gp), experimentalDesign.py:64) share device state,
     # which is immutable once built: a refit replaces the handles instead of mutating them.
@@ -97,10 +102,21 @@ class GP:
         ctx = _dev.context()
         spec = self.kernel._spec()
         X = _dev.points(ctx, nodes)
+        keep = self._reusable_rows(nodes, nugget, spec)
+        if keep > 0:
+            try:
+                L = _dev.refit_rows(ctx, spec, X, nugget, self._fcache[3], keep)
+                self._remember(nodes, nugget, spec, L)
+                return X, L, 0.0
+            except NotPositiveDefinite:
+                pass  # fall through to the full path and its jitter policy
         K = _dev.kfill(ctx, spec, X, nugget=nugget)
         try:
-            return X, _dev.potrf(ctx, K), 0.0
+            L = _dev.potrf(ctx, K)
+            self._remember(nodes, nugget, spec, L)
+            return X, L, 0.0
         except NotPositiveDefinite as first:
+            self._fcache = None
             base = 1e-12 * float(np.mean(_dev.kdiag(ctx, spec, X)) + np.mean(np.asarray(nugget, dtype=float)))
             jit = base
             for _ in range(4):
@@ -115,6 +131,39 @@ class GP:
                 except NotPositiveDefinite:
                     jit *= 100.0
             raise
+
+    @staticmethod
+    def _spec_key(spec):
+        return (spec.kind, spec.d, tuple(spec.hyp.tolist()))
+
+    def _remember(self, nodes, nugget, spec, L):
+        if self.reuseFactor and nodes.shape[0] >= 256:
+            nug = None if np.ndim(nugget) == 0 else np.array(nugget, dtype=float, copy=True)
+            self._fcache = (nodes.copy(), float(nugget) if nug is None else nug, self._spec_key(spec), L)
+        else:
+            self._fcache = None
+
+    def _reusable_rows(self, nodes, nugget, spec):
+        """Leading rows (multiple of 128) whose factor can be taken from the previous fit: same kernel and
+        hyper-parameters, same nugget on those rows, bit-identical points.  0 = factor from scratch."""
+        c = self._fcache
+        if not self.reuseFactor or c is None or c[2] != self._spec_key(spec):
+            return 0
+        old, onug = c[0], c[1]
+        m = min(old.shape[0], nodes.shape[0])
+        if m < 128:
+            return 0
+        same = np.all(old[:m] == nodes[:m], axis=1)
+        if np.ndim(nugget) == 0 and np.ndim(onug) == 0:
+            if float(nugget) != onug:
+                return 0
+        else:
+            a = np.broadcast_to(np.asarray(nugget, dtype=float), (nodes.shape[0],))[:m]
+            b = np.broadcast_to(np.asarray(onug, dtype=float), (old.shape[0],))[:m]
+            same = same & (a == b)
+        p = m if same.all() else int(np.argmin(same))
+        keep = (p // 128) * 128
+        return keep if keep * 4 >= nodes.shape[0] else 0  # below a quarter of the rows the copy buys nothing
 
     # ---- training ---------------------------------------------------------------------------------------------
     def addNodesAndComputeCovariance(self, nodes, noiseIn=None):

@@ -106,6 +106,12 @@ int gpx_kernel_eval(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp,
 /* ---- L2: factorisation and solves (replace numpy.linalg.pinv / slogdet) ---------------------- */
 /* in-place lower Cholesky K = L L^T (strict upper left undefined); replaces pinv at gp.py:181, 400 */
 int gpx_potrf(gpx_ctx* ctx, gpx_mat* K);
+/* factor K(X)+nugget when its leading `keep` (multiple of 128) rows/columns equal the matrix Lold factors
+ * (the design loop pins earlier points by bounds, experimentalDesign.py:722-724, and only the last batch moves): the
+ * leading factor block is copied, rows >= keep are assembled and the factorisation is completed in O(N^2 b).
+ * keep == 0 (Lold may be NULL) is a plain assemble + factor.  Status as gpx_potrf; *outL is a new library-owned matrix. */
+int gpx_refit_rows(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* X,
+                   const double* nugget, int64_t nugget_len, const gpx_mat* Lold, int64_t keep, gpx_mat** outL);
 /* alpha = K^{-1} y from the factor; y, alpha host (N)                 gp.py:101, 435 */
 int gpx_potrs(gpx_ctx* ctx, const gpx_mat* L, const double* y, double* alpha);
 /* the same on device vectors (y, alpha: at least padded-N doubles, zero padded), ASYNCHRONOUS on the selected

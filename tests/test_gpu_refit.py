@@ -1,0 +1,131 @@
+"""refits that only change the trailing design points (gpx_refit_rows), through the C ABI, against the
+full assemble + factor path and the oracle."""
+import numpy as np
+import pytest
+
+from oracle import gpexp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from gpexp_amd import device
+    return device
+
+
+@pytest.fixture(scope="module")
+def ctx(dev):
+    return dev.context()
+
+
+@pytest.mark.parametrize("n_old,n_new,keep", [(300, 300, 128), (300, 300, 256), (700, 700, 512), (500, 650, 384),
+                                              (650, 500, 384), (1025, 1025, 1024), (400, 400, 0)])
+@pytest.mark.parametrize("kind", ["se", "matern52"])
+def test_refit_rows_equals_full_factorisation(dev, ctx, n_old, n_new, keep, kind):
+    rng = np.random.default_rng(n_old + 7 * n_new + keep)
+    d = 3
+    Xo = rng.uniform(-1, 1, (n_old, d))
+    Xn = rng.uniform(-1, 1, (n_new, d))
+    Xn[:keep] = Xo[:keep]                       # shared leading points; everything after them differs
+    if kind == "se":
+        sp = dev.KernelSpec(dev.K_SE, d, [0.5, 0.7, 0.9, 1.2])
+        s = dict(kind="se", cl=[0.5, 0.7, 0.9], signalSize=1.2, d=d)
+    else:
+        sp = dev.KernelSpec(dev.K_MATERN52, d, [0.8, 1.1])
+        s = dict(kind="matern52", rho=0.8, signalSize=1.1, d=d)
+    nug = 0.05
+    L_old = dev.potrf(ctx, dev.kfill(ctx, sp, dev.points(ctx, Xo), nugget=nug))
+    Xd = dev.points(ctx, Xn)
+    L_ref = dev.potrf(ctx, dev.kfill(ctx, sp, Xd, nugget=nug))
+    L_new = dev.refit_rows(ctx, sp, Xd, nug, L_old, keep)
+    a, b = np.tril(L_new.to_host()), np.tril(L_ref.to_host())
+    assert rel(a, b) <= 1e-12
+    K = orc.cov_matrix(s, Xn, nug, row_loop=False)
+    assert rel(a @ a.T, K) <= 1e-13                                     # it factors the right matrix
+    y = rng.standard_normal(n_new)
+    assert rel(dev.potrs(ctx, L_new, y), dev.potrs(ctx, L_ref, y)) <= 1e-10
+    assert dev.logdet(ctx, L_new) == pytest.approx(dev.logdet(ctx, L_ref), rel=1e-12)
+    # the old factor is untouched (shallow GP copies may still hold it)
+    assert rel(np.tril(L_old.to_host()), np.linalg.cholesky(orc.cov_matrix(s, Xo, nug, row_loop=False))) <= 1e-11
+
+
+def test_refit_rows_with_per_point_nugget_and_rejects_bad_keep(dev, ctx):
+    rng = np.random.default_rng(5)
+    n, d, keep = 520, 2, 256
+    X = rng.uniform(-1, 1, (n, d))
+    nug = 0.01 + 0.05 * rng.uniform(size=n)
+    sp = dev.KernelSpec(dev.K_SE, d, [0.6, 0.8, 1.0])
+    Xd = dev.points(ctx, X)
+    L_old = dev.potrf(ctx, dev.kfill(ctx, sp, Xd, nugget=nug))
+    X2 = X.copy(); X2[keep:] = rng.uniform(-1, 1, (n - keep, d))
+    nug2 = nug.copy(); nug2[keep:] *= 2.0
+    X2d = dev.points(ctx, X2)
+    L_ref = dev.potrf(ctx, dev.kfill(ctx, sp, X2d, nugget=nug2))
+    L_new = dev.refit_rows(ctx, sp, X2d, nug2, L_old, keep)
+    assert rel(np.tril(L_new.to_host()), np.tril(L_ref.to_host())) <= 1e-12
+    with pytest.raises(Exception):
+        dev.refit_rows(ctx, sp, X2d, nug2, L_old, 100)       # not a multiple of 128
+    with pytest.raises(Exception):
+        dev.refit_rows(ctx, sp, X2d, nug2, L_old, 1024)      # beyond both point sets
+
+
+def test_gp_reuses_the_leading_factor_transparently(dev, ctx):
+    from gpExp.kernels import KernelSquaredExponential
+    from gpExp.gp import GP
+    rng = np.random.default_rng(11)
+    d, n, p = 2, 800, 650
+    X1 = rng.uniform(-1, 1, (n, d))
+    X2 = X1.copy(); X2[p:] = rng.uniform(-1, 1, (n - p, d))
+    Z = rng.uniform(-1, 1, (300, d))
+    k = KernelSquaredExponential([0.4, 0.6], 1.3, d)
+    g = GP(k, 1e-2)
+    g.addNodesAndComputeCovariance(X1)
+    assert g._reusable_rows(X2, 1e-2, g.kernel._spec()) == 640
+    g.addNodesAndComputeCovariance(X2)                         # takes the gpx_refit_rows path
+    fresh = GP(k, 1e-2); fresh.reuseFactor = False
+    fresh.addNodesAndComputeCovariance(X2)
+    assert rel(g.evaluateVariance(Z), fresh.evaluateVariance(Z)) <= 1e-10
+    # growing design across a padding boundary
+    X3 = np.vstack((X2, rng.uniform(-1, 1, (150, d))))
+    g.addNodesAndComputeCovariance(X3)
+    fresh.addNodesAndComputeCovariance(X3)
+    assert rel(g.evaluateVariance(Z), fresh.evaluateVariance(Z)) <= 1e-10
+    # a hyper-parameter change invalidates the cached factor
+    g.kernel.updateHyperParameters({"cl0": 0.55, "cl1": 0.6, "signalSize": 1.3})   # (replaces the whole dict, kernels.py:44-47)
+    fresh.kernel.updateHyperParameters({"cl0": 0.55, "cl1": 0.6, "signalSize": 1.3})
+    assert g._reusable_rows(X3, 1e-2, g.kernel._spec()) == 0
+    g.addNodesAndComputeCovariance(X3); fresh.addNodesAndComputeCovariance(X3)
+    assert rel(g.evaluateVariance(Z), fresh.evaluateVariance(Z)) <= 1e-10
+    # so does a different noise
+    g.noise = 2e-2
+    assert g._reusable_rows(X3, g.noise, g.kernel._spec()) == 0
+
+
+def test_greedy_with_derivatives_driver_pins_earlier_batches(dev, ctx, capsys):
+    """experimentalDesign.py:694-751 (no continuation): batches of new points, earlier ones pinned by bounds."""
+    from gpExp.kernels import KernelSquaredExponential
+    from gpExp.gp import GP
+    from gpExp.approximation import Space
+    from gpExp.experimentalDesign import costFunctionGP_IVAR, ExperimentalDesignGreedyWithDerivatives
+    rng = np.random.default_rng(3)
+    d = 2
+    mc = rng.uniform(-1, 1, (400, d))
+    space = Space(d, lambda size: rng.uniform(-1, 1, size), lambda p: np.all(np.abs(p) < 1.0, axis=1) * 0.25)
+    gp = GP(KernelSquaredExponential([0.5, 0.5], 1.0, d), 1e-4)
+    cf = costFunctionGP_IVAR(gp, 6, space, mcPoints=mc)
+    des = ExperimentalDesignGreedyWithDerivatives(cf, 6, 3, d)
+    first = ExperimentalDesignGreedyWithDerivatives(costFunctionGP_IVAR(gp, 3, space, mcPoints=mc), 3, 3, d).begin()
+    pts = des.begin()
+    capsys.readouterr()
+    assert pts.shape == (6, d) and first.shape == (3, d)
+    assert rel(pts[:3], first) <= 1e-9                       # the first batch stays where its own optimisation left it
+    assert np.all(np.abs(pts) <= 1.0 + 1e-9)
+    c3 = costFunctionGP_IVAR(gp, 3, space, mcPoints=mc).evaluate(first)
+    c6 = costFunctionGP_IVAR(gp, 6, space, mcPoints=mc).evaluate(pts)
+    assert c6 < c3
