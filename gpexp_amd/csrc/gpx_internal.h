@@ -160,6 +160,8 @@ int launch_logdet(gpx_ctx* ctx, const double* L, int64_t ld, int64_t n, double* 
 int launch_colreduce(gpx_ctx* ctx, const double* B, int64_t ld, int64_t rows, int64_t pcols, const double* v,
                      double* out, double* d_partial);
 int64_t colreduce_partial_elems(int64_t rows, int64_t pcols);
+int launch_rowreduce(gpx_ctx* ctx, const double* B, int64_t ld, int64_t rows, int64_t cols, const double* v,
+                     double* out);
 int launch_sum(gpx_ctx* ctx, const double* x, int64_t n, double* d_out);
 
 // design.hip
