@@ -118,3 +118,32 @@ def test_c5_mi_and_loglike_gradient(dev, ctx):
         assert g[k] == pytest.approx(fd, rel=1e-7)
     fdn = (ll(hyp, 0.1 + 1e-6)[0] - ll(hyp, 0.1 - 1e-6)[0]) / 2e-6
     assert g[-1] == pytest.approx(fdn, rel=1e-6)
+
+
+def test_c5_full_size_fit_on_one_gpu(dev, ctx):
+    """BASELINE config C5 at its full size: N=65536, d=10 ARD-SE (K = 34.4 GB, resident in HBM): K alpha = y on exact rows
+    of K, 0 < var < noise at training points, log-likelihood reproducible bit for bit, gradient entries finite."""
+    N, d = 65536, 10
+    rng = np.random.default_rng(65536)
+    Xh = rng.uniform(-1, 1, (N, d))
+    y = np.sin(2 * np.pi * Xh.sum(1) / d) + np.sqrt(0.1) * rng.standard_normal(N)
+    hyp = list(0.5 + 0.03 * np.arange(d)) + [1.0]
+    sp = dev.KernelSpec(dev.K_SE, d, hyp)
+    X = dev.points(ctx, Xh)
+    K = dev.kfill(ctx, sp, X, nugget=0.1)
+    rows = rng.choice(N, 5, replace=False)
+    Krows = np.stack([dev.kernel_eval(ctx, sp, Xh, Xh[r:r + 1]) for r in rows])
+    Krows[np.arange(5), rows] += 0.1
+    dev.potrf(ctx, K)
+    alpha = dev.potrs(ctx, K, y)
+    assert np.max(np.abs(Krows @ alpha - y[rows])) <= 1e-9 * np.max(np.abs(y))
+    ld = dev.logdet(ctx, K)
+    ll = -0.5 * y @ alpha - 0.5 * ld - N / 2 * np.log(2 * np.pi)
+    assert np.isfinite(ll)
+    _, var = dev.posterior(ctx, sp, K, X, None, dev.points(ctx, Xh[:2048]), want_mean=False)
+    assert np.all(var > 0) and np.all(var < 0.1)
+    dev.kfill_into(ctx, sp, X, K, nugget=0.1)
+    dev.potrf(ctx, K)
+    assert dev.logdet(ctx, K) == ld and np.array_equal(dev.potrs(ctx, K, y), alpha)
+    del K
+    ctx.trim()
