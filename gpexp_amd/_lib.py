@@ -38,6 +38,14 @@ _SIGS = {
     "gpx_potrf": (C.c_int, [c_vp, c_vp]),
     "gpx_refit_rows": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_dp, c_i64, c_vp, c_i64, C.POINTER(c_vp)]),
     "gpx_potrs": (C.c_int, [c_vp, c_vp, c_dp, c_dp]),
+    "gpx_matvec": (C.c_int, [c_vp, c_vp, c_dp, c_dp]),
+    "gpx_fitc_fit": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, C.c_double, C.POINTER(c_vp)]),
+    "gpx_fitc_free": (C.c_int, [c_vp, c_vp]),
+    "gpx_fitc_shape": (C.c_int, [c_vp, C.POINTER(c_i64), C.POINTER(c_i64)]),
+    "gpx_fitc_solve": (C.c_int, [c_vp, c_vp, c_dp, c_dp, c_dp]),
+    "gpx_fitc_logdet": (C.c_int, [c_vp, c_vp, c_dp]),
+    "gpx_fitc_posterior": (C.c_int, [c_vp, c_vp, c_vp, c_dp, c_vp, c_dp, c_dp]),
+    "gpx_fitc_dense": (C.c_int, [c_vp, c_vp, c_dp, c_dp]),
     "gpx_potrs_dev": (C.c_int, [c_vp, c_vp, c_vp, c_vp]),
     "gpx_logdet": (C.c_int, [c_vp, c_vp, c_dp]),
     "gpx_potri": (C.c_int, [c_vp, c_vp, C.POINTER(c_vp)]),

@@ -698,6 +698,28 @@ int gpx_ivar(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const g
   return 0;
 }
 
+// out[rows] = A v (host vectors; v has A->cols entries): a deterministic row reduction over the resident matrix
+int gpx_matvec(gpx_ctx* ctx, const gpx_mat* A, const double* v, double* out) {
+  GPX_ARG(ctx && A && v && out, "NULL argument");
+  GPX_ARG(A->pcols % 2 == 0 && A->ld % 2 == 0, "matvec needs an even padded width");
+  void *pv, *po;
+  GPX_TRY(gpx_dev_alloc(ctx, A->pcols * 8, &pv));
+  int r = gpx_dev_alloc(ctx, (A->rows > 0 ? A->rows : 1) * 8, &po);
+  if (r == 0) {
+    do {
+      if (hipMemsetAsync(pv, 0, (size_t)A->pcols * 8, ctx->stream) != hipSuccess ||
+          hipMemcpyAsync(pv, v, (size_t)A->cols * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { r = -2; break; }
+      if ((r = launch_rowreduce(ctx, A->p, A->ld, A->rows, A->pcols, (const double*)pv, (double*)po)) != 0) break;
+      if (hipMemcpyAsync(out, po, (size_t)A->rows * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { r = -2; break; }
+    } while (0);
+    (void)hipStreamSynchronize(ctx->stream);
+    gpx_dev_release(ctx, po, (A->rows > 0 ? A->rows : 1) * 8);
+  }
+  gpx_dev_release(ctx, pv, A->pcols * 8);
+  if (r == -2) gpx_set_error("matvec: HIP copy failed");
+  return r;
+}
+
 // ---- measurement ---------------------------------------------------------------------------------------
 int gpx_profile_enable(gpx_ctx* ctx, int on) {
   GPX_ARG(ctx != nullptr, "ctx is NULL");

@@ -161,7 +161,7 @@ int launch_colreduce(gpx_ctx* ctx, const double* B, int64_t ld, int64_t rows, in
                      double* out, double* d_partial);
 int64_t colreduce_partial_elems(int64_t rows, int64_t pcols);
 int launch_rowreduce(gpx_ctx* ctx, const double* B, int64_t ld, int64_t rows, int64_t cols, const double* v,
-                     double* out);
+                     double* out, int weighted_squares = 0);
 int launch_sum(gpx_ctx* ctx, const double* x, int64_t n, double* d_out);
 
 // design.hip

@@ -100,15 +100,24 @@ int launch_colreduce(gpx_ctx* ctx, const double* B, int64_t ld, int64_t rows, in
 
 namespace {
 
-// out[r] = sum_c B[r][c] * v[c]  (v != nullptr)  or  sum_c B[r][c]^2  (v == nullptr): one workgroup per row, every thread
-// a fixed strided subset of the columns, fixed-shape tree over the 256 partial sums -> bit-reproducible
+// out[r] = sum_c B[r][c] * v[c]  (v != nullptr)  or  sum_c B[r][c]^2  (v == nullptr)  or  sum_c v[c] B[r][c]^2
+// (v != nullptr, weighted_squares): one workgroup per row, every thread a fixed strided subset of the columns,
+// fixed-shape tree over the 256 partial sums -> bit-reproducible
 __global__ __launch_bounds__(256) void rowreduce_kernel(const double* __restrict__ B, int64_t ld, int64_t cols,
-                                                        const double* __restrict__ v, double* __restrict__ out) {
+                                                        const double* __restrict__ v, double* __restrict__ out,
+                                                        int weighted_squares) {
   __shared__ double red[256];
   const int t = threadIdx.x;
   const double* row = B + (int64_t)blockIdx.x * ld;
   double s0 = 0.0, s1 = 0.0;
-  if (v) {
+  if (v && weighted_squares) {
+    for (int64_t c = 2 * t; c < cols; c += 512) {
+      const double2 b = *reinterpret_cast<const double2*>(row + c);
+      const double2 w = *reinterpret_cast<const double2*>(v + c);
+      s0 = fma(b.x * w.x, b.x, s0);
+      s1 = fma(b.y * w.y, b.y, s1);
+    }
+  } else if (v) {
     for (int64_t c = 2 * t; c < cols; c += 512) {
       const double2 b = *reinterpret_cast<const double2*>(row + c);
       const double2 w = *reinterpret_cast<const double2*>(v + c);
@@ -135,11 +144,12 @@ __global__ __launch_bounds__(256) void rowreduce_kernel(const double* __restrict
 
 // rows x cols (cols even, v padded to cols) -> out[rows]
 int launch_rowreduce(gpx_ctx* ctx, const double* B, int64_t ld, int64_t rows, int64_t cols, const double* v,
-                     double* out) {
+                     double* out, int weighted_squares) {
   if (rows <= 0) return 0;
   GPX_ARG(cols % 2 == 0 && ld % 2 == 0, "rowreduce: even column count and leading dimension");
   ProfScope ps(ctx, GPX_PROF_REDUCE, 2.0 * (double)rows * cols, 8.0 * (double)rows * cols);
-  hipLaunchKernelGGL(rowreduce_kernel, dim3((unsigned)rows), dim3(256), 0, ctx->stream, B, ld, cols, v, out);
+  hipLaunchKernelGGL(rowreduce_kernel, dim3((unsigned)rows), dim3(256), 0, ctx->stream, B, ld, cols, v, out,
+                     weighted_squares);
   GPX_HIP(hipGetLastError());
   return 0;
 }

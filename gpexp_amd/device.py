@@ -208,6 +208,60 @@ def refit_rows(ctx, spec, X, nugget, L_old, keep):
     return DeviceMatrix(ctx, h)
 
 
+def matvec(ctx, A, v):
+    """A @ v for a resident DeviceMatrix (deterministic row reduction)."""
+    v = as_f64(v)
+    assert v.shape == (A.shape[1],)
+    out = np.empty(A.shape[0])
+    check(ctx.lib.gpx_matvec(ctx.h, A.h, dptr(v), dptr(out)))
+    return out
+
+
+class FitcModel:
+    """Device-resident FITC model (gpx_fitc_*): chol(Quu), Kuf, G and chol(Quu + Kuf G^-1 Kfu)."""
+
+    def __init__(self, ctx, spec, X, S, noise):
+        self.ctx, self.X = ctx, X
+        h = c_vp()
+        check(ctx.lib.gpx_fitc_fit(ctx.h, *spec.args(), X.h, S.h, float(noise), C.byref(h)))
+        self.h = h
+        self.n = X.shape[0]
+
+    def solve(self, y):
+        y = as_f64(y)
+        coeff = np.empty(self.n)
+        quad = C.c_double()
+        check(self.ctx.lib.gpx_fitc_solve(self.ctx.h, self.h, dptr(y), dptr(coeff), C.byref(quad)))
+        return coeff, quad.value
+
+    def logdet(self):
+        out = C.c_double()
+        check(self.ctx.lib.gpx_fitc_logdet(self.ctx.h, self.h, C.byref(out)))
+        return out.value
+
+    def posterior(self, coeff, Z, want_mean=True, want_var=True):
+        m = Z.shape[0]
+        mean = np.empty(m) if want_mean else None
+        var = np.empty(m) if want_var else None
+        co = as_f64(coeff) if want_mean else None
+        check(self.ctx.lib.gpx_fitc_posterior(self.ctx.h, self.h, self.X.h, dptr(co), Z.h, dptr(mean), dptr(var)))
+        return mean, var
+
+    def dense(self, cov=True, prec=True):
+        c = np.empty((self.n, self.n)) if cov else None
+        p = np.empty((self.n, self.n)) if prec else None
+        check(self.ctx.lib.gpx_fitc_dense(self.ctx.h, self.h, dptr(c), dptr(p)))
+        return c, p
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.ctx.lib.gpx_fitc_free(self.ctx.h, self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
 def potrs(ctx, L, y):
     y = as_f64(y)
     out = np.empty_like(y)

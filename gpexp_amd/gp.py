@@ -17,7 +17,12 @@ Rank-deficient K (e.g. noise 0.0 with coincident points): pinv truncates silentl
 factorisation is retried with a relative diagonal jitter (1e-12 * mean diag, x100 per retry, at most 4 retries)
 and a RuntimeWarning names the jitter used; if that fails NotPositiveDefinite propagates.
 
-Out of scope: the FITC inducing-point branches and `generateSamples`.
+FITC (gp.py:182-210, 401-426): `GP(kernel, noise, FITC=fraction)` draws the inducing points with
+`np.random.permutation` exactly as the reference does (seed it the same way and the same points come out) and keeps
+chol(Quu), Kuf, G and chol(Quu + Kuf G^-1 Kfu) on the device (gpx_fitc_*); predictions use the Woodbury form, the
+N x N `covarianceMatrix` / `precisionMatrix` are only built when read.  The reference compares `self.fitcnodes == None`,
+which raises for an ndarray, so there a GP instance survives only ONE FITC operation; here refits simply reuse
+`fitcnodes`.  `generateSamples` stays out of scope.
 """
 import copy
 import warnings
@@ -51,8 +56,9 @@ class GP:
             print("warning ")
             self.kernel = copy.copy(kernel_in)
         self.noise = noiseIn  # added to the diagonal as a VARIANCE (gp.py:68, 178)
-        if 'FITC' in kwargs and kwargs['FITC'] is not None:
-            raise NotImplementedError("the FITC sparse approximation (gp.py:182-210) is outside the GPU hot path")
+        if 'FITC' in kwargs:
+            self.FITC = kwargs['FITC']  # fraction of the nodes used as inducing points (gp.py:69-70, 187)
+        self._fitc = None    # device FITC model (gpx_fitc_*)
         self._X = None       # device point set
         self._L = None       # device Cholesky factor of K(pts) + nugget
         self._nugget = None  # nugget that went into _L
@@ -71,7 +77,9 @@ class GP:
     # ---- lazy dense attributes -------------------------------------------------------------------------
     @property
     def covarianceMatrix(self):
-        if self._K_host is None and self.pts is not None:
+        if self._K_host is None and self._fitc is not None:
+            self._K_host = self._fitc.dense(cov=True, prec=False)[0]
+        elif self._K_host is None and self.pts is not None:
             self._K_host = calculateCovarianceMatrix(self.kernel, self.pts, self._nugget)
         return self._K_host
 
@@ -81,7 +89,9 @@ class GP:
 
     @property
     def precisionMatrix(self):
-        if self._P_host is None and self._L is not None:
+        if self._P_host is None and self._fitc is not None:
+            self._P_host = self._fitc.dense(cov=False, prec=True)[1]
+        elif self._P_host is None and self._L is not None:
             self._P_host = _dev.potri(_dev.context(), self._L).to_host()
         return self._P_host
 
@@ -166,8 +176,34 @@ class GP:
         return keep if keep * 4 >= nodes.shape[0] else 0  # below a quarter of the rows the copy buys nothing
 
     # ---- training ---------------------------------------------------------------------------------------------
+    def _fitc_model(self, nodes):
+        """FITC branch of addNodesAndComputeCovariance / loglikeParams (gp.py:182-206, 401-426): inducing points are a
+        random subset of the nodes, drawn once with np.random.permutation and then kept in `fitcnodes`."""
+        nodes = np.asarray(nodes, dtype=float)
+        assert nodes.ndim == 2 and nodes.shape[1] == self.kernel.dimension, \
+            (" Incorrect dimension of input points fed to kernel ", nodes.shape)
+        if self.fitcnodes is None:
+            nNodes = len(nodes)
+            nu = int(np.floor(nNodes * self.FITC))
+            indu = np.random.permutation(nNodes)[0:nu]
+            self.fitcnodes = np.array(nodes[indu], dtype=float)
+        ctx = _dev.context()
+        X = _dev.points(ctx, nodes)
+        return X, _dev.FitcModel(ctx, self.kernel._spec(), X, _dev.points(ctx, self.fitcnodes), float(self.noise))
+
     def addNodesAndComputeCovariance(self, nodes, noiseIn=None):
         """Set the training locations and factor their covariance (no function values needed)."""
+        if self.FITC is not None:
+            if noiseIn is not None:
+                print("NOT IMPLEMENTED YET")  # gp.py:208-209: per-point noise with FITC leaves the old state in place
+            else:
+                self._X, self._fitc = self._fitc_model(nodes)
+                self._L = None
+                self._nugget = self.noise
+                self._K_host = None
+                self._P_host = None
+            self.pts = np.array(nodes, dtype=float, copy=True)
+            return
         nugget = self.noise if noiseIn is None else noiseIn
         self._X, self._L, self.jitter = self._factor(nodes, nugget)
         self._nugget = nugget
@@ -181,6 +217,9 @@ class GP:
         evals = evalsIn - self.gpPriorMean(pts)
         self.addNodesAndComputeCovariance(pts, noiseIn)
         self.fVals = evals.copy()
+        if self._fitc is not None:
+            self.coeff = self._fitc.solve(evals)[0]
+            return
         self.coeff = _dev.potrs(_dev.context(), self._L, evals)
 
     # ---- prediction ---------------------------------------------------------------------------------------------
@@ -190,6 +229,15 @@ class GP:
         ctx = _dev.context()
         spec = self.kernel._spec()
         Z = _dev.points(ctx, newpt)
+        if self._fitc is not None:
+            mean, var = self._fitc.posterior(self.coeff, Z, want_mean=True, want_var=(compvar == 1))
+            out = mean + self.gpPriorMean(newpt)
+            if compvar == 1:
+                return out, np.abs(var)
+            elif compvar == 2:  # dense by definition (gp.py:146-152); built from the materialised precision
+                kv = _dev.kfill(ctx, spec, Z, Z=self._X).to_host()
+                return out, _dev.kfill(ctx, spec, Z, Z=Z).to_host() - kv @ (self.precisionMatrix @ kv.T)
+            return out
         mean, var = _dev.posterior(ctx, spec, self._L, self._X, self.coeff, Z, want_mean=True,
                                    want_var=(compvar == 1))
         out = mean + self.gpPriorMean(newpt)
@@ -205,6 +253,8 @@ class GP:
         assert self.pts is not None
         assert newpt.shape[1] == self.kernel.dimension, "evaluation points for GP is incorrect shape"
         ctx = _dev.context()
+        if self._fitc is not None:
+            return self._fitc.posterior(None, _dev.points(ctx, newpt), want_mean=False, want_var=True)[1]
         _, var = _dev.posterior(ctx, self.kernel._spec(), self._L, self._X, None, _dev.points(ctx, newpt),
                                 want_mean=False, want_var=True)
         return var
@@ -270,6 +320,13 @@ class GP:
         Does not touch the trained state.  `noiseIn` (per-point nugget) works here; in the reference that branch
         passes an unknown keyword and raises TypeError (gp.py:429-430)."""
         evals = np.asarray(evals, dtype=float)
+        if self.FITC is not None and noiseIn is None:
+            if returnDeriv == 1:
+                raise NotImplementedError("no hyper-parameter gradient for the FITC likelihood (the reference's own is "
+                                          "unrunnable, kernels.py:140-141)")
+            _, model = self._fitc_model(pts)
+            quad = model.solve(evals)[1]
+            return -0.5 * quad - 0.5 * model.logdet() - len(evals) / 2.0 * np.log(2.0 * np.pi)
         nugget = self.noise if noiseIn is None else noiseIn
         X, L, _ = self._factor(pts, nugget)
         ctx = _dev.context()

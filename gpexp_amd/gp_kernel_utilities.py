@@ -2,8 +2,9 @@
 
 The reference fills K with one `kernel.evaluate` call per row (N Python iterations, an (N,d) `np.tile`
 temporary each) and then adds `np.diag(nugget)`; here one tiled HIP kernel (`gpx_kfill`) writes K and the
-nugget in a single pass over HBM.  The FITC / Nystrom helpers of the reference file (:70-232) are outside the
-hot path and are not provided.
+nugget in a single pass over HBM.  SURVEY.md 8 f4: the FITC helper (:70-104) runs on the device FITC model
+(gpx_fitc_*), and the Nystrom eigen-basis (:107-194) keeps ARPACK on the host with the covariance resident in HBM and
+every operator application a device row reduction.
 """
 import numpy as np
 
@@ -33,3 +34,50 @@ def calculateCovarianceMatrix(kernel, points, nugget=0.0):
     """Dense (N, N) covariance matrix as a NumPy array; `nugget` is a float (scalar * I) or an (N,) ndarray."""
     _, K = covariance_on_device(kernel, points, nugget)
     return K.to_host()
+
+
+def calculateCovarianceMatrixFITC(kernel, nodes, nugget, fitc, returnCov=False):
+    """Dense FITC precision (and covariance) with the reference's return convention (gp_kernel_utilities.py:70-104):
+    `fitc` is a float (fraction of the nodes, drawn with np.random.permutation) or an array of inducing points."""
+    nodes = np.asarray(nodes, dtype=float)
+    nNodes = len(nodes)
+    if isinstance(fitc, float):
+        nu = int(np.floor(nNodes * fitc))
+        indu = np.random.permutation(nNodes)[0:nu]
+        snodes = np.array(nodes[indu], dtype=float)
+    else:
+        snodes = np.asarray(fitc, dtype=float)
+    ctx = _dev.context()
+    model = _dev.FitcModel(ctx, kernel._spec(), _dev.points(ctx, nodes), _dev.points(ctx, snodes), float(nugget))
+    covmat, precMat = model.dense(cov=bool(returnCov), prec=True)
+    if returnCov is False:
+        return precMat, snodes
+    return covmat, precMat, snodes
+
+
+def covTimesV(b, kernel, mcPoints):
+    """K(mcPoints, mcPoints) @ b (gp_kernel_utilities.py:107-143: one kernel row per entry, forked over processes).
+    The covariance stays in HBM between calls with the same point set; each application is one device reduction."""
+    b = np.asarray(b, dtype=float)
+    ctx = _dev.context()
+    key = (id(mcPoints), mcPoints.shape, kernel._spec().kind, tuple(kernel._spec().hyp.tolist()))
+    if covTimesV._cache is None or covTimesV._cache[0] != key:
+        X = _dev.points(ctx, np.asarray(mcPoints, dtype=float))
+        covTimesV._cache = (key, _dev.kfill(ctx, kernel._spec(), X, nugget=0.0))
+    return _dev.matvec(ctx, covTimesV._cache[1], b.ravel()).reshape(b.shape)
+
+
+covTimesV._cache = None
+
+
+def calculateKernelBasisFunctionsMC(kernel, numBasis, mcPoints):
+    """Leading eigen-pairs of the kernel by Monte Carlo + Nystrom (gp_kernel_utilities.py:145-194): ARPACK (eigsh) on the
+    matrix-free operator v -> K v, descending order, eigenvalues / nMC and eigenvectors * sqrt(nMC)."""
+    from scipy.sparse.linalg import LinearOperator, eigsh
+    nMC = mcPoints.shape[0]
+    numberEigenVectors = int(min(numBasis, nMC))
+    A = LinearOperator((nMC, nMC), matvec=lambda v, k=kernel, p=mcPoints: covTimesV(v, k, p), dtype=float)
+    eigv, eigve = eigsh(A, k=numberEigenVectors, maxiter=10 * numberEigenVectors)
+    eigv = eigv[::-1]
+    eigve = eigve[:, ::-1]
+    return eigv / float(nMC), eigve * np.sqrt(float(nMC))

@@ -199,6 +199,28 @@ int gpx_dist_panel_update(gpx_ctx* ctx, gpx_mat* K, int64_t k, int64_t nb, const
 /* mark K as a complete factor (every rank now holds all of L) */
 int gpx_dist_finish(gpx_ctx* ctx, gpx_mat* K);
 
+/* out[rows] = A v for a resident matrix (covTimesV, gp_kernel_utilities.py:107-143: the Nystrom operator application) */
+int gpx_matvec(gpx_ctx* ctx, const gpx_mat* A, const double* v, double* out);
+
+/* ---- f4: FITC sparse approximation (gp.py:182-210, 401-426; gp_kernel_utilities.py:70-104) ---------------------
+ * Inducing points S (nu x d, a subset of the nodes in the reference: np.random.permutation, gp.py:188).  The model keeps
+ * chol(Quu), Kuf, G = diag(K - Q) and chol(Quu + Kuf G^-1 Kfu) on the device; no N x N matrix is formed. */
+typedef struct gpx_fitc gpx_fitc;
+int gpx_fitc_fit(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* X, const gpx_mat* S,
+                 double noise, gpx_fitc** out);
+int gpx_fitc_free(gpx_ctx* ctx, gpx_fitc* f);
+int gpx_fitc_shape(const gpx_fitc* f, int64_t* n, int64_t* nu);
+/* coeff = P y with the Woodbury precision (GP.train, gp.py:100-101); quad (nullable) = y^T P y */
+int gpx_fitc_solve(gpx_ctx* ctx, const gpx_fitc* f, const double* y, double* coeff, double* quad);
+/* log det(Q + G) (loglikeParams, gp.py:434) */
+int gpx_fitc_logdet(gpx_ctx* ctx, const gpx_fitc* f, double* out);
+/* GP.evaluate / evaluateVariance with the FITC precision (gp.py:132-145, 246-255): mean (nullable; needs coeff) and the
+ * SIGNED variance (nullable) at the M points of Z */
+int gpx_fitc_posterior(gpx_ctx* ctx, const gpx_fitc* f, const gpx_mat* X, const double* coeff, const gpx_mat* Z,
+                       double* mean, double* var);
+/* dense Q + G and P (host n x n, each nullable): the covarianceMatrix / precisionMatrix attributes (gp.py:200-206) */
+int gpx_fitc_dense(gpx_ctx* ctx, const gpx_fitc* f, double* cov, double* prec);
+
 /* ---- measurement ------------------------------------------------------------------------------- */
 /* when enabled every kernel launch of a class is bracketed by HIP events on the launch stream */
 int gpx_profile_enable(gpx_ctx* ctx, int on);

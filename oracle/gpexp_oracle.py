@@ -300,3 +300,46 @@ def greedy_mi(spec, cand, noise, n_points, start=0):
         keep.append(new)
         options = np.setdiff1d(options, new)
     return keep, np.array(ratios)
+
+
+# ---- FITC sparse approximation and Nystrom eigen-basis -------------------------------------------
+def fitc_matrices(spec, X, noise, snodes):
+    """Covariance Q + G and its Woodbury precision for inducing points `snodes`, as the reference builds them
+    (gp.py:189-206 == gp_kernel_utilities.py:81-96): Quu and K both carry the nugget; G = diag(K - Q);
+    P = G^-1 - G^-1 Kfu (Quu + Kuf G^-1 Kfu)^-1 Kuf G^-1 with G^-1 = 1 / (g + 1e-12)."""
+    X = np.asarray(X, dtype=float)
+    snodes = np.asarray(snodes, dtype=float)
+    Quu = cov_matrix(spec, snodes, noise, row_loop=False)
+    Kuf = cross_matrix(spec, snodes, X)                      # (nu, N): kernelvals[jj, :] = k(snodes_jj, nodes)
+    Q = Kuf.T @ (np.linalg.pinv(Quu) @ Kuf)
+    K = cov_matrix(spec, X, noise, row_loop=False)
+    g = np.diag(K - Q)
+    ginv = 1.0 / (g + 1e-12)
+    inner = np.linalg.inv(Quu + (Kuf * ginv) @ Kuf.T)
+    prec = np.diag(ginv) - (ginv[:, None] * Kuf.T) @ inner @ (Kuf * ginv)
+    return Q + np.diag(g), prec
+
+
+def fitc_fit(spec, X, y, noise, snodes):
+    """GP.train with FITC (gp.py:76-101): coeff = P y (zero prior mean)."""
+    cov, prec = fitc_matrices(spec, X, noise, snodes)
+    return dict(X=np.asarray(X, dtype=float), cov=cov, prec=prec, P=prec, coeff=prec @ np.asarray(y, dtype=float))
+
+
+def fitc_loglike(spec, X, y, noise, snodes):
+    """loglikeParams, FITC branch (gp.py:401-440): slogdet of Q + G, quadratic form with the Woodbury precision."""
+    cov, prec = fitc_matrices(spec, X, noise, snodes)
+    y = np.asarray(y, dtype=float)
+    return -0.5 * y @ (prec @ y) - 0.5 * np.linalg.slogdet(cov)[1] - len(y) / 2.0 * np.log(2.0 * np.pi)
+
+
+def nystrom_basis(spec, num_basis, mc):
+    """calculateKernelBasisFunctionsMC (gp_kernel_utilities.py:147-194): leading eigen-pairs of K(mc, mc), descending,
+    eigenvalues / nMC and eigenvectors * sqrt(nMC).  (Dense eigh here; the reference runs ARPACK on a matrix-free
+    operator -- same eigen-pairs, eigenvectors defined up to sign.)"""
+    mc = np.asarray(mc, dtype=float)
+    n = mc.shape[0]
+    k = int(min(num_basis, n))
+    w, v = np.linalg.eigh(cov_matrix(spec, mc, 0.0, row_loop=False))
+    w, v = w[::-1][:k], v[:, ::-1][:, :k]
+    return w / float(n), v * np.sqrt(float(n))

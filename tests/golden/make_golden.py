@@ -15,6 +15,7 @@ Reference entry points exercised (file:line relative to /root/reference):
   gpExp/gp_kernel_utilities.py:34-68                      calculateCovarianceMatrix
   gpExp/gp.py:76-101,103-154,156-181,213-259,373-440      GP.train/evaluate/addNodes/evaluateVariance/loglike
   gpExp/experimentalDesign.py:60-117,223-285,753-845      IVAR, MI, greedy-variance, greedy-MI
+  gpExp/gp.py:182-210,401-426; gp_kernel_utilities.py:70-194   FITC sparse GP, Nystrom eigen-basis
 """
 import json
 import os
@@ -333,8 +334,46 @@ def varderiv_case():
     put(case, "kernel_derivative", g.kernel.derivative(X, Z[:1]))
 
 
+def fitc_case():
+    """FITC sparse GP (gp.py:182-210, 401-426; gp_kernel_utilities.py:70-104) and the Nystrom eigen-basis
+    (gp_kernel_utilities.py:107-194).  A fresh GP per operation: the reference compares `self.fitcnodes == None`, which
+    raises for an ndarray, so only the first FITC operation of an instance runs (numpy 2.x)."""
+    from gpExp.gp_kernel_utilities import calculateCovarianceMatrixFITC, calculateKernelBasisFunctionsMC
+    case = "fitc"
+    rng = np.random.default_rng(777001)
+    n, d, m = 60, 2, 11
+    X = rng.uniform(-1, 1, (n, d))
+    y = np.sin(2.0 * X[:, 0]) + 0.5 * X[:, 1] + 0.05 * rng.standard_normal(n)
+    Z = rng.uniform(-1, 1, (m, d))
+    spec = dict(kind="se", cl=[0.5, 0.8], signalSize=1.2, d=2)
+    noise, frac, seed = 0.05, 0.25, 3
+    index[case] = dict(type="fitc", kernel=spec, noise=noise, fitc=frac, seed=seed)
+    put(case, "X", X); put(case, "y", y); put(case, "Z", Z)
+    np.random.seed(seed)
+    g = GP(make_kernel(spec), noise, FITC=frac)
+    g.train(X, y)
+    put(case, "fitcnodes", g.fitcnodes)
+    put(case, "cov", g.covarianceMatrix)
+    put(case, "prec", g.precisionMatrix)
+    put(case, "coeff", g.coeff)
+    mean, var = g.evaluate(Z, compvar=1)
+    put(case, "mean", mean); put(case, "var", var)
+    put(case, "var_signed", g.evaluateVariance(Z, parallel=0))
+    np.random.seed(seed)
+    g2 = GP(make_kernel(spec), noise, FITC=frac)
+    put(case, "loglike", g2.computeLogLike(X, y))
+    assert np.array_equal(g2.fitcnodes, g.fitcnodes)
+    cov, prec, sn = calculateCovarianceMatrixFITC(make_kernel(spec), X, noise, g.fitcnodes.copy(), returnCov=True)
+    put(case, "util_cov", cov); put(case, "util_prec", prec)
+    mc = rng.uniform(-1, 1, (80, d))
+    put(case, "nys_mc", mc)
+    ev, evec = calculateKernelBasisFunctionsMC(make_kernel(spec), 6, mc)
+    put(case, "nys_eigv", ev); put(case, "nys_eigve", evec)
+
+
 demo_flow()
 varderiv_case()
+fitc_case()
 np.savez_compressed(os.path.join(OUT, "gpexp_golden.npz"), **arrays)
 with open(os.path.join(OUT, "gpexp_golden.json"), "w") as f:
     json.dump(index, f, indent=1, sort_keys=True)

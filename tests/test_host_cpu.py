@@ -102,8 +102,10 @@ def test_shape_assertions_before_any_device_work(built_lib):
         GP(k, 0.1).evaluateVariance(np.zeros((3, 2)))  # no training points yet
     with pytest.raises(AttributeError):
         KernelIsoMatern(0.5, 1.0, 2).derivativeWrtHypParams(np.zeros((2, 2)), np.zeros((2, 2)))
+    g = GP(k, 0.1, FITC=0.5)          # f4: accepted; the attribute is stored as in the reference (gp.py:69-70)
+    assert g.FITC == 0.5 and g.fitcnodes is None
     with pytest.raises(NotImplementedError):
-        GP(k, 0.1, FITC=0.5)
+        GP(k, 0.1).generateSamples(np.zeros((2, 2)))
 
 
 def test_kernel_hyperparameter_dicts(built_lib):

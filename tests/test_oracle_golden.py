@@ -151,3 +151,23 @@ def test_matern52_unpinned_sanity():
     assert np.all(np.diff(k) < 0)
     t = np.sqrt(5) * 0.5 / 0.5
     assert k[2] == pytest.approx(1.3 * (1 + t + t * t / 3) * np.exp(-t), rel=1e-15)
+
+
+def test_fitc_and_nystrom_against_reference(golden):
+    """f4: FITC covariance / Woodbury precision / coefficients / posterior / log-likelihood and the Nystrom eigen-basis,
+    against what the reference produced (seeded inducing-point draw, tests/golden/make_golden.py:fitc_case)."""
+    c = "fitc"
+    s = golden.index[c]["kernel"]
+    X, y, Z, sn = golden(c, "X"), golden(c, "y"), golden(c, "Z"), golden(c, "fitcnodes")
+    noise = golden.noise(c)
+    m = orc.fitc_fit(s, X, y, noise, sn)
+    assert rel(m["cov"], golden(c, "cov")) <= 1e-12 and rel(m["cov"], golden(c, "util_cov")) <= 1e-12
+    assert rel(m["prec"], golden(c, "prec")) <= 1e-9 and rel(m["prec"], golden(c, "util_prec")) <= 1e-9
+    assert rel(m["coeff"], golden(c, "coeff")) <= 1e-9
+    mean, var = orc.posterior(s, m, Z, compvar=1)
+    assert rel(mean, golden(c, "mean")) <= 1e-9
+    assert rel(np.abs(var), golden(c, "var")) <= 1e-9 and rel(var, golden(c, "var_signed")) <= 1e-9
+    assert orc.fitc_loglike(s, X, y, noise, sn) == pytest.approx(float(golden(c, "loglike")), rel=1e-10)
+    ev, evec = orc.nystrom_basis(s, 6, golden(c, "nys_mc"))
+    assert rel(ev, golden(c, "nys_eigv")) <= 1e-10
+    assert rel(np.abs(evec), np.abs(golden(c, "nys_eigve"))) <= 1e-7   # eigenvectors up to sign
