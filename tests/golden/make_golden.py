@@ -371,9 +371,34 @@ def fitc_case():
     put(case, "nys_eigv", ev); put(case, "nys_eigve", evec)
 
 
+def c2_case():
+    """BASELINE config C2 at full size (N=4096, d=3, iso-SE l=0.2, s=1, noise=0.05, seed 4096): the one
+    config the reference itself can run (~25 s here).  Inputs are regenerated from the seed by the tests; only compact
+    outputs are stored."""
+    case = "c2_full"
+    N, d, M = 4096, 3, 4096
+    rng = np.random.default_rng(4096)
+    X = rng.uniform(-1, 1, (N, d))
+    noise = 0.05
+    y = np.sin(2 * np.pi * X.sum(1) / d) + np.sqrt(noise) * rng.standard_normal(N)
+    Z = rng.uniform(-1, 1, (M, d))
+    spec = dict(kind="se", cl=[0.2], signalSize=1.0, d=3)
+    g = GP(make_kernel(spec), noise)
+    g.train(X, y)
+    mean, var = g.evaluate(Z[:256], compvar=1)
+    index[case] = dict(type="c2", kernel=spec, noise=noise, N=N, M=M, seed=4096)
+    put(case, "loglike", g.computeLogLike(X, y))
+    put(case, "coeff", g.coeff)
+    put(case, "mean256", mean)
+    put(case, "var256", var)
+    put(case, "ytalpha", float(y @ g.coeff))
+    put(case, "cond_proxy", np.linalg.cond(g.covarianceMatrix))
+
+
 demo_flow()
 varderiv_case()
 fitc_case()
+c2_case()
 np.savez_compressed(os.path.join(OUT, "gpexp_golden.npz"), **arrays)
 with open(os.path.join(OUT, "gpexp_golden.json"), "w") as f:
     json.dump(index, f, indent=1, sort_keys=True)

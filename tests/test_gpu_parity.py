@@ -237,3 +237,26 @@ def test_empty_evaluation_set(dev, ctx):
     L = dev.potrf(ctx, dev.kfill(ctx, sp, X, nugget=0.1))
     m, v = dev.posterior(ctx, sp, L, X, np.zeros(10), dev.points(ctx, np.zeros((0, 2))))
     assert m.shape == (0,) and v.shape == (0,)
+
+
+@pytest.mark.gpu
+def test_c2_full_size_against_reference(dev, ctx, golden):
+    """BASELINE config C2 at full size (N=4096, d=3, iso-SE, cond(K) = 1.2e3): Cholesky on the GPU against the reference's
+    pinv / slogdet results (north_star tolerance 1e-10 on mean, variance and log-marginal)."""
+    from gpExp.kernels import KernelSquaredExponential
+    from gpExp.gp import GP
+    c = "c2_full"
+    ix = golden.index[c]
+    rng = np.random.default_rng(ix["seed"])
+    N, M, d = ix["N"], ix["M"], ix["kernel"]["d"]
+    X = rng.uniform(-1, 1, (N, d))
+    y = np.sin(2 * np.pi * X.sum(1) / d) + np.sqrt(ix["noise"]) * rng.standard_normal(N)
+    Z = rng.uniform(-1, 1, (M, d))
+    g = GP(KernelSquaredExponential(list(ix["kernel"]["cl"]), ix["kernel"]["signalSize"], d), ix["noise"])
+    g.train(X, y)
+    assert rel(g.coeff, golden(c, "coeff")) <= 1e-10
+    mean, var = g.evaluate(Z[:256], compvar=1)
+    assert rel(mean, golden(c, "mean256")) <= 1e-10
+    assert rel(var, golden(c, "var256")) <= 1e-10
+    assert g.computeLogLike(X, y) == pytest.approx(float(golden(c, "loglike")), rel=1e-10)
+    assert float(y @ g.coeff) == pytest.approx(float(golden(c, "ytalpha")), rel=1e-10)

@@ -171,3 +171,25 @@ def test_fitc_and_nystrom_against_reference(golden):
     ev, evec = orc.nystrom_basis(s, 6, golden(c, "nys_mc"))
     assert rel(ev, golden(c, "nys_eigv")) <= 1e-10
     assert rel(np.abs(evec), np.abs(golden(c, "nys_eigve"))) <= 1e-7   # eigenvectors up to sign
+
+
+def _c2_inputs(ix):
+    rng = np.random.default_rng(ix["seed"])
+    N, M, d = ix["N"], ix["M"], ix["kernel"]["d"]
+    X = rng.uniform(-1, 1, (N, d))
+    y = np.sin(2 * np.pi * X.sum(1) / d) + np.sqrt(ix["noise"]) * rng.standard_normal(N)
+    Z = rng.uniform(-1, 1, (M, d))
+    return X, y, Z
+
+
+def test_c2_full_size_against_reference(golden):
+    """BASELINE config C2 (N=4096, d=3 iso-SE): the oracle's pinv path against what the reference computed at full size."""
+    c = "c2_full"
+    ix = golden.index[c]
+    X, y, Z = _c2_inputs(ix)
+    s = ix["kernel"]
+    m = orc.fit(s, X, y, ix["noise"])
+    assert rel(m["coeff"], golden(c, "coeff")) <= 1e-9
+    mean, var = orc.posterior(s, m, Z[:256], compvar=1)
+    assert rel(mean, golden(c, "mean256")) <= 1e-9 and rel(np.abs(var), golden(c, "var256")) <= 1e-9
+    assert orc.loglike(s, X, y, ix["noise"]) == pytest.approx(float(golden(c, "loglike")), rel=1e-10)
