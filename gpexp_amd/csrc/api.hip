@@ -600,11 +600,10 @@ static int64_t eval_chunk(int64_t np) {
   return mc;
 }
 
-// Shared body; mean/var are host arrays of length M (nullable).
-// Posterior mean / variance over the evaluation points, chunked.  The cross matrix is stored EVALUATION-POINT-major,
-// Bt = K(Z, X) (chunk x N): the mean is a row-dot with alpha, and Wt = Bt L^-T is a RIGHT triangular solve, whose
-// updates X2 -= X1 L21^T are the NT form of the GEMM kernel (the fastest one: both operands stream k-contiguous rows);
-// var = k(z,z) - row-sum(Wt^2).  (Round 1 first stored it N x M with a left solve on the NN form: 1-3 % slower.)
+// Shared body; mean/var are host arrays of length M (nullable).  For every chunk of Z: B = K(X, Zc) (N x chunk),
+// mean = B^T alpha (column dots), W = L^-1 B (recursive LEFT triangular solve: NN updates B2 -= L21 W1), var = k(z,z) -
+// colsum(W^2).  Layout measured both ways at C4 after the GEMM schedule change: this N x M form (NN GEMMs, 74 TF/s on
+// large launches) 494.6 ms; the transposed M x N form (right solve, NT GEMMs, 72.9 TF/s) 513.8 ms.
 static int posterior_impl(gpx_ctx* ctx, const KParams& kp, const gpx_mat* L, const gpx_mat* X, const double* alpha,
                           const gpx_mat* Z, double* mean, double* var) {
   const int64_t n = L->rows, np = L->prows, M = Z->rows, d = kp.d;
@@ -612,15 +611,17 @@ static int posterior_impl(gpx_ctx* ctx, const KParams& kp, const gpx_mat* L, con
   if (M == 0) return 0;
   const int64_t mcmax = eval_chunk(np);
   const int64_t mc_alloc = gpx_round_up(M < mcmax ? M : mcmax, GPX_TILE);
-  void *pB = nullptr, *pal = nullptr, *pout = nullptr, *pkd = nullptr;
-  const int64_t ldb = gpx_skew_ld(np);
-  const int64_t bytesB = mc_alloc * ldb * 8, bytes_out = mc_alloc * 8;
+  void *pB = nullptr, *pal = nullptr, *pout = nullptr, *ppart = nullptr, *pkd = nullptr;
+  const int64_t ldb_alloc = gpx_skew_ld(mc_alloc);
+  const int64_t bytesB = np * ldb_alloc * 8, bytes_out = mc_alloc * 8;
+  const int64_t bytes_part = colreduce_partial_elems(np, mc_alloc) * 8 + 8;
   int r = 0;
   std::vector<double> hbuf((size_t)mc_alloc), hk((size_t)mc_alloc);
   do {
     if ((r = gpx_dev_alloc(ctx, bytesB, &pB)) != 0) break;
     if ((r = gpx_dev_alloc(ctx, bytes_out, &pout)) != 0) break;
     if ((r = gpx_dev_alloc(ctx, bytes_out, &pkd)) != 0) break;
+    if ((r = gpx_dev_alloc(ctx, bytes_part, &ppart)) != 0) break;
     if (mean) {
       if ((r = gpx_dev_alloc(ctx, np * 8, &pal)) != 0) break;
       if (hipMemsetAsync(pal, 0, (size_t)np * 8, ctx->stream) != hipSuccess ||
@@ -634,17 +635,18 @@ static int posterior_impl(gpx_ctx* ctx, const KParams& kp, const gpx_mat* L, con
       const int64_t mcp = gpx_round_up(mc, GPX_TILE);
       double* B = (double*)pB;
       const double* Zc = Z->p + j0 * d;
-      if ((r = launch_kfill(ctx, kp, Zc, mc, X->p, n, 0, nullptr, 0, 0.0, B, mcp, np, ldb)) != 0) break;
+      const int64_t ldb = gpx_skew_ld(mcp);
+      if ((r = launch_kfill(ctx, kp, X->p, n, Zc, mc, 0, nullptr, 0, 0.0, B, np, mcp, ldb)) != 0) break;
       if (mean) {
-        if ((r = launch_rowreduce(ctx, B, ldb, mc, np, (const double*)pal, (double*)pout)) != 0) break;
+        if ((r = launch_colreduce(ctx, B, ldb, n, mcp, (const double*)pal, (double*)pout, (double*)ppart)) != 0) break;
         if (hipMemcpyAsync(mean + j0, pout, (size_t)mc * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) {
           r = -2;
           break;
         }
       }
       if (var) {
-        if ((r = chol_trsm_right(ctx, L->p, L->ld, L->aux, B, ldb, mcp, np)) != 0) break;
-        if ((r = launch_rowreduce(ctx, B, ldb, mc, np, nullptr, (double*)pout)) != 0) break;
+        if ((r = chol_trsm_left(ctx, L->p, L->ld, L->aux, B, ldb, np, mcp)) != 0) break;
+        if ((r = launch_colreduce(ctx, B, ldb, n, mcp, nullptr, (double*)pout, (double*)ppart)) != 0) break;
         if ((r = launch_kdiag(ctx, kp, Zc, mc, (double*)pkd)) != 0) break;
         if (hipMemcpyAsync(hbuf.data(), pout, (size_t)mc * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipMemcpyAsync(hk.data(), pkd, (size_t)mc * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
@@ -660,6 +662,7 @@ static int posterior_impl(gpx_ctx* ctx, const KParams& kp, const gpx_mat* L, con
   gpx_dev_release(ctx, pB, bytesB);
   gpx_dev_release(ctx, pout, bytes_out);
   gpx_dev_release(ctx, pkd, bytes_out);
+  gpx_dev_release(ctx, ppart, bytes_part);
   if (pal) gpx_dev_release(ctx, pal, np * 8);
   if (r == -2) gpx_set_error("posterior: HIP copy failed: %s", hipGetErrorString(hipGetLastError()));
   return r;

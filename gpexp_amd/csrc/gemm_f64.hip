@@ -472,8 +472,8 @@ int launch_gemm(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int
       GPX_K(BT_, ACC_, LOW_, 1, 2, 128);                                                                             \
     else if (pf == 14)                                                                                               \
       GPX_K(BT_, ACC_, LOW_, 1, 4, 128);                                                                             \
-    else /* default: measured best per operand form (C4 step: NT full unroll 287 vs 295 ms; NN unroll-2 534 vs 600) */ \
-      GPX_K(BT_, ACC_, LOW_, 1, (BT_ ? 4 : 2), 128);                                                                 \
+    else /* default: all four k-substeps' fragments in registers (with the hand schedule: NN 74.0 vs 71.3 TF/s at KU=2) */ \
+      GPX_K(BT_, ACC_, LOW_, 1, 4, 128);                                                                 \
   } while (0)
   if (bt) {
     if (accumulate) {
