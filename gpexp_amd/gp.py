@@ -103,8 +103,9 @@ class GP:
     def gpPriorMean(self, pts):
         return np.zeros((pts.shape[0]))
 
-    def _factor(self, nodes, nugget):
-        """Assemble K(nodes)+diag(nugget) and factor it in place on the device -> (X, L, jitter)."""
+    def _factor(self, nodes, nugget, remember=True):
+        """Assemble K(nodes)+diag(nugget) and factor it in place on the device -> (X, L, jitter).  `remember=False`
+        (likelihood evaluations: every call has new hyper-parameters) neither consults nor replaces the kept factor."""
         _check_nugget(nugget)
         nodes = np.asarray(nodes, dtype=float)
         assert nodes.ndim == 2 and nodes.shape[1] == self.kernel.dimension, \
@@ -112,7 +113,7 @@ class GP:
         ctx = _dev.context()
         spec = self.kernel._spec()
         X = _dev.points(ctx, nodes)
-        keep = self._reusable_rows(nodes, nugget, spec)
+        keep = self._reusable_rows(nodes, nugget, spec) if remember else 0
         if keep > 0:
             try:
                 L = _dev.refit_rows(ctx, spec, X, nugget, self._fcache[3], keep)
@@ -123,10 +124,12 @@ class GP:
         K = _dev.kfill(ctx, spec, X, nugget=nugget)
         try:
             L = _dev.potrf(ctx, K)
-            self._remember(nodes, nugget, spec, L)
+            if remember:
+                self._remember(nodes, nugget, spec, L)
             return X, L, 0.0
         except NotPositiveDefinite as first:
-            self._fcache = None
+            if remember:
+                self._fcache = None
             base = 1e-12 * float(np.mean(_dev.kdiag(ctx, spec, X)) + np.mean(np.asarray(nugget, dtype=float)))
             jit = base
             for _ in range(4):
@@ -328,7 +331,7 @@ class GP:
             quad = model.solve(evals)[1]
             return -0.5 * quad - 0.5 * model.logdet() - len(evals) / 2.0 * np.log(2.0 * np.pi)
         nugget = self.noise if noiseIn is None else noiseIn
-        X, L, _ = self._factor(pts, nugget)
+        X, L, _ = self._factor(pts, nugget, remember=False)
         ctx = _dev.context()
         alpha = _dev.potrs(ctx, L, evals)
         out = -0.5 * np.dot(evals, alpha) - 0.5 * _dev.logdet(ctx, L) - len(evals) / 2.0 * np.log(2.0 * np.pi)
