@@ -38,6 +38,8 @@ _SIGS = {
     "gpx_potrf": (C.c_int, [c_vp, c_vp]),
     "gpx_refit_rows": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_dp, c_i64, c_vp, c_i64, C.POINTER(c_vp)]),
     "gpx_potrs": (C.c_int, [c_vp, c_vp, c_dp, c_dp]),
+    "gpx_col_sumsq": (C.c_int, [c_vp, c_vp, c_i64, c_dp]),
+    "gpx_dist_ivar_step": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp]),
     "gpx_matvec": (C.c_int, [c_vp, c_vp, c_dp, c_dp]),
     "gpx_fitc_fit": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, C.c_double, C.POINTER(c_vp)]),
     "gpx_fitc_free": (C.c_int, [c_vp, c_vp]),

@@ -209,6 +209,23 @@ int gpx_create(int device, gpx_ctx** out) {
   hipDeviceProp_t prop;
   GPX_HIP(hipGetDeviceProperties(&prop, device));
   c->cus = prop.multiProcessorCount;
+  {
+    // Background stream for work that should fill idle time without standing in the way of a latency-critical chain
+    // (the streamed IVAR of the multi-GPU path).  A chip-filling kernel keeps refilling every slot it frees, so a small
+    // kernel on another stream -- whatever its priority -- waits for the big kernel to END (scripts/cumask_check.hip:
+    // 4 ms vs 14 us).  Mask bit i = CU i/8 of XCD i%8 (scripts/cumask_map.hip): the lowest 32 bits = 4 CUs on every XCD
+    // stay free for the other streams.
+    const int words = (c->cus + 31) / 32;
+    std::vector<uint32_t> mask((size_t)words, 0xffffffffu);
+    mask[0] = 0u;
+    if (c->cus % 32) mask[(size_t)words - 1] = (1u << (c->cus % 32)) - 1u;
+    if (words < 2 || hipExtStreamCreateWithCUMask(&c->streams[3], (uint32_t)words, mask.data()) != hipSuccess) {
+      (void)hipGetLastError();
+      int lo = 0, hi = 0;
+      GPX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      GPX_HIP(hipStreamCreateWithPriority(&c->streams[3], hipStreamNonBlocking, lo));
+    }
+  }
   GPX_HIP(hipMalloc((void**)&c->d_info, 256));
   GPX_HIP(hipMalloc((void**)&c->d_scal, 64 * sizeof(double)));
   GPX_HIP(hipMemset(c->d_info, 0, 256));
@@ -238,7 +255,7 @@ int gpx_destroy(gpx_ctx* ctx) {
   (void)hipFree(ctx->d_scal);
   if (ctx->trsv_scratch) (void)hipFree(ctx->trsv_scratch);
   for (auto ev : ctx->sync_events) (void)hipEventDestroy(ev);
-  for (int i = 0; i < 3; ++i) (void)hipStreamDestroy(ctx->streams[i]);
+  for (int i = 0; i < 4; ++i) (void)hipStreamDestroy(ctx->streams[i]);
   delete ctx;
   return 0;
 }
@@ -251,7 +268,7 @@ int gpx_sync(gpx_ctx* ctx) {
 }
 
 int gpx_stream_select(gpx_ctx* ctx, int which) {
-  GPX_ARG(ctx && which >= 0 && which < 3, "stream index must be 0 (main), 1 (panel) or 2 (communication)");
+  GPX_ARG(ctx && which >= 0 && which < 4, "stream index must be 0 (main), 1 (panel), 2 (communication) or 3 (background)");
   ctx->stream = ctx->streams[which];
   return 0;
 }
@@ -699,6 +716,24 @@ int gpx_ivar(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const g
   }
   *out = v[0] / (double)Z->rows;
   return 0;
+}
+
+// out[j] = sum_{i < rows} B[i][j]^2 for the logical columns of B (host out[B->cols]); deterministic
+int gpx_col_sumsq(gpx_ctx* ctx, const gpx_mat* B, int64_t rows, double* out) {
+  GPX_ARG(ctx && B && out && rows >= 0 && rows <= B->prows, "bad arguments");
+  void *po, *pp;
+  const int64_t bytes_part = colreduce_partial_elems(B->prows, B->pcols) * 8 + 8;
+  GPX_TRY(gpx_dev_alloc(ctx, B->pcols * 8, &po));
+  int r = gpx_dev_alloc(ctx, bytes_part, &pp);
+  if (r == 0) {
+    r = launch_colreduce(ctx, B->p, B->ld, rows, B->pcols, nullptr, (double*)po, (double*)pp);
+    if (r == 0 && hipMemcpyAsync(out, po, (size_t)B->cols * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) r = -2;
+    (void)hipStreamSynchronize(ctx->stream);
+    gpx_dev_release(ctx, pp, bytes_part);
+  }
+  gpx_dev_release(ctx, po, B->pcols * 8);
+  if (r == -2) gpx_set_error("col_sumsq: HIP copy failed");
+  return r;
 }
 
 // out[rows] = A v (host vectors; v has A->cols entries): a deterministic row reduction over the resident matrix

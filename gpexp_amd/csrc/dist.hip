@@ -282,6 +282,25 @@ int gpx_dist_panel_update(gpx_ctx* ctx, gpx_mat* K, int64_t k, int64_t nb, const
   return 0;
 }
 
+// Streamed evaluation: step k of a right-looking LEFT triangular solve of B (np x mcp, the cross matrix K(X, Z_local))
+// against the factor, using only block column k of L -- i.e. exactly the panel that has just arrived and been stored:
+//   B_k <- L_kk^-1 B_k;   B[(k+1)nb:, :] -= L[(k+1)nb:, k] B_k.
+// Issued on the background stream right after panel_store(k), it fills the time the rank would otherwise idle waiting
+// for the next panel (at 8 GPUs the panel chain is broadcast-bound and the trailing update per rank is short).
+int gpx_dist_ivar_step(gpx_ctx* ctx, const gpx_mat* K, int64_t k, int64_t nb, gpx_mat* B) {
+  GPX_ARG(ctx && K && B && K->aux, "NULL argument / no stored panel yet");
+  const int64_t np = K->prows, r0 = k * nb;
+  GPX_ARG(nb % GPX_TILE == 0 && r0 < np && B->prows == np, "bad panel index / B does not match the factor");
+  const int64_t w = (np - r0) < nb ? (np - r0) : nb, below = np - r0 - w, mcp = B->pcols;
+  double* Bk = B->p + r0 * B->ld;
+  GPX_TRY(chol_trsm_left(ctx, K->p + r0 * K->ld + r0, K->ld, K->aux + (r0 / GPX_TILE) * GPX_TILE * GPX_TILE, Bk, B->ld, w,
+                         mcp));
+  if (below > 0)
+    GPX_TRY(launch_gemm(ctx, K->p + (r0 + w) * K->ld + r0, K->ld, Bk, B->ld, B->p + (r0 + w) * B->ld, B->ld, below, mcp, w,
+                        false, true, false));
+  return 0;
+}
+
 int gpx_dist_finish(gpx_ctx* ctx, gpx_mat* K) {
   GPX_ARG(ctx && K && K->aux, "matrix was not factored by the distributed panel loop");
   GPX_HIP(hipStreamSynchronize(ctx->stream));

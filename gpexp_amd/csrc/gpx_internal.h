@@ -78,7 +78,8 @@ struct ProfRec {
 struct gpx_ctx {
   int device;
   hipStream_t stream;        // currently selected stream (all launches go here)
-  hipStream_t streams[3];    // 0 = main, 1 = panel (high priority), 2 = communication (high priority)
+  hipStream_t streams[4];    // 0 = main, 1 = panel (high priority), 2 = communication (high priority),
+                             // 3 = background: CU-masked (leaves 4 CUs per XCD to the other streams) when the runtime allows
   std::vector<hipEvent_t> sync_events;  // gpx_event_record / gpx_event_wait ids
   int cus;
   // cached device allocations (exact-size reuse)

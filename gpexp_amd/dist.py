@@ -230,7 +230,7 @@ def init_from_env(ctx):
 
 
 # ---- distributed operations -----------------------------------------------------------------------------------
-MAIN, PANEL, COMM = 0, 1, 2  # stream indices of the context (gpx_stream_select)
+MAIN, PANEL, COMM, BACK = 0, 1, 2, 3  # stream indices of the context (gpx_stream_select); BACK = CU-masked background
 
 
 class DeviceOps:
@@ -272,6 +272,22 @@ class DeviceOps:
     def finish(self, K):
         check(self.ctx.lib.gpx_dist_finish(self.ctx.h, K.h))
 
+    # streamed evaluation (one right-looking solve step per stored panel)
+    def alloc_cross(self, n, m):
+        return _dev.DeviceMatrix.zeros(self.ctx, n, m)
+
+    def cross_fill(self, spec, X, Z, B):
+        _dev.kfill_into(self.ctx, spec, X, B, Z=Z)
+
+    def ivar_step(self, K, k, nb, B):
+        check(self.ctx.lib.gpx_dist_ivar_step(self.ctx.h, K.h, int(k), int(nb), B.h))
+
+    def variances(self, spec, Z, B, n):
+        """k(z,z) - column sums of squares of the solved cross matrix (signed, as evaluateVariance)."""
+        ss = np.empty(B.shape[1])
+        check(self.ctx.lib.gpx_col_sumsq(self.ctx.h, B.h, int(n), dptr(ss)))
+        return _dev.kdiag(self.ctx, spec, Z) - ss
+
     # stream / event plumbing of the look-ahead pipeline
     def stream(self, which):
         check(self.ctx.lib.gpx_stream_select(self.ctx.h, int(which)))
@@ -283,15 +299,15 @@ class DeviceOps:
         check(self.ctx.lib.gpx_event_wait(self.ctx.h, int(ev)))
 
 
-# event ids of the pipeline (per step k, 4 kinds)
+# event ids of the pipeline (per step k, 5 kinds)
 def _ev(kind, k):
-    return 4 * (k + 1) + kind
+    return 5 * (k + 1) + kind
 
 
-EV_COLREADY, EV_FACT, EV_BCAST, EV_APPLIED = 0, 1, 2, 3
+EV_COLREADY, EV_FACT, EV_BCAST, EV_APPLIED, EV_STORED = 0, 1, 2, 3, 4
 
 
-def dist_potrf(ops, comm, K, n, nb, panels):
+def dist_potrf(ops, comm, K, n, nb, panels, on_stored=None):
     """Right-looking block-column Cholesky of the distributed matrix K (in place) with one step of LOOK-AHEAD; every
     rank ends with all of L.  `panels` = two packed panel buffers used alternately.
 
@@ -303,6 +319,9 @@ def dist_potrf(ops, comm, K, n, nb, panels):
     so the factorisation and broadcast of panel k+1 run underneath the bulk of update k.  A buffer is reused at step
     k+2 only after EV_APPLIED[k].  Everything is enqueued asynchronously in step order, hence every rank issues its
     collectives in the same order.  Returns 0 or the 1-based index of the first non-positive pivot (agreed by all).
+
+    `on_stored(k)` (optional) is called right after panel k has been stored (event EV_STORED[k] recorded on MAIN): the
+    hook of the streamed evaluation, which enqueues its step k on the BACK stream behind that event.
     """
     nblk = num_blocks(n, nb)
     np_ = padded(n)
@@ -331,6 +350,10 @@ def dist_potrf(ops, comm, K, n, nb, panels):
         ops.stream(MAIN)
         ops.wait(_ev(EV_BCAST, k))
         ops.panel_store(K, k, nb, P)
+        if on_stored is not None:
+            ops.record(_ev(EV_STORED, k))
+            on_stored(k)
+            ops.stream(MAIN)
         if k + 1 < nblk:
             ops.panel_update(K, k, nb, P, k + 1, k + 2, comm.rank, comm.world)
             ops.record(_ev(EV_COLREADY, k + 1))
@@ -347,9 +370,16 @@ def dist_potrf(ops, comm, K, n, nb, panels):
 class DistFitIvar:
     """bench.py's multi-GPU step: distributed fit (kfill + potrf), alpha/logdet/log-likelihood, sharded IVAR."""
 
-    def __init__(self, ctx, comm, spec, Xh, yh, Zh, noise, nb=512, ops=None):
+    def __init__(self, ctx, comm, spec, Xh, yh, Zh, noise, nb=512, ops=None, streamed=None):
         self.ctx, self.comm, self.spec = ctx, comm, spec
         self.ops = ops or DeviceOps(ctx)
+        # Streamed evaluation (default with more than one rank; GPX_DIST_STREAM_IVAR=0/1 overrides): the rank's slice of
+        # the IVAR solve advances by one right-looking step per arrived panel on the background stream, underneath the
+        # broadcast-bound panel chain, instead of starting after the factorisation.
+        env = os.environ.get("GPX_DIST_STREAM_IVAR")
+        self.streamed = (comm.world > 1) if streamed is None else bool(streamed)
+        if env is not None:
+            self.streamed = env == "1"
         self.n, self.noise, self.nb = Xh.shape[0], float(noise), int(nb)
         self.yh = np.ascontiguousarray(yh, dtype=np.float64)
         self.m = Zh.shape[0]
@@ -360,11 +390,24 @@ class DistFitIvar:
         self.P = [self.ops.alloc_panel(self.n, self.nb), self.ops.alloc_panel(self.n, self.nb)]
         self.y_dev = _dev.padded_vector(ctx, self.yh)
         self.alpha_dev = _dev.padded_vector(ctx, np.zeros(self.n))
+        self.B = self.ops.alloc_cross(self.n, hi - lo) if (self.streamed and hi > lo) else None
 
     def step(self):
         ctx, comm = self.ctx, self.comm
         self.ops.kfill_owned(self.spec, self.X, self.K, self.noise, self.nb, comm.rank, comm.world)
-        info = dist_potrf(self.ops, comm, self.K, self.n, self.nb, self.P)
+        hook = None
+        if self.B is not None:
+            ops = self.ops
+            ops.stream(BACK)
+            ops.cross_fill(self.spec, self.X, self.Zloc, self.B)   # independent of the factorisation
+            ops.stream(MAIN)
+
+            def hook(k):
+                ops.stream(BACK)
+                ops.wait(_ev(EV_STORED, k))
+                ops.ivar_step(self.K, k, self.nb, self.B)
+
+        info = dist_potrf(self.ops, comm, self.K, self.n, self.nb, self.P, on_stored=hook)
         if info:
             from ._lib import NotPositiveDefinite
             raise NotPositiveDefinite(info)
@@ -375,7 +418,9 @@ class DistFitIvar:
             _dev.potrs_dev(ctx, self.K, self.y_dev, self.alpha_dev)
             ctx.stream(MAIN)
         part = 0.0
-        if self.Zloc is not None:
+        if self.B is not None:     # the solve finished with the last panel (dist_potrf synchronised every stream)
+            part = float(np.sum(self.ops.variances(self.spec, self.Zloc, self.B, self.n)))
+        elif self.Zloc is not None:
             _, var = _dev.posterior(ctx, self.spec, self.K, self.X, None, self.Zloc, want_mean=False)
             part = float(np.sum(var))
         ll = 0.0

@@ -197,8 +197,13 @@ int gpx_dist_panel_store(gpx_ctx* ctx, gpx_mat* K, int64_t k, int64_t nb, const 
 int gpx_dist_panel_update(gpx_ctx* ctx, gpx_mat* K, int64_t k, int64_t nb, const gpx_mat* P, int64_t j0, int64_t j1,
                           int rank, int world);
 /* mark K as a complete factor (every rank now holds all of L) */
+/* streamed evaluation (multi-GPU): step k of a right-looking left solve of B = K(X, Z_local) (padded N x m) against block
+ * column k of the factor, valid as soon as gpx_dist_panel_store(k) has run; asynchronous on the selected stream */
+int gpx_dist_ivar_step(gpx_ctx* ctx, const gpx_mat* K, int64_t k, int64_t nb, gpx_mat* B);
 int gpx_dist_finish(gpx_ctx* ctx, gpx_mat* K);
 
+/* out[j] = sum over the first `rows` rows of B[i][j]^2 (host out[B->cols]): variance reduction of a solved cross matrix */
+int gpx_col_sumsq(gpx_ctx* ctx, const gpx_mat* B, int64_t rows, double* out);
 /* out[rows] = A v for a resident matrix (covTimesV, gp_kernel_utilities.py:107-143: the Nystrom operator application) */
 int gpx_matvec(gpx_ctx* ctx, const gpx_mat* A, const double* v, double* out);
 

@@ -111,6 +111,26 @@ class NumpyOps:
     def finish(self, K):
         pass
 
+    # streamed evaluation (same semantics as gpx_dist_ivar_step): one right-looking solve step per stored panel
+    def alloc_cross(self, n, m):
+        return NumpyMat(np.zeros((dist.padded(n), m)))
+
+    def cross_fill(self, spec, X, Z, B):
+        B.a[:] = 0.0
+        B.a[:X.shape[0], :] = self.orc.cross_matrix(self.spec, Z, X).T
+
+    def ivar_step(self, K, k, nb, B):
+        np_ = K.a.shape[0]
+        r0 = k * nb
+        w = min(nb, np_ - r0)
+        Lkk = np.tril(K.a[r0:r0 + w, r0:r0 + w])
+        B.a[r0:r0 + w] = np.linalg.solve(Lkk, B.a[r0:r0 + w])
+        if r0 + w < np_:
+            B.a[r0 + w:] -= K.a[r0 + w:, r0:r0 + w] @ B.a[r0:r0 + w]
+
+    def variances(self, spec, Z, B, n):
+        return self.orc.kernel_diag(self.spec, Z) - np.sum(B.a[:n] ** 2, axis=0)
+
 
 class NumpyComm:
     def __init__(self):
@@ -151,6 +171,27 @@ def run_cpu(args):
     assert err < 1e-12, err
     # every rank must hold the complete factor (that is what lets evaluation shard without moving L)
     allerr = comm.allgather(np.array([err]))[:, 0]
+    # streamed evaluation hook: one solve step per stored panel, in panel order, ends with L^-1 K(X, Z_local)
+    Z = rng.uniform(-1, 1, (41 + comm.world, d))
+    lo, hi = dist.eval_slice(len(Z), comm.rank, comm.world)
+    K2 = ops.alloc_matrix(args.n)
+    ops.kfill_owned(None, X, K2, 0.05, args.nb, comm.rank, comm.world)
+    B = ops.alloc_cross(args.n, hi - lo)
+    ops.cross_fill(None, X, Z[lo:hi], B)
+    seen = []
+
+    def hook(k):
+        seen.append(k)
+        ops.ivar_step(K2, k, args.nb, B)
+
+    assert dist.dist_potrf(ops, comm, K2, args.n, args.nb, P, on_stored=hook) == 0
+    assert seen == list(range(dist.num_blocks(args.n, args.nb)))
+    Wref = np.linalg.solve(Lref, orc.cross_matrix(spec, Z[lo:hi], X).T)
+    assert np.max(np.abs(B.a[:args.n] - Wref)) <= 1e-11 * max(np.max(np.abs(Wref)), 1e-300)
+    var = ops.variances(None, Z[lo:hi], B, args.n)
+    allvar = np.concatenate([v[:c] for v, c in zip(comm.allgather(np.pad(var, (0, 64 - len(var)))), [e - b for b, e in (dist.eval_slice(len(Z), r, comm.world) for r in range(comm.world))])])
+    m_ref = orc.fit(spec, X, np.zeros(args.n), 0.05)
+    assert np.max(np.abs(allvar - orc.posterior(spec, m_ref, Z, compvar=1)[1])) <= 1e-10
     # evaluation slices tile the index range exactly
     m = 1000 + comm.world
     sl = [dist.eval_slice(m, r, comm.world) for r in range(comm.world)]
@@ -184,6 +225,13 @@ def run_gpu(args):
     ll, iv = runner.step()
     ll2, iv2 = runner.step()  # second step re-assembles in place
     assert ll == ll2 and iv == iv2
+    # the other evaluation schedule (streamed <-> after the factorisation) must agree
+    other = dist.DistFitIvar(ctx, comm, spec, Xh, yh, Zh, 0.1, nb=args.nb, streamed=not runner.streamed)
+    ll3, iv3 = other.step()
+    assert abs(iv3 - iv) <= 1e-11 * abs(iv), (runner.streamed, iv, iv3)
+    if comm.rank == 0:
+        assert abs(ll3 - ll) <= 1e-12 * abs(ll), (ll, ll3)
+    del other
     Ld = runner.K.to_host(tri=1)
     # single-GPU path on the same inputs (every rank checks its own copy of L)
     X = dev.points(ctx, Xh)
