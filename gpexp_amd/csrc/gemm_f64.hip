@@ -1,9 +1,9 @@
 // fp64 MFMA GEMM for gfx950:  C = C - A*op(B)  or  C = A*op(B)   (row-major)
 //
-// This is the one compute kernel behind the Cholesky trailing update (SYRK, lower tiles only), the
-// recursive TRSM updates and the leaf "multiply by the inverted diagonal block" steps -- i.e. it
-// carries the N^3/3 flops that replace numpy.linalg.pinv (gp.py:181,400) and the N^2*M flops that
-// replace the per-point k^T P k loop (gp.py:142-144, 253-255).
+// This is the one compute kernel behind the Cholesky trailing update (SYRK, lower tiles only) and the recursive TRSM
+// updates -- i.e. it carries the N^3/3 flops that replace numpy.linalg.pinv (gp.py:181,400) and the N^2*M flops that
+// replace the per-point k^T P k loop (gp.py:142-144, 253-255).  (Products with the inverted 128x128 diagonal leaves have
+// their own kernels in chol.hip.)
 //
 // Tiling (64-wide wavefronts): a 256-thread workgroup owns a TE x TE tile of C; its four waves form a 2x2
 // grid, each wave an FI x FI array of v_mfma_f64_16x16x4_f64 accumulators (measured issue rate of that MFMA:
@@ -12,9 +12,9 @@
 //   TE =  64 (FI = 2)                                          the latency kernel for launches with too few
 //       128-tiles to fill the chip: 4x the workgroups, 1/4 of the serial MFMA chain each (a 128x128x128 tile
 //       cannot finish in less than 8 k-steps x 64 MFMAs x 64 cycles = 13.6 us however empty the GPU is).
-// K is consumed in steps of 16 through a double-buffered LDS stage fed by a register prefetch (global loads for
-// step t+1 are issued before the MFMAs of step t and written to the other LDS buffer after them; one barrier
-// per step).
+// K is consumed in steps of 16 through a double-buffered LDS stage fed by a register prefetch, on a hand-pinned
+// schedule (see the loop): loads for step t+1 first, 48 of step t's 64 MFMAs, LDS store + the step's one barrier, the
+// fragment reads of step t+1 underneath the remaining 16 MFMAs.
 //
 // LDS images: [row][k] with an ODD row stride (17 doubles): hipcc fuses the per-lane fragment reads into
 // ds_read2_b64, which banks modulo 32 dwords over 16-lane groups -- 16 rows x 2 dwords then cover all
@@ -66,10 +66,8 @@ __device__ __forceinline__ bool tile_of(int sblk, int within, int tiles_m, int t
   return true;
 }
 
-// PF = register prefetch depth (1 or 2 k-steps); KU = k-substeps (of 4) unrolled together: 4 lets the compiler hoist
-// every fragment read of the step, 2 keeps fewer fragments live (measured best for the NN form, and what lets PF=2
-// fit under the 256-VGPR cap).
-template <bool BT, bool ACC, int PF, int KU, int TE>
+// (Variants measured and dropped: a 2-deep register prefetch; reading only two k-substeps' fragments at a time.)
+template <bool BT, bool ACC, int TE>
 __device__ __forceinline__ void gemm_tile(Smem<BT, TE>& sm, const double* A, int64_t lda, const double* B, int64_t ldb,
                                           double* C, int64_t ldc, int nk, int by, int bx) {
   constexpr int SBN = TE + 16;     // row stride of the [k][n] image
@@ -100,7 +98,6 @@ __device__ __forceinline__ void gemm_tile(Smem<BT, TE>& sm, const double* A, int
   // Staging registers.  For the 128-tile they are NAMED scalars with the address chain written out: the equivalent
   // array form compiles to a measurably slower NN loop (IVAR 551 vs 534 ms at C4) -- hipcc scheduling lottery.
   double2 Pa0, Pa1, Pa2, Pa3, Pb0, Pb1, Pb2, Pb3;
-  double2 Qa0, Qa1, Qa2, Qa3, Qb0, Qb1, Qb2, Qb3;  // only used by PF == 2
   const int64_t b_rs2 = 2 * b_rs, b_rs3 = 3 * b_rs, a_rs2 = 2 * a_rs, a_rs3 = 3 * a_rs;
 #define GPX_LD16(base_, voff_) (*reinterpret_cast<const double2*>((base_) + (voff_)))
 #define GPX_GLOAD(S_, kt_)                                                                            \
@@ -165,54 +162,7 @@ __device__ __forceinline__ void gemm_tile(Smem<BT, TE>& sm, const double* A, int
   const int fr = lane & 15, fk = lane >> 4;
   const double* const as0 = &sm.a[0][(wm * WS + fr) * SA + fk];
   const double* const bs0 = BT ? &sm.b[0][(wn * WS + fr) * SA + fk] : &sm.b[0][fk * SBN + wn * WS + fr];
-#define GPX_COMPUTE(buf_)                                                                             \
-  do {                                                                                                \
-    const double* as = as0 + (buf_) * A_BUF;                                                          \
-    const double* bs = bs0 + (buf_) * B_BUF;                                                          \
-    _Pragma("unroll 1") for (int kk0 = 0; kk0 < KB / 4; kk0 += KU) {                                  \
-      _Pragma("unroll") for (int ku = 0; ku < KU; ++ku) {                                             \
-        const int kk = kk0 + ku;                                                                      \
-        double af[FI], bf[FI];                                                                        \
-        _Pragma("unroll") for (int i = 0; i < FI; ++i) af[i] = as[(i * 16) * SA + kk * 4];            \
-        _Pragma("unroll") for (int j = 0; j < FI; ++j)                                                \
-            bf[j] = BT ? bs[(j * 16) * SA + kk * 4] : bs[(kk * 4) * SBN + j * 16];                    \
-        _Pragma("unroll") for (int i = 0; i < FI; ++i) _Pragma("unroll") for (int j = 0; j < FI; ++j) \
-            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);       \
-      }                                                                                               \
-    }                                                                                                 \
-  } while (0)
-
-  if (PF == 2) {
-    // prologue: steps 0 and 1 in flight, step 0 staged
-    GPX_GLOAD(P, 0);
-    if (nk > 1) GPX_GLOAD(Q, 1);
-    GPX_SSTORE(P, 0);
-    __syncthreads();
-    int kt = 0;
-    for (; kt + 3 < nk; kt += 2) {  // steady state, two steps per trip so that the register sets stay static
-      GPX_GLOAD(P, kt + 2);
-      GPX_COMPUTE(0);
-      GPX_SSTORE(Q, 1);
-      __syncthreads();
-      GPX_GLOAD(Q, kt + 3);
-      GPX_COMPUTE(1);
-      GPX_SSTORE(P, 0);
-      __syncthreads();
-    }
-    // tail: 1..3 steps left; at entry LDS buffer 0 holds step kt and q holds step kt+1 (if it exists)
-    if (kt + 2 < nk) GPX_GLOAD(P, kt + 2);
-    GPX_COMPUTE(0);
-    if (kt + 1 < nk) {
-      GPX_SSTORE(Q, 1);
-      __syncthreads();
-      GPX_COMPUTE(1);
-      if (kt + 2 < nk) {
-        GPX_SSTORE(P, 0);
-        __syncthreads();
-        GPX_COMPUTE(0);
-      }
-    }
-  } else {
+  {
     // Steady state, scheduled by hand (GPX_PIN pins it): the global loads of step kt+1 are issued first and are
     // only waited for after three quarters of this step's MFMAs (left alone, hipcc hoists the LDS store + barrier to
     // after the first 20 MFMAs, ~1 us after the loads were issued: a vmcnt stall on every step -- 13 % of the MFMA
@@ -235,94 +185,39 @@ __device__ __forceinline__ void gemm_tile(Smem<BT, TE>& sm, const double* A, int
     // and the barrier stay behind the third substep's MFMAs, the fourth substep stays behind the barrier
 #define GPX_PIN() asm volatile("" : "+v"(acc[FI - 1][FI - 1]) : : "memory")
     static_assert(KB == 16, "the hand schedule below is written for four k-substeps");
-    double fa0[FI], fa1[FI], fa2[FI], fa3[FI], fb0[FI], fb1[FI], fb2[FI], fb3[FI];  // slots 2, 3 only used by KU == 4
+    double fa0[FI], fa1[FI], fa2[FI], fa3[FI], fb0[FI], fb1[FI], fb2[FI], fb3[FI];  // one slot per k-substep
     GPX_GLOAD(P, 0);
     GPX_SSTORE(P, 0);
     __syncthreads();
     // The loop is rotated: on entry to a step its first fragments are already in registers -- they were read right after
     // the previous barrier, underneath that step's last 16 MFMAs -- so no LDS latency is exposed at the top.
-#ifndef GPX_GEMM_ROT
-#define GPX_GEMM_ROT 1
-#endif
-    if (GPX_GEMM_ROT) {
-      GPX_FRAGS(0, 0, 0);
-      GPX_FRAGS(0, 1, 1);
-      if (KU == 4) {
-        GPX_FRAGS(0, 2, 2);
-        GPX_FRAGS(0, 3, 3);
-      }
-    }
+    GPX_FRAGS(0, 0, 0);
+    GPX_FRAGS(0, 1, 1);
+    GPX_FRAGS(0, 2, 2);
+    GPX_FRAGS(0, 3, 3);
     int kt = 0;
     for (; kt + 1 < nk; ++kt) {
       const int buf = kt & 1;
       GPX_GLOAD(P, kt + 1);
-      if (!GPX_GEMM_ROT) {
-        GPX_FRAGS(buf, 0, 0);
-        GPX_FRAGS(buf, 1, 1);
-        if (KU == 4) {
-          GPX_FRAGS(buf, 2, 2);
-          GPX_FRAGS(buf, 3, 3);
-        }
-      }
-      if (KU == 4) {
-        GPX_MFMAS(0);
-        GPX_MFMAS(1);
-        GPX_MFMAS(2);
-      } else {
-        GPX_MFMAS(0);
-        GPX_FRAGS(buf, 2, 0);
-        GPX_MFMAS(1);
-        GPX_FRAGS(buf, 3, 1);
-        GPX_MFMAS(0);
-      }
+      GPX_MFMAS(0);
+      GPX_MFMAS(1);
+      GPX_MFMAS(2);
       GPX_PIN();
       GPX_SSTORE(P, buf ^ 1);
       __syncthreads();
       GPX_PIN();
-      if (!GPX_GEMM_ROT) {
-        if (KU == 4) {
-          GPX_MFMAS(3);
-        } else {
-          GPX_MFMAS(1);
-        }
-      } else if (KU == 4) {
-        GPX_FRAGS(buf ^ 1, 0, 0);
-        GPX_FRAGS(buf ^ 1, 1, 1);
-        GPX_FRAGS(buf ^ 1, 2, 2);
-        GPX_PIN();  // the reads above are issued BEFORE the last 16 MFMAs (hipcc would sink most of them below)
-        GPX_MFMAS(3);
-        GPX_FRAGS(buf ^ 1, 3, 3);
-      } else {
-        GPX_FRAGS(buf ^ 1, 0, 0);
-        GPX_PIN();
-        GPX_MFMAS(1);
-        GPX_FRAGS(buf ^ 1, 1, 1);
-      }
+      GPX_FRAGS(buf ^ 1, 0, 0);
+      GPX_FRAGS(buf ^ 1, 1, 1);
+      GPX_FRAGS(buf ^ 1, 2, 2);
+      GPX_PIN();  // the reads above are issued BEFORE the last 16 MFMAs (hipcc would sink most of them below)
+      GPX_MFMAS(3);
+      GPX_FRAGS(buf ^ 1, 3, 3);
     }
-    {  // last step: fragments 0, 1 (KU == 4: all four) are loaded
-      const int buf = kt & 1;
-      if (!GPX_GEMM_ROT) {
-        GPX_FRAGS(buf, 0, 0);
-        GPX_FRAGS(buf, 1, 1);
-        if (KU == 4) {
-          GPX_FRAGS(buf, 2, 2);
-          GPX_FRAGS(buf, 3, 3);
-        }
-      }
-      if (KU == 4) {
-        GPX_MFMAS(0);
-        GPX_MFMAS(1);
-        GPX_MFMAS(2);
-        GPX_MFMAS(3);
-      } else {
-        GPX_MFMAS(0);
-        GPX_FRAGS(buf, 2, 0);
-        GPX_MFMAS(1);
-        GPX_FRAGS(buf, 3, 1);
-        GPX_MFMAS(0);
-        GPX_MFMAS(1);
-      }
-    }
+    // last step: its fragments are loaded
+    GPX_MFMAS(0);
+    GPX_MFMAS(1);
+    GPX_MFMAS(2);
+    GPX_MFMAS(3);
 #undef GPX_FRAGS
 #undef GPX_MFMAS
 #undef GPX_PIN
@@ -359,7 +254,7 @@ __device__ __forceinline__ void gemm_tile(Smem<BT, TE>& sm, const double* A, int
 // the workgroups with the highest ids, i.e. the ones dispatched last.  All tiles of a launch take the same time, so a
 // launch whose tile count is not a multiple of the resident workgroups ends with a mostly idle round; tiles with a
 // quarter of the work shorten it.
-template <bool BT, bool ACC, bool LOWER, int PF, int KU, int TE>
+template <bool BT, bool ACC, bool LOWER, int TE>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64_t lda, const double* B, int64_t ldb,
                                                           double* C, int64_t ldc, int nk, int tiles_m, int tiles_n,
                                                           int sb_cols, int sb_shift, int main_wgs, int tail_m0,
@@ -370,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64
     const int wt = w - main_wgs;
     const int by = wt / tail_tn, bx = wt - by * tail_tn;
     if (LOWER && 64 * bx > tail_m0 + 64 * by + 63) return;  // tile entirely above the diagonal
-    gemm_tile<BT, ACC, 1, 4, 64>(reinterpret_cast<Smem<BT, 64>&>(sm), A + (int64_t)tail_m0 * lda, lda, B, ldb,
+    gemm_tile<BT, ACC, 64>(reinterpret_cast<Smem<BT, 64>&>(sm), A + (int64_t)tail_m0 * lda, lda, B, ldb,
                                  C + (int64_t)tail_m0 * ldc, ldc, nk, by, bx);
     return;
   }
@@ -379,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64
   int by, bx;
   if (!tile_of<LOWER>((q >> sbs2) * 8 + xcd, q & ((1 << sbs2) - 1), tiles_m, tiles_n, sb_cols, sb_shift, &by, &bx))
     return;
-  gemm_tile<BT, ACC, PF, KU, TE>(sm, A, lda, B, ldb, C, ldc, nk, by, bx);
+  gemm_tile<BT, ACC, TE>(sm, A, lda, B, ldb, C, ldc, nk, by, bx);
 }
 
 // (A persistent per-XCD work-queue variant of this kernel was measured in round 1 and removed: exact XCD placement
@@ -418,10 +313,8 @@ int launch_gemm(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int
   GPX_ARG(m % 128 == 0 && n % 128 == 0 && k % KB == 0 && k > 0, "gemm: m,n must be multiples of 128 and k of 16");
   GPX_ARG((lda % 2) == 0 && (ldb % 2) == 0, "gemm: leading dimensions must be even (16-byte loads)");
   GPX_ARG(!lower || m == n, "gemm: lower-only update needs a square C");
-  static int pf = -1, small_max = -1;
-  if (pf < 0) {
-    const char* e = getenv("GPX_GEMM_PF");
-    pf = e ? atoi(e) : 0;  // 0: default (per-variant best); 2: depth-2 prefetch; 12/14: depth-1 + inner unroll 2/4
+  static int small_max = -1;
+  if (small_max < 0) {
     const char* e3 = getenv("GPX_GEMM_SMALL_MAX");    // use 64x64 tiles while the 128-tile count is below this
     small_max = e3 ? atoi(e3) : 1024;  // C4 potrf: 270 ms without, 251 ms at 256, 247 ms at 1024
   }
@@ -459,21 +352,15 @@ int launch_gemm(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int
   dim3 grid((unsigned)(p.wgs + tail_wgs));
   const int nk = (int)(k / KB);
   ProfScope ps(ctx, GPX_PROF_GEMM, 2.0 * tiles128 * 128.0 * 128.0 * (double)k, 0.0);
-#define GPX_K(BT_, ACC_, LOW_, PF_, KU_, TE_)                                                                       \
-  hipLaunchKernelGGL((gemm_f64_kernel<BT_, ACC_, LOW_, PF_, KU_, TE_>), grid, dim3(256), 0, ctx->stream, A, lda, B, \
-                     ldb, C, ldc, nk, p.tm, p.tn, p.sbc, p.sb_shift, (int)p.wgs, (int)m_main, (int)tail_tn)
-#define GPX_G(BT_, ACC_, LOW_)                                                                                       \
-  do {                                                                                                               \
-    if (te == 64)                                                                                                    \
-      GPX_K(BT_, ACC_, LOW_, 1, 4, 64);                                                                              \
-    else if (pf == 2)                                                                                                \
-      GPX_K(BT_, ACC_, LOW_, 2, 2, 128);                                                                             \
-    else if (pf == 12)                                                                                               \
-      GPX_K(BT_, ACC_, LOW_, 1, 2, 128);                                                                             \
-    else if (pf == 14)                                                                                               \
-      GPX_K(BT_, ACC_, LOW_, 1, 4, 128);                                                                             \
-    else /* default: all four k-substeps' fragments in registers (with the hand schedule: NN 74.0 vs 71.3 TF/s at KU=2) */ \
-      GPX_K(BT_, ACC_, LOW_, 1, 4, 128);                                                                 \
+#define GPX_K(BT_, ACC_, LOW_, TE_)                                                                           \
+  hipLaunchKernelGGL((gemm_f64_kernel<BT_, ACC_, LOW_, TE_>), grid, dim3(256), 0, ctx->stream, A, lda, B, ldb, C, ldc, \
+                     nk, p.tm, p.tn, p.sbc, p.sb_shift, (int)p.wgs, (int)m_main, (int)tail_tn)
+#define GPX_G(BT_, ACC_, LOW_)          \
+  do {                                  \
+    if (te == 64)                       \
+      GPX_K(BT_, ACC_, LOW_, 64);       \
+    else                                \
+      GPX_K(BT_, ACC_, LOW_, 128);      \
   } while (0)
   if (bt) {
     if (accumulate) {
