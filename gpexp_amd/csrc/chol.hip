@@ -443,36 +443,123 @@ __global__ __launch_bounds__(256) void leaf_mul_left_kernel(double* __restrict__
 // times that solution from the second half as ONE bandwidth-bound GEMV over the whole block, solve the second half
 // (transposed sweep: the other way round).  Leaves multiply by the inverted 128x128 diagonal block.
 
-// y <- inv * y (forward) : wave per row, lanes across the 128 columns (coalesced 1 KiB rows), shuffle reduction
-__global__ __launch_bounds__(256) void trsv_leaf_fwd_kernel(const double* __restrict__ inv, double* __restrict__ y) {
-  __shared__ double ys[NB];
-  __shared__ double out[NB];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  if (t < NB) ys[t] = y[t];
-  __syncthreads();
-  const double2 v = reinterpret_cast<const double2*>(ys)[lane];
-  for (int r = wave * 32; r < wave * 32 + 32; ++r) {
-    const double2 l = reinterpret_cast<const double2*>(inv + r * NB)[lane];
-    double s = fma(l.x, v.x, l.y * v.y);
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) out[r] = s;
-  }
-  __syncthreads();
-  if (t < NB) y[t] = out[t];
+// ---- fused sweeps over a diagonal block of up to TRSV_BLOCK rows: the latency-bound bottom of the recursion ----------
+// One workgroup solves the whole block -- leaf inverses and the coupling between the leaves -- instead of one launch per
+// leaf and per coupling product (7 launches per 512 rows and sweep): potrs was ~45 us per 128 rows, all of it launch
+// and load latency, and up to a third of GP.train at N <= 8192.
+constexpr int TRSV_BLOCK = 512;
+
+// dots of R consecutive 128-wide rows (row stride `stride`; lane: columns 2*lane, 2*lane+1) with a vector held two entries
+// per lane; all R loads are issued before the first use (the sweeps are latency-bound: memory-level parallelism is all
+// that counts), results in every lane
+template <int R>
+__device__ __forceinline__ void wave_rowdots(const double* __restrict__ base, int64_t stride, double2 v, int lane,
+                                             double (&out)[R]) {
+  double2 a[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) a[i] = reinterpret_cast<const double2*>(base + (int64_t)i * stride)[lane];
+#pragma unroll
+  for (int i = 0; i < R; ++i) out[i] = fma(a[i].x, v.x, a[i].y * v.y);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+    for (int i = 0; i < R; ++i) out[i] += __shfl_xor(out[i], off, 64);
 }
 
-// z <- inv^T * z (backward): thread per column, rows walked with coalesced loads
-__global__ __launch_bounds__(128) void trsv_leaf_bwd_kernel(const double* __restrict__ inv, double* __restrict__ z) {
-  __shared__ double zs[NB];
-  const int t = threadIdx.x;
-  zs[t] = z[t];
+// y <- L^-1 y for the n x n diagonal block at L (n = 128 * nleaf <= TRSV_BLOCK), leaf inverses at inv
+__global__ __launch_bounds__(256) void trsv_block_fwd_kernel(const double* __restrict__ L, int64_t ld,
+                                                             const double* __restrict__ inv, double* __restrict__ y,
+                                                             int nleaf) {
+  __shared__ double ys[TRSV_BLOCK];
+  __shared__ double tmp[NB];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int n = NB * nleaf;
+  for (int i = t; i < n; i += 256) ys[i] = y[i];
   __syncthreads();
-  double s0 = 0.0, s1 = 0.0;
-  for (int i = 0; i < NB; i += 2) {
-    s0 = fma(inv[i * NB + t], zs[i], s0);
-    s1 = fma(inv[(i + 1) * NB + t], zs[i + 1], s1);
+  for (int k = 0; k < nleaf; ++k) {
+    const double* ik = inv + (int64_t)k * NB * NB;
+    const double2 v = reinterpret_cast<const double2*>(ys + NB * k)[lane];
+    // y_k = inv_k y_k: wave w takes rows 32w .. 32w+31, all 32 loads in flight at once (one memory round trip)
+    {
+      const int r = wave * 32;
+      double s[32];
+      wave_rowdots<32>(ik + r * NB, NB, v, lane, s);
+      if (lane < 32) {
+        double mine = s[0];
+#pragma unroll
+        for (int i = 1; i < 32; ++i) mine = (lane == i) ? s[i] : mine;
+        tmp[r + lane] = mine;
+      }
+    }
+    __syncthreads();
+    if (t < NB) ys[NB * k + t] = tmp[t];
+    __syncthreads();
+    // rows of the later leaves: y[r] -= L[r][128k .. 128k+127] . y_k, 32 rows per wave and trip (a whole leaf per trip)
+    const double2 w = reinterpret_cast<const double2*>(ys + NB * k)[lane];
+    for (int r = NB * (k + 1) + 32 * wave; r < n; r += NB) {
+      double s[32];
+      wave_rowdots<32>(L + (int64_t)r * ld + NB * k, ld, w, lane, s);
+      if (lane < 32) {
+        double mine = s[0];
+#pragma unroll
+        for (int i = 1; i < 32; ++i) mine = (lane == i) ? s[i] : mine;
+        ys[r + lane] -= mine;
+      }
+    }
+    __syncthreads();
   }
-  z[t] = s0 + s1;
+  for (int i = t; i < n; i += 256) y[i] = ys[i];
+}
+
+// z <- L^-T z for the same block: leaves in descending order; thread per column, rows walked with coalesced loads
+__global__ __launch_bounds__(256) void trsv_block_bwd_kernel(const double* __restrict__ L, int64_t ld,
+                                                             const double* __restrict__ inv, double* __restrict__ z,
+                                                             int nleaf) {
+  __shared__ double zs[TRSV_BLOCK];
+  __shared__ double half[2][NB];
+  const int t = threadIdx.x;
+  const int n = NB * nleaf;
+  for (int i = t; i < n; i += 256) zs[i] = z[i];
+  __syncthreads();
+  for (int k = nleaf - 1; k >= 0; --k) {
+    // z_k = inv_k^T z_k: column c = t & 127, the two thread halves take rows 0..63 / 64..127
+    {
+      const double* ik = inv + (int64_t)k * NB * NB;
+      const int c = t & 127, r0 = (t >> 7) * 64;
+      double a[64];  // all 64 loads of this thread in flight at once
+#pragma unroll
+      for (int r = 0; r < 64; ++r) a[r] = ik[(r0 + r) * NB + c];
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int r = 0; r < 64; r += 2) {
+        s0 = fma(a[r], zs[NB * k + r0 + r], s0);
+        s1 = fma(a[r + 1], zs[NB * k + r0 + r + 1], s1);
+      }
+      half[t >> 7][c] = s0 + s1;
+    }
+    __syncthreads();
+    if (t < NB) zs[NB * k + t] = half[0][t] + half[1][t];
+    __syncthreads();
+    // columns of the earlier leaves: z[c] -= sum_r L[128k + r][c] z_k[r]
+    for (int c = t; c < NB * k; c += 256) {
+      const double* lc = L + (int64_t)(NB * k) * ld + c;
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll 1
+      for (int rb = 0; rb < NB; rb += 64) {
+        double a[64];
+#pragma unroll
+        for (int r = 0; r < 64; ++r) a[r] = lc[(int64_t)(rb + r) * ld];
+#pragma unroll
+        for (int r = 0; r < 64; r += 2) {
+          s0 = fma(a[r], zs[NB * k + rb + r], s0);
+          s1 = fma(a[r + 1], zs[NB * k + rb + r + 1], s1);
+        }
+      }
+      zs[c] -= s0 + s1;
+    }
+    __syncthreads();
+  }
+  for (int i = t; i < n; i += 256) z[i] = zs[i];
 }
 
 // y[r] -= sum_c A[r][c] x[c]   (rows x cols block, cols a multiple of 128): one wave per row, 8 rows per workgroup pass
@@ -493,11 +580,6 @@ __global__ __launch_bounds__(256) void gemv_sub_kernel(const double* __restrict_
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if (lane == 0) y[r] -= s;
   }
-}
-
-__global__ __launch_bounds__(256) void vec_sub_kernel(double* __restrict__ y, const double* __restrict__ d, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) y[i] -= d[i];
 }
 
 __global__ __launch_bounds__(256) void logdet_kernel(const double* __restrict__ L, int64_t ld, int64_t n,
@@ -633,8 +715,8 @@ int chol_potrf_nozero(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double* in
 }
 
 static int trsv_fwd_rec(gpx_ctx* ctx, const double* L, int64_t ld, const double* invd, double* y, int64_t n) {
-  if (n == NB) {
-    hipLaunchKernelGGL(trsv_leaf_fwd_kernel, dim3(1), dim3(256), 0, ctx->stream, invd, y);
+  if (n <= TRSV_BLOCK) {
+    hipLaunchKernelGGL(trsv_block_fwd_kernel, dim3(1), dim3(256), 0, ctx->stream, L, ld, invd, y, (int)(n / NB));
     return 0;
   }
   const int64_t n1 = split(n), n2 = n - n1;
@@ -648,15 +730,14 @@ static int trsv_fwd_rec(gpx_ctx* ctx, const double* L, int64_t ld, const double*
 // scratch: tmp (>= n doubles) and part (>= colreduce_partial_elems(n, n) doubles) for the transposed GEMV
 static int trsv_bwd_rec(gpx_ctx* ctx, const double* L, int64_t ld, const double* invd, double* z, int64_t n,
                         double* tmp, double* part) {
-  if (n == NB) {
-    hipLaunchKernelGGL(trsv_leaf_bwd_kernel, dim3(1), dim3(128), 0, ctx->stream, invd, z);
+  if (n <= TRSV_BLOCK) {
+    hipLaunchKernelGGL(trsv_block_bwd_kernel, dim3(1), dim3(256), 0, ctx->stream, L, ld, invd, z, (int)(n / NB));
     return 0;
   }
   const int64_t n1 = split(n), n2 = n - n1;
   GPX_TRY(trsv_bwd_rec(ctx, L + n1 * ld + n1, ld, invd + (n1 / NB) * NB * NB, z + n1, n2, tmp, part));
-  // z1 -= L21^T z2 : deterministic column reduction of the (n2 x n1) block against z2
-  GPX_TRY(launch_colreduce(ctx, L + n1 * ld, ld, n2, n1, z + n1, tmp, part));
-  hipLaunchKernelGGL(vec_sub_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, ctx->stream, z, tmp, n1);
+  // z1 -= L21^T z2 : deterministic column reduction of the (n2 x n1) block against z2, subtracted in its final pass
+  GPX_TRY(launch_colreduce(ctx, L + n1 * ld, ld, n2, n1, z + n1, z, part, 1));
   return trsv_bwd_rec(ctx, L, ld, invd, z, n1, tmp, part);
 }
 

@@ -159,7 +159,7 @@ int launch_logdet(gpx_ctx* ctx, const double* L, int64_t ld, int64_t n, double* 
 // reduce.hip
 // out[j] = sum_i B[i][j] * v[i]   (v == nullptr: sum_i B[i][j]^2), i < rows, j < pcols; deterministic
 int launch_colreduce(gpx_ctx* ctx, const double* B, int64_t ld, int64_t rows, int64_t pcols, const double* v,
-                     double* out, double* d_partial);
+                     double* out, double* d_partial, int subtract = 0);
 int64_t colreduce_partial_elems(int64_t rows, int64_t pcols);
 int launch_rowreduce(gpx_ctx* ctx, const double* B, int64_t ld, int64_t rows, int64_t cols, const double* v,
                      double* out, int weighted_squares = 0);

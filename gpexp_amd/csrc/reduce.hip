@@ -43,13 +43,14 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const double* __restrict
   partial[(int64_t)blockIdx.y * pcols + j] = (s0 + s1) + (s2 + s3);
 }
 
+// out[j] = sum of the partials, or (subtract) out[j] -= sum: the transposed-GEMV update of the triangular sweeps in one pass
 __global__ __launch_bounds__(256) void colreduce_final_kernel(const double* __restrict__ partial, int64_t nchunk,
-                                                              int64_t pcols, double* __restrict__ out) {
+                                                              int64_t pcols, double* __restrict__ out, int subtract) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= pcols) return;
   double s = 0.0;
   for (int64_t c = 0; c < nchunk; ++c) s += partial[c * pcols + j];
-  out[j] = s;
+  out[j] = subtract ? out[j] - s : s;
 }
 
 __global__ __launch_bounds__(256) void sum_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ out) {
@@ -87,13 +88,14 @@ int64_t colreduce_partial_elems(int64_t rows, int64_t pcols) {
 }
 
 int launch_colreduce(gpx_ctx* ctx, const double* B, int64_t ld, int64_t rows, int64_t pcols, const double* v,
-                     double* out, double* d_partial) {
+                     double* out, double* d_partial, int subtract) {
   int64_t chunk, nchunk;
   plan(rows, pcols, &chunk, &nchunk);
   ProfScope ps(ctx, GPX_PROF_REDUCE, 2.0 * (double)rows * pcols, 8.0 * (double)rows * pcols);
   dim3 grid((unsigned)((pcols + 255) / 256), (unsigned)nchunk);
   hipLaunchKernelGGL(colreduce_kernel, grid, dim3(256), 0, ctx->stream, B, ld, rows, chunk, v, d_partial, pcols);
-  hipLaunchKernelGGL(colreduce_final_kernel, dim3(grid.x), dim3(256), 0, ctx->stream, d_partial, nchunk, pcols, out);
+  hipLaunchKernelGGL(colreduce_final_kernel, dim3(grid.x), dim3(256), 0, ctx->stream, d_partial, nchunk, pcols, out,
+                     subtract);
   GPX_HIP(hipGetLastError());
   return 0;
 }

@@ -1,6 +1,7 @@
 """Thin Python objects over the C ABI: Context (one per process/GPU), DeviceMatrix, and the
 function wrappers the GPEXP-API classes call.  All arithmetic happens in libgpx_hip.so."""
 import ctypes as C
+import atexit
 import os
 
 import numpy as np
@@ -76,11 +77,23 @@ class Context:
         return out
 
 
+def _shutdown():
+    # destroy the context (streams, pool) while the HIP runtime and any profiler tool library are still loaded: leaving it
+    # to interpreter teardown crashes at exit under rocprofv3; matrices that outlive it see ctx.h == None and do nothing
+    global _ctx
+    if _ctx is not None and _ctx.h:
+        try:
+            _ctx.close()
+        except Exception:
+            pass
+
+
 def context():
     """Process-wide context, created on first use (fails loudly without a GPU)."""
     global _ctx
     if _ctx is None:
         _ctx = Context()
+        atexit.register(_shutdown)
     return _ctx
 
 
@@ -255,9 +268,9 @@ class FitcModel:
 
     def __del__(self):
         try:
-            if self.h:
+            if self.h and self.ctx.h:
                 self.ctx.lib.gpx_fitc_free(self.ctx.h, self.h)
-                self.h = None
+            self.h = None
         except Exception:
             pass
 
