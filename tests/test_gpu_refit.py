@@ -25,7 +25,8 @@ def ctx(dev):
 
 
 @pytest.mark.parametrize("n_old,n_new,keep", [(300, 300, 128), (300, 300, 256), (700, 700, 512), (500, 650, 384),
-                                              (650, 500, 384), (1025, 1025, 1024), (400, 400, 0)])
+                                              (650, 500, 384), (1025, 1025, 1024), (400, 400, 0),
+                                              (512, 512, 512), (600, 512, 512)])
 @pytest.mark.parametrize("kind", ["se", "matern52"])
 def test_refit_rows_equals_full_factorisation(dev, ctx, n_old, n_new, keep, kind):
     rng = np.random.default_rng(n_old + 7 * n_new + keep)
