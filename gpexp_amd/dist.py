@@ -373,11 +373,13 @@ class DistFitIvar:
     def __init__(self, ctx, comm, spec, Xh, yh, Zh, noise, nb=512, ops=None, streamed=None):
         self.ctx, self.comm, self.spec = ctx, comm, spec
         self.ops = ops or DeviceOps(ctx)
-        # Streamed evaluation (default with more than one rank; GPX_DIST_STREAM_IVAR=0/1 overrides): the rank's slice of
-        # the IVAR solve advances by one right-looking step per arrived panel on the background stream, underneath the
-        # broadcast-bound panel chain, instead of starting after the factorisation.
+        # Streamed evaluation (default from 4 ranks; GPX_DIST_STREAM_IVAR=0/1 overrides): the rank's slice of the IVAR
+        # solve advances by one right-looking step per arrived panel on the background stream, underneath the
+        # broadcast-bound panel chain, instead of starting after the factorisation.  It pays where the panel chain leaves
+        # the GPU idle: with 2 ranks each GPU still carries half of the trailing update and half of the solve (GPU-bound),
+        # and the streamed form's K=512 updates on 224 CUs would cost more than the idle time they fill.
         env = os.environ.get("GPX_DIST_STREAM_IVAR")
-        self.streamed = (comm.world > 1) if streamed is None else bool(streamed)
+        self.streamed = (comm.world >= 4) if streamed is None else bool(streamed)
         if env is not None:
             self.streamed = env == "1"
         self.n, self.noise, self.nb = Xh.shape[0], float(noise), int(nb)
