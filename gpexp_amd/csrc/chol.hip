@@ -73,7 +73,7 @@ __device__ __forceinline__ void leaf_inverse_column(const double* S, const doubl
 // lane N of the caller's 16-lane row, broadcast to the row (64-bit DPP supports exactly this: row_newbcast)
 template <int N>
 __device__ __forceinline__ double row_bcast(double v) {
-  return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + N, 0xf, 0xf, false);
+  return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + N, 0xf, 0xf, true);  // bound_ctrl: no 'old' value to materialise
 }
 __device__ __forceinline__ double row_bcast_n(double v, int n) {  // n is a constant after unrolling
   switch (n) {
@@ -103,19 +103,20 @@ __device__ __forceinline__ double row_bcast_n(double v, int n) {  // n is a cons
 // v_rsq_f64 + two coupled Goldschmidt steps + a residual correction: 8 dependent fp64 ops instead of sqrt + division.
 __device__ __forceinline__ void leaf_diag(double* __restrict__ S, double* __restrict__ Tp, int c0, int q, int lane,
                                           int64_t base_index, int64_t n_valid, int* __restrict__ info) {
-  double a[LB], sacc[LB], x[LB];
+  double a[LB], sacc[LB];
 #pragma unroll
   for (int c = 0; c < LB; ++c) {
     a[c] = (c <= q) ? S[(c0 + q) * LS + c0 + c] : 0.0;
     sacc[c] = (c == q) ? 1.0 : 0.0;
   }
+  int first_bad = LB;  // first column with a non-positive (or NaN) pivot; wave-uniform
+  double* const srow = S + (c0 + q) * LS + c0;
 #pragma unroll
   for (int j = 0; j < LB; ++j) {
     double piv = row_bcast_n(a[j], j);
-    if (!(piv > 0.0)) {  // non-positive or NaN pivot: record the first one, continue with 1.0
-      if (lane == 0 && base_index + c0 + j < n_valid) atomicCAS(info, 0, (int)(base_index + c0 + j + 1));
-      piv = 1.0;
-    }
+    const bool ok = piv > 0.0;  // branch-free on the pivot chain: a bad pivot is replaced by 1.0 and reported after the loop
+    first_bad = (!ok && first_bad == LB) ? j : first_bad;
+    piv = ok ? piv : 1.0;
     const double y = __builtin_amdgcn_rsq(piv);
     double g = piv * y, h = 0.5 * y;
     double r = fma(-g, h, 0.5);
@@ -126,22 +127,23 @@ __device__ __forceinline__ void leaf_diag(double* __restrict__ S, double* __rest
     h = fma(h, r, h);
     g = fma(fma(-g, g, piv), h, g);  // sqrt(piv)
     const double rs = h + h;         // 1/sqrt(piv)
-    a[j] = (q == j) ? g : a[j] * rs;
-    x[j] = sacc[j] * rs;
-    const double naj = -a[j], nxj = -x[j];
+    const double aj = (q == j) ? g : a[j] * rs;
+    const double xj = sacc[j] * rs;
+    const double naj = -aj, nxj = -xj;
 #pragma unroll
     for (int c = j + 1; c < LB; ++c) {
-      const double l = row_bcast_n(a[j], c);  // L[c][j]
+      const double l = row_bcast_n(aj, c);  // L[c][j]
       a[c] = fma(l, naj, a[c]);
       sacc[c] = fma(l, nxj, sacc[c]);
     }
+    // column j of the factor and row j of the inverse are final: to LDS now, their registers are free
+    if (lane < LB) {
+      srow[j] = (j <= q) ? aj : 0.0;
+      Tp[j * TS17 + q] = xj;
+    }
   }
-  if (lane < LB) {
-#pragma unroll
-    for (int c = 0; c < LB; ++c) S[(c0 + q) * LS + c0 + c] = (c <= q) ? a[c] : 0.0;
-#pragma unroll
-    for (int r = 0; r < LB; ++r) Tp[r * TS17 + q] = x[r];
-  }
+  if (first_bad < LB && lane == 0 && base_index + c0 + first_bad < n_valid)
+    atomicCAS(info, 0, (int)(base_index + c0 + first_bad + 1));
 }
 
 // The 28 blocks (I,K), 1 <= K <= I <= 7, of the trailing matrix live in REGISTERS (MFMA accumulator layout) from the
