@@ -147,8 +147,7 @@ __device__ __forceinline__ void leaf_diag(double* __restrict__ S, double* __rest
 }
 
 // The 28 blocks (I,K), 1 <= K <= I <= 7, of the trailing matrix live in REGISTERS (MFMA accumulator layout) from the
-// first step to the step that makes their block column current: wave W owns blocks 4s+W of the column-major
-// enumeration, s = 0..6, so the block column of a wave's slots never decreases with s.
+// first step to the step that makes their block column current (column-major enumeration below).
 struct LeafBlk { int I, K; };
 __device__ constexpr int kLeafI[28] = {1, 2, 3, 4, 5, 6, 7, 2, 3, 4, 5, 6, 7, 3, 4, 5, 6, 7, 4, 5, 6, 7, 5, 6, 7, 6, 7, 7};
 __device__ constexpr int kLeafK[28] = {1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 6, 6, 7};
@@ -156,14 +155,24 @@ __device__ __forceinline__ constexpr LeafBlk leaf_blk(int b) {  // b-th block, c
   return LeafBlk{kLeafI[b], kLeafK[b]};
 }
 
-// C(slot) -= B_I B_K^T for slots S0..6 of wave W, from the scaled block column at c0; the MFMAs of different slots interleave
-template <int W, int S0>
-__device__ __forceinline__ void leaf_update(const double* __restrict__ S, d4 (&blk)[7], int c0, int g, int q) {
+// Ownership with look-ahead: wave 0 only factors diagonal blocks; waves 1..3 own the 28 blocks, block 3s + (W-1) of the
+// column-major enumeration in slot s (10 / 9 / 9 slots), so a wave's block column never decreases with s.
+constexpr int leaf_nslots(int W) { return (28 - (W - 1) + 2) / 3; }
+constexpr int leaf_first_slot(int W, int kmin) {  // first slot of wave W whose block column is >= kmin
+  int s = 0;
+  while (s < leaf_nslots(W) && kLeafK[3 * s + (W - 1)] < kmin) ++s;
+  return s;
+}
+
+// C(slot) -= B_I B_K^T for slots [S0, S1) of wave W, from the scaled block column at c0; the MFMAs of different slots
+// interleave (independent accumulators)
+template <int W, int S0, int S1, int NS>
+__device__ __forceinline__ void leaf_update(const double* __restrict__ S, d4 (&blk)[NS], int c0, int g, int q) {
 #pragma unroll
   for (int s4 = 0; s4 < 4; ++s4) {
 #pragma unroll
-    for (int s = S0; s < 7; ++s) {
-      const LeafBlk bk = leaf_blk(4 * s + W);
+    for (int s = S0; s < S1; ++s) {
+      const LeafBlk bk = leaf_blk(3 * s + (W - 1));
       const double a = -S[(LB * bk.I + q) * LS + c0 + 4 * s4 + g];
       const double b = S[(LB * bk.K + q) * LS + c0 + 4 * s4 + g];
       blk[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, blk[s], 0, 0, 0);
@@ -171,59 +180,84 @@ __device__ __forceinline__ void leaf_update(const double* __restrict__ S, d4 (&b
   }
 }
 
+// step P's update split in two: PRIORITY = the blocks of column P+1 (they gate the next diagonal factor) and DEFERRED =
+// everything to the right of it, which waves 1..3 run underneath wave 0's factorisation of diagonal block P+1
+template <int W, int P, int NS>
+__device__ __forceinline__ void leaf_update_priority(double* __restrict__ S, d4 (&blk)[NS], int g, int q) {
+  constexpr int S0 = leaf_first_slot(W, P + 1), S1 = leaf_first_slot(W, P + 2);
+  leaf_update<W, S0, S1, NS>(S, blk, LB * P, g, q);
+#pragma unroll
+  for (int s = S0; s < S1; ++s) {  // column P+1 becomes current: back to LDS for the diagonal factor and the scaling
+    const LeafBlk bk = leaf_blk(3 * s + (W - 1));
+#pragma unroll
+    for (int v = 0; v < 4; ++v) S[(LB * bk.I + g + 4 * v) * LS + LB * bk.K + q] = blk[s][v];
+  }
+}
+template <int W, int P, int NS>
+__device__ __forceinline__ void leaf_update_deferred(const double* __restrict__ S, d4 (&blk)[NS], int g, int q) {
+  leaf_update<W, leaf_first_slot(W, P + 2), NS, NS>(S, blk, LB * P, g, q);
+}
+
+// (2) of a step: the blocks below the diagonal of column p are multiplied by T[p]^T (all four waves)
+__device__ __forceinline__ void leaf_scale(double* __restrict__ S, const double* __restrict__ Tp, int p, int wave, int g,
+                                           int q) {
+  const int c0 = LB * p;
+  for (int I = p + 1 + wave; I < 8; I += 4) {
+    double af[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) af[s4] = S[(LB * I + q) * LS + c0 + 4 * s4 + g];
+    d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s4], Tp[q * TS17 + 4 * s4 + g], acc, 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) S[(LB * I + g + 4 * v) * LS + c0 + q] = acc[v];
+  }
+}
+
+// Per step p, every wave passes the same three barriers:
+//   [A] column p is in LDS        wave 0: factor + invert diagonal block p      waves 1..3: DEFERRED part of update p-1
+//   [B] T[p] ready                all: scale the blocks below the diagonal
+//   [C] column p scaled           waves 1..3: PRIORITY part of update p (column p+1 -> LDS)
 template <int W>
 __device__ __forceinline__ void leaf_factor(double* __restrict__ S, double (*T)[LB * TS17], int g, int q, int lane,
                                             int64_t base_index, int64_t n_valid, int* __restrict__ info) {
-  d4 blk[7];
+  constexpr int NS = leaf_nslots(W);
+  d4 blk[NS];
 #pragma unroll
-  for (int s = 0; s < 7; ++s) {
-    const LeafBlk bk = leaf_blk(4 * s + W);
+  for (int s = 0; s < NS; ++s) {
+    const LeafBlk bk = leaf_blk(3 * s + (W - 1));
 #pragma unroll
     for (int v = 0; v < 4; ++v) blk[s][v] = S[(LB * bk.I + g + 4 * v) * LS + LB * bk.K + q];
   }
+#define GPX_LEAF_STEP(P_)                                                     \
+  do {                                                                        \
+    if (P_ > 0) leaf_update_deferred<W, (P_ > 0 ? P_ - 1 : 0), NS>(S, blk, g, q); \
+    __syncthreads(); /* [B] */                                                \
+    leaf_scale(S, T[P_], P_, W, g, q);                                        \
+    __syncthreads(); /* [C] */                                                \
+    if (P_ < 7) leaf_update_priority<W, (P_ < 7 ? P_ : 6), NS>(S, blk, g, q);  \
+    __syncthreads(); /* [A] of the next step */                               \
+  } while (0)
+  GPX_LEAF_STEP(0);
+  GPX_LEAF_STEP(1);
+  GPX_LEAF_STEP(2);
+  GPX_LEAF_STEP(3);
+  GPX_LEAF_STEP(4);
+  GPX_LEAF_STEP(5);
+  GPX_LEAF_STEP(6);
+  GPX_LEAF_STEP(7);
+#undef GPX_LEAF_STEP
+}
+
+// wave 0: the diagonal blocks
+__device__ __forceinline__ void leaf_panel_wave(double* __restrict__ S, double (*T)[LB * TS17], int g, int q, int lane,
+                                                int64_t base_index, int64_t n_valid, int* __restrict__ info) {
   for (int p = 0; p < 8; ++p) {
-    const int c0 = LB * p;
-    if (W == 0) leaf_diag(S, T[p], c0, q, lane, base_index, n_valid, info);
-    __syncthreads();
-    // (2) blocks below the diagonal: B <- B * T^T
-    for (int I = p + 1 + W; I < 8; I += 4) {
-      double af[4];
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) af[s4] = S[(LB * I + q) * LS + c0 + 4 * s4 + g];
-      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s4], T[p][q * TS17 + 4 * s4 + g], acc, 0, 0, 0);
-#pragma unroll
-      for (int v = 0; v < 4; ++v) S[(LB * I + g + 4 * v) * LS + c0 + q] = acc[v];
-    }
-    __syncthreads();
-    if (p == 7) break;
-    // (3) trailing blocks in registers.  Slots whose column is <= p are finished (already back in LDS): skipped.
-    int s0 = 0;
-#pragma unroll
-    for (int s = 0; s < 7; ++s)
-      if (leaf_blk(4 * s + W).K <= p) s0 = s + 1;
-    switch (s0) {
-      case 0: leaf_update<W, 0>(S, blk, c0, g, q); break;
-      case 1: leaf_update<W, 1>(S, blk, c0, g, q); break;
-      case 2: leaf_update<W, 2>(S, blk, c0, g, q); break;
-      case 3: leaf_update<W, 3>(S, blk, c0, g, q); break;
-      case 4: leaf_update<W, 4>(S, blk, c0, g, q); break;
-      case 5: leaf_update<W, 5>(S, blk, c0, g, q); break;
-      case 6: leaf_update<W, 6>(S, blk, c0, g, q); break;
-      default: break;
-    }
-    // the next block column becomes current: its blocks go back to LDS for the diagonal factor and the scaling
-#pragma unroll
-    for (int s = 0; s < 7; ++s) {
-      const LeafBlk bk = leaf_blk(4 * s + W);
-      if (bk.K == p + 1) {
-#pragma unroll
-        for (int v = 0; v < 4; ++v) S[(LB * bk.I + g + 4 * v) * LS + LB * bk.K + q] = blk[s][v];
-      }
-    }
-    __syncthreads();
+    leaf_diag(S, T[p], LB * p, q, lane, base_index, n_valid, info);
+    __syncthreads();  // [B]
+    leaf_scale(S, T[p], p, 0, g, q);
+    __syncthreads();  // [C]
+    __syncthreads();  // [A] of the next step
   }
 }
 
@@ -255,7 +289,7 @@ __global__ __launch_bounds__(256) void leaf_kernel(double* __restrict__ A, int64
   }
   __syncthreads();
   switch (wave) {
-    case 0: leaf_factor<0>(S, T, g, q, lane, base_index, n_valid, info); break;
+    case 0: leaf_panel_wave(S, T, g, q, lane, base_index, n_valid, info); break;
     case 1: leaf_factor<1>(S, T, g, q, lane, base_index, n_valid, info); break;
     case 2: leaf_factor<2>(S, T, g, q, lane, base_index, n_valid, info); break;
     default: leaf_factor<3>(S, T, g, q, lane, base_index, n_valid, info); break;
