@@ -729,8 +729,36 @@ int chol_trsm_left(gpx_ctx* ctx, const double* L, int64_t ldl, const double* inv
   return chol_trsm_left(ctx, L + n1 * ldl + n1, ldl, invd + (n1 / NB) * NB * NB, B + n1 * ldb, ldb, n2, m);
 }
 
+// Right-looking factorisation with 128-wide panels: leaf, one multiply of everything below it by the leaf's inverse, one
+// rank-128 lower update of the whole trailing block -- three launches per 128 columns.  Its updates have K = 128 (the C
+// read-modify-write dominates), so it only pays where the recursion below would spend its time in launches anyway.
+static int potrf_right_looking(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double* invd, int64_t base,
+                               int64_t n_valid) {
+  for (int64_t j = 0; j < n; j += NB) {
+    double* inv_j = invd + (j / NB) * NB * NB;
+    GPX_TRY(launch_leaf(ctx, A + j * ld + j, ld, inv_j, base + j, n_valid));
+    const int64_t m = n - j - NB;
+    if (m > 0) {
+      double* X = A + (j + NB) * ld + j;
+      GPX_TRY(launch_leaf_mul_right(ctx, X, ld, inv_j, m));
+      GPX_TRY(launch_gemm(ctx, X, ld, X, ld, X + NB, ld, m, m, NB, true, true, true));
+    }
+  }
+  return 0;
+}
+
+static int64_t potrf_rl_max() {
+  static int64_t v = -1;
+  if (v < 0) {
+    const char* e = getenv("GPX_POTRF_RL");  // diagonal blocks up to this order are factored right-looking
+    v = e ? atoll(e) : 4096;
+  }
+  return v;
+}
+
 static int potrf_rec(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double* invd, int64_t base, int64_t n_valid) {
   if (n == NB) return launch_leaf(ctx, A, ld, invd, base, n_valid);
+  if (n <= potrf_rl_max()) return potrf_right_looking(ctx, A, ld, n, invd, base, n_valid);
   const int64_t n1 = split(n), n2 = n - n1;
   GPX_TRY(potrf_rec(ctx, A, ld, n1, invd, base, n_valid));
   double* A21 = A + n1 * ld;
