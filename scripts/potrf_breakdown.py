@@ -28,9 +28,20 @@ def trsm_right(m, n):
     trsm_right(m, n2)
 
 
+RL_MAX = 4096  # diagonal blocks up to this order are factored right-looking (chol.hip: potrf_right_looking)
+
+
 def potrf(n):
     if n == NB:
         calls.append(("leaf", NB, NB, NB, 2.0 * NB ** 3 / 3))
+        return
+    if n <= RL_MAX:
+        for j in range(0, n, NB):
+            calls.append(("leaf", NB, NB, NB, 2.0 * NB ** 3 / 3))
+            m = n - j - NB
+            if m > 0:
+                gemm(m, NB, NB, tag="trsm-leaf")
+                gemm(m, m, NB, lower=True, tag="syrk-rl")
         return
     n1 = split(n); n2 = n - n1
     potrf(n1)
