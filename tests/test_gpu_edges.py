@@ -128,3 +128,36 @@ def test_single_candidate_and_single_selection(dev, ctx):
     assert list(dev.greedy_var(ctx, sp, C, 1)) == [0]
     idx, ratios = dev.mi_greedy(ctx, sp, dev.points(ctx, np.array([[0.1], [0.5], [-0.7]])), 0.1, 1, 2)
     assert list(idx) == [2] and ratios.size == 0
+
+
+def test_wide_and_narrow_leaf_multiply_strips_agree(dev, ctx, monkeypatch):
+    """The in-place leaf multiplies use 64-wide strips beyond 8192 rows/columns and 32-wide ones below: the same evaluation
+    in one 9000-point chunk (wide strips) and in 2048-point chunks (narrow strips) must agree bit for bit, and the factor
+    of a 8448-row panel (wide right-multiply strips) must still solve K alpha = y."""
+    rng = np.random.default_rng(77)
+    n, d, m = 700, 3, 9000
+    Xh, Zh = rng.uniform(-1, 1, (n, d)), rng.uniform(-1, 1, (m, d))
+    sp = dev.KernelSpec(dev.K_SE, d, [0.5, 0.6, 0.7, 1.2])
+    X, Z = dev.points(ctx, Xh), dev.points(ctx, Zh)
+    L = dev.potrf(ctx, dev.kfill(ctx, sp, X, nugget=0.05))
+    y = rng.standard_normal(n)
+    alpha = dev.potrs(ctx, L, y)
+    m1, v1 = dev.posterior(ctx, sp, L, X, alpha, Z)
+    monkeypatch.setenv("GPX_CROSS_BYTES", str(768 * 8 * 2048))   # padded N = 768 -> chunks of 2048 evaluation points
+    m2, v2 = dev.posterior(ctx, sp, L, X, alpha, Z)
+    assert np.array_equal(m1, m2) and np.array_equal(v1, v2)
+    monkeypatch.delenv("GPX_CROSS_BYTES")
+    s = dict(kind="se", cl=[0.5, 0.6, 0.7], signalSize=1.2, d=d)
+    mo, vo = orc.posterior(s, orc.fit(s, Xh, y, 0.05), Zh[:200])
+    assert rel(m1[:200], mo) <= 1e-10 and rel(v1[:200], vo) <= 1e-10
+    # tall panel: N = 16896 rows (> 32 * 256) under a 128-wide leaf exercises the 64-row right strips
+    N2 = 16896
+    X2h = rng.uniform(-1, 1, (N2, d))
+    y2 = rng.standard_normal(N2)
+    K2 = dev.kfill(ctx, sp, dev.points(ctx, X2h), nugget=0.1)
+    rows = rng.choice(N2, 4, replace=False)
+    Krows = np.stack([dev.kernel_eval(ctx, sp, X2h, X2h[r:r + 1]) for r in rows])
+    Krows[np.arange(4), rows] += 0.1
+    dev.potrf(ctx, K2)
+    a2 = dev.potrs(ctx, K2, y2)
+    assert np.max(np.abs(Krows @ a2 - y2[rows])) <= 1e-9 * np.max(np.abs(y2))
