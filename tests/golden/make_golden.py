@@ -395,10 +395,29 @@ def c2_case():
     put(case, "cond_proxy", np.linalg.cond(g.covarianceMatrix))
 
 
+def hetero_ivar_case():
+    """costFunctionGP_IVAR.evaluate with a heteroscedastic space.noiseFunc (experimentalDesign.py:107-117): the design
+    points' own noise enters K as a per-point nugget."""
+    case = "ivar_noisefunc"
+    rng = np.random.default_rng(909)
+    d, n, nmc = 2, 23, 150
+    X = rng.uniform(-1, 1, (n, d))
+    mc = rng.uniform(-1, 1, (nmc, d))
+    spec = dict(kind="se", cl=[0.45, 0.7], signalSize=1.4, d=2)
+    nf = lambda p: 0.01 + 0.05 * (p[:, 0] ** 2 + 0.5 * p[:, 1] ** 2)   # noqa: E731
+    space = Space(d, lambda size: np.random.rand(size[0], size[1]) * 2 - 1, lambda p: 0.25 * np.ones(len(p)), noise=nf)
+    cf = ED.costFunctionGP_IVAR(GP(make_kernel(spec), 1e-3), n, space, mcPoints=mc)
+    index[case] = dict(type="ivar_noisefunc", kernel=spec, noise=1e-3, noisefunc="0.01 + 0.05*(x0^2 + 0.5*x1^2)")
+    put(case, "X", X); put(case, "mc", mc)
+    put(case, "pointnoise", nf(X))
+    put(case, "ivar", cf.evaluate(X))
+
+
 demo_flow()
 varderiv_case()
 fitc_case()
 c2_case()
+hetero_ivar_case()
 np.savez_compressed(os.path.join(OUT, "gpexp_golden.npz"), **arrays)
 with open(os.path.join(OUT, "gpexp_golden.json"), "w") as f:
     json.dump(index, f, indent=1, sort_keys=True)

@@ -395,3 +395,19 @@ def test_hyperparameter_fit_with_analytic_gradient_f3():
     assert va <= vn + 1e-6 * abs(vn)           # values are NEGATIVE log-likelihoods
     assert 0.3 < pa["cl0"] < 1.2 and 0.4 < pa["cl1"] < 2.0 and 1e-3 < pa["noise"] < 5e-2
     assert ga.noise == pytest.approx(pa["noise"])
+
+
+def test_ivar_cost_with_heteroscedastic_noise_function(golden):
+    """a13 with space.noiseFunc (experimentalDesign.py:107-117): per-point nugget from the design's own noise."""
+    from gpExp.kernels import KernelSquaredExponential
+    from gpExp.gp import GP
+    from gpExp.approximation import Space
+    from gpExp.experimentalDesign import costFunctionGP_IVAR
+    c = "ivar_noisefunc"
+    ix = golden.index[c]
+    X, mc = golden(c, "X"), golden(c, "mc")
+    nf = lambda p: 0.01 + 0.05 * (p[:, 0] ** 2 + 0.5 * p[:, 1] ** 2)   # noqa: E731
+    space = Space(2, lambda size: np.random.rand(size[0], size[1]) * 2 - 1, lambda p: 0.25 * np.ones(len(p)), noise=nf)
+    k = KernelSquaredExponential(list(ix["kernel"]["cl"]), ix["kernel"]["signalSize"], 2)
+    cf = costFunctionGP_IVAR(GP(k, ix["noise"]), len(X), space, mcPoints=mc)
+    assert cf.evaluate(X) == pytest.approx(float(golden(c, "ivar")), rel=1e-10)

@@ -193,3 +193,13 @@ def test_c2_full_size_against_reference(golden):
     mean, var = orc.posterior(s, m, Z[:256], compvar=1)
     assert rel(mean, golden(c, "mean256")) <= 1e-9 and rel(np.abs(var), golden(c, "var256")) <= 1e-9
     assert orc.loglike(s, X, y, ix["noise"]) == pytest.approx(float(golden(c, "loglike")), rel=1e-10)
+
+
+def test_ivar_with_heteroscedastic_noise_function(golden):
+    """experimentalDesign.py:111-115: space.noiseFunc(design) is the per-point nugget of the design's covariance."""
+    c = "ivar_noisefunc"
+    s = golden.index[c]["kernel"]
+    X, mc = golden(c, "X"), golden(c, "mc")
+    nz = 0.01 + 0.05 * (X[:, 0] ** 2 + 0.5 * X[:, 1] ** 2)
+    assert np.array_equal(nz, golden(c, "pointnoise"))
+    assert orc.ivar(s, X, mc, nz) == pytest.approx(float(golden(c, "ivar")), rel=1e-10)
