@@ -24,10 +24,16 @@ def launch(world, extra, env_extra=None, timeout=600):
     env = dict(os.environ)
     env.update({"MASTER_ADDR": "127.0.0.1", "OMP_NUM_THREADS": "2", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     env.update(env_extra or {})
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
-           os.path.join(ROOT, "tests", "dist_worker.py")] + extra
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    for attempt in range(2):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+               os.path.join(ROOT, "tests", "dist_worker.py")] + extra
+        r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+        # the port is picked, released and only then bound by the launcher: a rendezvous that lost that race (address in
+        # use / connection refused before any worker ran) is retried once on a fresh port; worker failures are not
+        if r.returncode == 0 or not any(m in r.stderr for m in ("EADDRINUSE", "Address already in use",
+                                                                  "DistNetworkError", "Connection refused")):
+            break
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "DIST_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     return r.stdout
