@@ -148,6 +148,70 @@ int gpx_make_kparams(int kind, int d, const double* hyp, int nhyp, KParams* kp) 
   return 0;
 }
 
+// ---- point-set bounding boxes, centring and the exact-path decision (see KParams) -----------------------
+static void bbox_from_host(gpx_mat* m, const double* src, int64_t rows, int64_t cols, int64_t ld) {
+  m->bbox_ok = 0;
+  if (cols < 1 || cols > GPX_MAXD || rows < 1) return;
+  for (int64_t k = 0; k < cols; ++k) m->lo[k] = m->hi[k] = src[k];
+  for (int64_t i = 1; i < rows; ++i) {
+    const double* r = src + i * ld;
+    for (int64_t k = 0; k < cols; ++k) {
+      const double v = r[k];
+      if (v < m->lo[k]) m->lo[k] = v;
+      if (v > m->hi[k]) m->hi[k] = v;
+    }
+  }
+  m->bbox_ok = 1;
+}
+
+static int mat_bbox(gpx_ctx* ctx, const gpx_mat* cm) {
+  gpx_mat* m = const_cast<gpx_mat*>(cm);  // a cache: the matrix itself is not modified
+  if (m->bbox_ok || m->rows < 1) return 0;
+  GPX_ARG(m->cols >= 1 && m->cols <= GPX_MAXD, "point set has more than GPX_MAX_DIM columns");
+  std::vector<double> h((size_t)(m->rows * m->cols));
+  GPX_HIP(hipMemcpy2DAsync(h.data(), (size_t)m->cols * 8, m->p, (size_t)m->ld * 8, (size_t)m->cols * 8, (size_t)m->rows,
+                           hipMemcpyDeviceToHost, ctx->stream));
+  GPX_HIP(hipStreamSynchronize(ctx->stream));
+  bbox_from_host(m, h.data(), m->rows, m->cols, m->cols);
+  return 0;
+}
+
+// S * sensitivity above which the expanded-form distance would cost more than ~2e-14 of relative kernel error
+// (measured: 7.6e-15 at S*sens = 75); sensitivity = max |dk/ds| / sig: 1/2 for SE and Matern-3/2, 1/6 for Matern-5/2
+static double exact_threshold() {
+  const char* e = getenv("GPX_EXACT_S");  // read per call: the tests force either path on the same data
+  return e ? atof(e) : 120.0;
+}
+
+int gpx_kparams_sets(gpx_ctx* ctx, KParams* kp, const gpx_mat* A, const gpx_mat* B, const gpx_mat* C) {
+  for (int k = 0; k < GPX_MAXD; ++k) kp->center[k] = 0.0;
+  kp->exact = 0;
+  if (kp->kind == GPX_K_MEHLER) return 0;
+  const gpx_mat* sets[3] = {A, B, C};
+  double lo[GPX_MAXD], hi[GPX_MAXD];
+  bool any = false;
+  for (const gpx_mat* s : sets) {
+    if (!s || s->rows < 1) continue;
+    GPX_TRY(mat_bbox(ctx, s));
+    for (int k = 0; k < kp->d; ++k) {
+      if (!any || s->lo[k] < lo[k]) lo[k] = s->lo[k];
+      if (!any || s->hi[k] > hi[k]) hi[k] = s->hi[k];
+    }
+    any = true;
+  }
+  if (!any) return 0;
+  double S = 0.0;
+  for (int k = 0; k < kp->d; ++k) {
+    const double c = 0.5 * lo[k] + 0.5 * hi[k];
+    kp->center[k] = (c == c && fabs(c) < 1e300) ? c : 0.0;  // non-finite inputs: leave them to the kernel
+    const double hw = (hi[k] - kp->center[k]) * kp->scale[k];
+    S += 2.0 * hw * hw;  // both operands of a pair may sit at the edge of the box
+  }
+  const double sens = kp->kind == GPX_K_MATERN52 ? 1.0 / 6.0 : 0.5;
+  kp->exact = !(S * sens <= exact_threshold());  // NaN -> exact
+  return 0;
+}
+
 // ---- matrices ----------------------------------------------------------------------------------------
 int gpx_mat_new(gpx_ctx* ctx, int64_t rows, int64_t cols, int pad, gpx_mat** out) {
   GPX_ARG(rows >= 0 && cols >= 0, "negative shape");
@@ -161,6 +225,7 @@ int gpx_mat_new(gpx_ctx* ctx, int64_t rows, int64_t cols, int pad, gpx_mat** out
   m->aux = nullptr;
   m->aux_bytes = 0;
   m->factored = 0;
+  m->bbox_ok = 0;
   void* p = nullptr;
   int r = gpx_dev_alloc(ctx, m->bytes, &p);
   if (r != 0) {
@@ -325,6 +390,7 @@ int gpx_mat_from_host(gpx_ctx* ctx, const double* src, int64_t rows, int64_t col
   if (rows > 0 && cols > 0)
     GPX_HIP(hipMemcpy2DAsync(m->p, (size_t)m->ld * 8, src, (size_t)cols * 8, (size_t)cols * 8, (size_t)rows,
                              hipMemcpyHostToDevice, ctx->stream));
+  if (!pad) bbox_from_host(m, src, rows, cols, cols);  // point sets are uploaded unpadded
   GPX_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
 }
@@ -378,6 +444,7 @@ int gpx_mat_read(gpx_ctx* ctx, const gpx_mat* m, int64_t offset, int64_t count, 
 int gpx_mat_write(gpx_ctx* ctx, gpx_mat* m, int64_t offset, int64_t count, const double* src) {
   GPX_ARG(ctx && m && src && offset >= 0 && count >= 0 && (offset + count) * 8 <= m->bytes, "bad raw write");
   if (count == 0) return 0;
+  m->bbox_ok = 0;
   GPX_HIP(hipMemcpyAsync(m->p + offset, src, (size_t)count * 8, hipMemcpyHostToDevice, ctx->stream));
   GPX_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
@@ -398,6 +465,7 @@ int gpx_kfill_into(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, c
   GPX_ARG(nugget_len == 0 || nugget_len == 1 || nugget_len == X->rows, "nugget_len must be 0, 1 or N");
   GPX_ARG(symmetric || nugget_len == 0, "nugget only applies to the symmetric form");
   GPX_ARG(nugget_len == 0 || nugget != nullptr, "nugget is NULL");
+  GPX_TRY(gpx_kparams_sets(ctx, &kp, X, Bp));
   double* d_nug = nullptr;
   int64_t nug_bytes = 0;
   double nscal = 0.0;
@@ -490,6 +558,7 @@ int gpx_refit_rows(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, c
     GPX_TRY(need_factor(Lold));
     GPX_ARG(keep <= Lold->rows && keep <= n, "keep exceeds the old factor or the new point set");
   }
+  GPX_TRY(gpx_kparams_sets(ctx, &kp, X));
   gpx_mat* K = nullptr;
   GPX_TRY(gpx_mat_new(ctx, n, n, 1, &K));
   const int64_t np = K->prows;
@@ -693,6 +762,7 @@ int gpx_posterior(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, co
   KParams kp;
   GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
   GPX_ARG(X->cols == d && X->pcols == d && Z->cols == d && Z->pcols == d, "point sets must be unpadded (n x d)");
+  GPX_TRY(gpx_kparams_sets(ctx, &kp, X, Z));
   return posterior_impl(ctx, kp, L, X, alpha, Z, mean, var);
 }
 
@@ -704,6 +774,7 @@ int gpx_ivar(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const g
   GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
   GPX_ARG(X->cols == d && X->pcols == d && Z->cols == d && Z->pcols == d, "point sets must be unpadded (n x d)");
   GPX_ARG(Z->rows > 0, "IVAR needs at least one integration point");
+  GPX_TRY(gpx_kparams_sets(ctx, &kp, X, Z));
   std::vector<double> var((size_t)Z->rows);
   GPX_TRY(posterior_impl(ctx, kp, L, X, nullptr, Z, nullptr, var.data()));
   // fixed-order pairwise sum (deterministic, independent of chunking)
@@ -788,6 +859,17 @@ int gpx_profile_get(gpx_ctx* ctx, int cls, int64_t* launches, double* ms, double
 }
 
 // ---- test hooks ------------------------------------------------------------------------------------------
+int gpx_dbg_kfill_plan(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* X, const gpx_mat* Z,
+                       int* exact, double* center) {
+  GPX_ARG(ctx && X && exact && center, "NULL argument");
+  KParams kp;
+  GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
+  GPX_TRY(gpx_kparams_sets(ctx, &kp, X, Z));
+  *exact = kp.exact;
+  for (int k = 0; k < d; ++k) center[k] = kp.center[k];
+  return 0;
+}
+
 int gpx_dbg_gemm(gpx_ctx* ctx, const gpx_mat* A, const gpx_mat* B, gpx_mat* C, int bt, int accumulate, int lower) {
   GPX_ARG(ctx && A && B && C, "NULL argument");
   const int64_t m = C->prows, n = C->pcols, k = A->pcols;

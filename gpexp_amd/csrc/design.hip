@@ -45,7 +45,7 @@ __device__ __forceinline__ double kpair(const KParams& kp, const double* __restr
     return kp.sig * exp(-(pa + pb - cr));
   }
   for (int k = 0; k < kp.d; ++k) {
-    const double e = a[k] * kp.scale[k] - b[k] * kp.scale[k];
+    const double e = (a[k] - b[k]) * kp.scale[k];  // difference first, as the reference (kernels.py:121-122)
     acc = fma(e, e, acc);
   }
   if (kp.kind == GPX_K_SE) return kp.sig * exp(-0.5 * acc);
@@ -231,6 +231,7 @@ int gpx_posterior_cov(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp
   const int64_t n = L->rows, np = L->prows, m = Z->rows, mp = gpx_round_up(m > 0 ? m : 1, GPX_TILE);
   GPX_ARG(X->rows == n, "X does not match the factor");
   if (m == 0) return 0;
+  GPX_TRY(gpx_kparams_sets(ctx, &kp, X, Z));
   Scratch sc(ctx);
   void *pW, *pWt, *pK;
   GPX_TRY(sc.get(np * mp * 8, &pW));
@@ -345,6 +346,7 @@ int gpx_greedy_ivar_step(gpx_ctx* ctx, int kind, int d, const double* hyp, int n
   const int64_t n = L->rows, np = L->prows, M = Cm->rows, nmc = Z->rows;
   GPX_ARG(X->rows == n, "X does not match the factor");
   GPX_ARG(M > 0 && nmc > 0, "need candidates and integration points");
+  GPX_TRY(gpx_kparams_sets(ctx, &kp, X, Z, Cm));
   const int64_t zp = gpx_round_up(nmc, GPX_TILE);
   // candidate chunk: W_C (np x mc) + G (zp x mc) under ~24 GiB
   int64_t budget = (int64_t)24 << 30;

@@ -175,6 +175,7 @@ int gpx_dist_kfill(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, c
   GPX_ARG(X->cols == d && X->pcols == d, "X must be an unpadded (N x d) point set");
   GPX_ARG(K->rows == X->rows && K->cols == X->rows && K->prows == K->pcols, "K must be the padded N x N matrix");
   GPX_ARG(nugget_len == 0 || nugget_len == 1 || nugget_len == X->rows, "nugget_len must be 0, 1 or N");
+  GPX_TRY(gpx_kparams_sets(ctx, &kp, X));
   const int64_t n = X->rows, np = K->prows;
   double* d_nug = nullptr;
   int64_t nug_bytes = 0;

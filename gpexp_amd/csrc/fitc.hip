@@ -173,6 +173,10 @@ int gpx_fitc_fit(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, con
     gpx_set_error("fitc: X and the inducing points must be non-empty unpadded (n x d) point sets");
     return -1;
   }
+  if ((r = gpx_kparams_sets(ctx, &f->kp, X, S)) != 0) {
+    delete f;
+    return r;
+  }
   const KParams& kp = f->kp;
   f->n = X->rows;
   f->nu = S->rows;
@@ -293,6 +297,8 @@ int gpx_fitc_posterior(gpx_ctx* ctx, const gpx_fitc* f, const gpx_mat* X, const 
   GPX_ARG(mean == nullptr || coeff != nullptr, "coeff is required for the mean");
   const int64_t M = Z->rows, d = f->kp.d, np = f->np, nup = f->nup;
   if (M == 0) return 0;
+  KParams kpz = f->kp;  // the evaluation points may reach beyond the training domain
+  GPX_TRY(gpx_kparams_sets(ctx, &kpz, X, Z));
   const int64_t mcmax = eval_chunk(np);
   const int64_t mc_alloc = gpx_round_up(M < mcmax ? M : mcmax, GPX_TILE);
   Tmp tmp(ctx);
@@ -313,7 +319,7 @@ int gpx_fitc_posterior(gpx_ctx* ctx, const gpx_fitc* f, const gpx_mat* X, const 
     const int64_t mc = (M - j0) < mcmax ? (M - j0) : mcmax;
     const int64_t mcp = gpx_round_up(mc, GPX_TILE);
     const double* Zc = Z->p + j0 * d;
-    GPX_TRY(launch_kfill(ctx, f->kp, Zc, mc, X->p, f->n, 0, nullptr, 0, 0.0, B, mcp, np, ldb));
+    GPX_TRY(launch_kfill(ctx, kpz, Zc, mc, X->p, f->n, 0, nullptr, 0, 0.0, B, mcp, np, ldb));
     if (mean) {
       GPX_TRY(launch_rowreduce(ctx, B, ldb, mc, np, dc, o1));
       GPX_HIP(hipMemcpyAsync(mean + j0, o1, (size_t)mc * 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -46,6 +46,17 @@ static inline int64_t gpx_skew_ld(int64_t cols) { return (cols >= 1024 && cols %
 //   Matern52 : t = |a-b|, k = sig*(1+t+t^2/3)*exp(-t)    scale   = sqrt(5)/rho     (not in reference)
 //   Mehler   : k = sig * exp(-sum_k c1_k (a^2+b^2) - c2_k a b), sig = prod (1-t^2)^-1/2,
 //              c1_k = t^2/(2(1-t^2)), c2_k = t/(1-t^2), scale = 1               (kernels.py:282-285)
+//
+// Stationary kernels are translation invariant, and the tiled assembly forms |a-b|^2 from the EXPANDED product
+// |a|^2 + |b|^2 - 2 a.b on the MFMA pipe, whose absolute error grows like eps * (|a|^2 + |b|^2) * scale^2 -- the reference
+// subtracts coordinates first (kernels.py:121-122, 87-89).  Two measures keep the assembly at the reference's accuracy
+// for any input placement (gpx_kparams_sets):
+//   center  the midpoint of the point sets' bounding box is subtracted from every coordinate before scaling, so the
+//           expanded form only ever sees offsets of the size of the domain, not of its distance from the origin;
+//   exact   when even the centred, scaled domain is wide (half-width / length scale large: S = sum_k scale_k^2 *
+//           (hwA_k^2 + hwB_k^2) above GPX_EXACT_S / sensitivity), the fill forms (a_k - b_k) * scale_k directly from the
+//           raw coordinates on the VALU instead -- the reference's own operation order, exact where Sterbenz applies.
+// Mehler is not stationary: center = 0, exact = 0 (the reference expands its exponent the same way, kernels.py:282-285).
 struct KParams {
   int kind;
   int d;
@@ -53,6 +64,8 @@ struct KParams {
   double scale[GPX_MAXD];
   double c1[GPX_MAXD];
   double c2[GPX_MAXD];
+  double center[GPX_MAXD];
+  int exact;
 };
 int gpx_make_kparams(int kind, int d, const double* hyp, int nhyp, KParams* out);
 
@@ -66,6 +79,9 @@ struct gpx_mat {
   double* aux;        // after gpx_potrf: inverses of the 128x128 diagonal blocks, (prows/128) x 128 x 128
   int64_t aux_bytes;
   int factored;
+  // bounding box of a point set (cols <= GPX_MAXD), computed on the host at upload (gpx_mat_from_host) or on first use
+  int bbox_ok;
+  double lo[GPX_MAXD], hi[GPX_MAXD];
 };
 
 struct ProfRec {
@@ -103,6 +119,8 @@ struct gpx_ctx {
   double prof_bytes[GPX_PROF_NCLASS];
 };
 
+// centre + exact-path decision for fills between the given point sets (any may be NULL); see KParams
+int gpx_kparams_sets(gpx_ctx* ctx, KParams* kp, const gpx_mat* A, const gpx_mat* B = nullptr, const gpx_mat* C = nullptr);
 int gpx_dev_alloc(gpx_ctx* ctx, int64_t bytes, void** out);
 void gpx_dev_release(gpx_ctx* ctx, void* p, int64_t bytes);
 int gpx_mat_new(gpx_ctx* ctx, int64_t rows, int64_t cols, int pad, gpx_mat** out);

@@ -113,6 +113,7 @@ int gpx_ivar_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, co
   GPX_ARG(X->cols == d && X->pcols == d && Z->cols == d && Z->pcols == d, "point sets must be unpadded (n x d)");
   const int64_t n = L->rows, np = L->prows, m = Z->rows;
   GPX_ARG(X->rows == n && m > 0, "X does not match the factor / no integration points");
+  GPX_TRY(gpx_kparams_sets(ctx, &kp, X, Z));
   const int64_t mp = gpx_round_up(m, GPX_TILE);
   Scratch sc(ctx);
   void *pW, *pWt, *pS, *pg;

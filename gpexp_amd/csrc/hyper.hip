@@ -24,16 +24,16 @@ __global__ __launch_bounds__(256) void lmlgrad_kernel(KParams kp, const double* 
                                                       double* __restrict__ partial) {
   extern __shared__ double sm[];
   const int d = kp.d;
-  double* As = sm;               // [TS][d] scaled coords of the row points
-  double* Bs = sm + TS * d;      // [TS][d] of the column points
+  double* As = sm;               // [TS][d] raw coords of the row points (differences are taken first, then scaled:
+  double* Bs = sm + TS * d;      // [TS][d] of the column points          kernels.py:121-122)
   double* red = Bs + TS * d;     // [4] per-wave partials
   const int t = threadIdx.x;
   const int64_t i0 = (int64_t)blockIdx.y * TS, j0 = (int64_t)blockIdx.x * TS;
   for (int idx = t; idx < TS * d; idx += 256) {
     int p = idx / d, k = idx - p * d;
     int64_t gi = i0 + p, gj = j0 + p;
-    As[idx] = gi < n ? X[gi * d + k] * kp.scale[k] : 0.0;
-    Bs[idx] = gj < n ? X[gj * d + k] * kp.scale[k] : 0.0;
+    As[idx] = gi < n ? X[gi * d + k] : 0.0;
+    Bs[idx] = gj < n ? X[gj * d + k] : 0.0;
   }
   __syncthreads();
   const int tx = t & 31, ty = t >> 5;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void lmlgrad_kernel(KParams kp, const double* 
       if (gi < n && gj < n) {
         double acc = 0.0;
         for (int k = 0; k < d; ++k) {
-          const double e = As[r * d + k] - Bs[cc * d + k];
+          const double e = (As[r * d + k] - Bs[cc * d + k]) * kp.scale[k];
           acc = fma(e, e, acc);
         }
         const double tij = alpha[gi] * alpha[gj] - P[gi * ld + gj];
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void lmlgrad_kernel(KParams kp, const double* 
         const int r = ty + 8 * a;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-          const double e = As[r * d + q] - Bs[(2 * tx + c) * d + q];
+          const double e = (As[r * d + q] - Bs[(2 * tx + c) * d + q]) * kp.scale[q];
           s = fma(tk[a * 2 + c], e * e, s);
         }
       }
@@ -119,7 +119,7 @@ __device__ __forceinline__ double kpair_se_like(const KParams& kp, const double*
   }
   double acc = 0.0;
   for (int k = 0; k < kp.d; ++k) {
-    const double e = a[k] * kp.scale[k] - b[k] * kp.scale[k];
+    const double e = (a[k] - b[k]) * kp.scale[k];  // difference first, as the reference (kernels.py:121-122)
     acc = fma(e, e, acc);
   }
   if (kp.kind == GPX_K_SE) return kp.sig * exp(-0.5 * acc);

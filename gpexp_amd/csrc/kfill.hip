@@ -15,6 +15,10 @@
 //   * symmetric fill: only tiles on/below the diagonal are COMPUTED; each is also written transposed through a
 //     padded LDS image (coalesced mirror stores) -- half the exp/sqrt work for the same 8*N^2 bytes.
 //   * interior tiles (no padding, no diagonal) take a branch-free path selected by a scalar branch.
+//   * placement independence (KParams in gpx_internal.h): coordinates are centred on the bounding-box midpoint before
+//     scaling, and fills whose centred, scaled domain is still wide take the EXACT variant, which forms
+//     (a_k - b_k) * scale_k from the raw coordinates on the VALU -- the reference's own order of operations
+//     (kernels.py:121-122) -- instead of the expanded product.
 //   * exp: shifter-trick rounding + one-constant reduction to |r| <= ln2/128 + 64-entry 2^(j/64) table in LDS + degree-5
 //     polynomial + v_ldexp; sqrt: v_rsq_f64 (2^-23) + one coupled Newton step + residual correction.  Both stay within
 //     2 ulp (tests: 1e-13 against the oracle / the reference).
@@ -129,7 +133,7 @@ __device__ __forceinline__ void stage_points(const KParams& kp, int d, int dpad,
         part = fma(kp.c1[k] * x[i], x[i], part);
         x[i] = SIDE_A ? kp.c2[k] * x[i] : -x[i];
       } else {
-        const double w = x[i] * kp.scale[k];
+        const double w = (x[i] - kp.center[k]) * kp.scale[k];
         part = fma(w, w, part);
         x[i] = SIDE_A ? w : -2.0 * w;
       }
@@ -147,6 +151,37 @@ __device__ __forceinline__ void stage_points(const KParams& kp, int d, int dpad,
       if (k == d + 1) v = SIDE_A ? one : own;
       P[p * sl + k] = v;
     }
+  }
+}
+
+// EXACT variant: raw coordinates of a 64-point tile -> LDS ([point][k], odd stride), zeros beyond the set
+__device__ __forceinline__ void stage_raw(int d, int sl, const double* __restrict__ X, int64_t n, int64_t g0, double* P) {
+  for (int idx = threadIdx.x; idx < TM * d; idx += 256) {
+    const int p = idx / d, k = idx - p * d;
+    const int64_t g = g0 + p;
+    P[p * sl + k] = g < n ? X[g * d + k] : 0.0;
+  }
+}
+
+// acc[mi][ni][v] = sum_k ((a[r][k] - b[c][k]) * scale_k)^2 for the lane's rows r = rbase + 16 mi + 4 v and columns c0 + ni:
+// the coordinate difference is taken FIRST, as the reference does (kernels.py:121-122, 87), so nearby points far from the
+// origin or in a wide domain keep their full relative accuracy
+__device__ __forceinline__ void exact_dist(const KParams& kp, int d, int sl, const double* __restrict__ As,
+                                           const double* __restrict__ Bs, int rbase, int c0, d4 (&acc)[2][2]) {
+  const double* ap = As + rbase * sl;
+  const double* bp = Bs + c0 * sl;
+  for (int k = 0; k < d; ++k) {
+    const double sc = kp.scale[k];
+    const double b0 = bp[k], b1 = bp[sl + k];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const double a = ap[(mi * 16 + 4 * v) * sl + k];
+        const double e0 = (a - b0) * sc, e1 = (a - b1) * sc;
+        acc[mi][0][v] = fma(e0, e0, acc[mi][0][v]);
+        acc[mi][1][v] = fma(e1, e1, acc[mi][1][v]);
+      }
   }
 }
 
@@ -207,7 +242,8 @@ __device__ __forceinline__ void finish_tile(const d4 (&acc)[2][2], double2 (&val
 // stores, 256-byte row segments per 16-lane group.
 // SYM: 1-D grid over the tiles on/below the diagonal, mirror-written; otherwise 2-D grid over all tiles.
 // K4 = augmented K (d + 2) rounded up to the MFMA step, in units of 4: compile-time so staging holds K4 registers a side.
-template <int KIND, bool SYM, int K4>
+// EXACT: distances from raw coordinate differences on the VALU (K4 unused), see exact_dist.
+template <int KIND, bool SYM, int K4, bool EXACT>
 __global__ __launch_bounds__(256, WAVES_PER_EU) void kfill_kernel(KParams kp, const double* __restrict__ A, int64_t na,
                                                     const double* __restrict__ B, int64_t nb, int symmetric,
                                                     const double* __restrict__ nugget, int64_t nugget_len,
@@ -216,7 +252,7 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void kfill_kernel(KParams kp, co
   extern __shared__ double sm[];
   const int d = kp.d;
   constexpr int dpad = 4 * K4;  // coordinates + the two augmentation slots, padded to the MFMA K step
-  constexpr int sl = dpad + 1;  // odd stride
+  const int sl = EXACT ? (d | 1) : dpad + 1;  // odd stride
   double* As = sm;
   double* Bs = As + TM * sl;
   double* tab = Bs + TN * sl;  // 2^(j/64) table
@@ -233,8 +269,13 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void kfill_kernel(KParams kp, co
     tj = blockIdx.x;
   }
   const int64_t i0 = (int64_t)ti * TM, j0 = (int64_t)tj * TN;
-  stage_points<KIND, true, K4>(kp, d, dpad, sl, A, na, i0, As);
-  stage_points<KIND, false, K4>(kp, d, dpad, sl, B, nb, j0, Bs);
+  if (EXACT) {
+    stage_raw(d, sl, A, na, i0, As);
+    stage_raw(d, sl, B, nb, j0, Bs);
+  } else {
+    stage_points<KIND, true, K4>(kp, d, dpad, sl, A, na, i0, As);
+    stage_points<KIND, false, K4>(kp, d, dpad, sl, B, nb, j0, Bs);
+  }
   if (threadIdx.x < EXP_TAB) tab[threadIdx.x] = kExp2Tab[threadIdx.x];
   __syncthreads();
 
@@ -247,19 +288,23 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void kfill_kernel(KParams kp, co
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
-  const double* ap = As + (wm * 32 + q) * sl + g;           // A'[row = mi*16 + q][k = 4s + g]
-  const double* bp = Bs + (wn * 32 + 2 * q) * sl + g;       // B'[col = 2q + ni][k = 4s + g]
+  const int c0 = wn * 32 + 2 * q;
+  if (EXACT) {
+    exact_dist(kp, d, sl, As, Bs, wm * 32 + g, c0, acc);
+  } else {
+    const double* ap = As + (wm * 32 + q) * sl + g;           // A'[row = mi*16 + q][k = 4s + g]
+    const double* bp = Bs + (wn * 32 + 2 * q) * sl + g;       // B'[col = 2q + ni][k = 4s + g]
 #pragma unroll
-  for (int ks = 0; ks < dpad; ks += 4) {
-    const double a0 = ap[ks], a1 = ap[16 * sl + ks];
-    const double b0 = bp[ks], b1 = bp[sl + ks];
-    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    for (int ks = 0; ks < dpad; ks += 4) {
+      const double a0 = ap[ks], a1 = ap[16 * sl + ks];
+      const double b0 = bp[ks], b1 = bp[sl + ks];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
   }
 
-  const int c0 = wn * 32 + 2 * q;
   // row_shift: the row set starts `row_shift` entries into the column set (row-band refill): diagonal at gj == gi + shift
   const int64_t is0 = i0 + row_shift;
   const bool interior = (i0 + TM <= na) && (j0 + TN <= nb) && (!symmetric || (is0 + TM <= j0) || (j0 + TN <= is0));
@@ -324,7 +369,7 @@ __global__ __launch_bounds__(256) void kdiag_kernel(KParams kp, const double* __
   out[j] = kvalue<KIND>(acc, kp.sig, kp.sig * (1.0 / 3.0), kExp2Tab);
 }
 
-template <int KIND, bool SYM, int K4>
+template <int KIND, bool SYM, int K4, bool EXACT = false>
 int launch_k4(gpx_ctx* ctx, const KParams& kp, const double* A, int64_t na, const double* B, int64_t nb, int symmetric,
               const double* d_nugget, int64_t nugget_len, double nugget_scalar, double* out, int64_t prows,
               int64_t pcols, int64_t ld, int64_t row_shift) {
@@ -335,8 +380,8 @@ int launch_k4(gpx_ctx* ctx, const KParams& kp, const double* A, int64_t na, cons
   } else {
     grid = dim3((unsigned)(pcols / TN), (unsigned)(prows / TM));
   }
-  const size_t sh = (size_t)(2 * TM * (4 * K4 + 1) + EXP_TAB + (SYM ? 32 * TP : 0)) * sizeof(double);
-  hipLaunchKernelGGL((kfill_kernel<KIND, SYM, K4>), grid, dim3(256), sh, ctx->stream, kp, A, na, B, nb, symmetric,
+  const size_t sh = (size_t)(2 * TM * (EXACT ? (kp.d | 1) : 4 * K4 + 1) + EXP_TAB + (SYM ? 32 * TP : 0)) * sizeof(double);
+  hipLaunchKernelGGL((kfill_kernel<KIND, SYM, K4, EXACT>), grid, dim3(256), sh, ctx->stream, kp, A, na, B, nb, symmetric,
                      d_nugget, nugget_len, nugget_scalar, out, ld, row_shift);
   GPX_HIP(hipGetLastError());
   return 0;
@@ -349,6 +394,9 @@ int launch_kind(gpx_ctx* ctx, const KParams& kp, const double* A, int64_t na, co
 #define GPX_K4(N_)                                                                                                      \
   launch_k4<KIND, SYM, N_>(ctx, kp, A, na, B, nb, symmetric, d_nugget, nugget_len, nugget_scalar, out, prows, pcols, ld, \
                            row_shift)
+  if (KIND != GPX_K_MEHLER && kp.exact)
+    return launch_k4<KIND, SYM, 1, KIND != GPX_K_MEHLER>(ctx, kp, A, na, B, nb, symmetric, d_nugget, nugget_len,
+                                                         nugget_scalar, out, prows, pcols, ld, row_shift);
   const int k4 = (kp.d + 2 + 3) / 4;
   if (k4 <= 2) return GPX_K4(2);   // d <= 6
   if (k4 <= 3) return GPX_K4(3);   // d <= 10

@@ -372,5 +372,13 @@ def ivar_grad(ctx, spec, L, X, Z):
     return out
 
 
+def kfill_plan(ctx, spec, X, Z=None):
+    """(exact, center): which distance form an assembly between X and Z takes (test hook, gpx_dbg_kfill_plan)."""
+    ex = C.c_int()
+    cen = np.zeros(spec.d)
+    check(ctx.lib.gpx_dbg_kfill_plan(ctx.h, *spec.args(), X.h, Z.h if Z is not None else None, C.byref(ex), dptr(cen)))
+    return bool(ex.value), cen
+
+
 def dbg_gemm(ctx, A, B, Cm, bt, accumulate, lower=False):
     check(ctx.lib.gpx_dbg_gemm(ctx.h, A.h, B.h, Cm.h, int(bt), int(accumulate), int(lower)))

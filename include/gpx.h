@@ -17,6 +17,10 @@
  *    <0 = argument / HIP / RCCL error, text via gpx_last_error().
  *  - Calls are blocking unless stated; one gpx_ctx per process (= per GPU); not thread-safe by
  *    contract (the reference's callers are single-threaded).
+ *  - Placement independence: the stationary kernels subtract coordinates before anything else in the reference
+ *    (kernels.py:121-122, 87-89).  The assembly centres every point set on its bounding-box midpoint (computed on the
+ *    host at gpx_mat_from_host) and switches to raw coordinate differences when the centred domain is still wide
+ *    relative to the length scales, so results do not depend on where the inputs sit (gpx_dbg_kfill_plan reports it).
  *  - Covariance kernels are passed flat as (kind, d, hyp[nhyp]):
  *      GPX_K_SE        hyp = {cl_0..cl_{d-1}, signalSize}          kernels.py:100-123
  *      GPX_K_MATERN32  hyp = {rho, signalSize}                      kernels.py:72-91
@@ -237,6 +241,11 @@ int gpx_profile_get(gpx_ctx* ctx, int prof_class, int64_t* launches, double* ms,
 /* C (m x n) = beta*C + alpha*A*op(B); bt != 0: B is (n x k) used transposed; alpha,beta in {(-1,1),(1,0)};
  * lower != 0: only tiles on/below the diagonal are touched */
 int gpx_dbg_gemm(gpx_ctx* ctx, const gpx_mat* A, const gpx_mat* B, gpx_mat* C, int bt, int accumulate, int lower);
+/* what an assembly between X and Z (NULL: X with itself) would do: *exact = 1 when distances are formed from raw
+ * coordinate differences on the VALU (wide domain relative to the length scale) instead of the centred expanded MFMA
+ * product; center[d] = the origin subtracted before scaling (bounding-box midpoint; 0 for Mehler) */
+int gpx_dbg_kfill_plan(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* X, const gpx_mat* Z,
+                       int* exact, double* center);
 
 #ifdef __cplusplus
 }

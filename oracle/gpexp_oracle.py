@@ -31,6 +31,7 @@ import numpy as np
 __all__ = [
     "kernel_eval", "kernel_diag", "cov_matrix", "cross_matrix", "fit", "posterior",
     "loglike", "loglike_grad", "ivar", "greedy_var", "greedy_ivar", "mi_evaluate", "greedy_mi",
+    "kernel_derivative", "variance_deriv_wrt_newpt", "variance_derivative", "ivar_grad",
 ]
 
 
@@ -77,7 +78,7 @@ def kernel_eval(spec, x1, x2):
         r = np.sqrt(np.sum((x1 - x2) ** 2.0, axis=1))
         t = np.sqrt(5) * r / spec["rho"]
         return spec["signalSize"] * (1.0 + t + t * t / 3.0) * np.exp(-t)
-    if kind == "mehler":
+    if kind in ("mehler", "mehler1d"):   # KernelMehler1D (kernels.py:264-293) = the d = 1 factor of KernelMehlerND
         out = np.ones(x1.shape[0])
         for k, t in enumerate(spec["t"]):
             a = x1[:, k]
@@ -217,6 +218,90 @@ def loglike_grad(spec, X, y, noise):
     out["signalSize"] = 0.5 * np.trace(T @ (K0 / spec["signalSize"]))
     out["noise"] = 0.5 * np.trace(T) * noise * 2.0
     return val, out
+
+
+# --------------------------------------------------------------------------------------------
+# f1  derivatives w.r.t. point locations  (reference gpExp/kernels.py, gpExp/gp.py)
+# --------------------------------------------------------------------------------------------
+def kernel_derivative(spec, x1, x2):
+    """Kernel.derivative(x1, x2): out[j, i] = dK(x1[j], x2) / d x1[j, i], x2 a single (1, d) point.
+
+    Squared exponential (kernels.py:146-181): -signalSize * (x1 - x2) / cl^2 * evaluate(x1, x2) -- the kernel value
+    already carries signalSize, so it enters twice (:177), kept as is.  1-D Mehler (kernels.py:295-324):
+    -1/2 (2 x1 t^2 - 2 t x2) / (1 - t^2) * evaluate(x1, x2).  Other kernels have no derivative in the reference.
+    A 1-D "mehler" spec is the reference's KernelMehler1D."""
+    x1 = np.asarray(x1, dtype=float)
+    x2 = np.asarray(x2, dtype=float)
+    assert x2.ndim == 2 and x1.ndim == 2 and x2.shape == (1, spec["d"]) and x1.shape[1] == spec["d"]
+    n = x1.shape[0]
+    r = kernel_eval(spec, x1, x2)
+    if spec["kind"] == "se":
+        cl = _cl(spec)
+        return (-spec["signalSize"] * 0.5 * 2 * (x1 - np.tile(x2, (n, 1))) / np.tile(cl ** 2.0, (n, 1))
+                * np.tile(np.reshape(r, (n, 1)), (1, spec["d"])))
+    if spec["kind"] in ("mehler", "mehler1d") and spec["d"] == 1:
+        t = spec["t"][0]
+        return -0.5 * (2.0 * x1 * t ** 2.0 - 2.0 * t * np.tile(x2, (n, 1))) / (1.0 - t ** 2.0) * np.reshape(r, (n, 1))
+    raise NotImplementedError("the reference defines derivative() for SE and 1-D Mehler only")
+
+
+def variance_deriv_wrt_newpt(spec, model, Z):
+    """GP.evaluateVarianceDerivWRTnewpt (gp.py:261-280): d var(z_i) / d z_i, flattened point-major."""
+    X, P = model["X"], model["P"]
+    Z = np.asarray(Z, dtype=float)
+    derivs = np.zeros((Z.shape[0], Z.shape[1], len(X)))
+    evals = np.zeros((Z.shape[0], len(X)))
+    for ii in range(len(X)):
+        p = X[ii:ii + 1, :]
+        derivs[:, :, ii] = kernel_derivative(spec, Z, p)
+        evals[:, ii] = kernel_eval(spec, p, Z)
+    es = P @ evals.T
+    out = np.zeros(Z.shape)
+    for ii in range(len(Z)):
+        out[ii, :] = -2.0 * derivs[ii, :, :] @ es[:, ii]
+    return out.reshape(np.prod(Z.shape))
+
+
+def variance_derivative(spec, model, Z, noise_func=None):
+    """GP.evaluateVarianceDerivative (gp.py:282-341): out[k*d + l, j] = d var(z_j) / d X[k, l] for the model fitted on
+    X = model["X"] with precision model["P"]; `noise_func` = callable with .deriv (demo2.py:45-58), its terms at
+    gp.py:314-320 (including the whole-set norm test of :318)."""
+    X, P = model["X"], model["P"]
+    Z = np.asarray(Z, dtype=float)
+    n, d = X.shape
+    dcov = np.zeros((n, n, d))
+    tot = np.zeros((len(Z), n))
+    dtot = []
+    for zz in range(n):
+        p = X[zz:zz + 1, :]
+        ind = np.array([np.linalg.norm(pp - p) < 1e-10 for pp in X])
+        dcov[zz, :, :] = kernel_derivative(spec, X, p)
+        tot[:, zz] = kernel_eval(spec, p, Z)
+        dtot.append(-kernel_derivative(spec, Z, p))
+        if noise_func is not None:
+            dcov[zz, :, :] += np.tile(ind.reshape((n, 1)), d) * noise_func.deriv(X)
+            if np.linalg.norm(p - Z) < 1e-10:
+                tot[:, zz] += noise_func(p)
+                dtot[-1] -= noise_func.deriv(p)
+    e = tot @ P
+    out1 = np.zeros((n * d, len(Z)))
+    out2 = np.zeros((n * d, len(Z)))
+    for jj in range(n):
+        for kk in range(d):
+            out1[jj * d + kk, :] = 2.0 * e[:, jj] * dtot[jj][:, kk]
+            dS = np.zeros((n, n))
+            dS[jj, :] = dcov[:, jj, kk]
+            dS[:, jj] = dcov[:, jj, kk]
+            out2[jj * d + kk, :] = -np.sum((e @ dS) * e, axis=1)
+    return -(out1 + out2)
+
+
+def ivar_grad(spec, design, mc, noise, noise_func=None):
+    """costFunctionGP_IVAR.derivative, version 1 (experimentalDesign.py:168-179): refit on the design points (with the
+    per-point noise noise_func(design) when given), mean over the MC points of variance_derivative."""
+    nug = noise if noise_func is None else noise_func(design)
+    model = fit(spec, design, None, nug)
+    return np.sum(variance_derivative(spec, model, mc, noise_func), axis=1) / float(len(mc))
 
 
 # --------------------------------------------------------------------------------------------

@@ -19,8 +19,82 @@ def rel(a, b):
     return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
 
 
+# round-2 cases (tests/golden/make_golden_r2.py): inputs far from the origin / wide relative to the length scale
+GP_CASES_R2 = ["se_iso_d3_n96_off100", "se_ard_d8_n130_off1000", "matern32_d8_n200_off1000", "se_iso_d2_n300_l002",
+               "matern32_d2_n300_rho002", "mehler_d2_off2"]
+
+
 def test_case_list_complete(golden):
-    assert golden.cases("gp") == sorted(GP_CASES)
+    assert golden.cases("gp") == sorted(GP_CASES + GP_CASES_R2)
+
+
+@pytest.mark.parametrize("case", GP_CASES_R2)
+def test_offset_cases(golden, case):
+    """The oracle takes coordinate differences first, like the reference (kernels.py:121-122, 87-89): same bits."""
+    spec = golden.index[case]["kernel"]
+    X, y, Z = golden(case, "X"), golden(case, "y"), golden(case, "Z")
+    nz = golden.noise(case)
+    assert rel(orc.cov_matrix(spec, X, nz), golden(case, "K")) <= 1e-15
+    assert rel(orc.cross_matrix(spec, Z, X).T, golden(case, "Kxz")) <= 1e-15
+    m = orc.fit(spec, X, y, nz)
+    assert rel(m["coeff"], golden(case, "coeff")) <= 1e-12
+    mean, var = orc.posterior(spec, m, Z)
+    assert rel(mean, golden(case, "mean")) <= 1e-12
+    assert rel(var, golden(case, "var")) <= 1e-11
+    assert abs(orc.loglike(spec, X, y, nz) - golden(case, "loglike")) <= 1e-12 * abs(golden(case, "loglike"))
+
+
+def test_point_derivatives_round1(golden):
+    c = "varderiv"
+    spec = golden.index[c]["kernel"]
+    X, Z = golden(c, "X"), golden(c, "Z")
+    m = orc.fit(spec, X, None, golden.index[c]["noise"])
+    assert rel(orc.kernel_derivative(spec, X, Z[:1]), golden(c, "kernel_derivative")) <= 1e-15
+    assert rel(orc.variance_derivative(spec, m, Z), golden(c, "dvar_dpts")) <= 1e-13
+    assert rel(orc.variance_deriv_wrt_newpt(spec, m, Z), golden(c, "dvar_dnew")) <= 1e-13
+
+
+def test_point_derivatives_noisefunc(golden):
+    from helpers import NoiseFunc
+    c = "varderiv_nf"
+    spec = golden.index[c]["kernel"]
+    X, Z = golden(c, "X"), golden(c, "Z")
+    nf = NoiseFunc(2)
+    assert rel(nf(X), golden(c, "pointnoise")) == 0.0 and rel(nf.deriv(X), golden(c, "pointnoise_deriv")) == 0.0
+    m = orc.fit(spec, X, None, nf(X))
+    assert rel(orc.variance_derivative(spec, m, Z, nf), golden(c, "dvar_dpts")) <= 1e-13
+    assert rel(orc.ivar_grad(spec, X, Z, 1e-3, nf), golden(c, "ivar_grad")) <= 1e-13
+    assert rel(orc.ivar_grad(spec, X, Z, 1e-3), golden(c, "ivar_grad_homo")) <= 1e-13
+    c = "varderiv_single"   # whole-set norm branch of gp.py:318-320
+    spec = golden.index[c]["kernel"]
+    X, Z = golden(c, "X"), golden(c, "Z")
+    m = orc.fit(spec, X, None, nf(X))
+    assert rel(orc.variance_derivative(spec, m, Z, nf), golden(c, "dvar_dpts")) <= 1e-13
+
+
+def test_point_derivatives_mehler1d(golden):
+    c = "varderiv_mehler1d"
+    spec = golden.index[c]["kernel"]
+    X, Z = golden(c, "X"), golden(c, "Z")
+    m = orc.fit(spec, X, None, golden.index[c]["noise"])
+    assert rel(m["K"], golden(c, "K")) <= 1e-15
+    assert rel(orc.kernel_derivative(spec, Z, X[:1]), golden(c, "kernel_derivative")) <= 1e-15
+    assert rel(orc.variance_derivative(spec, m, Z), golden(c, "dvar_dpts")) <= 1e-13
+    assert rel(orc.variance_deriv_wrt_newpt(spec, m, Z), golden(c, "dvar_dnew")) <= 1e-13
+    assert rel(orc.ivar_grad(spec, X, Z, golden.index[c]["noise"]), golden(c, "ivar_grad")) <= 1e-13
+
+
+def test_rank_deficient_pinv(golden):
+    """Duplicated point, noise 0: the oracle's pinv reproduces the reference's truncation (gp.py:181)."""
+    c = "rankdef"
+    spec = golden.index[c]["kernel"]
+    X, y, Z = golden(c, "X"), golden(c, "y"), golden(c, "Z")
+    m = orc.fit(spec, X, y, 0.0)
+    assert rel(m["coeff"], golden(c, "coeff")) <= 1e-10
+    mean, var = orc.posterior(spec, m, Z)
+    assert rel(mean, golden(c, "mean")) <= 1e-10
+    assert rel(var, golden(c, "var")) <= 1e-9
+    assert abs(orc.ivar(spec, X, Z, 0.0) - float(golden(c, "ivar"))) <= 1e-10 * float(golden(c, "ivar"))
 
 
 @pytest.mark.parametrize("case", GP_CASES)
