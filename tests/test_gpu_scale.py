@@ -122,7 +122,12 @@ def test_c5_mi_and_loglike_gradient(dev, ctx):
 
 def test_c5_full_size_fit_on_one_gpu(dev, ctx):
     """BASELINE config C5 at its full size: N=65536, d=10 ARD-SE (K = 34.4 GB, resident in HBM): K alpha = y on exact rows
-    of K, 0 < var < noise at training points, log-likelihood reproducible bit for bit, gradient entries finite."""
+    of K, 0 < var < noise at training points, log-likelihood reproducible bit for bit, and the hyper-parameter gradient
+    (gpx_lml_grad: potri + one fused trace pass over K^-1) against central differences of the GPU log-likelihood at the
+    same size.  Phase times go to gpurun_out/r02_c5_times.json (copied to profiles/)."""
+    import json
+    import os
+    import time
     N, d = 65536, 10
     rng = np.random.default_rng(65536)
     Xh = rng.uniform(-1, 1, (N, d))
@@ -130,20 +135,55 @@ def test_c5_full_size_fit_on_one_gpu(dev, ctx):
     hyp = list(0.5 + 0.03 * np.arange(d)) + [1.0]
     sp = dev.KernelSpec(dev.K_SE, d, hyp)
     X = dev.points(ctx, Xh)
-    K = dev.kfill(ctx, sp, X, nugget=0.1)
+    times = {}
+
+    def timed(name, fn):
+        ctx.sync()
+        t0 = time.perf_counter()
+        out = fn()
+        ctx.sync()
+        times[name] = time.perf_counter() - t0
+        return out
+
+    K = timed("kfill_s", lambda: dev.kfill(ctx, sp, X, nugget=0.1))
     rows = rng.choice(N, 5, replace=False)
     Krows = np.stack([dev.kernel_eval(ctx, sp, Xh, Xh[r:r + 1]) for r in rows])
     Krows[np.arange(5), rows] += 0.1
-    dev.potrf(ctx, K)
-    alpha = dev.potrs(ctx, K, y)
+    timed("potrf_s", lambda: dev.potrf(ctx, K))
+    alpha = timed("potrs_s", lambda: dev.potrs(ctx, K, y))
     assert np.max(np.abs(Krows @ alpha - y[rows])) <= 1e-9 * np.max(np.abs(y))
     ld = dev.logdet(ctx, K)
     ll = -0.5 * y @ alpha - 0.5 * ld - N / 2 * np.log(2 * np.pi)
     assert np.isfinite(ll)
     _, var = dev.posterior(ctx, sp, K, X, None, dev.points(ctx, Xh[:2048]), want_mean=False)
     assert np.all(var > 0) and np.all(var < 0.1)
+    # hyper-parameter gradient at full size (d + 2 = 12 entries)
+    g = timed("lml_grad_s", lambda: dev.lml_grad(ctx, sp, K, X, alpha))
+    assert g.shape == (d + 2,) and np.all(np.isfinite(g))
     dev.kfill_into(ctx, sp, X, K, nugget=0.1)
     dev.potrf(ctx, K)
     assert dev.logdet(ctx, K) == ld and np.array_equal(dev.potrs(ctx, K, y), alpha)
+
+    def loglike(h, noise):
+        dev.kfill_into(ctx, dev.KernelSpec(dev.K_SE, d, h), X, K, nugget=noise)
+        dev.potrf(ctx, K)
+        a = dev.potrs(ctx, K, y)
+        return -0.5 * y @ a - 0.5 * dev.logdet(ctx, K) - N / 2 * np.log(2 * np.pi)
+
+    t0 = time.perf_counter()
+    for k in (0, 6, 10):   # a length scale at each end of the ARD range and signalSize
+        hp, hm = list(hyp), list(hyp)
+        h = 1e-4 * hyp[k]
+        hp[k] += h
+        hm[k] -= h
+        fd = (loglike(hp, 0.1) - loglike(hm, 0.1)) / (2 * h)
+        assert g[k] == pytest.approx(fd, rel=2e-6), (k, g[k], fd)
+    fdn = (loglike(hyp, 0.1 + 1e-5) - loglike(hyp, 0.1 - 1e-5)) / 2e-5
+    assert g[-1] == pytest.approx(fdn, rel=2e-6), (g[-1], fdn)
+    times["eight_full_fits_for_fd_s"] = time.perf_counter() - t0
+    times.update(N=N, d=d, loglike=float(ll), grad=[float(v) for v in g])
+    if os.path.isdir("gpurun_out"):
+        with open(os.path.join("gpurun_out", "r02_c5_times.json"), "w") as f:
+            json.dump(times, f, indent=1)
     del K
     ctx.trim()
