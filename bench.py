@@ -115,11 +115,20 @@ def main():
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
-        runner = dist.DistFitIvar(ctx, comm, spec, Xh, yh, Zh, noise, nb=int(os.environ.get("GPX_DIST_NB", "512")))
+        # default: north_star's 2-D block-cyclic layout (Pr x Pc grid, gpexp_amd/dist.py); GPX_DIST_LAYOUT=1d selects the
+        # round-1 block-column layout (every rank holds the full matrix, one ncclBroadcast per panel)
+        nb = int(os.environ.get("GPX_DIST_NB", "512"))
+        if os.environ.get("GPX_DIST_LAYOUT", "2d") == "1d":
+            runner = dist.DistFitIvar(ctx, comm, spec, Xh, yh, Zh, noise, nb=nb)
+            layout = "1-D block-cyclic columns"
+        else:
+            runner = dist.DistFitIvar2D(ctx, comm, spec, Xh, yh, Zh, noise, nb=nb)
+            layout = "2-D block-cyclic %dx%d grid, nb=%d" % (runner.geo.Pr, runner.geo.Pc, nb)
         step = runner.step
         barrier = comm.barrier
         reduce_max = comm.max_float
     else:
+        layout = "1 GPU"
         X = dev.points(ctx, Xh)
         Z = dev.points(ctx, Zh)
         K = dev.DeviceMatrix.zeros(ctx, N, N)   # allocated once; refilled in place every step
@@ -201,7 +210,7 @@ def main():
             "config": {"workload": "C4: N=%d d=%d Matern-5/2 (rho=0.5,s=1,noise=0.1) kfill+potrf+potrs+logdet+"
                                    "IVAR over M=%d MC points" % (N, d, M),
                        "N": N, "d": d, "M": M, "kernel": "matern52", "seed": N,
-                       "parallelism": "1 GPU" if world == 1 else "%d ranks, 1-D block-cyclic columns" % world},
+                       "parallelism": "1 GPU" if world == 1 else "%d ranks, %s" % (world, layout)},
             "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel (SYRK/TRSM updates)", "achieved": ach,
                          "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
                          "traffic": traffic, "traffic_unit": "bytes per launch (mean over the step's launches)",

@@ -74,6 +74,24 @@ _SIGS = {
     "gpx_dist_info": (C.c_int, [c_vp, C.POINTER(C.c_int)]),
     "gpx_dist_panel_store": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp]),
     "gpx_dist_panel_update": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, C.c_int, C.c_int]),
+    "gpx_vec_op": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, C.c_int]),
+    "gpx_comm_grid": (C.c_int, [c_vp, C.c_int, C.c_int]),
+    "gpx_comm_bcast_grp": (C.c_int, [c_vp, c_vp, c_i64, c_i64, C.c_int, C.c_int]),
+    "gpx_comm_reduce_grp": (C.c_int, [c_vp, c_vp, c_i64, c_i64, C.c_int, C.c_int]),
+    "gpx_comm_allreduce": (C.c_int, [c_vp, c_vp, c_i64, c_i64]),
+    "gpx_comm_allreduce_host": (C.c_int, [c_vp, c_dp, c_i64]),
+    "gpx_comm_panel_bcast": (C.c_int, [c_vp, c_vp, c_ip, c_ip, C.POINTER(C.c_int), C.c_int]),
+    "gpx_dist2_diag_elems": (c_i64, [c_i64]),
+    "gpx_dist2_kfill": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_dp, c_i64, c_vp, c_i64, C.c_int, C.c_int,
+                                  C.c_int, C.c_int]),
+    "gpx_dist2_diag_factor": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64]),
+    "gpx_dist2_panel_trsm": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64]),
+    "gpx_dist2_update": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64]),
+    "gpx_dist2_unpack_rows": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64]),
+    "gpx_dist2_unpack_diag": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64]),
+    "gpx_dist2_trsv_diag": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, C.c_int]),
+    "gpx_dist2_gemv": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, C.c_int]),
+    "gpx_dist2_logdet_acc": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp]),
     "gpx_stream_select": (C.c_int, [c_vp, C.c_int]),
     "gpx_event_record": (C.c_int, [c_vp, C.c_int]),
     "gpx_event_wait": (C.c_int, [c_vp, C.c_int]),

@@ -258,6 +258,12 @@ int gpx_create(int device, gpx_ctx** out) {
   c->comm = nullptr;
   c->rank = 0;
   c->world = 1;
+  for (int i = 0; i < 3; ++i) {
+    c->grp[i] = nullptr;
+    c->grp_size[i] = 1;
+    c->grp_rank[i] = 0;
+  }
+  c->Pr = c->Pc = 1;
   c->prof_on = 0;
   for (int i = 0; i < GPX_PROF_NCLASS; ++i) {
     c->prof_launches[i] = 0;
@@ -447,6 +453,26 @@ int gpx_mat_write(gpx_ctx* ctx, gpx_mat* m, int64_t offset, int64_t count, const
   m->bbox_ok = 0;
   GPX_HIP(hipMemcpyAsync(m->p + offset, src, (size_t)count * 8, hipMemcpyHostToDevice, ctx->stream));
   GPX_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// dst[doff : doff+n] = src[soff : soff+n] (mode 0), += src (mode 1), = 0 (mode 2; src ignored); asynchronous.
+// The vector glue of the distributed substitution sweeps (gpexp_amd/dist.py).
+__global__ __launch_bounds__(256) static void vec_op_kernel(double* __restrict__ dst, const double* __restrict__ src,
+                                                            int64_t n, int mode) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  dst[i] = mode == 0 ? src[i] : (mode == 1 ? dst[i] + src[i] : 0.0);
+}
+
+int gpx_vec_op(gpx_ctx* ctx, gpx_mat* dst, int64_t doff, const gpx_mat* src, int64_t soff, int64_t n, int mode) {
+  GPX_ARG(ctx && dst && mode >= 0 && mode <= 2 && (mode == 2 || src), "bad vector operation");
+  GPX_ARG(doff >= 0 && n >= 0 && (doff + n) * 8 <= dst->bytes, "destination range out of bounds");
+  GPX_ARG(mode == 2 || (soff >= 0 && (soff + n) * 8 <= src->bytes), "source range out of bounds");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(vec_op_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dst->p + doff,
+                     mode == 2 ? nullptr : src->p + soff, n, mode);
+  GPX_HIP(hipGetLastError());
   return 0;
 }
 

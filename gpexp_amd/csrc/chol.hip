@@ -830,6 +830,17 @@ int chol_trsv(gpx_ctx* ctx, const double* L, int64_t ld, const double* invd, dou
   return r;
 }
 
+int launch_gemv_sub(gpx_ctx* ctx, const double* A, int64_t ld, int64_t rows, int64_t cols, const double* x, double* y) {
+  if (rows <= 0 || cols <= 0) return 0;
+  GPX_ARG(cols % 2 == 0 && ld % 2 == 0, "gemv_sub: even column count and leading dimension");
+  int64_t wg = (rows + 3) / 4;
+  if (wg > 4096) wg = 4096;
+  ProfScope ps(ctx, GPX_PROF_TRSV, 2.0 * (double)rows * cols, 8.0 * (double)rows * cols);
+  hipLaunchKernelGGL(gemv_sub_kernel, dim3((unsigned)wg), dim3(256), 0, ctx->stream, A, ld, rows, cols, x, y);
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_logdet(gpx_ctx* ctx, const double* L, int64_t ld, int64_t n, double* d_out) {
   ProfScope ps(ctx, GPX_PROF_REDUCE, 0.0, 8.0 * (double)n);
   hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(256), 0, ctx->stream, L, ld, n, d_out);

@@ -109,6 +109,11 @@ struct gpx_ctx {
   // multi-GPU (RCCL communicator, opaque here; see dist.hip)
   void* comm;
   int rank, world;
+  // process grid of the 2-D block-cyclic path (gpx_comm_grid): rank = pr * Pc + pc; sub-communicators from ncclCommSplit:
+  // grp[0] = world (== comm), grp[1] = my process row (Pc ranks, rank pc), grp[2] = my process column (Pr ranks, rank pr)
+  void* grp[3];
+  int grp_size[3], grp_rank[3];
+  int Pr, Pc;
   // profiling
   int prof_on;
   std::vector<ProfRec> prof_recs;
@@ -144,6 +149,9 @@ int launch_kfill_offset(gpx_ctx* ctx, const KParams& kp, const double* X, int64_
                         const double* d_nugget, int64_t nugget_len, double nugget_scalar, double* out, int64_t prows,
                         int64_t pcols, int64_t ld);
 int launch_kdiag(gpx_ctx* ctx, const KParams& kp, const double* Z, int64_t m, double* out);
+int launch_kfill_cyclic(gpx_ctx* ctx, const KParams& kp, const double* X, int64_t n, const double* d_nugget,
+                        int64_t nugget_len, double nugget_scalar, double* out, int64_t prows, int64_t pcols, int64_t ld,
+                        int64_t nb, int Pr, int pr, int Pc, int pc);
 int gpx_copy2d(gpx_ctx* ctx, const double* src, int64_t lds_, double* dst, int64_t ldd, int64_t rows, int64_t cols);
 int launch_kfill_rows(gpx_ctx* ctx, const KParams& kp, const double* X, int64_t n, int64_t row0, const double* d_nugget,
                       int64_t nugget_len, double nugget_scalar, double* out, int64_t prows_band, int64_t pcols,
@@ -173,6 +181,8 @@ int64_t chol_trsv_scratch_bytes(int64_t n);
 int chol_trsv_with_scratch(gpx_ctx* ctx, const double* L, int64_t ld, const double* invd, double* y, int64_t n,
                            bool transposed, double* scratch);
 int launch_logdet(gpx_ctx* ctx, const double* L, int64_t ld, int64_t n, double* d_out);
+// y[r] -= sum_c A[r][c] x[c] over a rows x cols block (cols a multiple of 2, ld even)
+int launch_gemv_sub(gpx_ctx* ctx, const double* A, int64_t ld, int64_t rows, int64_t cols, const double* x, double* y);
 
 // reduce.hip
 // out[j] = sum_i B[i][j] * v[i]   (v == nullptr: sum_i B[i][j]^2), i < rows, j < pcols; deterministic

@@ -31,6 +31,7 @@ namespace {
 constexpr int TM = 64;  // tile rows
 constexpr int TN = 64;  // tile cols
 constexpr int TP = TN + 1;  // padded stride of the transpose image
+struct KCyclic { int nbt, Pr, pr, Pc, pc; };  // nbt = block size in tiles; 0 = plain (identity) tile map
 #ifndef WAVES_PER_EU
 #define WAVES_PER_EU 5
 #endif
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void kfill_kernel(KParams kp, co
                                                     const double* __restrict__ B, int64_t nb, int symmetric,
                                                     const double* __restrict__ nugget, int64_t nugget_len,
                                                     double nugget_scalar, double* __restrict__ out, int64_t ld,
-                                                    int64_t row_shift) {
+                                                    int64_t row_shift, KCyclic cyc) {
   extern __shared__ double sm[];
   const int d = kp.d;
   constexpr int dpad = 4 * K4;  // coordinates + the two augmentation slots, padded to the MFMA K step
@@ -268,7 +269,16 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void kfill_kernel(KParams kp, co
     ti = blockIdx.y;
     tj = blockIdx.x;
   }
-  const int64_t i0 = (int64_t)ti * TM, j0 = (int64_t)tj * TN;
+  // i0, j0: first point of the tile's row / column set; oi0, oj0: where the tile lands in `out`.  They differ only for the
+  // 2-D block-cyclic local matrices of the multi-GPU path (cyc.nbt > 0): local block (ti / nbt, tj / nbt) holds the global
+  // block (.. * Pr + pr, .. * Pc + pc); tiles strictly above the global diagonal are not needed there.
+  const int64_t oi0 = (int64_t)ti * TM, oj0 = (int64_t)tj * TN;
+  int64_t i0 = oi0, j0 = oj0;
+  if (!SYM && cyc.nbt > 0) {
+    i0 = ((int64_t)(ti / cyc.nbt) * cyc.Pr + cyc.pr) * cyc.nbt * TM + (int64_t)(ti % cyc.nbt) * TM;
+    j0 = ((int64_t)(tj / cyc.nbt) * cyc.Pc + cyc.pc) * cyc.nbt * TN + (int64_t)(tj % cyc.nbt) * TN;
+    if (i0 + TM <= j0) return;
+  }
   if (EXACT) {
     stage_raw(d, sl, A, na, i0, As);
     stage_raw(d, sl, B, nb, j0, Bs);
@@ -308,7 +318,7 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void kfill_kernel(KParams kp, co
   // row_shift: the row set starts `row_shift` entries into the column set (row-band refill): diagonal at gj == gi + shift
   const int64_t is0 = i0 + row_shift;
   const bool interior = (i0 + TM <= na) && (j0 + TN <= nb) && (!symmetric || (is0 + TM <= j0) || (j0 + TN <= is0));
-  char* const otile = reinterpret_cast<char*>(out + i0 * ld + j0);
+  char* const otile = reinterpret_cast<char*>(out + oi0 * ld + oj0);
   const unsigned ooff = (unsigned)(((wm * 32 + g) * ld + c0) * 8);
   double2 val[2][4];
   if (__builtin_amdgcn_readfirstlane((int)interior))
@@ -372,7 +382,7 @@ __global__ __launch_bounds__(256) void kdiag_kernel(KParams kp, const double* __
 template <int KIND, bool SYM, int K4, bool EXACT = false>
 int launch_k4(gpx_ctx* ctx, const KParams& kp, const double* A, int64_t na, const double* B, int64_t nb, int symmetric,
               const double* d_nugget, int64_t nugget_len, double nugget_scalar, double* out, int64_t prows,
-              int64_t pcols, int64_t ld, int64_t row_shift) {
+              int64_t pcols, int64_t ld, int64_t row_shift, KCyclic cyc = KCyclic{0, 1, 0, 1, 0}) {
   dim3 grid;
   if (SYM) {
     const int64_t t = prows / TM;
@@ -382,7 +392,7 @@ int launch_k4(gpx_ctx* ctx, const KParams& kp, const double* A, int64_t na, cons
   }
   const size_t sh = (size_t)(2 * TM * (EXACT ? (kp.d | 1) : 4 * K4 + 1) + EXP_TAB + (SYM ? 32 * TP : 0)) * sizeof(double);
   hipLaunchKernelGGL((kfill_kernel<KIND, SYM, K4, EXACT>), grid, dim3(256), sh, ctx->stream, kp, A, na, B, nb, symmetric,
-                     d_nugget, nugget_len, nugget_scalar, out, ld, row_shift);
+                     d_nugget, nugget_len, nugget_scalar, out, ld, row_shift, cyc);
   GPX_HIP(hipGetLastError());
   return 0;
 }
@@ -390,13 +400,14 @@ int launch_k4(gpx_ctx* ctx, const KParams& kp, const double* A, int64_t na, cons
 template <int KIND, bool SYM>
 int launch_kind(gpx_ctx* ctx, const KParams& kp, const double* A, int64_t na, const double* B, int64_t nb,
                 int symmetric, const double* d_nugget, int64_t nugget_len, double nugget_scalar, double* out,
-                int64_t prows, int64_t pcols, int64_t ld, int64_t row_shift = 0) {
+                int64_t prows, int64_t pcols, int64_t ld, int64_t row_shift = 0,
+                KCyclic cyc = KCyclic{0, 1, 0, 1, 0}) {
 #define GPX_K4(N_)                                                                                                      \
   launch_k4<KIND, SYM, N_>(ctx, kp, A, na, B, nb, symmetric, d_nugget, nugget_len, nugget_scalar, out, prows, pcols, ld, \
-                           row_shift)
+                           row_shift, cyc)
   if (KIND != GPX_K_MEHLER && kp.exact)
     return launch_k4<KIND, SYM, 1, KIND != GPX_K_MEHLER>(ctx, kp, A, na, B, nb, symmetric, d_nugget, nugget_len,
-                                                         nugget_scalar, out, prows, pcols, ld, row_shift);
+                                                         nugget_scalar, out, prows, pcols, ld, row_shift, cyc);
   const int k4 = (kp.d + 2 + 3) / 4;
   if (k4 <= 2) return GPX_K4(2);   // d <= 6
   if (k4 <= 3) return GPX_K4(3);   // d <= 10
@@ -466,6 +477,31 @@ int launch_kfill_offset(gpx_ctx* ctx, const KParams& kp, const double* X, int64_
   const double* nug = (d_nugget && nugget_len > 1) ? d_nugget + row_off : d_nugget;
   return launch_kfill(ctx, kp, X + row_off * kp.d, na, X + col_off * kp.d, nbp, 1, nug, nugget_len, nugget_scalar, out,
                       prows, pcols, ld);
+}
+
+// Local part of the symmetric covariance of X on rank (pr, pc) of a Pr x Pc process grid, 2-D block-cyclic with block size
+// nb: local block (bi, bj) of `out` (prows x pcols, multiples of nb except for the matrix's last, shorter block) is the
+// global block (bi * Pr + pr, bj * Pc + pc).  Diagonal, nugget and identity padding follow the global indices; blocks
+// strictly above the global diagonal are skipped.
+int launch_kfill_cyclic(gpx_ctx* ctx, const KParams& kp, const double* X, int64_t n, const double* d_nugget,
+                        int64_t nugget_len, double nugget_scalar, double* out, int64_t prows, int64_t pcols, int64_t ld,
+                        int64_t nb, int Pr, int pr, int Pc, int pc) {
+  GPX_ARG(nb % TM == 0 && prows % TM == 0 && pcols % TN == 0, "kfill_cyclic: block size and local shape must be multiples of 64");
+  GPX_ARG(prows / TM <= 65535, "kfill: too many row tiles");
+  if (prows == 0 || pcols == 0) return 0;
+  ProfScope ps(ctx, GPX_PROF_KFILL, 0.0, 8.0 * (double)prows * (double)pcols + 8.0 * (double)n * kp.d);
+  const KCyclic cyc{(int)(nb / TM), Pr, pr, Pc, pc};
+#define GPX_KIND(K_) \
+  launch_kind<K_, false>(ctx, kp, X, n, X, n, 1, d_nugget, nugget_len, nugget_scalar, out, prows, pcols, ld, 0, cyc)
+  switch (kp.kind) {
+    case GPX_K_SE: return GPX_KIND(GPX_K_SE);
+    case GPX_K_MATERN32: return GPX_KIND(GPX_K_MATERN32);
+    case GPX_K_MATERN52: return GPX_KIND(GPX_K_MATERN52);
+    case GPX_K_MEHLER: return GPX_KIND(GPX_K_MEHLER);
+  }
+#undef GPX_KIND
+  gpx_set_error("kfill: unknown kernel kind %d", kp.kind);
+  return -1;
 }
 
 int launch_kdiag(gpx_ctx* ctx, const KParams& kp, const double* Z, int64_t m, double* out) {

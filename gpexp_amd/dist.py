@@ -106,6 +106,38 @@ class _TorchGroup:
         self.td.broadcast(t, src=root)
         return a
 
+    def make_grid(self, Pr, Pc):
+        """Process-row / process-column groups (every rank creates every group, in the same order)."""
+        self.rows = [self.td.new_group([p * Pc + q for q in range(Pc)]) for p in range(Pr)]
+        self.cols = [self.td.new_group([p * Pc + q for p in range(Pr)]) for q in range(Pc)]
+        self.Pr, self.Pc = Pr, Pc
+
+    def _group(self, grp):
+        """(process group, world ranks of its members) for WORLD / ROW / COL of this rank."""
+        pr, pc = self.rank // self.Pc, self.rank % self.Pc
+        if grp == 1:
+            return self.rows[pr], [pr * self.Pc + q for q in range(self.Pc)]
+        if grp == 2:
+            return self.cols[pc], [p * self.Pc + pc for p in range(self.Pr)]
+        return None, list(range(self.world))
+
+    def bcast_array_grp(self, a, root, grp):
+        g, members = self._group(grp)
+        self.td.broadcast(self.torch.from_numpy(a), src=members[root], group=g)
+        return a
+
+    def reduce_array_grp(self, a, root, grp):
+        g, members = self._group(grp)
+        t = self.torch.from_numpy(a.copy())
+        self.td.reduce(t, dst=members[root], op=self.td.ReduceOp.SUM, group=g)
+        if self.rank == members[root]:
+            a[:] = t.numpy()
+        return a
+
+    def allreduce_array(self, a):
+        self.td.all_reduce(self.torch.from_numpy(a), op=self.td.ReduceOp.SUM)
+        return a
+
     def allgather(self, vec):
         vec = np.ascontiguousarray(vec, dtype=np.float64)
         outs = [self.torch.zeros(vec.size, dtype=self.torch.float64) for _ in range(self.world)]
@@ -176,6 +208,33 @@ class RcclComm:
     def bcast_panel(self, P, count, root):
         check(self.ctx.lib.gpx_comm_bcast(self.ctx.h, P.h, int(count), int(root)))
 
+    # ---- 2-D path: process grid, sub-communicators (ncclCommSplit), all-link panel broadcast ----
+    def set_grid(self, Pr, Pc):
+        if getattr(self, "grid", None) != (Pr, Pc):
+            check(self.ctx.lib.gpx_comm_grid(self.ctx.h, int(Pr), int(Pc)))
+            self.grid = (Pr, Pc)
+
+    def bcast_grp(self, buf, offset, count, root, grp):
+        check(self.ctx.lib.gpx_comm_bcast_grp(self.ctx.h, buf.h, int(offset), int(count), int(root), int(grp)))
+
+    def reduce_grp(self, buf, offset, count, root, grp):
+        check(self.ctx.lib.gpx_comm_reduce_grp(self.ctx.h, buf.h, int(offset), int(count), int(root), int(grp)))
+
+    def allreduce(self, buf, offset, count):
+        check(self.ctx.lib.gpx_comm_allreduce(self.ctx.h, buf.h, int(offset), int(count)))
+
+    def allreduce_host(self, vec):
+        vec = as_f64(np.atleast_1d(vec)).copy()
+        check(self.ctx.lib.gpx_comm_allreduce_host(self.ctx.h, dptr(vec), vec.size))
+        return vec
+
+    def panel_bcast(self, buf, pieces):
+        n = len(pieces)
+        offs = (c_i64 * n)(*[int(p[0]) for p in pieces])
+        cnts = (c_i64 * n)(*[int(p[1]) for p in pieces])
+        roots = (C.c_int * n)(*[int(p[2]) for p in pieces])
+        check(self.ctx.lib.gpx_comm_panel_bcast(self.ctx.h, buf.h, offs, cnts, roots, n))
+
     def allgather(self, vec):
         vec = as_f64(np.atleast_1d(vec))
         out = np.empty((self.world, vec.size))
@@ -209,6 +268,43 @@ class HostStagedComm:
         if self.rank != root:
             check(self.ctx.lib.gpx_mat_write(self.ctx.h, P.h, 0, int(count), dptr(buf)))
 
+    # ---- 2-D path (same interface as RcclComm) ----
+    def set_grid(self, Pr, Pc):
+        if getattr(self, "grid", None) != (Pr, Pc):
+            self.group.make_grid(Pr, Pc)
+            self.grid = (Pr, Pc)
+
+    def _read(self, buf, offset, count):
+        a = np.empty(int(count))
+        check(self.ctx.lib.gpx_mat_read(self.ctx.h, buf.h, int(offset), int(count), dptr(a)))
+        return a
+
+    def _write(self, buf, offset, a):
+        check(self.ctx.lib.gpx_mat_write(self.ctx.h, buf.h, int(offset), a.size, dptr(a)))
+
+    def bcast_grp(self, buf, offset, count, root, grp):
+        if count == 0:
+            return
+        self._write(buf, offset, self.group.bcast_array_grp(self._read(buf, offset, count), root, grp))
+
+    def reduce_grp(self, buf, offset, count, root, grp):
+        if count == 0:
+            return
+        self._write(buf, offset, self.group.reduce_array_grp(self._read(buf, offset, count), root, grp))
+
+    def allreduce(self, buf, offset, count):
+        self._write(buf, offset, self.group.allreduce_array(self._read(buf, offset, count)))
+
+    def allreduce_host(self, vec):
+        return self.group.allreduce_array(np.array(np.atleast_1d(vec), dtype=np.float64))
+
+    def panel_bcast(self, buf, pieces):
+        for off, cnt, root in pieces:
+            a = self._read(buf, off, cnt)
+            self.group.bcast_array(a, root)
+            if self.rank != root:
+                self._write(buf, off, a)
+
     def allgather(self, vec):
         return self.group.allgather(np.atleast_1d(vec))
 
@@ -241,6 +337,12 @@ class DeviceOps:
 
     def alloc_matrix(self, n):
         return _dev.DeviceMatrix.zeros(self.ctx, n, n)
+
+    def points(self, x):
+        return _dev.points(self.ctx, x)
+
+    def posterior_var(self, spec, L, X, Z):
+        return _dev.posterior(self.ctx, spec, L, X, None, Z, want_mean=False)[1]
 
     def alloc_panel(self, n, nb):
         return _dev.DeviceMatrix.zeros(self.ctx, panel_elems(n, nb), 1, pad=False)
@@ -456,3 +558,363 @@ def dist_greedy_var(ctx, comm, spec, cand_host, nsel, keep=()):
     """Greedy maximum-variance design is O(M*n) per step and sequential in the steps: every rank runs the identical
     deterministic selection on the full candidate set (no exchange) -- "replicas" for this sub-path, by design."""
     return _dev.greedy_var(ctx, spec, _dev.points(ctx, cand_host), nsel, keep=keep)
+
+
+# =====================================================================================================================
+# 2-D block-cyclic fit (north_star; SURVEY.md 8e) -- the default multi-GPU path
+# =====================================================================================================================
+# Process grid Pr x Pc (8 -> 2 x 4, 4 -> 2 x 2, 2 -> 1 x 2), rank (pr, pc) = (rank // Pc, rank % Pc).  Global block (I, J)
+# of the padded matrix lives on rank (I % Pr, J % Pc) at local block (I // Pr, J // Pc): every rank allocates only its
+# ~N^2 / (Pr Pc) share of the working matrix.  Right-looking step k:
+#   owner (k % Pr, k % Pc)   factors the diagonal block            gpx_dist2_diag_factor            PANEL stream
+#   process column k % Pc    receives it                            ncclBroadcast on the column sub-communicator
+#                            solves its rows of the panel           gpx_dist2_panel_trsm             PANEL stream
+#   all ranks                receive every piece of the panel       gpx_comm_panel_bcast: scatter + all-gather over grouped
+#                                                                   ncclSend/ncclRecv, every xGMI link carries 2/(W-1) of it
+#                            update the local block columns         gpx_dist2_update (column k+1 first: look-ahead)
+#                            keep the panel in the replicated L     gpx_dist2_unpack_*               BACK stream
+# The replicated copy of L (finished panels only) is what lets the evaluation phase shard the evaluation points with no
+# exchange (and stream, see DistFitIvar); alpha / logdet come from the block-cyclic factor by distributed forward / back
+# substitution (reduce along process rows, broadcast down process columns) and ncclAllReduce.
+WORLD, ROW, COL = 0, 1, 2   # communicator groups (gpx_comm_grid)
+
+
+def choose_grid(world):
+    """Pr x Pc with Pr <= Pc, Pr the largest divisor of `world` not above sqrt(world): 8 -> 2x4, 4 -> 2x2, 2 -> 1x2."""
+    pr = 1
+    for c in range(1, int(world ** 0.5) + 1):
+        if world % c == 0:
+            pr = c
+    return pr, world // pr
+
+
+class Grid2D:
+    """Pure index logic of the 2-D block-cyclic layout (CPU-testable)."""
+
+    def __init__(self, n, nb, Pr, Pc, rank):
+        assert nb % TILE == 0 and 0 <= rank < Pr * Pc
+        self.n, self.nb, self.Pr, self.Pc, self.rank = int(n), int(nb), int(Pr), int(Pc), int(rank)
+        self.pr, self.pc = rank // Pc, rank % Pc
+        self.np = padded(n)
+        self.nblk = num_blocks(n, nb)
+        self.dsz = nb * nb + (nb // TILE) * TILE * TILE
+        self.piece_stride = self.dsz + max(self.local_rows(p) for p in range(Pr)) * nb
+
+    def height(self, I):
+        return min(self.nb, self.np - I * self.nb)
+
+    def owner_rank(self, I, J):
+        return (I % self.Pr) * self.Pc + (J % self.Pc)
+
+    def blocks_before(self, p, P, I):
+        """Number of blocks I' < I with I' % P == p."""
+        return 0 if I <= p else (I - 1 - p) // P + 1
+
+    def local_rows(self, p):
+        return sum(self.height(I) for I in range(p, self.nblk, self.Pr))
+
+    def local_cols(self, q):
+        return sum(self.height(J) for J in range(q, self.nblk, self.Pc))
+
+    def li0(self, p, k):
+        """First local block row of process row p whose global block index exceeds k."""
+        return self.blocks_before(p, self.Pr, k + 1)
+
+    def piece_rows(self, p, k):
+        """Rows of panel k held by process row p: the blocks I > k with I % Pr == p."""
+        return max(self.local_rows(p) - self.li0(p, k) * self.nb, 0)
+
+    def piece_off(self, p):
+        return p * self.piece_stride
+
+    def buf_elems(self):
+        return self.Pr * self.piece_stride
+
+    def pieces(self, k):
+        """(offset, count, world root) of every region the panel broadcast of step k delivers."""
+        kr, kc = k % self.Pr, k % self.Pc
+        out = []
+        for p in range(self.Pr):
+            m = self.piece_rows(p, k)
+            if p == kr:
+                out.append((self.piece_off(p), self.dsz + m * self.nb, p * self.Pc + kc))
+            elif m > 0:
+                out.append((self.piece_off(p) + self.dsz, m * self.nb, p * self.Pc + kc))
+        return out
+
+    def my_cols_after(self, k):
+        """Global block columns J > k owned by this rank's process column."""
+        return [J for J in range(self.pc, self.nblk, self.Pc) if J > k]
+
+    def update_args(self, k, J):
+        """(lr0, m, lc0, n, aoff, boff) of the local trailing update of block column J > k by panel k (this rank)."""
+        nb, pr = self.nb, self.pr
+        liJ = self.blocks_before(pr, self.Pr, J)            # first local block row with I >= J
+        m = max(self.local_rows(pr) - liJ * nb, 0)
+        aoff = self.piece_off(pr) + self.dsz + (liJ - self.li0(pr, k)) * nb * nb
+        pj = J % self.Pr
+        boff = self.piece_off(pj) + self.dsz + (J // self.Pr - self.li0(pj, k)) * nb * nb
+        return liJ * nb, m, (J // self.Pc) * nb, self.height(J), aoff, boff
+
+
+class DeviceOps2D(DeviceOps):
+    """Device primitives of the 2-D panel loop (gpx_dist2_*); the tests substitute a NumPy double."""
+
+    def alloc_local(self, geo):
+        return _dev.DeviceMatrix.zeros(self.ctx, max(geo.local_rows(geo.pr), 1), max(geo.local_cols(geo.pc), 1))
+
+    def alloc_buf(self, geo):
+        return _dev.DeviceMatrix.zeros(self.ctx, geo.buf_elems(), 1, pad=False)
+
+    def alloc_vec(self, n):
+        return _dev.DeviceMatrix.zeros(self.ctx, max(int(n), 1), 1, pad=False)
+
+    def kfill_local(self, spec, X, A, nugget, geo):
+        nug, nlen = _dev._nugget_args(nugget, X.shape[0])
+        check(self.ctx.lib.gpx_dist2_kfill(self.ctx.h, *spec.args(), X.h, dptr(nug), nlen, A.h, geo.nb, geo.Pr, geo.Pc,
+                                           geo.pr, geo.pc))
+
+    def diag_factor(self, A, lr, lc, w, G, doff, nb, base, n_valid):
+        check(self.ctx.lib.gpx_dist2_diag_factor(self.ctx.h, A.h, lr, lc, w, G.h, doff, nb, base, n_valid))
+
+    def panel_trsm(self, A, lr0, m, lc, w, G, doff, roff, nb):
+        check(self.ctx.lib.gpx_dist2_panel_trsm(self.ctx.h, A.h, lr0, m, lc, w, G.h, doff, roff, nb))
+
+    def update(self, A, lr0, m, lc0, n, G, aoff, boff, w, nb):
+        check(self.ctx.lib.gpx_dist2_update(self.ctx.h, A.h, lr0, m, lc0, n, G.h, aoff, boff, w, nb))
+
+    def unpack_rows(self, G, roff, m, w, nb, L, first_block, stride, col0):
+        check(self.ctx.lib.gpx_dist2_unpack_rows(self.ctx.h, G.h, roff, m, w, nb, L.h, first_block, stride, col0))
+
+    def unpack_diag(self, G, doff, w, nb, L, r0):
+        check(self.ctx.lib.gpx_dist2_unpack_diag(self.ctx.h, G.h, doff, w, nb, L.h, r0))
+
+    def trsv_diag(self, A, lr, lc, w, v, voff, transposed):
+        check(self.ctx.lib.gpx_dist2_trsv_diag(self.ctx.h, A.h, lr, lc, w, v.h, voff, int(transposed)))
+
+    def gemv(self, A, lr0, m, lc, w, x, xoff, acc, aoff, transposed):
+        check(self.ctx.lib.gpx_dist2_gemv(self.ctx.h, A.h, lr0, m, lc, w, x.h, xoff, acc.h, aoff, int(transposed)))
+
+    def logdet_acc(self, A, lr, lc, w, n_valid, acc):
+        check(self.ctx.lib.gpx_dist2_logdet_acc(self.ctx.h, A.h, lr, lc, w, n_valid, acc.h))
+
+    def vec_op(self, dst, doff, src, soff, n, mode):
+        check(self.ctx.lib.gpx_vec_op(self.ctx.h, dst.h, doff, src.h if src is not None else None, soff, n, mode))
+
+    def vec_to_host(self, v, n):
+        return v.to_host()[:n, 0]
+
+    def vec_from_host(self, v, a):
+        a = as_f64(np.ravel(a))
+        check(self.ctx.lib.gpx_mat_write(self.ctx.h, v.h, 0, a.size, dptr(a)))
+
+
+# event kinds of the 2-D pipeline (per step k)
+E_COLREADY, E_DFACT, E_DBC, E_PIECE, E_ARRIVED, E_STORED, E_UPD = range(7)
+
+
+def _ev2(kind, k):
+    return 8 * (k + 1) + kind
+
+
+def dist2_potrf(ops, comm, geo, A, G, L=None, on_stored=None):
+    """2-D block-cyclic right-looking Cholesky of the distributed matrix A (in place: A ends as the block-cyclic factor)
+    with one step of look-ahead.  G = two packed panel buffers (geo.buf_elems() doubles) used alternately; L (optional) =
+    full-size matrix that receives every finished panel (replicated factor for the evaluation phase).
+
+    Streams per rank: PANEL (diagonal factor, panel solve), COMM (collectives, in step order on every rank, so every
+    communicator sees its operations in the same order everywhere), MAIN (trailing updates; the local part of block column
+    k+1 first, which releases the PANEL stream of its holders for step k+1 underneath the rest of update k), BACK (copies
+    into L, then the streamed-evaluation hook `on_stored(k)`).  A panel buffer is rewritten at step k+2 only after update k
+    and the copy of panel k are done.  Returns 0 or the 1-based index of the first non-positive pivot (agreed by all)."""
+    nb, Pr, Pc, pr, pc = geo.nb, geo.Pr, geo.Pc, geo.pr, geo.pc
+    ops.stream(MAIN)
+    ops.begin()
+    ops.record(_ev2(E_COLREADY, 0))  # the assembly was queued on MAIN
+    for k in range(geo.nblk):
+        kr, kc = k % Pr, k % Pc
+        g = G[k & 1]
+        w = geo.height(k)
+        lr, lc = (k // Pr) * nb, (k // Pc) * nb
+        holder = pc == kc
+        owner = holder and pr == kr
+
+        def wait_free():
+            if k >= 2:
+                ops.wait(_ev2(E_UPD, k - 2))
+                ops.wait(_ev2(E_STORED, k - 2))
+
+        if owner:
+            ops.stream(PANEL)
+            ops.wait(_ev2(E_COLREADY, k))
+            wait_free()
+            ops.diag_factor(A, lr, lc, w, g, geo.piece_off(kr), nb, k * nb, geo.n)
+            ops.record(_ev2(E_DFACT, k))
+        if holder:
+            ops.stream(COMM)
+            if owner:
+                ops.wait(_ev2(E_DFACT, k))
+            else:
+                wait_free()
+            comm.bcast_grp(g, geo.piece_off(kr), geo.dsz, kr, COL)      # L_kk (+ leaf inverses) down the process column
+            ops.record(_ev2(E_DBC, k))
+            ops.stream(PANEL)
+            ops.wait(_ev2(E_DBC, k))
+            ops.wait(_ev2(E_COLREADY, k))
+            ops.panel_trsm(A, geo.li0(pr, k) * nb, geo.piece_rows(pr, k), lc, w, g, geo.piece_off(kr),
+                           geo.piece_off(pr) + geo.dsz, nb)
+            ops.record(_ev2(E_PIECE, k))
+        ops.stream(COMM)
+        if holder:
+            ops.wait(_ev2(E_PIECE, k))
+        else:
+            wait_free()
+        comm.panel_bcast(g, geo.pieces(k))                               # every piece to every rank, all links
+        ops.record(_ev2(E_ARRIVED, k))
+        ops.stream(BACK)
+        ops.wait(_ev2(E_ARRIVED, k))
+        if L is not None:
+            ops.unpack_diag(g, geo.piece_off(kr), w, nb, L, k * nb)
+            for p in range(Pr):
+                m = geo.piece_rows(p, k)
+                if m > 0:
+                    ops.unpack_rows(g, geo.piece_off(p) + geo.dsz, m, w, nb, L, p + geo.li0(p, k) * Pr, Pr, k * nb)
+        ops.record(_ev2(E_STORED, k))
+        if on_stored is not None:
+            on_stored(k)
+        ops.stream(MAIN)
+        ops.wait(_ev2(E_ARRIVED, k))
+        cols = geo.my_cols_after(k)
+        if cols and cols[0] == k + 1:                                    # look-ahead: the next panel's column first
+            lr0, m, lc0, n, aoff, boff = geo.update_args(k, k + 1)
+            ops.update(A, lr0, m, lc0, n, g, aoff, boff, w, nb)
+            cols = cols[1:]
+        if k + 1 < geo.nblk and (k + 1) % Pc == pc:
+            ops.record(_ev2(E_COLREADY, k + 1))
+        for J in cols:
+            lr0, m, lc0, n, aoff, boff = geo.update_args(k, J)
+            ops.update(A, lr0, m, lc0, n, g, aoff, boff, w, nb)
+        ops.record(_ev2(E_UPD, k))
+    ops.stream(MAIN)
+    info = ops.info()  # synchronises every stream
+    if L is not None:
+        ops.finish(L)
+    allinfo = comm.allgather(np.array([float(info)]))[:, 0]
+    bad = [int(v) for v in allinfo if v > 0]
+    return min(bad) if bad else 0
+
+
+def dist2_potrs(ops, comm, geo, A, yv, acc_r, acc_c, out):
+    """alpha = K^-1 y on the block-cyclic factor A: block forward substitution (partial sums reduced along the process
+    row of the diagonal owner, the solved block broadcast down its process column), then the transposed sweep with the
+    roles of rows and columns exchanged; the blocks of alpha (one per diagonal owner) are assembled on every rank by one
+    ncclAllReduce.  yv: device vector (padded N) holding y on every rank -- overwritten; acc_r / acc_c: scratch vectors
+    of local_rows / local_cols doubles; out: device vector (padded N) that receives alpha everywhere."""
+    nb, Pr, Pc, pr, pc = geo.nb, geo.Pr, geo.Pc, geo.pr, geo.pc
+    ops.stream(MAIN)
+    ops.vec_op(acc_r, 0, None, 0, max(geo.local_rows(pr), 1), 2)
+    ops.vec_op(acc_c, 0, None, 0, max(geo.local_cols(pc), 1), 2)
+    ops.vec_op(out, 0, None, 0, geo.np, 2)
+    for k in range(geo.nblk):                                   # L w = y
+        kr, kc = k % Pr, k % Pc
+        w = geo.height(k)
+        lr, lc = (k // Pr) * nb, (k // Pc) * nb
+        if pr == kr:
+            comm.reduce_grp(acc_r, lr, w, kc, ROW)              # -(sum_{J<k} L_kJ w_J), one partial per process column
+        if pr == kr and pc == kc:
+            ops.vec_op(yv, k * nb, acc_r, lr, w, 1)
+            ops.trsv_diag(A, lr, lc, w, yv, k * nb, 0)
+        if pc == kc:
+            comm.bcast_grp(yv, k * nb, w, kr, COL)
+            ops.gemv(A, geo.li0(pr, k) * nb, geo.piece_rows(pr, k), lc, w, yv, k * nb, acc_r, geo.li0(pr, k) * nb, 0)
+    for k in reversed(range(geo.nblk)):                         # L^T alpha = w
+        kr, kc = k % Pr, k % Pc
+        w = geo.height(k)
+        lr, lc = (k // Pr) * nb, (k // Pc) * nb
+        if pc == kc:
+            comm.reduce_grp(acc_c, lc, w, kr, COL)              # -(sum_{I>k} L_Ik^T alpha_I), one partial per process row
+        if pr == kr and pc == kc:
+            ops.vec_op(yv, k * nb, acc_c, lc, w, 1)
+            ops.trsv_diag(A, lr, lc, w, yv, k * nb, 1)
+            ops.vec_op(out, k * nb, yv, k * nb, w, 0)
+        if pr == kr:
+            comm.bcast_grp(yv, k * nb, w, kc, ROW)
+            ncb = geo.blocks_before(pc, Pc, k)                  # local block columns J < k
+            ops.gemv(A, lr, w, 0, ncb * nb, yv, k * nb, acc_c, 0, 1)
+    comm.allreduce(out, 0, geo.np)
+    return out
+
+
+def dist2_logdet(ops, comm, geo, A, scal):
+    """log det K = 2 sum log L_ii: every diagonal owner adds its blocks, one ncclAllReduce of a scalar."""
+    ops.stream(MAIN)
+    ops.vec_op(scal, 0, None, 0, 1, 2)
+    for k in range(geo.nblk):
+        if k % geo.Pr == geo.pr and k % geo.Pc == geo.pc:
+            ops.logdet_acc(A, (k // geo.Pr) * geo.nb, (k // geo.Pc) * geo.nb, geo.height(k), geo.height(k), scal)
+    return float(comm.allreduce_host(np.array([ops.vec_to_host(scal, 1)[0]]))[0])
+
+
+class DistFitIvar2D:
+    """bench.py's multi-GPU step on the 2-D block-cyclic layout: distributed fit (local assembly + dist2_potrf), alpha
+    by distributed substitution, logdet / y^T alpha through all-reduce, IVAR with the evaluation points sharded over the
+    ranks against the replicated factor (streamed underneath the factorisation from 4 ranks)."""
+
+    def __init__(self, ctx, comm, spec, Xh, yh, Zh, noise, nb=512, ops=None, streamed=None, grid=None):
+        self.ctx, self.comm, self.spec = ctx, comm, spec
+        self.ops = ops or DeviceOps2D(ctx)
+        Pr, Pc = grid or choose_grid(comm.world)
+        comm.set_grid(Pr, Pc)
+        self.n, self.noise = Xh.shape[0], float(noise)
+        self.geo = Grid2D(self.n, nb, Pr, Pc, comm.rank)
+        env = os.environ.get("GPX_DIST_STREAM_IVAR")
+        self.streamed = (comm.world >= 4) if streamed is None else bool(streamed)
+        if env is not None:
+            self.streamed = env == "1"
+        self.yh = np.ascontiguousarray(yh, dtype=np.float64)
+        self.m = Zh.shape[0]
+        self.X = self.ops.points(Xh)
+        lo, hi = eval_slice(self.m, comm.rank, comm.world)
+        self.Zloc = self.ops.points(Zh[lo:hi]) if hi > lo else None
+        self.A = self.ops.alloc_local(self.geo)
+        self.G = [self.ops.alloc_buf(self.geo), self.ops.alloc_buf(self.geo)]
+        self.L = self.ops.alloc_matrix(self.n)
+        self.yv = self.ops.alloc_vec(self.geo.np)
+        self.alpha = self.ops.alloc_vec(self.geo.np)
+        self.acc_r = self.ops.alloc_vec(self.geo.local_rows(self.geo.pr))
+        self.acc_c = self.ops.alloc_vec(self.geo.local_cols(self.geo.pc))
+        self.scal = self.ops.alloc_vec(8)
+        self.B = self.ops.alloc_cross(self.n, hi - lo) if (self.streamed and hi > lo) else None
+
+    def step(self):
+        ops, comm, geo = self.ops, self.comm, self.geo
+        ops.stream(MAIN)
+        ops.kfill_local(self.spec, self.X, self.A, self.noise, geo)
+        hook = None
+        if self.B is not None:
+            ops.stream(BACK)
+            ops.cross_fill(self.spec, self.X, self.Zloc, self.B)   # independent of the factorisation
+            ops.stream(MAIN)
+
+            def hook(k):
+                ops.stream(BACK)                                    # behind the copy of panel k into L (same stream)
+                ops.ivar_step(self.L, k, geo.nb, self.B)
+
+        info = dist2_potrf(ops, comm, geo, self.A, self.G, L=self.L, on_stored=hook)
+        if info:
+            from ._lib import NotPositiveDefinite
+            raise NotPositiveDefinite(info)
+        ypad = np.zeros(geo.np)
+        ypad[:self.n] = self.yh
+        ops.vec_from_host(self.yv, ypad)
+        dist2_potrs(ops, comm, geo, self.A, self.yv, self.acc_r, self.acc_c, self.alpha)
+        logdet = dist2_logdet(ops, comm, geo, self.A, self.scal)
+        part = 0.0
+        if self.B is not None:     # the solve finished with the last panel (dist2_potrf synchronised every stream)
+            part = float(np.sum(ops.variances(self.spec, self.Zloc, self.B, self.n)))
+        elif self.Zloc is not None:
+            part = float(np.sum(ops.posterior_var(self.spec, self.L, self.X, self.Zloc)))
+        alpha = ops.vec_to_host(self.alpha, self.n)
+        ll = -0.5 * float(self.yh @ alpha) - 0.5 * logdet - self.n / 2.0 * np.log(2 * np.pi)
+        iv = abs(ordered_sum(comm.allgather(np.array([part]))[:, 0]) / self.m)
+        return ll, iv

@@ -83,6 +83,9 @@ int gpx_mat_shape(const gpx_mat* m, int64_t* rows, int64_t* cols, int64_t* ld);
  * Backs the lazy GP.covarianceMatrix / GP.precisionMatrix attributes (gp.py:178-181). */
 int gpx_mat_to_host(gpx_ctx* ctx, const gpx_mat* m, double* dst, int tri);
 
+/* dst[doff : doff+n] = src[soff : soff+n] (mode 0), += src (mode 1), = 0 (mode 2): device-vector glue, asynchronous */
+int gpx_vec_op(gpx_ctx* ctx, gpx_mat* dst, int64_t doff, const gpx_mat* src, int64_t soff, int64_t n, int mode);
+
 /* raw access to the padded storage (element offsets); used by the host-staged communicator in tests */
 int gpx_mat_read(gpx_ctx* ctx, const gpx_mat* m, int64_t offset, int64_t count, double* dst);
 int gpx_mat_write(gpx_ctx* ctx, gpx_mat* m, int64_t offset, int64_t count, const double* src);
@@ -205,6 +208,49 @@ int gpx_dist_panel_update(gpx_ctx* ctx, gpx_mat* K, int64_t k, int64_t nb, const
  * column k of the factor, valid as soon as gpx_dist_panel_store(k) has run; asynchronous on the selected stream */
 int gpx_dist_ivar_step(gpx_ctx* ctx, const gpx_mat* K, int64_t k, int64_t nb, gpx_mat* B);
 int gpx_dist_finish(gpx_ctx* ctx, gpx_mat* K);
+
+/* ---- multi-GPU, 2-D block-cyclic (north_star) ---------------------------------------------------------
+ * Process grid Pr x Pc, rank (pr, pc) = (rank / Pc, rank % Pc).  Global block (I, J) of the padded matrix (block size nb,
+ * a multiple of 128; the last block may be shorter) lives on rank (I % Pr, J % Pc) at local block (I / Pr, J / Pc) of that
+ * rank's LOCAL matrix: every rank allocates only its share.  gpexp_amd/dist.py drives the panel loop (diagonal block
+ * broadcast down the process column on an ncclCommSplit sub-communicator, panel pieces to every rank over all xGMI links,
+ * look-ahead, streamed evaluation) on these primitives; every call is asynchronous on the selected stream unless stated. */
+/* sub-communicators: group 0 = world, 1 = the rank's process row, 2 = its process column (ncclCommSplit) */
+int gpx_comm_grid(gpx_ctx* ctx, int Pr, int Pc);
+int gpx_comm_bcast_grp(gpx_ctx* ctx, gpx_mat* buf, int64_t offset, int64_t count, int root, int grp);
+/* in-place sum inside a group, result on group rank `root` (ncclReduce) / over all ranks, result everywhere (ncclAllReduce) */
+int gpx_comm_reduce_grp(gpx_ctx* ctx, gpx_mat* buf, int64_t offset, int64_t count, int root, int grp);
+int gpx_comm_allreduce(gpx_ctx* ctx, gpx_mat* buf, int64_t offset, int64_t count);
+int gpx_comm_allreduce_host(gpx_ctx* ctx, double* inout, int64_t n);   /* <= 64 host scalars, blocking */
+/* all-link broadcast: npieces regions of buf (same layout on every rank), region i owned by world rank roots[i], reach
+ * every rank as a scatter + all-gather over grouped ncclSend / ncclRecv -- 2/(W-1) of the bytes per xGMI link instead of
+ * all of them over one (ring / tree ncclBroadcast).  Every rank calls it with identical arguments. */
+int gpx_comm_panel_bcast(gpx_ctx* ctx, gpx_mat* buf, const int64_t* offsets, const int64_t* counts, const int* roots,
+                         int npieces);
+/* doubles of a packed diagonal block: nb x nb factor + nb/128 inverted 128 x 128 leaves */
+int64_t gpx_dist2_diag_elems(int64_t nb);
+/* local part of K(X) + nugget on rank (pr, pc)   (gp_kernel_utilities.py:34-68, communication-free) */
+int gpx_dist2_kfill(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* X, const double* nugget,
+                    int64_t nugget_len, gpx_mat* A, int64_t nb, int Pr, int Pc, int pr, int pc);
+/* diagonal owner: factor the w x w block at local (lr, lc) into the D region of the panel buffer G (offset doff) */
+int gpx_dist2_diag_factor(gpx_ctx* ctx, gpx_mat* A, int64_t lr, int64_t lc, int64_t w, gpx_mat* G, int64_t doff,
+                          int64_t nb, int64_t base, int64_t n_valid);
+/* holders of block column k: local rows [lr0, lr0+m) of the column <- X L_kk^-T, packed into G at roff */
+int gpx_dist2_panel_trsm(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t lc, int64_t w, gpx_mat* G, int64_t doff,
+                         int64_t roff, int64_t nb);
+/* A[lr0:lr0+m, lc0:lc0+n] -= G[aoff] (m x w) * G[boff] (n x w)^T : trailing update of one local block column */
+int gpx_dist2_update(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t lc0, int64_t n, const gpx_mat* G,
+                     int64_t aoff, int64_t boff, int64_t w, int64_t nb);
+/* replicated factor for the evaluation phase: piece rows / diagonal block of panel k into the full-size matrix L */
+int gpx_dist2_unpack_rows(gpx_ctx* ctx, const gpx_mat* G, int64_t roff, int64_t m, int64_t w, int64_t nb, gpx_mat* L,
+                          int64_t first_block, int64_t stride, int64_t col0);
+int gpx_dist2_unpack_diag(gpx_ctx* ctx, const gpx_mat* G, int64_t doff, int64_t w, int64_t nb, gpx_mat* L, int64_t r0);
+/* distributed forward / back substitution on the block-cyclic factor: diagonal-block solve, block GEMV, log-det partial */
+int gpx_dist2_trsv_diag(gpx_ctx* ctx, const gpx_mat* A, int64_t lr, int64_t lc, int64_t w, gpx_mat* v, int64_t voff,
+                        int transposed);
+int gpx_dist2_gemv(gpx_ctx* ctx, const gpx_mat* A, int64_t lr0, int64_t m, int64_t lc, int64_t w, const gpx_mat* x,
+                   int64_t xoff, gpx_mat* acc, int64_t aoff, int transposed);
+int gpx_dist2_logdet_acc(gpx_ctx* ctx, const gpx_mat* A, int64_t lr, int64_t lc, int64_t w, int64_t n_valid, gpx_mat* acc);
 
 /* out[j] = sum over the first `rows` rows of B[i][j]^2 (host out[B->cols]): variance reduction of a solved cross matrix */
 int gpx_col_sumsq(gpx_ctx* ctx, const gpx_mat* B, int64_t rows, double* out);

@@ -132,10 +132,164 @@ class NumpyOps:
         return self.orc.kernel_diag(self.spec, Z) - np.sum(B.a[:n] ** 2, axis=0)
 
 
+class NumpyOps2D(NumpyOps):
+    """NumPy double of gpexp_amd.dist.DeviceOps2D: same call signatures, same packed-buffer layout, executed
+    synchronously -- checks the index logic of the 2-D block-cyclic loop (ownership, piece offsets, update operands,
+    unpacking into the replicated factor, the distributed substitution sweeps)."""
+    poison = True   # unwritten storage is NaN and every read of it asserts; switched off for the non-PD run (inf - inf)
+
+    def alloc_local(self, geo):
+        return NumpyMat(np.full((max(geo.local_rows(geo.pr), 1), max(geo.local_cols(geo.pc), 1)), np.nan))
+
+    def alloc_buf(self, geo):
+        return NumpyMat(np.full(geo.buf_elems(), np.nan))
+
+    def alloc_vec(self, n):
+        return NumpyMat(np.zeros(max(int(n), 1)))
+
+    def points(self, x):
+        return np.asarray(x, dtype=float)
+
+    def kfill_local(self, spec, X, A, nugget, geo):
+        n, nb = X.shape[0], geo.nb
+        full = np.eye(geo.np)
+        full[:n, :n] = self.orc.cov_matrix(self.spec, X, float(nugget), row_loop=False)
+        A.a[:] = np.nan
+        for I in range(geo.pr, geo.nblk, geo.Pr):
+            for J in range(geo.pc, geo.nblk, geo.Pc):
+                if I >= J:
+                    A.a[(I // geo.Pr) * nb:(I // geo.Pr) * nb + geo.height(I),
+                        (J // geo.Pc) * nb:(J // geo.Pc) * nb + geo.height(J)] = \
+                        full[I * nb:I * nb + geo.height(I), J * nb:J * nb + geo.height(J)]
+
+    @staticmethod
+    def _D(G, doff, nb):
+        return G.a[doff:doff + nb * nb].reshape(nb, nb)
+
+    def diag_factor(self, A, lr, lc, w, G, doff, nb, base, n_valid):
+        blk = A.a[lr:lr + w, lc:lc + w]
+        assert not self.poison or not np.isnan(np.tril(blk)).any(), "owner factors a diagonal block it never assembled/updated"
+        try:
+            L11 = np.linalg.cholesky(np.tril(blk) + np.tril(blk, -1).T)
+        except (np.linalg.LinAlgError, ValueError):
+            if self._info == 0:
+                self._info = base + 1
+            L11 = np.eye(w)
+        D = self._D(G, doff, nb)
+        D[:] = 0.0
+        D[:w, :w] = L11
+        A.a[lr:lr + w, lc:lc + w] = L11
+        inv = G.a[doff + nb * nb: doff + nb * nb + (nb // 128) * 128 * 128]
+        inv[:] = 0.0
+        for q in range(w // 128):
+            inv[q * 128 * 128:(q + 1) * 128 * 128] = np.linalg.inv(L11[q * 128:(q + 1) * 128, q * 128:(q + 1) * 128]).ravel()
+        self.aux[("A", lr)] = inv[:(w // 128) * 128 * 128].copy()
+
+    def panel_trsm(self, A, lr0, m, lc, w, G, doff, roff, nb):
+        if m == 0:
+            return
+        L11 = self._D(G, doff, nb)[:w, :w]
+        assert not self.poison or not np.isnan(L11).any(), "holder solves against a diagonal block that never arrived"
+        X = A.a[lr0:lr0 + m, lc:lc + w]
+        assert not self.poison or not np.isnan(X).any(), "holder solves rows it never assembled/updated"
+        X[:] = np.linalg.solve(L11, X.T).T
+        rows = G.a[roff:roff + m * nb].reshape(m, nb)
+        rows[:] = 0.0
+        rows[:, :w] = X
+
+    def update(self, A, lr0, m, lc0, n, G, aoff, boff, w, nb):
+        if m == 0 or n == 0:
+            return
+        a = G.a[aoff:aoff + m * nb].reshape(m, nb)[:, :w]
+        b = G.a[boff:boff + n * nb].reshape(n, nb)[:, :w]
+        assert not self.poison or not (np.isnan(a).any() or np.isnan(b).any()), "update reads a piece that never arrived"
+        A.a[lr0:lr0 + m, lc0:lc0 + n] -= a @ b.T
+
+    def unpack_rows(self, G, roff, m, w, nb, L, first_block, stride, col0):
+        rows = G.a[roff:roff + m * nb].reshape(m, nb)[:, :w]
+        for t in range((m + nb - 1) // nb):
+            h = min(nb, m - t * nb)
+            g0 = (first_block + t * stride) * nb
+            L.a[g0:g0 + h, col0:col0 + w] = rows[t * nb:t * nb + h]
+
+    def unpack_diag(self, G, doff, w, nb, L, r0):
+        L.a[r0:r0 + w, r0:r0 + w] = self._D(G, doff, nb)[:w, :w]
+
+    def trsv_diag(self, A, lr, lc, w, v, voff, transposed):
+        Lkk = np.tril(A.a[lr:lr + w, lc:lc + w])
+        v.a[voff:voff + w] = np.linalg.solve(Lkk.T if transposed else Lkk, v.a[voff:voff + w])
+
+    def gemv(self, A, lr0, m, lc, w, x, xoff, acc, aoff, transposed):
+        if m == 0 or w == 0:
+            return
+        blk = A.a[lr0:lr0 + m, lc:lc + w]
+        assert not np.isnan(blk).any(), "substitution reads a block of the factor that was never written"
+        if transposed:
+            acc.a[aoff:aoff + w] -= blk.T @ x.a[xoff:xoff + m]
+        else:
+            acc.a[aoff:aoff + m] -= blk @ x.a[xoff:xoff + w]
+
+    def logdet_acc(self, A, lr, lc, w, n_valid, acc):
+        acc.a[0] += 2.0 * np.sum(np.log(np.diag(A.a[lr:lr + w, lc:lc + w])[:n_valid]))
+
+    def vec_op(self, dst, doff, src, soff, n, mode):
+        if mode == 2:
+            dst.a[doff:doff + n] = 0.0
+        elif mode == 1:
+            dst.a[doff:doff + n] += src.a[soff:soff + n]
+        else:
+            dst.a[doff:doff + n] = src.a[soff:soff + n]
+
+    def vec_to_host(self, v, n):
+        return v.a[:n].copy()
+
+    def vec_from_host(self, v, a):
+        v.a[:len(a)] = a
+
+    def alloc_matrix(self, n):
+        np_ = dist.padded(n)
+        return NumpyMat(np.full((np_, np_), np.nan))
+
+    def finish(self, L):
+        pass
+
+    def posterior_var(self, spec, L, X, Z):
+        n = X.shape[0]
+        W = np.linalg.solve(np.tril(L.a[:n, :n]), self.orc.cross_matrix(self.spec, Z, X).T)
+        return self.orc.kernel_diag(self.spec, Z) - np.sum(W ** 2, axis=0)
+
+
 class NumpyComm:
     def __init__(self):
         self.group = dist._TorchGroup()
         self.rank, self.world = self.group.rank, self.group.world
+
+    # 2-D path: same interface as gpexp_amd.dist.RcclComm, on host arrays over gloo
+    def set_grid(self, Pr, Pc):
+        if getattr(self, "grid", None) != (Pr, Pc):
+            self.group.make_grid(Pr, Pc)
+            self.grid = (Pr, Pc)
+
+    def bcast_grp(self, buf, offset, count, root, grp):
+        seg = np.ascontiguousarray(buf.a[offset:offset + count])
+        buf.a[offset:offset + count] = self.group.bcast_array_grp(seg, root, grp)
+
+    def reduce_grp(self, buf, offset, count, root, grp):
+        seg = np.ascontiguousarray(buf.a[offset:offset + count])
+        buf.a[offset:offset + count] = self.group.reduce_array_grp(seg, root, grp)
+
+    def allreduce(self, buf, offset, count):
+        seg = np.ascontiguousarray(buf.a[offset:offset + count])
+        buf.a[offset:offset + count] = self.group.allreduce_array(seg)
+
+    def allreduce_host(self, vec):
+        return self.group.allreduce_array(np.array(np.atleast_1d(vec), dtype=np.float64))
+
+    def panel_bcast(self, buf, pieces):
+        for off, cnt, root in pieces:
+            seg = np.ascontiguousarray(buf.a[off:off + cnt])
+            self.group.bcast_array(seg, root)
+            buf.a[off:off + cnt] = seg
 
     def bcast_panel(self, P, count, root):
         buf = np.ascontiguousarray(P.a[:count])
@@ -209,6 +363,122 @@ def run_cpu(args):
         print("DIST_OK cpu world=%d n=%d nb=%d maxerr=%.2e" % (comm.world, args.n, args.nb, float(allerr.max())), flush=True)
 
 
+def run_cpu2d(args):
+    """The real 2-D block-cyclic loop (dist2_potrf / dist2_potrs / dist2_logdet / DistFitIvar2D) over gloo with the NumPy
+    double: factor (distributed AND replicated copies), non-PD agreement, streamed hook order, alpha, logdet, IVAR."""
+    from oracle import gpexp_oracle as orc
+    rng = np.random.default_rng(args.n)
+    d = 3
+    n, nb = args.n, args.nb
+    X = rng.uniform(-1, 1, (n, d))
+    y = np.sin(2 * np.pi * X.sum(1) / d) + 0.2 * rng.standard_normal(n)
+    Z = rng.uniform(-1, 1, (53 + 2 * int(os.environ.get("WORLD_SIZE", "1")), d))
+    spec = dict(kind="se", cl=[0.3], signalSize=1.0, d=d)
+    comm = NumpyComm()
+    grid = tuple(int(v) for v in args.grid.split("x")) if args.grid else dist.choose_grid(comm.world)
+    ops = NumpyOps2D(spec)
+    Kref = orc.cov_matrix(spec, X, 0.05, row_loop=False)
+    Lref = np.linalg.cholesky(Kref)
+    aref = np.linalg.solve(Kref, y)
+    for streamed in (False, True):
+        run = dist.DistFitIvar2D(None, comm, None, X, y, Z, 0.05, nb=nb, ops=ops, streamed=streamed, grid=grid)
+        geo = run.geo
+        assert (geo.Pr, geo.Pc) == grid and geo.Pr * geo.Pc == comm.world
+        seen = []
+        if streamed:
+            orig = ops.ivar_step
+
+            def spy(K, k, nb_, B):
+                seen.append(k)
+                orig(K, k, nb_, B)
+            ops.ivar_step = spy
+        ll, iv = run.step()
+        if streamed:
+            ops.ivar_step = orig
+            if run.B is not None:
+                assert seen == list(range(geo.nblk)), seen
+        # replicated factor on every rank
+        L = np.tril(run.L.a[:n, :n])
+        err = np.max(np.abs(L - Lref)) / np.max(np.abs(Lref))
+        assert err < 1e-12, err
+        # the local matrix holds exactly this rank's blocks of the factor (2-D block-cyclic)
+        for I in range(geo.pr, geo.nblk, geo.Pr):
+            for J in range(geo.pc, geo.nblk, geo.Pc):
+                if I >= J:
+                    hi_, hj_ = min(geo.height(I), n - I * nb), min(geo.height(J), n - J * nb)
+                    if hi_ <= 0 or hj_ <= 0:
+                        continue
+                    loc = run.A.a[(I // geo.Pr) * nb:(I // geo.Pr) * nb + hi_, (J // geo.Pc) * nb:(J // geo.Pc) * nb + hj_]
+                    ref = Lref[I * nb:I * nb + hi_, J * nb:J * nb + hj_]
+                    if I == J:
+                        loc, ref = np.tril(loc), np.tril(ref)
+                    assert np.max(np.abs(loc - ref)) <= 1e-12 * np.max(np.abs(Lref)), (I, J)
+        alpha = run.ops.vec_to_host(run.alpha, n)
+        assert np.max(np.abs(alpha - aref)) <= 1e-10 * np.max(np.abs(aref))
+        llref = -0.5 * y @ aref - 0.5 * np.linalg.slogdet(Kref)[1] - n / 2.0 * np.log(2 * np.pi)
+        assert abs(ll - llref) <= 1e-11 * abs(llref), (ll, llref)
+        m_ref = orc.fit(spec, X, np.zeros(n), 0.05)
+        ivref = abs(np.mean(orc.posterior(spec, m_ref, Z, compvar=1)[1]))
+        assert abs(iv - ivref) <= 1e-10 * ivref, (iv, ivref)
+    # non-positive-definite input: every rank reports the same pivot
+    geo = run.geo
+    ops.poison = False
+    ops.kfill_local(None, X, run.A, 0.05, geo)
+    if geo.owner_rank(0, 0) == comm.rank:
+        run.A.a[5, 5] = -1.0
+    info = dist.dist2_potrf(ops, comm, geo, run.A, run.G, L=run.L)
+    assert info == 1, info
+    if comm.rank == 0:
+        print("DIST_OK cpu2d world=%d grid=%dx%d n=%d nb=%d maxerr=%.2e" % (comm.world, geo.Pr, geo.Pc, n, nb, err),
+              flush=True)
+
+
+def run_gpu2d(args):
+    """2-D path on the real HIP primitives: ranks share GPU 0 and exchange through the host-staged gloo communicator."""
+    from gpexp_amd import device as dev
+    ctx = dev.Context(int(os.environ.get("GPX_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+    dev._ctx = ctx
+    comm = dist.init_from_env(ctx)
+    rng = np.random.default_rng(args.n)
+    d = 4
+    N, M = args.n, args.m
+    Xh = rng.uniform(-1, 1, (N, d))
+    yh = np.sin(2 * np.pi * Xh.sum(1) / d) + 0.3 * rng.standard_normal(N)
+    Zh = rng.uniform(-1, 1, (M, d))
+    spec = dev.KernelSpec(dev.K_MATERN52, d, [0.5, 1.0])
+    grid = tuple(int(v) for v in args.grid.split("x")) if args.grid else None
+    runner = dist.DistFitIvar2D(ctx, comm, spec, Xh, yh, Zh, 0.1, nb=args.nb, grid=grid)
+    ll, iv = runner.step()
+    ll2, iv2 = runner.step()  # second step re-assembles in place
+    assert ll == ll2 and iv == iv2, (ll, ll2, iv, iv2)
+    other = dist.DistFitIvar2D(ctx, comm, spec, Xh, yh, Zh, 0.1, nb=args.nb, streamed=not runner.streamed, grid=grid)
+    ll3, iv3 = other.step()
+    assert abs(iv3 - iv) <= 1e-11 * abs(iv) and abs(ll3 - ll) <= 1e-12 * abs(ll), (iv, iv3, ll, ll3)
+    del other
+    Ld = runner.L.to_host(tri=1)
+    X = dev.points(ctx, Xh)
+    K1 = dev.kfill(ctx, spec, X, nugget=0.1)
+    dev.potrf(ctx, K1)
+    L1 = K1.to_host(tri=1)
+    errL = float(np.max(np.abs(Ld - L1)) / np.max(np.abs(L1)))
+    alpha1 = dev.potrs(ctx, K1, yh)
+    ll1 = -0.5 * float(yh @ alpha1) - 0.5 * dev.logdet(ctx, K1) - N / 2.0 * np.log(2 * np.pi)
+    iv1 = abs(dev.ivar(ctx, spec, K1, X, dev.points(ctx, Zh)))
+    assert errL < 1e-12, errL
+    alpha = runner.ops.vec_to_host(runner.alpha, N)
+    assert np.max(np.abs(alpha - alpha1)) <= 1e-10 * np.max(np.abs(alpha1))
+    assert abs(ll - ll1) <= 1e-11 * abs(ll1), (ll, ll1)      # every rank has the log-likelihood (all-reduced pieces)
+    assert abs(iv - iv1) <= 1e-11 * abs(iv1), (iv, iv1)
+    errs = comm.allgather(np.array([errL]))[:, 0]
+    comm.barrier()
+    if comm.rank == 0:
+        print("DIST_OK gpu2d world=%d grid=%dx%d n=%d nb=%d comm=%s errL=%.2e ll=%.12g ivar=%.12g" %
+              (comm.world, runner.geo.Pr, runner.geo.Pc, N, args.nb, type(comm).__name__, float(errs.max()), ll, iv),
+              flush=True)
+    comm.close()
+    ctx.close()
+
+
 def run_gpu(args):
     from gpexp_amd import device as dev
     ctx = dev.Context(int(os.environ.get("GPX_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
@@ -273,5 +543,12 @@ if __name__ == "__main__":
     ap.add_argument("--npts", dest="n", type=int, default=700)
     ap.add_argument("--mpts", dest="m", type=int, default=333)
     ap.add_argument("--blk", dest="nb", type=int, default=256)
+    ap.add_argument("--grid", default="")
     a = ap.parse_args()
-    (run_cpu if a.mode == "cpu" else run_gpu)(a)
+    print("WORKER_UP rank=%s mode=%s" % (os.environ.get("RANK", "0"), a.mode), flush=True)
+    {"cpu": run_cpu, "gpu": run_gpu, "cpu2d": run_cpu2d, "gpu2d": run_gpu2d}[a.mode](a)
+    if "torch" in sys.modules:  # orderly gloo teardown: a rank that exits while its peers still hold sub-group
+        import torch.distributed as td   # connections aborts in a gloo thread (the RCCL path never imports torch)
+        if td.is_initialized():
+            td.barrier()
+            td.destroy_process_group()

@@ -1,6 +1,8 @@
-"""Multi-rank tests.  CPU (-m "not gpu"): pure index logic + the real panel loop over gloo with world_size 2 and 3
-and a NumPy device double.  GPU (-m gpu): real kernels, 2 and 3 ranks sharing the GPU through the host-staged
-communicator, and the RCCL communicator with world_size 1."""
+"""Multi-rank tests.  CPU (-m "not gpu"): pure index logic + the real panel loops over gloo with a NumPy device double:
+the 2-D block-cyclic path (north_star) at world 2, 4, 6 and 8 on 1x2 / 2x2 / 2x3 / 2x4 grids with ragged N, and the 1-D
+block-column path at world 2 and 3.  GPU (-m gpu): real kernels, 2 to 6 ranks sharing the GPU through the host-staged
+communicator, and the RCCL communicator (ncclCommSplit, grouped send/recv) with world_size 1 -- RCCL with more than one
+rank needs more than one GPU and has not run anywhere yet."""
 import os
 import socket
 import subprocess
@@ -29,11 +31,14 @@ def launch(world, extra, env_extra=None, timeout=600):
                "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
                os.path.join(ROOT, "tests", "dist_worker.py")] + extra
         r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
-        # the port is picked, released and only then bound by the launcher: a rendezvous that lost that race (address in
-        # use / connection refused before any worker ran) is retried once on a fresh port; worker failures are not
-        if r.returncode == 0 or not any(m in r.stderr for m in ("EADDRINUSE", "Address already in use",
-                                                                  "DistNetworkError", "Connection refused")):
+        # the port is picked, released and only then bound by the launcher: a rendezvous that lost that race is retried
+        # once on a fresh port -- but ONLY when no worker got as far as its first line (every worker prints WORKER_UP
+        # right after the process group is up), so a rank dying mid-run is never retried into a pass
+        started = "WORKER_UP" in r.stdout or "WORKER_UP" in r.stderr
+        if r.returncode == 0 or started or not any(m in r.stderr for m in ("EADDRINUSE", "Address already in use",
+                                                                             "DistNetworkError", "Connection refused")):
             break
+        print("launcher retry after rendezvous failure:\n" + r.stderr[-1500:], file=sys.stderr)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "DIST_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     return r.stdout
@@ -62,6 +67,65 @@ def test_index_logic():
 def test_panel_loop_gloo_cpu(world, n, nb):
     out = launch(world, ["--mode", "cpu", "--npts", str(n), "--blk", str(nb)])
     assert "world=%d" % world in out
+
+
+@pytest.mark.parametrize("world,n,nb,grid", [(2, 700, 128, ""), (4, 1000, 256, ""), (6, 900, 128, ""), (8, 1300, 128, ""),
+                                             (8, 333, 256, ""), (4, 1100, 256, "4x1")])
+def test_panel_loop_2d_gloo_cpu(world, n, nb, grid):
+    """North-star layout: Pr x Pc block-cyclic ownership, column-communicator diagonal broadcast, all-rank panel pieces,
+    look-ahead order, replicated + distributed factor, distributed substitution (reduce / bcast on sub-groups),
+    all-reduced log-determinant, streamed evaluation hook -- on gloo with the NumPy device double."""
+    out = launch(world, ["--mode", "cpu2d", "--npts", str(n), "--blk", str(nb), "--grid", grid], timeout=900)
+    assert "world=%d" % world in out
+    if not grid:
+        from gpexp_amd import dist
+        assert "grid=%dx%d" % dist.choose_grid(world) in out
+
+
+def test_grid_logic():
+    from gpexp_amd import dist
+    assert [dist.choose_grid(w) for w in (1, 2, 3, 4, 6, 8, 16)] == [(1, 1), (1, 2), (1, 3), (2, 2), (2, 3), (2, 4), (4, 4)]
+    n, nb = 5000, 512
+    for Pr, Pc in ((2, 4), (1, 2), (2, 2), (3, 2)):
+        geos = [dist.Grid2D(n, nb, Pr, Pc, r) for r in range(Pr * Pc)]
+        g0 = geos[0]
+        assert g0.nblk == 10 and g0.np == 5120 and g0.height(9) == 512
+        # every block of the lower triangle has exactly one owner, local shapes add up to the padded order
+        assert sum(g.local_rows(g.pr) for g in geos if g.pc == 0) == g0.np
+        assert sum(g.local_cols(g.pc) for g in geos if g.pr == 0) == g0.np
+        for k in range(g0.nblk):
+            # the pieces of a panel partition its rows below the diagonal block
+            assert sum(g0.piece_rows(p, k) for p in range(Pr)) == g0.np - (k + 1) * nb
+            roots = {root for _, _, root in g0.pieces(k)}
+            assert all(r % Pc == k % Pc for r in roots)                    # pieces come from the process column of k
+            for g in geos:
+                for J in g.my_cols_after(k):
+                    lr0, m, lc0, ncols, aoff, boff = g.update_args(k, J)
+                    assert J % Pc == g.pc and lc0 == (J // Pc) * nb and ncols == g.height(J)
+                    assert lr0 + m == g.local_rows(g.pr)
+                    assert aoff + m * nb <= g.buf_elems() and boff + ncols * nb <= g.buf_elems()
+    g = dist.Grid2D(700, 256, 2, 4, 5)     # ragged: padded 768 = 3 blocks of 256
+    assert g.nblk == 3 and [g.height(i) for i in range(3)] == [256, 256, 256]
+    g = dist.Grid2D(333, 256, 1, 3, 1)     # padded 384: last block is 128 tall
+    assert g.nblk == 2 and g.height(1) == 128
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n,nb,grid", [(2, 1500, 256, ""), (4, 2100, 256, ""), (6, 1900, 128, ""), (4, 900, 512, "4x1")])
+def test_distributed_fit_ivar_2d_shared_gpu(world, n, nb, grid):
+    """The 2-D path on the real HIP primitives (ranks share the GPU, host-staged exchange): replicated factor, alpha,
+    log-likelihood and IVAR equal the single-GPU path; both evaluation schedules; repeatable bit for bit."""
+    out = launch(world, ["--mode", "gpu2d", "--npts", str(n), "--mpts", "777", "--blk", str(nb), "--grid", grid],
+                 {"GPX_COMM": "host", "GPX_FORCE_DEVICE": "0"}, timeout=900)
+    assert "HostStagedComm" in out
+
+
+@pytest.mark.gpu
+def test_rccl_2d_world1():
+    """RCCL code path of the 2-D loop at world 1: ncclCommSplit sub-communicators, group broadcasts / reductions, the
+    grouped send/recv panel broadcast (degenerate: nothing to send) and the all-reduces."""
+    out = launch(1, ["--mode", "gpu2d", "--npts", "1100", "--mpts", "300", "--blk", "256"], {"GPX_COMM": "rccl"})
+    assert "RcclComm" in out
 
 
 @pytest.mark.gpu
