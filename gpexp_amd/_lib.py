@@ -96,7 +96,9 @@ _SIGS = {
     "gpx_event_record": (C.c_int, [c_vp, C.c_int]),
     "gpx_event_wait": (C.c_int, [c_vp, C.c_int]),
     "gpx_dist_finish": (C.c_int, [c_vp, c_vp]),
-    "gpx_ivar_grad": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_dp]),
+    "gpx_ivar_grad": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_dp, c_dp]),
+    "gpx_var_grad": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_dp, c_dp, c_dp, c_dp]),
+    "gpx_var_grad_newpt": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_dp]),
     "gpx_profile_enable": (C.c_int, [c_vp, C.c_int]),
     "gpx_profile_reset": (C.c_int, [c_vp]),
     "gpx_profile_get": (C.c_int, [c_vp, C.c_int, c_ip, c_dp, c_dp, c_dp]),
@@ -122,7 +124,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.gpx_abi_version() != 1:
+    if lib.gpx_abi_version() != 2:
         raise ImportError("gpexp_amd: libgpx_hip.so ABI version mismatch")
     _lib = lib
     return lib

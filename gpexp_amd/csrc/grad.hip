@@ -1,27 +1,67 @@
-// f1: gradient of the integrated posterior variance w.r.t. the design (training) points -- gfx950.
+// f1: gradients of the posterior variance w.r.t. point locations -- gfx950.
 //
-// Replaces costFunctionGP_IVAR.derivative (experimentalDesign.py:168-172) -> GP.evaluateVarianceDerivative
-// (gp.py:282-341), which builds an (N*d x M) matrix with O(N*d) dense N x N products in Python and then averages its
-// columns.  With beta = K^-1 K(X,Z) (N x M) and S = beta beta^T (N x N) the averaged gradient collapses to
+// Replaces GP.evaluateVarianceDerivative (gp.py:282-341: an (N*d x M) matrix built from O(N*d) dense N x N products in
+// Python), GP.evaluateVarianceDerivWRTnewpt (gp.py:261-280) and costFunctionGP_IVAR.derivative (experimentalDesign.py:
+// 168-179: the column mean of the former), for the two kernels the reference differentiates: the squared exponential
+// (kernels.py:146-181) and the 1-D Mehler kernel (kernels.py:295-324), with or without a heteroscedastic noise model
+// (gp.py:314-320).  Nothing N x N ever goes to the host.
 //
-//   G[a,l] = -2 s / cl_l^2 * [ sum_n beta[a,n] (z_n,l - x_a,l) k(z_n, x_a)  +  sum_i S[a,i] (x_a,l - x_i,l) k(x_a, x_i) ],
-//   dIVAR/dx_{a,l} = G[a,l] / M
-//
-// (squared-exponential kernel; the extra factor s is the reference's own convention: kernels.py:177 multiplies the
-// kernel value, which already contains signalSize, by signalSize again -- kept for parity).  beta comes from two
-// triangular solves against the factor (W = L^-1 K(X,Z), beta^T = W^T L^-1), S from one MFMA GEMM, and the two sums
-// from one fused row kernel that recomputes the kernel values from the coordinates.
+// Notation: dk(u, p)[l] = d k(u, p) / d u_l in the REFERENCE's convention --
+//     SE        -s (u_l - p_l) / cl_l^2 * k(u, p)   with k already containing s: the doubled signalSize of kernels.py:177
+//     Mehler1D  -(t^2 u - t p) / (1 - t^2) * k(u, p)
+// beta = K^-1 K(X, Z) (N x M, two triangular solves against the factor), nd[j][l] = d noise(x_j) / d x_jl (optional).
+// With c_jl[i] = dk(x_j, x_i)[l] + [x_i == x_j] nd[j][l]   (gp.py:310, 316: `indUse` marks coincident training points)
+// and  T_j[m][l] = -dk(z_m, x_j)[l]                        (gp.py:312)
+//     d var(z_m) / d x_jl = beta[j][m] * ( -2 T_j[m][l] + 2 sum_i c_jl[i] beta[i][m] - c_jl[j] beta[j][m] )     (gp.py:322-338)
+// The sum over i is one MFMA GEMM per coordinate (A_l = [c_jl[i]] is N x N, C_l = A_l beta); its column mean -- the IVAR
+// gradient -- collapses to one GEMM S = beta beta^T and a fused row kernel:
+//     d IVAR / d x_jl = 1/M ( -2 sum_m beta[j][m] T_j[m][l] + 2 sum_i c_jl[i] S[j][i] - c_jl[j] S[j][j] ).
 #include "gpx_internal.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
-// one workgroup per design point a: T[a][l] = sum_n Bm[a][n] k(z_n,x_a)(z_n,l - x_a,l) + sum_i S[a][i] k0(x_a,x_i)(x_a,l - x_i,l)
+// k(a, b) and, through `dk`, the reference's point derivative (SE any d; Mehler d == 1)
+__device__ __forceinline__ double kval(const KParams& kp, const double* __restrict__ a, const double* __restrict__ b) {
+  if (kp.kind == GPX_K_MEHLER) {
+    double pa = 0.0, pb = 0.0, cr = 0.0;
+    for (int k = 0; k < kp.d; ++k) {
+      pa = fma(kp.c1[k] * a[k], a[k], pa);
+      pb = fma(kp.c1[k] * b[k], b[k], pb);
+      cr = fma(kp.c2[k] * a[k], b[k], cr);
+    }
+    return kp.sig * exp(-(pa + pb - cr));
+  }
+  double r2 = 0.0;
+  for (int k = 0; k < kp.d; ++k) {
+    const double e = (a[k] - b[k]) * kp.scale[k];  // difference first (kernels.py:121-122)
+    r2 = fma(e, e, r2);
+  }
+  return kp.sig * exp(-0.5 * r2);
+}
+
+// d k(u, p) / d u_l given kv = k(u, p)
+__device__ __forceinline__ double dk(const KParams& kp, double ul, double pl, int l, double kv) {
+  if (kp.kind == GPX_K_MEHLER) return -(2.0 * kp.c1[l] * ul - kp.c2[l] * pl) * kv;
+  return -kp.sig * (ul - pl) * kp.scale[l] * kp.scale[l] * kv;
+}
+
+// coincident training points: np.linalg.norm(pp - p) < 1e-10 (gp.py:308)
+__device__ __forceinline__ bool same_point(const double* __restrict__ a, const double* __restrict__ b, int d) {
+  double s = 0.0;
+  for (int k = 0; k < d; ++k) s = fma(a[k] - b[k], a[k] - b[k], s);
+  return sqrt(s) < 1e-10;
+}
+
+// ---- IVAR gradient: one workgroup per design point a ------------------------------------------------------------------
+// grad[a][l] = 1/M ( 2 sum_m Bm[a][m] dk(z_m, x_a)[l] + 2 sum_i c_al[i] S[a][i] - c_al[a] S[a][a] )
 __global__ __launch_bounds__(256) void ivar_grad_row_kernel(KParams kp, const double* __restrict__ X, int64_t n,
                                                             const double* __restrict__ Z, int64_t m,
                                                             const double* __restrict__ Bm, int64_t ldb,
                                                             const double* __restrict__ S, int64_t lds_,
-                                                            double scale_out, double* __restrict__ grad) {
+                                                            const double* __restrict__ nd, double inv_m,
+                                                            double* __restrict__ grad) {
   __shared__ double red[256];
   __shared__ double xa[GPX_MAXD];
   const int64_t a = blockIdx.x;
@@ -32,39 +72,26 @@ __global__ __launch_bounds__(256) void ivar_grad_row_kernel(KParams kp, const do
   double acc[GPX_MAXD];
 #pragma unroll
   for (int l = 0; l < GPX_MAXD; ++l) acc[l] = 0.0;
-  // evaluation points
+  // evaluation points: -2 beta T = 2 beta dk(z, x_a)
   for (int64_t j = t; j < m; j += 256) {
-    double r2 = 0.0;
-    double dz[GPX_MAXD];
-#pragma unroll
-    for (int l = 0; l < GPX_MAXD; ++l) {
-      if (l < d) {
-        dz[l] = Z[j * d + l] - xa[l];
-        const double e = dz[l] * kp.scale[l];
-        r2 = fma(e, e, r2);
-      }
-    }
-    const double w = Bm[a * ldb + j] * kp.sig * exp(-0.5 * r2);
+    const double* z = Z + j * d;
+    const double w = 2.0 * Bm[a * ldb + j] * kval(kp, z, xa);
 #pragma unroll
     for (int l = 0; l < GPX_MAXD; ++l)
-      if (l < d) acc[l] = fma(w, dz[l], acc[l]);
+      if (l < d) acc[l] += dk(kp, z[l], xa[l], l, w);
   }
-  // other design points
+  // other design points: 2 c_al[i] S[a][i]; the diagonal entry counts once (2 c S - c S)
   for (int64_t i = t; i < n; i += 256) {
-    double r2 = 0.0;
-    double dx[GPX_MAXD];
-#pragma unroll
-    for (int l = 0; l < GPX_MAXD; ++l) {
-      if (l < d) {
-        dx[l] = xa[l] - X[i * d + l];
-        const double e = dx[l] * kp.scale[l];
-        r2 = fma(e, e, r2);
-      }
-    }
-    const double w = S[a * lds_ + i] * kp.sig * exp(-0.5 * r2);
+    const double* xi = X + i * d;
+    const double sai = (i == a ? 1.0 : 2.0) * S[a * lds_ + i];
+    const double w = sai * kval(kp, xa, xi);
+    const bool dup = nd != nullptr && (i == a || same_point(xa, xi, d));
 #pragma unroll
     for (int l = 0; l < GPX_MAXD; ++l)
-      if (l < d) acc[l] = fma(w, dx[l], acc[l]);
+      if (l < d) {
+        acc[l] += dk(kp, xa[l], xi[l], l, w);
+        if (dup) acc[l] += sai * nd[a * d + l];
+      }
   }
   // deterministic tree reduction per coordinate
   for (int l = 0; l < d; ++l) {
@@ -78,7 +105,89 @@ __global__ __launch_bounds__(256) void ivar_grad_row_kernel(KParams kp, const do
       if (t < w) red[t] += red[t + w];
       __syncthreads();
     }
-    if (t == 0) grad[a * d + l] = scale_out * kp.sig * kp.scale[l] * kp.scale[l] * red[0];
+    if (t == 0) grad[a * d + l] = inv_m * red[0];
+    __syncthreads();
+  }
+}
+
+// ---- full matrix: A_l[j][i] = c_jl[i] (np x np, zero outside the n x n block) ----------------------------------------
+__global__ __launch_bounds__(256) void dcov_kernel(KParams kp, const double* __restrict__ X, int64_t n, int l,
+                                                   const double* __restrict__ nd, double* __restrict__ A, int64_t lda,
+                                                   int64_t np) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t j = blockIdx.y;
+  if (i >= np) return;
+  double v = 0.0;
+  if (i < n && j < n) {
+    const int d = kp.d;
+    const double* xj = X + j * d;
+    const double* xi = X + i * d;
+    v = dk(kp, xj[l], xi[l], l, kval(kp, xj, xi));
+    if (nd != nullptr && (i == j || same_point(xj, xi, d))) v += nd[j * d + l];
+  }
+  A[j * lda + i] = v;
+}
+
+// out[j][m] = beta[j][m] * ( 2 dk(z_m, x_j)[l] (+ 2 dkb[j][l]) + 2 C[j][m] - A[j][j] beta[j][m] )  for coordinate l
+__global__ __launch_bounds__(256) void var_grad_finish_kernel(KParams kp, const double* __restrict__ X, int64_t n,
+                                                              const double* __restrict__ Z, int64_t m, int l,
+                                                              const double* __restrict__ beta, int64_t ldb,
+                                                              const double* __restrict__ Cl,
+                                                              const double* __restrict__ A, int64_t lda,
+                                                              const double* __restrict__ dkb,
+                                                              double* __restrict__ out, int64_t ldo) {
+  const int64_t mm = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t j = blockIdx.y;
+  if (mm >= m || j >= n) return;
+  const int d = kp.d;
+  const double* z = Z + mm * d;
+  const double* xj = X + j * d;
+  const double b = beta[j * ldb + mm];
+  double t2 = 2.0 * dk(kp, z[l], xj[l], l, kval(kp, z, xj));  // -2 T
+  if (dkb) t2 += 2.0 * dkb[j * d + l];                          // gp.py:320: derivTotal[-1] -= noiseFunc.deriv(p)
+  out[j * ldo + mm] = b * (t2 + 2.0 * Cl[j * ldb + mm] - A[j * lda + j] * b);
+}
+
+// B[j][m] += bias[j]   (gp.py:319: totEvals[:, zz] += noiseFunc(p))
+__global__ __launch_bounds__(256) void add_row_bias_kernel(double* __restrict__ B, int64_t ldb, int64_t n, int64_t m,
+                                                           const double* __restrict__ bias) {
+  const int64_t mm = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t j = blockIdx.y;
+  if (mm < m && j < n) B[j * ldb + mm] += bias[j];
+}
+
+// out[m][l] = -2 sum_j dk(z_m, x_j)[l] beta[j][m]: one workgroup per evaluation point (gp.py:261-280)
+__global__ __launch_bounds__(256) void var_grad_newpt_kernel(KParams kp, const double* __restrict__ X, int64_t n,
+                                                             const double* __restrict__ Z, const double* __restrict__ beta,
+                                                             int64_t ldb, int64_t col0, double* __restrict__ out) {
+  __shared__ double red[256];
+  __shared__ double zs[GPX_MAXD];
+  const int64_t mm = blockIdx.x;  // column inside the chunk; global evaluation point col0 + mm
+  const int d = kp.d, t = threadIdx.x;
+  if (t < d) zs[t] = Z[(col0 + mm) * d + t];
+  __syncthreads();
+  double acc[GPX_MAXD];
+#pragma unroll
+  for (int l = 0; l < GPX_MAXD; ++l) acc[l] = 0.0;
+  for (int64_t j = t; j < n; j += 256) {
+    const double* xj = X + j * d;
+    const double w = -2.0 * beta[j * ldb + mm] * kval(kp, zs, xj);
+#pragma unroll
+    for (int l = 0; l < GPX_MAXD; ++l)
+      if (l < d) acc[l] += dk(kp, zs[l], xj[l], l, w);
+  }
+  for (int l = 0; l < d; ++l) {
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < GPX_MAXD; ++q)
+      if (q == l) v = acc[q];
+    red[t] = v;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (t < w) red[t] += red[t + w];
+      __syncthreads();
+    }
+    if (t == 0) out[(col0 + mm) * d + l] = red[0];
     __syncthreads();
   }
 }
@@ -98,22 +207,64 @@ struct Scratch {
   }
 };
 
+int check_args(int kind, int d, const gpx_mat* L, const gpx_mat* X, const gpx_mat* Z) {
+  GPX_ARG(L && X && Z, "NULL argument");
+  GPX_ARG(L->factored && L->aux, "matrix has not been factored by gpx_potrf");
+  GPX_ARG(kind == GPX_K_SE || (kind == GPX_K_MEHLER && d == 1),
+          "point derivatives exist for the squared-exponential and the 1-D Mehler kernel only "
+          "(as in the reference: kernels.py:146-181, 295-324)");
+  GPX_ARG(X->cols == d && X->pcols == d && Z->cols == d && Z->pcols == d, "point sets must be unpadded (n x d)");
+  GPX_ARG(X->rows == L->rows && Z->rows > 0, "X does not match the factor / no evaluation points");
+  return 0;
+}
+
+// beta (np x mcp, ld mcp) for the evaluation points Zc[0 .. mc): W = L^-1 (K(X, Zc) + bias), beta = L^-T W.
+// Wt is scratch (mcp x np); beta lands in W.
+int solve_beta(gpx_ctx* ctx, const KParams& kp, const gpx_mat* L, const gpx_mat* X, const double* Zc, int64_t mc,
+               int64_t mcp, const double* d_bias, double* W, double* Wt) {
+  const int64_t n = L->rows, np = L->prows;
+  GPX_TRY(launch_kfill(ctx, kp, X->p, n, Zc, mc, 0, nullptr, 0, 0.0, W, np, mcp, mcp));
+  if (d_bias) {
+    dim3 grid((unsigned)((mc + 255) / 256), (unsigned)n);
+    hipLaunchKernelGGL(add_row_bias_kernel, grid, dim3(256), 0, ctx->stream, W, mcp, n, mc, d_bias);
+  }
+  GPX_TRY(chol_trsm_left(ctx, L->p, L->ld, L->aux, W, mcp, np, mcp));
+  GPX_TRY(launch_transpose(ctx, W, np, mcp, mcp, Wt, np));
+  GPX_TRY(chol_trsm_right_n(ctx, L->p, L->ld, L->aux, Wt, np, mcp, np));
+  return launch_transpose(ctx, Wt, mcp, np, np, W, mcp);
+}
+
+int upload(gpx_ctx* ctx, Scratch& sc, const double* host, int64_t count, double** dev) {
+  *dev = nullptr;
+  if (!host) return 0;
+  void* p;
+  GPX_TRY(sc.get(count * 8, &p));
+  GPX_HIP(hipMemcpyAsync(p, host, (size_t)count * 8, hipMemcpyHostToDevice, ctx->stream));
+  *dev = (double*)p;
+  return 0;
+}
+
+// evaluation points per chunk: beta and the transpose scratch / C_l (two np x mc matrices) + the output slab under ~12 GiB
+int64_t grad_chunk(int64_t np) {
+  int64_t budget = (int64_t)12 << 30;
+  const char* e = getenv("GPX_CROSS_BYTES");
+  if (e && atoll(e) > 0) budget = atoll(e);
+  int64_t mc = budget / (3 * np * 8) / GPX_TILE * GPX_TILE;
+  return mc < GPX_TILE ? GPX_TILE : mc;
+}
+
 }  // namespace
 
 extern "C" {
 
 int gpx_ivar_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
-                  const gpx_mat* Z, double* grad) {
-  GPX_ARG(ctx && L && X && Z && grad, "NULL argument");
-  GPX_ARG(L->factored && L->aux, "matrix has not been factored by gpx_potrf");
-  GPX_ARG(kind == GPX_K_SE, "ivar_grad: only the squared-exponential kernel has a point derivative here "
-                            "(the reference defines it for SE and 1-D Mehler only, kernels.py:146-181, 295-324)");
+                  const gpx_mat* Z, const double* noise_deriv, double* grad) {
+  GPX_ARG(ctx && grad, "NULL argument");
+  GPX_TRY(check_args(kind, d, L, X, Z));
   KParams kp;
   GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
-  GPX_ARG(X->cols == d && X->pcols == d && Z->cols == d && Z->pcols == d, "point sets must be unpadded (n x d)");
-  const int64_t n = L->rows, np = L->prows, m = Z->rows;
-  GPX_ARG(X->rows == n && m > 0, "X does not match the factor / no integration points");
   GPX_TRY(gpx_kparams_sets(ctx, &kp, X, Z));
+  const int64_t n = L->rows, np = L->prows, m = Z->rows;
   const int64_t mp = gpx_round_up(m, GPX_TILE);
   Scratch sc(ctx);
   void *pW, *pWt, *pS, *pg;
@@ -121,24 +272,92 @@ int gpx_ivar_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, co
   GPX_TRY(sc.get(mp * np * 8, &pWt));
   GPX_TRY(sc.get(np * np * 8, &pS));
   GPX_TRY(sc.get(n * d * 8, &pg));
+  double* d_nd;
+  GPX_TRY(upload(ctx, sc, noise_deriv, n * d, &d_nd));
   double* W = (double*)pW;
-  double* Wt = (double*)pWt;
-  // W = L^-1 K(X,Z)
-  GPX_TRY(launch_kfill(ctx, kp, X->p, n, Z->p, m, 0, nullptr, 0, 0.0, W, np, mp, mp));
-  GPX_TRY(chol_trsm_left(ctx, L->p, L->ld, L->aux, W, mp, np, mp));
-  // beta^T = W^T L^-1   (mp x np)
-  GPX_TRY(launch_transpose(ctx, W, np, mp, mp, Wt, np));
-  GPX_TRY(chol_trsm_right_n(ctx, L->p, L->ld, L->aux, Wt, np, mp, np));
-  // beta (np x mp) back in W;  S = beta beta^T
-  GPX_TRY(launch_transpose(ctx, Wt, mp, np, np, W, mp));
-  GPX_TRY(launch_gemm(ctx, W, mp, W, mp, (double*)pS, np, np, np, mp, true, false, false));
+  GPX_TRY(solve_beta(ctx, kp, L, X, Z->p, m, mp, nullptr, W, (double*)pWt));
+  GPX_TRY(launch_gemm(ctx, W, mp, W, mp, (double*)pS, np, np, np, mp, true, false, false));  // S = beta beta^T
   {
     ProfScope ps(ctx, GPX_PROF_REDUCE, 0.0, 8.0 * ((double)n * m + (double)n * n));
     hipLaunchKernelGGL(ivar_grad_row_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, kp, X->p, n, Z->p, m,
-                       (const double*)W, mp, (const double*)pS, np, -2.0 / (double)m, (double*)pg);
+                       (const double*)W, mp, (const double*)pS, np, (const double*)d_nd, 1.0 / (double)m, (double*)pg);
   }
   GPX_HIP(hipGetLastError());
   GPX_HIP(hipMemcpyAsync(grad, pg, (size_t)(n * d * 8), hipMemcpyDeviceToHost, ctx->stream));
+  GPX_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int gpx_var_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
+                 const gpx_mat* Z, const double* noise_deriv, const double* eval_bias, const double* dk_bias,
+                 double* out) {
+  GPX_ARG(ctx && out, "NULL argument");
+  GPX_TRY(check_args(kind, d, L, X, Z));
+  KParams kp;
+  GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
+  GPX_TRY(gpx_kparams_sets(ctx, &kp, X, Z));
+  const int64_t n = L->rows, np = L->prows, M = Z->rows;
+  GPX_ARG(np <= 65535, "var_grad: at most 65535 training points");
+  const int64_t mcmax = grad_chunk(np);
+  const int64_t mc_alloc = gpx_round_up(M < mcmax ? M : mcmax, GPX_TILE);
+  Scratch sc(ctx);
+  void *pW, *pWt, *pA, *pO;
+  GPX_TRY(sc.get(np * mc_alloc * 8, &pW));
+  GPX_TRY(sc.get(np * mc_alloc * 8, &pWt));   // transpose scratch, then C_l
+  GPX_TRY(sc.get(np * np * 8, &pA));
+  GPX_TRY(sc.get(n * mc_alloc * 8, &pO));
+  double *d_nd, *d_eb, *d_db;
+  GPX_TRY(upload(ctx, sc, noise_deriv, n * d, &d_nd));
+  GPX_TRY(upload(ctx, sc, eval_bias, n, &d_eb));
+  GPX_TRY(upload(ctx, sc, dk_bias, n * d, &d_db));
+  double* W = (double*)pW;
+  double* Cl = (double*)pWt;
+  for (int64_t j0 = 0; j0 < M; j0 += mcmax) {
+    const int64_t mc = (M - j0) < mcmax ? (M - j0) : mcmax;
+    const int64_t mcp = gpx_round_up(mc, GPX_TILE);
+    const double* Zc = Z->p + j0 * d;
+    GPX_TRY(solve_beta(ctx, kp, L, X, Zc, mc, mcp, d_eb, W, (double*)pWt));
+    for (int l = 0; l < d; ++l) {
+      dim3 ga((unsigned)((np + 255) / 256), (unsigned)np);
+      hipLaunchKernelGGL(dcov_kernel, ga, dim3(256), 0, ctx->stream, kp, X->p, n, l, (const double*)d_nd, (double*)pA, np, np);
+      GPX_TRY(launch_gemm(ctx, (double*)pA, np, W, mcp, Cl, mcp, np, mcp, np, false, false, false));  // C_l = A_l beta
+      dim3 gf((unsigned)((mc + 255) / 256), (unsigned)n);
+      hipLaunchKernelGGL(var_grad_finish_kernel, gf, dim3(256), 0, ctx->stream, kp, X->p, n, Zc, mc, l, (const double*)W,
+                         mcp, (const double*)Cl, (const double*)pA, np, (const double*)d_db, (double*)pO, mc);
+      GPX_HIP(hipGetLastError());
+      // rows j*d + l of the (N*d x M) result, columns [j0, j0+mc)
+      GPX_HIP(hipMemcpy2DAsync(out + (int64_t)l * M + j0, (size_t)d * M * 8, pO, (size_t)mc * 8, (size_t)mc * 8, (size_t)n,
+                               hipMemcpyDeviceToHost, ctx->stream));
+      GPX_HIP(hipStreamSynchronize(ctx->stream));  // pO is rewritten by the next coordinate
+    }
+  }
+  return 0;
+}
+
+int gpx_var_grad_newpt(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
+                       const gpx_mat* Z, double* out) {
+  GPX_ARG(ctx && out, "NULL argument");
+  GPX_TRY(check_args(kind, d, L, X, Z));
+  KParams kp;
+  GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
+  GPX_TRY(gpx_kparams_sets(ctx, &kp, X, Z));
+  const int64_t n = L->rows, np = L->prows, M = Z->rows;
+  const int64_t mcmax = grad_chunk(np);
+  const int64_t mc_alloc = gpx_round_up(M < mcmax ? M : mcmax, GPX_TILE);
+  Scratch sc(ctx);
+  void *pW, *pWt, *pO;
+  GPX_TRY(sc.get(np * mc_alloc * 8, &pW));
+  GPX_TRY(sc.get(np * mc_alloc * 8, &pWt));
+  GPX_TRY(sc.get(M * d * 8, &pO));
+  for (int64_t j0 = 0; j0 < M; j0 += mcmax) {
+    const int64_t mc = (M - j0) < mcmax ? (M - j0) : mcmax;
+    const int64_t mcp = gpx_round_up(mc, GPX_TILE);
+    GPX_TRY(solve_beta(ctx, kp, L, X, Z->p + j0 * d, mc, mcp, nullptr, (double*)pW, (double*)pWt));
+    hipLaunchKernelGGL(var_grad_newpt_kernel, dim3((unsigned)mc), dim3(256), 0, ctx->stream, kp, X->p, n, Z->p,
+                       (const double*)pW, mcp, j0, (double*)pO);
+    GPX_HIP(hipGetLastError());
+  }
+  GPX_HIP(hipMemcpyAsync(out, pO, (size_t)(M * d * 8), hipMemcpyDeviceToHost, ctx->stream));
   GPX_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
 }

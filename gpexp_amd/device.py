@@ -365,10 +365,29 @@ def lml_grad(ctx, spec, L, X, alpha):
     return out
 
 
-def ivar_grad(ctx, spec, L, X, Z):
-    """d IVAR / d design coordinates, flattened (N*d) in the reference's row order (point-major)."""
+def ivar_grad(ctx, spec, L, X, Z, noise_deriv=None):
+    """d IVAR / d design coordinates, flattened (N*d) in the reference's row order (point-major); noise_deriv (N, d) =
+    d noise(x_j)/d x_j of a heteroscedastic noise model."""
     out = np.empty(X.shape[0] * spec.d)
-    check(ctx.lib.gpx_ivar_grad(ctx.h, *spec.args(), L.h, X.h, Z.h, dptr(out)))
+    nd = as_f64(noise_deriv) if noise_deriv is not None else None
+    check(ctx.lib.gpx_ivar_grad(ctx.h, *spec.args(), L.h, X.h, Z.h, dptr(nd), dptr(out)))
+    return out
+
+
+def var_grad(ctx, spec, L, X, Z, noise_deriv=None, eval_bias=None, dk_bias=None):
+    """(N*d, M) matrix d var(z_m) / d X[j][l] (GP.evaluateVarianceDerivative, gp.py:282-341)."""
+    out = np.empty((X.shape[0] * spec.d, Z.shape[0]))
+    nd = as_f64(noise_deriv) if noise_deriv is not None else None
+    eb = as_f64(eval_bias) if eval_bias is not None else None
+    db = as_f64(dk_bias) if dk_bias is not None else None
+    check(ctx.lib.gpx_var_grad(ctx.h, *spec.args(), L.h, X.h, Z.h, dptr(nd), dptr(eb), dptr(db), dptr(out)))
+    return out
+
+
+def var_grad_newpt(ctx, spec, L, X, Z):
+    """(M*d,) vector d var(z_m) / d z_m (GP.evaluateVarianceDerivWRTnewpt, gp.py:261-280)."""
+    out = np.empty(Z.shape[0] * spec.d)
+    check(ctx.lib.gpx_var_grad_newpt(ctx.h, *spec.args(), L.h, X.h, Z.h, dptr(out)))
     return out
 
 

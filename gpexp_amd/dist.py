@@ -620,6 +620,11 @@ class Grid2D:
         """First local block row of process row p whose global block index exceeds k."""
         return self.blocks_before(p, self.Pr, k + 1)
 
+    def row_off(self, p, li):
+        """Local row offset of local block row li on process row p (only the matrix's last block can be short, so the
+        offset one past the last local block is the local row count, not li * nb)."""
+        return min(li * self.nb, self.local_rows(p))
+
     def piece_rows(self, p, k):
         """Rows of panel k held by process row p: the blocks I > k with I % Pr == p."""
         return max(self.local_rows(p) - self.li0(p, k) * self.nb, 0)
@@ -651,10 +656,12 @@ class Grid2D:
         nb, pr = self.nb, self.pr
         liJ = self.blocks_before(pr, self.Pr, J)            # first local block row with I >= J
         m = max(self.local_rows(pr) - liJ * nb, 0)
+        if m == 0:
+            liJ = self.local_rows(pr) // nb                    # nothing below: stay inside the local matrix
         aoff = self.piece_off(pr) + self.dsz + (liJ - self.li0(pr, k)) * nb * nb
         pj = J % self.Pr
         boff = self.piece_off(pj) + self.dsz + (J // self.Pr - self.li0(pj, k)) * nb * nb
-        return liJ * nb, m, (J // self.Pc) * nb, self.height(J), aoff, boff
+        return self.row_off(pr, liJ), m, (J // self.Pc) * nb, self.height(J), aoff, boff
 
 
 class DeviceOps2D(DeviceOps):
@@ -761,7 +768,7 @@ def dist2_potrf(ops, comm, geo, A, G, L=None, on_stored=None):
             ops.stream(PANEL)
             ops.wait(_ev2(E_DBC, k))
             ops.wait(_ev2(E_COLREADY, k))
-            ops.panel_trsm(A, geo.li0(pr, k) * nb, geo.piece_rows(pr, k), lc, w, g, geo.piece_off(kr),
+            ops.panel_trsm(A, geo.row_off(pr, geo.li0(pr, k)), geo.piece_rows(pr, k), lc, w, g, geo.piece_off(kr),
                            geo.piece_off(pr) + geo.dsz, nb)
             ops.record(_ev2(E_PIECE, k))
         ops.stream(COMM)
@@ -826,7 +833,8 @@ def dist2_potrs(ops, comm, geo, A, yv, acc_r, acc_c, out):
             ops.trsv_diag(A, lr, lc, w, yv, k * nb, 0)
         if pc == kc:
             comm.bcast_grp(yv, k * nb, w, kr, COL)
-            ops.gemv(A, geo.li0(pr, k) * nb, geo.piece_rows(pr, k), lc, w, yv, k * nb, acc_r, geo.li0(pr, k) * nb, 0)
+            r0 = geo.row_off(pr, geo.li0(pr, k))
+            ops.gemv(A, r0, geo.piece_rows(pr, k), lc, w, yv, k * nb, acc_r, r0, 0)
     for k in reversed(range(geo.nblk)):                         # L^T alpha = w
         kr, kc = k % Pr, k % Pc
         w = geo.height(k)

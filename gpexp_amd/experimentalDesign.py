@@ -76,26 +76,25 @@ class costFunctionGP_IVAR(costFunctionBase):
             gp.addNodesAndComputeCovariance(inputPoints)
         else:
             gp.addNodesAndComputeCovariance(inputPoints, self.space.noiseFunc(inputPoints))
+        if gp._L is None:   # FITC model: the same mean through the Woodbury precision (gp.py:246-255), as the reference
+            return np.abs(np.mean(gp.evaluateVariance(self.mcPoints)))
         cost = _dev.ivar(_dev.context(), gp.kernel._spec(), gp._L, gp._X, self._mc())
         return np.abs(cost)
 
     def derivative(self, inputPoints):
-        """d IVAR / d design coordinates, flattened (experimentalDesign.py:168-179).
-
-        Squared-exponential kernel with homoscedastic noise: computed on the GPU (gpx_ivar_grad: two triangular solves,
-        one MFMA GEMM and a fused row reduction instead of the reference's (N*d x M) matrix).  Other kernels /
-        a heteroscedastic `space.noiseFunc`: the host restatement of gp.py:282-341 in GP.evaluateVarianceDerivative."""
-        from .kernels import KernelSquaredExponential
+        """d IVAR / d design coordinates, flattened (experimentalDesign.py:168-179): gpx_ivar_grad --
+        two triangular solves, one MFMA GEMM and a fused row reduction instead of the reference's (N*d x M) matrix --
+        for the kernels the reference differentiates (squared exponential, 1-D Mehler), with the heteroscedastic terms of
+        `space.noiseFunc` when there is one."""
         gp = self.gaussianProcess
+        nd = None
         if self.space.noiseFunc is None:
             gp.addNodesAndComputeCovariance(inputPoints)
-            if isinstance(gp.kernel, KernelSquaredExponential):
-                return _dev.ivar_grad(_dev.context(), gp.kernel._spec(), gp._L, gp._X, self._mc())
-            out = gp.evaluateVarianceDerivative(self.mcPoints)
         else:
             gp.addNodesAndComputeCovariance(inputPoints, noiseIn=self.space.noiseFunc(inputPoints))
-            out = gp.evaluateVarianceDerivative(self.mcPoints, noiseFunc=self.space.noiseFunc)
-        return np.sum(out, axis=1) / float(self.nMC)
+            nd = np.asarray(self.space.noiseFunc.deriv(inputPoints), dtype=float).reshape(inputPoints.shape)
+        gp._point_derivative_ready(self.mcPoints)
+        return _dev.ivar_grad(_dev.context(), gp.kernel._spec(), gp._L, gp._X, self._mc(), nd)
 
 
 class costFunctionGP_MI(costFunctionBase):
@@ -314,6 +313,8 @@ def greedyIVARStep(gaussianProcess, candidates, mcPoints):
     (gp.addNodesAndComputeCovariance / train): returns (best_index, costs) where
     costs[j] = costFunctionGP_IVAR(gp, n+1, space, mcPoints=mcPoints).evaluate(vstack(gp.pts, candidates[j]))."""
     gp = gaussianProcess
+    if gp._L is None:
+        raise NotImplementedError("greedyIVARStep needs the dense Cholesky factor (GP built with FITC=... has none)")
     ctx = _dev.context()
     return _dev.greedy_ivar_step(ctx, gp.kernel._spec(), gp._L, gp._X, _dev.points(ctx, candidates),
                                  _dev.points(ctx, mcPoints), float(gp.noise))

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GPX_ABI_VERSION 1
+#define GPX_ABI_VERSION 2
 #define GPX_MAX_DIM 32
 
 typedef struct gpx_ctx gpx_ctx;
@@ -169,12 +169,25 @@ int gpx_mi_greedy(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, co
 int gpx_lml_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
                  const double* alpha, double* grad);
 
-/* ---- design-point gradient -------------------------------------------------------------
- * grad[a*d + l] = d IVAR / d X[a][l] = (1/M) sum_j d var(z_j) / d X[a][l]  for the GP factored on X (L), in the
- * reference's convention (costFunctionGP_IVAR.derivative, experimentalDesign.py:168-172 -> gp.py:282-341, including the
- * doubled signalSize of kernels.py:177).  Squared-exponential kernel, homoscedastic noise.  grad: host, N*d. */
+/* ---- point-location gradients of the posterior variance ----------------------------------------------
+ * For the two kernels the reference differentiates: squared exponential (kernels.py:146-181, including its doubled
+ * signalSize, :177) and 1-D Mehler (GPX_K_MEHLER with d == 1; kernels.py:295-324); any other kind is an argument error.
+ * noise_deriv (host N x d, nullable) = d noise(x_j) / d x_jl of a heteroscedastic noise model (space.noiseFunc.deriv,
+ * gp.py:314-317): it enters the derivative of the covariance at coincident training points.  Nothing N x N reaches the host. */
+/* grad[a*d + l] = d IVAR / d X[a][l] = (1/M) sum_m d var(z_m) / d X[a][l]
+ * (costFunctionGP_IVAR.derivative, experimentalDesign.py:168-179 -> gp.py:282-341).  grad: host, N*d. */
 int gpx_ivar_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
-                  const gpx_mat* Z, double* grad);
+                  const gpx_mat* Z, const double* noise_deriv, double* grad);
+/* out[(j*d + l) * M + m] = d var(z_m) / d X[j][l]  (GP.evaluateVarianceDerivative, gp.py:282-341; host, (N*d) x M).
+ * eval_bias (host N, nullable) / dk_bias (host N x d, nullable): the terms of gp.py:318-320 -- noise(x_j) added to
+ * k(x_j, z_m) and noise'(x_j) subtracted from -dk(z_m, x_j)/dz for every m -- which the reference applies when the WHOLE
+ * evaluation set coincides with training point j; the caller decides (rows of zeros otherwise). */
+int gpx_var_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
+                 const gpx_mat* Z, const double* noise_deriv, const double* eval_bias, const double* dk_bias,
+                 double* out);
+/* out[m*d + l] = d var(z_m) / d z_m[l]  (GP.evaluateVarianceDerivWRTnewpt, gp.py:261-280; host, M*d) */
+int gpx_var_grad_newpt(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
+                       const gpx_mat* Z, double* out);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ------------------------------------------------
  * Replaces the reference's only parallel backend, the fork + mp.Queue row-sharding helper

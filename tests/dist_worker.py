@@ -167,6 +167,7 @@ class NumpyOps2D(NumpyOps):
         return G.a[doff:doff + nb * nb].reshape(nb, nb)
 
     def diag_factor(self, A, lr, lc, w, G, doff, nb, base, n_valid):
+        self._inside(A, lr, w, lc, w)
         blk = A.a[lr:lr + w, lc:lc + w]
         assert not self.poison or not np.isnan(np.tril(blk)).any(), "owner factors a diagonal block it never assembled/updated"
         try:
@@ -185,7 +186,13 @@ class NumpyOps2D(NumpyOps):
             inv[q * 128 * 128:(q + 1) * 128 * 128] = np.linalg.inv(L11[q * 128:(q + 1) * 128, q * 128:(q + 1) * 128]).ravel()
         self.aux[("A", lr)] = inv[:(w // 128) * 128 * 128].copy()
 
+    @staticmethod
+    def _inside(A, lr0, m, lc, w):
+        """The C primitives reject blocks outside the local matrix (NumPy slicing would not)."""
+        assert 0 <= lr0 and lr0 + m <= A.a.shape[0] and 0 <= lc and lc + w <= A.a.shape[1], (lr0, m, lc, w, A.a.shape)
+
     def panel_trsm(self, A, lr0, m, lc, w, G, doff, roff, nb):
+        self._inside(A, lr0, m, lc, w)
         if m == 0:
             return
         L11 = self._D(G, doff, nb)[:w, :w]
@@ -198,6 +205,8 @@ class NumpyOps2D(NumpyOps):
         rows[:, :w] = X
 
     def update(self, A, lr0, m, lc0, n, G, aoff, boff, w, nb):
+        self._inside(A, lr0, m, lc0, n)
+        assert aoff + m * nb <= G.a.size and boff + n * nb <= G.a.size
         if m == 0 or n == 0:
             return
         a = G.a[aoff:aoff + m * nb].reshape(m, nb)[:, :w]
@@ -216,10 +225,12 @@ class NumpyOps2D(NumpyOps):
         L.a[r0:r0 + w, r0:r0 + w] = self._D(G, doff, nb)[:w, :w]
 
     def trsv_diag(self, A, lr, lc, w, v, voff, transposed):
+        self._inside(A, lr, w, lc, w)
         Lkk = np.tril(A.a[lr:lr + w, lc:lc + w])
         v.a[voff:voff + w] = np.linalg.solve(Lkk.T if transposed else Lkk, v.a[voff:voff + w])
 
     def gemv(self, A, lr0, m, lc, w, x, xoff, acc, aoff, transposed):
+        self._inside(A, lr0, m, lc, w)
         if m == 0 or w == 0:
             return
         blk = A.a[lr0:lr0 + m, lc:lc + w]

@@ -70,7 +70,7 @@ def test_panel_loop_gloo_cpu(world, n, nb):
 
 
 @pytest.mark.parametrize("world,n,nb,grid", [(2, 700, 128, ""), (4, 1000, 256, ""), (6, 900, 128, ""), (8, 1300, 128, ""),
-                                             (8, 333, 256, ""), (4, 1100, 256, "4x1")])
+                                             (8, 333, 256, ""), (4, 1100, 256, "4x1"), (4, 2100, 256, "")])
 def test_panel_loop_2d_gloo_cpu(world, n, nb, grid):
     """North-star layout: Pr x Pc block-cyclic ownership, column-communicator diagonal broadcast, all-rank panel pieces,
     look-ahead order, replicated + distributed factor, distributed substitution (reduce / bcast on sub-groups),
@@ -111,7 +111,7 @@ def test_grid_logic():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,n,nb,grid", [(2, 1500, 256, ""), (4, 2100, 256, ""), (6, 1900, 128, ""), (4, 900, 512, "4x1")])
+@pytest.mark.parametrize("world,n,nb,grid", [(2, 1500, 256, ""), (4, 2100, 256, ""), (3, 1900, 128, ""), (4, 900, 512, "4x1")])
 def test_distributed_fit_ivar_2d_shared_gpu(world, n, nb, grid):
     """The 2-D path on the real HIP primitives (ranks share the GPU, host-staged exchange): replicated factor, alpha,
     log-likelihood and IVAR equal the single-GPU path; both evaluation schedules; repeatable bit for bit."""

@@ -1,0 +1,162 @@
+"""SURVEY.md 8 f1 on the device (-m gpu): gradients of the posterior variance w.r.t. point locations --
+GP.evaluateVarianceDerivative (gp.py:282-341), GP.evaluateVarianceDerivWRTnewpt (gp.py:261-280) and
+costFunctionGP_IVAR.derivative (experimentalDesign.py:168-179) -- for the squared-exponential and the 1-D Mehler kernel,
+with and without a heteroscedastic noise model, against the reference's own vectors (tests/golden/make_golden*.py) and the
+oracle's restatement at larger sizes.  Tolerance 1e-9: the quantities are built on the explicit inverse in the reference
+(pinv) and on two triangular solves here."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import gpexp_oracle as orc
+from helpers import NoiseFunc, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def kernel_of(s):
+    from gpExp.kernels import KernelSquaredExponential, KernelMehler1D
+    if s["kind"] == "se":
+        return KernelSquaredExponential(list(s["cl"]), s["signalSize"], s["d"])
+    return KernelMehler1D(s["t"][0], 1)
+
+
+def space_of(d, nf=None):
+    from gpExp.approximation import Space
+    return Space(d, lambda size: np.random.rand(size[0], size[1]) * 2 - 1, lambda p: np.ones(len(p)) / 2 ** d, noise=nf)
+
+
+@pytest.mark.parametrize("case", ["varderiv", "varderiv_mehler1d"])
+def test_point_derivatives_vs_reference(golden, case):
+    from gpExp.gp import GP
+    s = golden.index[case]["kernel"]
+    X, Z = golden(case, "X"), golden(case, "Z")
+    g = GP(kernel_of(s), golden.index[case]["noise"])
+    g.addNodesAndComputeCovariance(X)
+    D = g.evaluateVarianceDerivative(Z)
+    assert D.shape == (X.size, len(Z))
+    assert rel(D, golden(case, "dvar_dpts")) <= 1e-9
+    assert rel(g.evaluateVarianceDerivWRTnewpt(Z), golden(case, "dvar_dnew")) <= 1e-9
+    assert rel(g.kernel.derivative(Z, X[:1]) if case.endswith("1d") else g.kernel.derivative(X, Z[:1]),
+               golden(case, "kernel_derivative")) <= 1e-12
+
+
+def test_heteroscedastic_derivatives_vs_reference(golden):
+    """noiseFunc terms of gp.py:314-317 and the IVAR gradient of experimentalDesign.py:173-177."""
+    from gpExp.gp import GP
+    from gpExp.experimentalDesign import costFunctionGP_IVAR
+    c = "varderiv_nf"
+    s = golden.index[c]["kernel"]
+    X, Z = golden(c, "X"), golden(c, "Z")
+    nf = NoiseFunc(2)
+    g = GP(kernel_of(s), 1e-3)
+    g.addNodesAndComputeCovariance(X, noiseIn=nf(X))
+    assert rel(g.evaluateVarianceDerivative(Z, noiseFunc=nf), golden(c, "dvar_dpts")) <= 1e-9
+    assert rel(g.evaluateVarianceDerivWRTnewpt(Z), golden(c, "dvar_dnew")) <= 1e-9
+    cf = costFunctionGP_IVAR(GP(kernel_of(s), 1e-3), len(X), space_of(2, nf), mcPoints=Z)
+    assert cf.evaluate(X) == pytest.approx(float(golden(c, "ivar")), rel=1e-10)
+    assert rel(cf.derivative(X), golden(c, "ivar_grad")) <= 1e-9
+    cf0 = costFunctionGP_IVAR(GP(kernel_of(s), 1e-3), len(X), space_of(2), mcPoints=Z)
+    assert cf0.evaluate(X) == pytest.approx(float(golden(c, "ivar_homo")), rel=1e-10)
+    assert rel(cf0.derivative(X), golden(c, "ivar_grad_homo")) <= 1e-9
+    g0 = GP(kernel_of(s), 1e-3)
+    g0.addNodesAndComputeCovariance(X)
+    assert rel(g0.evaluateVarianceDerivative(Z), golden(c, "dvar_dpts_homo")) <= 1e-9
+
+
+def test_whole_set_coincidence_branch_vs_reference(golden):
+    """ONE evaluation point equal to a training point + noiseFunc: the branch at gp.py:318-320."""
+    from gpExp.gp import GP
+    c = "varderiv_single"
+    X, Z = golden(c, "X"), golden(c, "Z")
+    nf = NoiseFunc(2)
+    g = GP(kernel_of(golden.index[c]["kernel"]), 1e-3)
+    g.addNodesAndComputeCovariance(X, noiseIn=nf(X))
+    assert rel(g.evaluateVarianceDerivative(Z, noiseFunc=nf), golden(c, "dvar_dpts")) <= 1e-9
+
+
+def test_mehler1d_ivar_gradient_vs_reference(golden):
+    from gpExp.gp import GP
+    from gpExp.experimentalDesign import costFunctionGP_IVAR
+    c = "varderiv_mehler1d"
+    X, Z = golden(c, "X"), golden(c, "Z")
+    cf = costFunctionGP_IVAR(GP(kernel_of(golden.index[c]["kernel"]), golden.index[c]["noise"]), len(X), space_of(1),
+                             mcPoints=Z)
+    assert cf.evaluate(X) == pytest.approx(float(golden(c, "ivar")), rel=1e-10)
+    assert rel(cf.derivative(X), golden(c, "ivar_grad")) <= 1e-9
+
+
+@pytest.mark.parametrize("kind,with_nf,dups", [("se", False, False), ("se", True, False), ("se", True, True),
+                                               ("mehler1d", False, False), ("mehler1d", True, True)])
+def test_derivatives_vs_oracle_larger(kind, with_nf, dups):
+    """n = 150 training points (ragged against the 128 tiles), M = 333 evaluation points, evaluation chunks of 128
+    forced through GPX_CROSS_BYTES; duplicated training points exercise the coincidence mask of gp.py:308."""
+    from gpExp.gp import GP
+    from gpExp.experimentalDesign import costFunctionGP_IVAR
+    rng = np.random.default_rng(5 + len(kind))
+    d = 1 if kind == "mehler1d" else 3
+    n, m = 150, 333
+    X = rng.uniform(-1, 1, (n, d))
+    if dups:
+        X[17] = X[3]
+        X[140] = X[3]
+    Z = rng.uniform(-1, 1, (m, d))
+    s = dict(kind="se", cl=[0.5, 0.7, 0.9], signalSize=1.3, d=3) if kind == "se" else dict(kind="mehler1d", t=[0.6], d=1)
+    nf = NoiseFunc(d) if with_nf else None
+    noise = 0.05
+    nug = nf(X) if with_nf else noise
+    model = orc.fit(s, X, None, nug)
+    want = orc.variance_derivative(s, model, Z, nf)
+    g = GP(kernel_of(s), noise)
+    g.addNodesAndComputeCovariance(X, noiseIn=(nug if with_nf else None))
+    old = os.environ.get("GPX_CROSS_BYTES")
+    os.environ["GPX_CROSS_BYTES"] = str(3 * 256 * 8 * 128)     # 128 evaluation points per chunk
+    try:
+        got = g.evaluateVarianceDerivative(Z, noiseFunc=nf)
+        gnew = g.evaluateVarianceDerivWRTnewpt(Z)
+    finally:
+        if old is None:
+            os.environ.pop("GPX_CROSS_BYTES", None)
+        else:
+            os.environ["GPX_CROSS_BYTES"] = old
+    assert rel(got, want) <= 1e-9
+    assert rel(gnew, orc.variance_deriv_wrt_newpt(s, model, Z)) <= 1e-9
+    assert rel(g.evaluateVarianceDerivative(Z, noiseFunc=nf), got) <= 1e-13      # one chunk == several chunks
+    cf = costFunctionGP_IVAR(GP(kernel_of(s), noise), n, space_of(d, nf), mcPoints=Z)
+    assert rel(cf.derivative(X), want.sum(axis=1) / m) <= 1e-9
+    assert rel(cf.derivative(X), orc.ivar_grad(s, X, Z, noise, nf)) <= 1e-9
+
+
+def test_unsupported_kernels_raise():
+    from gpExp.gp import GP
+    from gpExp.kernels import KernelIsoMatern, KernelMehlerND
+    X = np.random.default_rng(0).uniform(-1, 1, (9, 2))
+    g = GP(KernelIsoMatern(0.5, 1.0, 2), 0.01)
+    g.addNodesAndComputeCovariance(X)
+    with pytest.raises(AttributeError):        # the reference's KernelIsoMatern has no derivative() either
+        g.evaluateVarianceDerivative(X[:3])
+    g2 = GP(KernelMehlerND([0.5, 0.3], 2), 0.01)
+    g2.addNodesAndComputeCovariance(X)
+    with pytest.raises(AttributeError):        # kernels.py:246: "derivative of KernelMehlerND not yet implemented"
+        g2.evaluateVarianceDerivWRTnewpt(X[:3])
+
+
+def test_ivar_cost_with_fitc_model(golden):
+    """costFunctionGP_IVAR.evaluate on a GP built with FITC=... goes through the Woodbury variances
+    (gp.py:246-255) as the reference does, instead of dereferencing a dense factor that does not exist."""
+    from gpExp.gp import GP
+    from gpExp.experimentalDesign import costFunctionGP_IVAR, greedyIVARStep
+    c = "fitc"
+    s = golden.index[c]["kernel"]
+    X, Z = golden(c, "X"), golden(c, "Z")
+    np.random.seed(golden.index[c]["seed"])
+    g = GP(kernel_of(s), golden.index[c]["noise"], FITC=golden.index[c]["fitc"])
+    cf = costFunctionGP_IVAR(g, len(X), space_of(2), mcPoints=Z)
+    cost = cf.evaluate(X)
+    assert np.array_equal(cf.gaussianProcess.fitcnodes, golden(c, "fitcnodes"))
+    assert cost == pytest.approx(abs(np.mean(golden(c, "var_signed"))), rel=1e-9)
+    with pytest.raises(NotImplementedError):
+        cf.derivative(X)
+    with pytest.raises(NotImplementedError):
+        greedyIVARStep(cf.gaussianProcess, X[:5], Z)

@@ -43,7 +43,7 @@ def test_binding_matches_header(built_lib):
     from gpexp_amd import _lib
     assert sorted(_lib.exported_symbols()) == header_symbols()
     lib = _lib.load()
-    assert lib.gpx_abi_version() == 1
+    assert lib.gpx_abi_version() == 2
 
 
 def test_header_cites_reference_lines():
