@@ -36,6 +36,8 @@ _SIGS = {
     "gpx_kdiag": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_dp]),
     "gpx_kernel_eval": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_dp, c_i64, c_dp, c_i64, c_dp]),
     "gpx_potrf": (C.c_int, [c_vp, c_vp]),
+    "gpx_potrf_policy": (C.c_int, [c_vp, C.c_double, C.c_int]),
+    "gpx_potrf_dropped": (C.c_int, [c_vp, C.POINTER(C.c_int)]),
     "gpx_refit_rows": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_dp, c_i64, c_vp, c_i64, C.POINTER(c_vp)]),
     "gpx_potrs": (C.c_int, [c_vp, c_vp, c_dp, c_dp]),
     "gpx_col_sumsq": (C.c_int, [c_vp, c_vp, c_i64, c_dp]),

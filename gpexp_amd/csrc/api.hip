@@ -264,6 +264,8 @@ int gpx_create(int device, gpx_ctx** out) {
     c->grp_rank[i] = 0;
   }
   c->Pr = c->Pc = 1;
+  c->piv_min = 0.0;
+  c->piv_skip = 0;
   c->prof_on = 0;
   for (int i = 0; i < GPX_PROF_NCLASS; ++i) {
     c->prof_launches[i] = 0;
@@ -386,6 +388,9 @@ int gpx_mat_alloc(gpx_ctx* ctx, int64_t rows, int64_t cols, int pad, gpx_mat** o
   GPX_ARG(ctx && out, "NULL argument");
   GPX_TRY(gpx_mat_new(ctx, rows, cols, pad, out));
   GPX_HIP(hipMemsetAsync((*out)->p, 0, (size_t)(*out)->bytes, ctx->stream));
+  // the caller may use the matrix on ANY of the context's streams next (the multi-GPU pipeline fills cross matrices on
+  // the background stream): the zero fill must not still be in flight on this one
+  GPX_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
 }
 
@@ -404,8 +409,9 @@ int gpx_mat_from_host(gpx_ctx* ctx, const double* src, int64_t rows, int64_t col
 int gpx_mat_free(gpx_ctx* ctx, gpx_mat* m) {
   if (!m) return 0;
   GPX_ARG(ctx != nullptr, "ctx is NULL");
-  // work queued on the stream may still reference the buffers: order the reuse behind it
-  (void)hipStreamSynchronize(ctx->stream);
+  // work queued on ANY of the context's streams may still reference the buffers (side-stream solves, the background
+  // evaluation): the pool may hand them out again right away, so order the reuse behind all of it
+  (void)hipDeviceSynchronize();
   gpx_dev_release(ctx, m->p, m->bytes);
   if (m->aux) gpx_dev_release(ctx, m->aux, m->aux_bytes);
   delete m;
@@ -566,6 +572,20 @@ int gpx_potrf(gpx_ctx* ctx, gpx_mat* K) {
 
 static int need_factor(const gpx_mat* L);
 
+int gpx_potrf_policy(gpx_ctx* ctx, double piv_min, int skip) {
+  GPX_ARG(ctx != nullptr && piv_min >= 0.0, "bad pivot policy");
+  ctx->piv_min = piv_min;
+  ctx->piv_skip = skip ? 1 : 0;
+  return 0;
+}
+
+int gpx_potrf_dropped(gpx_ctx* ctx, int* count) {
+  GPX_ARG(ctx && count, "NULL argument");
+  GPX_HIP(hipMemcpyAsync(count, ctx->d_info + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  GPX_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
 // f2: refit when only the trailing points of the design changed.  The leading `keep` rows/columns of
 // K(X)+nugget equal the matrix `Lold` factors, so its leading keep x keep factor block and leaf inverses are copied, the
 // rows >= keep are assembled, and the factorisation is completed: A21 <- A21 L11^-T, A22 <- A22 - A21 A21^T, potrf(A22).
@@ -612,7 +632,7 @@ int gpx_refit_rows(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, c
         r = -2; gpx_set_error("refit_rows: nugget upload failed"); break;
       }
     }
-    if (hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream) != hipSuccess) { r = -2; break; }
+    if (hipMemsetAsync(ctx->d_info, 0, 2 * sizeof(int), ctx->stream) != hipSuccess) { r = -2; break; }
     const int64_t n2 = np - keep;
     if (n2 > 0) {
       double* A21 = K->p + keep * K->ld;

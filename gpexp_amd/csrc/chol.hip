@@ -101,8 +101,15 @@ __device__ __forceinline__ double row_bcast_n(double v, int n) {  // n is a cons
 // redundantly); L[c][j] reaches the other lanes through a DPP row broadcast, and one broadcast feeds both the
 // right-looking update of the factor and the forward substitution of the inverse.  sqrt and 1/sqrt of the pivot come from
 // v_rsq_f64 + two coupled Goldschmidt steps + a residual correction: 8 dependent fp64 ops instead of sqrt + division.
+//
+// Pivot policy (piv_min, skip): a pivot <= piv_min is "bad".  skip == 0: it is replaced by 1.0 and its global index is
+// reported (first one wins) -- the caller sees a non-positive-definite matrix.  skip != 0 (the rank-deficient retry of
+// GP._factor): the point is DROPPED -- L_jj = 1, the rest of column j and row j of the inverse are 0, so every solve
+// against the factor returns 0 in that component, exactly as if the point were not in the training set; this is what
+// numpy.linalg.pinv (gp.py:181) makes of an exactly duplicated point.  Dropped pivots are counted in info[1].
 __device__ __forceinline__ void leaf_diag(double* __restrict__ S, double* __restrict__ Tp, int c0, int q, int lane,
-                                          int64_t base_index, int64_t n_valid, int* __restrict__ info) {
+                                          int64_t base_index, int64_t n_valid, int* __restrict__ info, double piv_min,
+                                          int skip) {
   double a[LB], sacc[LB];
 #pragma unroll
   for (int c = 0; c < LB; ++c) {
@@ -110,12 +117,14 @@ __device__ __forceinline__ void leaf_diag(double* __restrict__ S, double* __rest
     sacc[c] = (c == q) ? 1.0 : 0.0;
   }
   int first_bad = LB;  // first column with a non-positive (or NaN) pivot; wave-uniform
+  int nbad = 0;
   double* const srow = S + (c0 + q) * LS + c0;
 #pragma unroll
   for (int j = 0; j < LB; ++j) {
     double piv = row_bcast_n(a[j], j);
-    const bool ok = piv > 0.0;  // branch-free on the pivot chain: a bad pivot is replaced by 1.0 and reported after the loop
+    const bool ok = piv > piv_min;  // branch-free on the pivot chain: a bad pivot is replaced by 1.0 and reported after the loop
     first_bad = (!ok && first_bad == LB) ? j : first_bad;
+    nbad += (!ok && base_index + c0 + j < n_valid) ? 1 : 0;
     piv = ok ? piv : 1.0;
     const double y = __builtin_amdgcn_rsq(piv);
     double g = piv * y, h = 0.5 * y;
@@ -126,7 +135,7 @@ __device__ __forceinline__ void leaf_diag(double* __restrict__ S, double* __rest
     g = fma(g, r, g);
     h = fma(h, r, h);
     g = fma(fma(-g, g, piv), h, g);  // sqrt(piv)
-    const double rs = h + h;         // 1/sqrt(piv)
+    const double rs = (ok || !skip) ? h + h : 0.0;  // 1/sqrt(piv); 0 drops the point (see the pivot policy above)
     const double aj = (q == j) ? g : a[j] * rs;
     const double xj = sacc[j] * rs;
     const double naj = -aj, nxj = -xj;
@@ -142,8 +151,12 @@ __device__ __forceinline__ void leaf_diag(double* __restrict__ S, double* __rest
       Tp[j * TS17 + q] = xj;
     }
   }
-  if (first_bad < LB && lane == 0 && base_index + c0 + first_bad < n_valid)
-    atomicCAS(info, 0, (int)(base_index + c0 + first_bad + 1));
+  if (first_bad < LB && lane == 0 && base_index + c0 + first_bad < n_valid) {
+    if (skip)
+      atomicAdd(info + 1, nbad);
+    else
+      atomicCAS(info, 0, (int)(base_index + c0 + first_bad + 1));
+  }
 }
 
 // The 28 blocks (I,K), 1 <= K <= I <= 7, of the trailing matrix live in REGISTERS (MFMA accumulator layout) from the
@@ -251,9 +264,10 @@ __device__ __forceinline__ void leaf_factor(double* __restrict__ S, double (*T)[
 
 // wave 0: the diagonal blocks
 __device__ __forceinline__ void leaf_panel_wave(double* __restrict__ S, double (*T)[LB * TS17], int g, int q, int lane,
-                                                int64_t base_index, int64_t n_valid, int* __restrict__ info) {
+                                                int64_t base_index, int64_t n_valid, int* __restrict__ info,
+                                                double piv_min, int skip) {
   for (int p = 0; p < 8; ++p) {
-    leaf_diag(S, T[p], LB * p, q, lane, base_index, n_valid, info);
+    leaf_diag(S, T[p], LB * p, q, lane, base_index, n_valid, info, piv_min, skip);
     __syncthreads();  // [B]
     leaf_scale(S, T[p], p, 0, g, q);
     __syncthreads();  // [C]
@@ -262,7 +276,8 @@ __device__ __forceinline__ void leaf_panel_wave(double* __restrict__ S, double (
 }
 
 __global__ __launch_bounds__(256) void leaf_kernel(double* __restrict__ A, int64_t ld, double* __restrict__ inv,
-                                                   int64_t base_index, int64_t n_valid, int* __restrict__ info) {
+                                                   int64_t base_index, int64_t n_valid, int* __restrict__ info,
+                                                   double piv_min, int skip) {
   __shared__ double S[NB * LS];
   __shared__ double T[8][LB * TS17];
   const int t = threadIdx.x;
@@ -289,7 +304,7 @@ __global__ __launch_bounds__(256) void leaf_kernel(double* __restrict__ A, int64
   }
   __syncthreads();
   switch (wave) {
-    case 0: leaf_panel_wave(S, T, g, q, lane, base_index, n_valid, info); break;
+    case 0: leaf_panel_wave(S, T, g, q, lane, base_index, n_valid, info, piv_min, skip); break;
     case 1: leaf_factor<1>(S, T, g, q, lane, base_index, n_valid, info); break;
     case 2: leaf_factor<2>(S, T, g, q, lane, base_index, n_valid, info); break;
     default: leaf_factor<3>(S, T, g, q, lane, base_index, n_valid, info); break;
@@ -688,7 +703,8 @@ static int launch_leaf_mul_left(gpx_ctx* ctx, double* B, int64_t ldb, const doub
 
 int launch_leaf(gpx_ctx* ctx, double* A, int64_t ld, double* inv, int64_t base_index, int64_t n_valid) {
   ProfScope ps(ctx, GPX_PROF_LEAF, 2.0 * NB * NB * NB / 3.0, 0.0);
-  hipLaunchKernelGGL(leaf_kernel, dim3(1), dim3(256), 0, ctx->stream, A, ld, inv, base_index, n_valid, ctx->d_info);
+  hipLaunchKernelGGL(leaf_kernel, dim3(1), dim3(256), 0, ctx->stream, A, ld, inv, base_index, n_valid, ctx->d_info,
+                     ctx->piv_min, ctx->piv_skip);
   GPX_HIP(hipGetLastError());
   return 0;
 }
@@ -769,7 +785,7 @@ static int potrf_rec(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double* inv
 
 int chol_potrf(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double* invd, int64_t n_valid) {
   GPX_ARG(n > 0 && n % NB == 0, "potrf: padded order must be a positive multiple of 128");
-  GPX_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
+  GPX_HIP(hipMemsetAsync(ctx->d_info, 0, 2 * sizeof(int), ctx->stream));
   return potrf_rec(ctx, A, ld, n, invd, 0, n_valid);
 }
 

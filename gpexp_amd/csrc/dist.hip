@@ -403,7 +403,7 @@ int64_t gpx_dist_panel_elems(int64_t np, int64_t nb) { return np * nb + (nb / GP
 // gpx_dist_begin before the first panel.
 int gpx_dist_begin(gpx_ctx* ctx) {
   GPX_ARG(ctx != nullptr, "ctx is NULL");
-  GPX_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
+  GPX_HIP(hipMemsetAsync(ctx->d_info, 0, 2 * sizeof(int), ctx->stream));
   return 0;
 }
 

@@ -102,7 +102,9 @@ struct gpx_ctx {
   std::multimap<int64_t, void*> pool;
   int64_t pool_bytes;
   // scalars
-  int* d_info;      // first failing pivot (1-based), 0 = ok
+  int* d_info;      // [0] first failing pivot (1-based), 0 = ok; [1] pivots dropped in skip mode
+  double piv_min;   // pivot policy of the leaf factorisation (gpx_potrf_policy): pivots <= piv_min are bad ...
+  int piv_skip;     // ... and reported (0) or dropped (1)
   double* d_scal;   // small scalar workspace (>= 64 doubles)
   double* trsv_scratch;      // grown on demand, kept until gpx_destroy (lets gpx_potrs_dev stay asynchronous)
   int64_t trsv_scratch_bytes;

@@ -212,6 +212,17 @@ def potrf(ctx, K):
     return K
 
 
+def potrf_policy(ctx, piv_min=0.0, skip=False):
+    """Pivot policy of the factorisations that follow (gpx_potrf_policy); (0, False) is the library default."""
+    check(ctx.lib.gpx_potrf_policy(ctx.h, float(piv_min), 1 if skip else 0))
+
+
+def potrf_dropped(ctx):
+    n = C.c_int()
+    check(ctx.lib.gpx_potrf_dropped(ctx.h, C.byref(n)))
+    return n.value
+
+
 def refit_rows(ctx, spec, X, nugget, L_old, keep):
     """Cholesky factor of K(X,X)+diag(nugget) re-using the leading `keep` (multiple of 128) rows of the factor `L_old`."""
     nug, nlen = _nugget_args(nugget, X.shape[0])

@@ -13,9 +13,12 @@ triangular solve or a column reduction against L:
 `covarianceMatrix` and `precisionMatrix` remain available as attributes (external code reads them,
 experimentalDesign.py:241-242) but are materialised lazily, on first access, from the device.
 
-Rank-deficient K (e.g. noise 0.0 with coincident points): pinv truncates silently, Cholesky cannot.  Policy: the
-factorisation is retried with a relative diagonal jitter (1e-12 * mean diag, x100 per retry, at most 4 retries)
-and a RuntimeWarning names the jitter used; if that fails NotPositiveDefinite propagates.
+Rank-deficient K (e.g. noise 0.0 with coincident points): pinv truncates silently, Cholesky cannot.  Policy: a pivot
+at round-off level (<= 1e-13 * largest diagonal entry) fails the factorisation, which is then repeated with those
+points DROPPED (gpx_potrf_policy: unit pivot, zero column, zero row of the inverse -- every solve returns 0 in that
+component, as if the point were not in the training set) and a RuntimeWarning says how many.  For an exactly duplicated
+point with equal function values that is the pinv answer (posterior mean and variance to 1e-8, reference fixture
+`rankdef`); `coeff` differs in how it is split between the duplicates (pinv: equal halves; here: all on the first).
 
 FITC (gp.py:182-210, 401-426): `GP(kernel, noise, FITC=fraction)` draws the inducing points with
 `np.random.permutation` exactly as the reference does (seed it the same way and the same points come out) and keeps
@@ -64,7 +67,8 @@ class GP:
         self._nugget = None  # nugget that went into _L
         self._K_host = None
         self._P_host = None
-        self.jitter = 0.0
+        self.jitter = 0.0    # kept for compatibility: the rank-deficient policy no longer perturbs the diagonal
+        self.dropped = 0     # points dropped by the rank-deficient policy in the last factorisation
         # f2: the last factorisation, kept so that a refit whose leading points (and hyper-parameters) did
         # not change -- the design loop pins earlier points by bounds, experimentalDesign.py:722-724 -- only assembles and
         # factors the trailing rows.  (host copy of the points, nugget, hyper-parameter key, device factor)
@@ -104,7 +108,7 @@ class GP:
         return np.zeros((pts.shape[0]))
 
     def _factor(self, nodes, nugget, remember=True):
-        """Assemble K(nodes)+diag(nugget) and factor it in place on the device -> (X, L, jitter).  `remember=False`
+        """Assemble K(nodes)+diag(nugget) and factor it in place on the device -> (X, L, 0.0).  `remember=False`
         (likelihood evaluations: every call has new hyper-parameters) neither consults nor replaces the kept factor."""
         _check_nugget(nugget)
         nodes = np.asarray(nodes, dtype=float)
@@ -113,37 +117,41 @@ class GP:
         ctx = _dev.context()
         spec = self.kernel._spec()
         X = _dev.points(ctx, nodes)
-        keep = self._reusable_rows(nodes, nugget, spec) if remember else 0
-        if keep > 0:
-            try:
-                L = _dev.refit_rows(ctx, spec, X, nugget, self._fcache[3], keep)
-                self._remember(nodes, nugget, spec, L)
-                return X, L, 0.0
-            except NotPositiveDefinite:
-                pass  # fall through to the full path and its jitter policy
-        K = _dev.kfill(ctx, spec, X, nugget=nugget)
+        # Rank-deficient policy (module docstring): pivots at round-off level count as failed, and the retry DROPS those
+        # points, which is what the reference's pinv does with an exactly duplicated point (gp.py:181).
+        diag = float(spec.hyp[-1]) if spec.kind != _dev.K_MEHLER else float(np.max(_dev.kdiag(ctx, spec, X)))
+        tau = 1e-13 * (diag + float(np.max(np.asarray(nugget, dtype=float))))
+        self.dropped = 0
         try:
-            L = _dev.potrf(ctx, K)
-            if remember:
-                self._remember(nodes, nugget, spec, L)
-            return X, L, 0.0
-        except NotPositiveDefinite as first:
-            if remember:
-                self._fcache = None
-            base = 1e-12 * float(np.mean(_dev.kdiag(ctx, spec, X)) + np.mean(np.asarray(nugget, dtype=float)))
-            jit = base
-            for _ in range(4):
-                nz = (np.asarray(nugget, dtype=float) + jit) * np.ones(nodes.shape[0])
-                _dev.kfill_into(ctx, spec, X, K, nugget=nz)
+            _dev.potrf_policy(ctx, tau, False)
+            keep = self._reusable_rows(nodes, nugget, spec) if remember else 0
+            if keep > 0:
                 try:
-                    _dev.potrf(ctx, K)
-                    warnings.warn("covariance matrix not positive definite (pivot %d); factored with diagonal "
-                                  "jitter %.3e (the reference's pinv would truncate instead)" % (first.pivot, jit),
-                                  RuntimeWarning)
-                    return X, K, jit
+                    L = _dev.refit_rows(ctx, spec, X, nugget, self._fcache[3], keep)
+                    self._remember(nodes, nugget, spec, L)
+                    return X, L, 0.0
                 except NotPositiveDefinite:
-                    jit *= 100.0
-            raise
+                    pass  # fall through to the full path and its rank-deficient policy
+            K = _dev.kfill(ctx, spec, X, nugget=nugget)
+            try:
+                L = _dev.potrf(ctx, K)
+                if remember:
+                    self._remember(nodes, nugget, spec, L)
+                return X, L, 0.0
+            except NotPositiveDefinite as first:
+                if remember:
+                    self._fcache = None
+                _dev.kfill_into(ctx, spec, X, K, nugget=nugget)
+                _dev.potrf_policy(ctx, tau, True)
+                _dev.potrf(ctx, K)
+                self.dropped = _dev.potrf_dropped(ctx)
+                warnings.warn("covariance matrix not positive definite (pivot %d <= %.1e): %d point(s) whose "
+                              "conditional variance is at round-off level were dropped from the factor (the "
+                              "reference's pinv truncates the same directions)" % (first.pivot, tau, self.dropped),
+                              RuntimeWarning)
+                return X, K, 0.0
+        finally:
+            _dev.potrf_policy(ctx, 0.0, False)
 
     @staticmethod
     def _spec_key(spec):

@@ -113,6 +113,13 @@ int gpx_kernel_eval(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp,
 /* ---- L2: factorisation and solves (replace numpy.linalg.pinv / slogdet) ---------------------- */
 /* in-place lower Cholesky K = L L^T (strict upper left undefined); replaces pinv at gp.py:181, 400 */
 int gpx_potrf(gpx_ctx* ctx, gpx_mat* K);
+/* Pivot policy of every factorisation that follows: a pivot <= piv_min is bad; skip == 0 reports it (status > 0 from
+ * gpx_potrf, the default with piv_min = 0), skip != 0 DROPS the point instead -- L_jj = 1, the rest of column j and row j of
+ * the inverse are 0, so solves return 0 in that component, as if the point were not in the set: what numpy.linalg.pinv
+ * (gp.py:181, experimentalDesign.py:826) makes of an exactly duplicated point.  gpx_potrf_dropped: pivots dropped by the
+ * last factorisation. */
+int gpx_potrf_policy(gpx_ctx* ctx, double piv_min, int skip);
+int gpx_potrf_dropped(gpx_ctx* ctx, int* count);
 /* factor K(X)+nugget when its leading `keep` (multiple of 128) rows/columns equal the matrix Lold factors
  * (the design loop pins earlier points by bounds, experimentalDesign.py:722-724, and only the last batch moves): the
  * leading factor block is copied, rows >= keep are assembled and the factorisation is completed in O(N^2 b).

@@ -216,18 +216,59 @@ def test_matern52_extension_vs_oracle():
         KernelIsoMatern(0.5, 1.0, 8, nu=0.5).evaluate(X, X)
 
 
-def test_rank_deficient_policy():
-    """noise 0.0 + coincident points: pinv truncates, Cholesky cannot -> documented jitter retry + warning."""
-    from gpExp.kernels import KernelSquaredExponential
+def test_rank_deficient_policy(golden):
+    """noise 0.0 + a duplicated training point: pinv (gp.py:181) truncates the null direction, i.e. predicts as if the
+    point were there once; the factorisation drops the second copy (pivot at round-off level) and must give the
+    reference's mean / variance / IVAR to 1e-8 (fixture `rankdef`)."""
     from gpExp.gp import GP
-    X = np.array([[0.1], [0.1], [0.5], [-0.3]])
-    y = np.array([1.0, 1.0, 0.2, -0.4])
-    g = GP(KernelSquaredExponential([0.3], 1.0, 1), 0.0)
+    from gpExp.experimentalDesign import costFunctionGP_IVAR
+    from gpExp.approximation import Space
+    c = "rankdef"
+    X, y, Z = golden(c, "X"), golden(c, "y"), golden(c, "Z")
+    g = GP(make_kernel(golden.index[c]["kernel"]), 0.0)
+    with pytest.warns(RuntimeWarning, match="dropped"):
+        g.train(X, y)
+    assert g.dropped == 1
+    i, j = golden.index[c]["duplicate"]
+    ref = golden(c, "coeff")
+    assert g.coeff[j] == 0.0 and g.coeff[i] == pytest.approx(ref[i] + ref[j], rel=1e-8)
+    keep = [k for k in range(len(X)) if k not in (i, j)]
+    assert rel(g.coeff[keep], ref[keep]) <= 1e-8
+    mean, absvar = g.evaluate(Z, compvar=1)
+    assert rel(mean, golden(c, "mean")) <= 1e-8
+    assert np.max(np.abs(absvar - golden(c, "absvar"))) <= 1e-8 * np.max(golden(c, "absvar"))
+    assert np.max(np.abs(g.evaluateVariance(Z) - golden(c, "var"))) <= 1e-8 * np.max(np.abs(golden(c, "var")))
+    space = Space(2, lambda size: np.random.rand(size[0], size[1]) * 2 - 1, lambda p: 0.25 * np.ones(len(p)))
+    cf = costFunctionGP_IVAR(GP(make_kernel(golden.index[c]["kernel"]), 0.0), len(X), space, mcPoints=Z)
+    with pytest.warns(RuntimeWarning, match="dropped"):
+        assert cf.evaluate(X) == pytest.approx(float(golden(c, "ivar")), rel=1e-8)
+    # a well-conditioned fit is untouched by the policy
+    g2 = GP(make_kernel(golden.index[c]["kernel"]), 1e-3)
+    g2.train(X, y)
+    assert g2.dropped == 0
+
+
+def test_rank_deficient_larger_vs_oracle():
+    """Three duplicated points among 300 (crossing 128-leaf and 16-block boundaries), noise 0: the posterior equals the
+    oracle's pinv posterior on the same inputs."""
+    from gpExp.gp import GP
+    rng = np.random.default_rng(12)
+    n, d = 300, 3
+    X = rng.uniform(-1, 1, (n, d))
+    X[130] = X[5]
+    X[255] = X[129]
+    X[17] = X[16]
+    y = np.sin(X.sum(1))
+    Z = rng.uniform(-1, 1, (40, d))
+    s = dict(kind="matern32", rho=0.8, signalSize=1.0, d=d)
+    g = GP(make_kernel(s), 0.0)
     with pytest.warns(RuntimeWarning):
         g.train(X, y)
-    assert g.jitter > 0
-    m = g.evaluate(np.array([[0.1], [0.5]]))
-    assert np.allclose(m, [1.0, 0.2], atol=1e-6)
+    assert g.dropped == 3
+    m = orc.fit(s, X, y, 0.0)
+    mo, vo = orc.posterior(s, m, Z)
+    mean, var = g.evaluate(Z, compvar=1)
+    assert rel(mean, mo) <= 1e-8 and np.max(np.abs(var - np.abs(vo))) <= 1e-8
 
 
 def test_variance_derivative_host_side_f1():
