@@ -2,17 +2,12 @@
 
 
 class Space:
-    """Describes the design space: dimension, a sampler `sample((n, d))`, a density `probDensity(points)` and an
-    optional heteroscedastic noise callable `noiseFunc(points)` (per-point nugget)."""
+    """Design space: `dimension`, a sampler `sample((n, d)) -> (n, d) points`, a density `probDensity(points)` and an
+    optional heteroscedastic noise model `noiseFunc` (callable on points -> per-point nugget; `.deriv(points)` when the
+    design gradient is wanted, demo2.py:45-58).  Attribute names are the reference's: callers read them directly
+    (experimentalDesign.py:72, 107-112)."""
 
-    dimension = None
-    inBoundsBool = None
-    sample = None
-    probDensity = None
-    noiseFunc = None
+    inBoundsBool = None   # declared by the reference, never set or read anywhere
 
     def __init__(self, dimensionIn, samplerIn, probDensityIn, noise=None):
-        self.dimension = dimensionIn
-        self.sample = samplerIn
-        self.probDensity = probDensityIn
-        self.noiseFunc = noise
+        self.dimension, self.sample, self.probDensity, self.noiseFunc = dimensionIn, samplerIn, probDensityIn, noise

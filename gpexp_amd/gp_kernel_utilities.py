@@ -60,11 +60,15 @@ def covTimesV(b, kernel, mcPoints):
     The covariance stays in HBM between calls with the same point set; each application is one device reduction."""
     b = np.asarray(b, dtype=float)
     ctx = _dev.context()
-    key = (id(mcPoints), mcPoints.shape, kernel._spec().kind, tuple(kernel._spec().hyp.tolist()))
-    if covTimesV._cache is None or covTimesV._cache[0] != key:
-        X = _dev.points(ctx, np.asarray(mcPoints, dtype=float))
-        covTimesV._cache = (key, _dev.kfill(ctx, kernel._spec(), X, nugget=0.0))
-    return _dev.matvec(ctx, covTimesV._cache[1], b.ravel()).reshape(b.shape)
+    pts = np.ascontiguousarray(mcPoints, dtype=float)
+    # keyed on the CONTENT of the point set (object ids are recycled and arrays can be edited in place): comparing
+    # N x d doubles per application is nothing next to the N x N product it guards
+    key = (pts.shape, kernel._spec().kind, tuple(kernel._spec().hyp.tolist()))
+    c = covTimesV._cache
+    if c is None or c[0] != key or not np.array_equal(c[1], pts):
+        X = _dev.points(ctx, pts)
+        covTimesV._cache = c = (key, pts.copy(), _dev.kfill(ctx, kernel._spec(), X, nugget=0.0))
+    return _dev.matvec(ctx, c[2], b.ravel()).reshape(b.shape)
 
 
 covTimesV._cache = None

@@ -83,13 +83,12 @@ class KernelSquaredExponential(Kernel):
     """signalSize * exp(-1/2 sum_k (x_k - x'_k)^2 / cl_k^2); a length-1 correlationLength is isotropic."""
 
     def __init__(self, correlationLength, signalSize, dimension):
-        hyperParam = dict({})
-        if len(correlationLength) == 1:
-            correlationLength = np.tile(correlationLength, (dimension))
-        for ii in range(len(correlationLength)):
-            hyperParam['cl' + str(ii)] = correlationLength[ii]
-        hyperParam['signalSize'] = signalSize
-        super(KernelSquaredExponential, self).__init__(hyperParam, dimension)
+        # keys 'cl0'..'cl{d-1}' then 'signalSize', in that order (kernels.py:103-112): the order is API -- it is the
+        # order of getHypParamNames() and of the optimiser's parameter vector (gp.py:566-582)
+        lengths = list(correlationLength) * dimension if len(correlationLength) == 1 else list(correlationLength)
+        params = {'cl%d' % k: lengths[k] for k in range(len(lengths))}
+        params['signalSize'] = signalSize
+        super(KernelSquaredExponential, self).__init__(params, dimension)
 
     def _cl(self):
         return np.array([self.hyperParam['cl' + str(ii)] for ii in range(self.dimension)], dtype=float)

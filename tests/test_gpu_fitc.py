@@ -98,6 +98,16 @@ def test_nystrom_basis_and_operator(golden):
     mc = golden(c, "nys_mc")
     b = np.random.default_rng(2).standard_normal(len(mc))
     assert rel(covTimesV(b, k, mc), calculateCovarianceMatrix(k, mc, 0.0) @ b) <= 1e-13
+    # the resident covariance is keyed on the CONTENT of the point set: an in-place edit and a fresh array of
+    # the same shape (object ids are recycled) must both give the new operator
+    mc2 = mc.copy()
+    assert rel(covTimesV(b, k, mc2), calculateCovarianceMatrix(k, mc, 0.0) @ b) <= 1e-13
+    mc2[:] = mc2[::-1] * 0.9
+    assert rel(covTimesV(b, k, mc2), calculateCovarianceMatrix(k, mc2, 0.0) @ b) <= 1e-13
+    for _ in range(3):
+        fresh = np.random.default_rng(_).uniform(-1, 1, mc.shape)
+        assert rel(covTimesV(b, k, fresh), calculateCovarianceMatrix(k, fresh, 0.0) @ b) <= 1e-13
+        del fresh
     ev, evec = calculateKernelBasisFunctionsMC(k, 6, mc)
     assert rel(ev, golden(c, "nys_eigv")) <= 1e-9
     assert rel(np.abs(evec), np.abs(golden(c, "nys_eigve"))) <= 1e-6      # ARPACK eigenvectors, up to sign
