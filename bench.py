@@ -44,32 +44,97 @@ def workload(n, d, m, seed):
     return X, y, Z, noise
 
 
-def cpu_baseline(d, seed):
-    """Reference algorithm on the host: bounded sample N=4096 (the SURVEY's C2 size), M=512."""
+def _cpu_info():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    blas, threads = "unknown", os.cpu_count() or 1
+    try:
+        import threadpoolctl
+        pools = [p for p in threadpoolctl.threadpool_info() if p.get("user_api") == "blas"]
+        if pools:
+            blas = "%s %s" % (pools[0].get("internal_api", "?"), pools[0].get("version", "?"))
+            threads = max(p.get("num_threads", 1) for p in pools)
+    except Exception:
+        pass
+    return model, blas, int(threads)
+
+
+def _ref_exact(n, m, d, seed):
+    """One pass of the REFERENCE ALGORITHM (the oracle's restatement) at N=n: row-loop assembly
+    (gp_kernel_utilities.py:56-60) + pinv (gp.py:181) + slogdet (gp.py:434) + per-point variance loop (gp.py:246-256)."""
     from oracle import gpexp_oracle as orc
-    n, m = 4096, 512
     X, y, Z, noise = workload(n, d, m, seed)
     spec = dict(kind="matern52", rho=0.5, signalSize=1.0, d=d)
     t0 = time.perf_counter()
-    K = orc.cov_matrix(spec, X, noise, row_loop=True)          # gp_kernel_utilities.py:56-60
-    P = np.linalg.pinv(K)                                      # gp.py:181
-    _, logdet = np.linalg.slogdet(K)                           # gp.py:434
+    K = orc.cov_matrix(spec, X, noise, row_loop=True)
+    t_fill = time.perf_counter() - t0
+    P = np.linalg.pinv(K)
+    _, logdet = np.linalg.slogdet(K)
     alpha = P @ y
     ll = -0.5 * y @ alpha - 0.5 * logdet - n / 2.0 * np.log(2 * np.pi)
-    model = dict(K=K, P=P, X=X)
-    _, var = orc.posterior(spec, model, Z)                     # gp.py:246-256 per-point loop
-    iv = abs(var.mean())
-    dt = time.perf_counter() - t0
-    try:
-        import threadpoolctl
-        threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] + [1])
-    except Exception:
-        threads = os.cpu_count() or 1
-    return dict(value=(n + m) / dt, unit="points/s", cores=int(threads), kind="port",
-                sample="N=%d train + M=%d MC points, d=%d Matern-5/2, reference algorithm (row-loop fill + pinv + "
-                       "slogdet + per-point variance loop), %.1f s; O(N^3): NOT extrapolated to N=32768"
-                       % (n, m, d, dt),
-                seconds=dt, loglike=float(ll), ivar=float(iv))
+    t_fit = time.perf_counter() - t0
+    _, var = orc.posterior(spec, dict(K=K, P=P, X=X), Z)
+    t_all = time.perf_counter() - t0
+    return dict(N=n, M=m, fill_s=t_fill, fit_s=t_fit, ivar_s=t_all - t_fit, total_s=t_all, loglike=float(ll),
+                ivar=float(abs(var.mean())))
+
+
+def _fair_chol(n, m, d, seed):
+    """The "fair CPU" line of SURVEY.md 8d: the algorithm the GPU runs (vectorised fill + LAPACK Cholesky + triangular
+    solves) on the host cores."""
+    import scipy.linalg as sl
+    from oracle import gpexp_oracle as orc
+    X, y, Z, noise = workload(n, d, m, seed)
+    spec = dict(kind="matern52", rho=0.5, signalSize=1.0, d=d)
+    t0 = time.perf_counter()
+    r2 = np.maximum(((X * X).sum(1)[:, None] + (X * X).sum(1)[None, :] - 2.0 * X @ X.T), 0.0)
+    t = np.sqrt(5.0 * r2) / 0.5
+    K = (1.0 + t + t * t / 3.0) * np.exp(-t)
+    K[np.diag_indices(n)] += noise
+    c = sl.cho_factor(K, lower=True, overwrite_a=True, check_finite=False)
+    alpha = sl.cho_solve(c, y, check_finite=False)
+    ll = -0.5 * y @ alpha - np.sum(np.log(np.diag(c[0]))) - n / 2.0 * np.log(2 * np.pi)
+    t_fit = time.perf_counter() - t0
+    kz = orc.cross_matrix(spec, Z, X).T if m <= 4096 else None
+    if kz is None:
+        r2 = np.maximum(((X * X).sum(1)[:, None] + (Z * Z).sum(1)[None, :] - 2.0 * X @ Z.T), 0.0)
+        t = np.sqrt(5.0 * r2) / 0.5
+        kz = (1.0 + t + t * t / 3.0) * np.exp(-t)
+    W = sl.solve_triangular(c[0], kz, lower=True, check_finite=False, overwrite_b=True)
+    iv = abs(np.mean(1.0 - np.sum(W * W, axis=0)))
+    t_all = time.perf_counter() - t0
+    return dict(N=n, M=m, fit_s=t_fit, ivar_s=t_all - t_fit, total_s=t_all, loglike=float(ll), ivar=float(iv))
+
+
+def cpu_baseline(d, full=False):
+    """SURVEY.md 8d protocol, bounded by default: the reference algorithm at N = 2048 and 4096 (M = 512 evaluation points;
+    `--cpu-baseline full` adds N = 8192 and the fair-CPU Cholesky line at the full N = 32768), a least-squares fit of
+    t = c N^3 through the measured fits, and the EXTRAPOLATED reference time at N = 32768 -- labelled as such.  `value` is
+    measured (the largest measured N), never extrapolated."""
+    model, blas, threads = _cpu_info()
+    sizes = [2048, 4096] + ([8192] if full else [])
+    runs = [_ref_exact(n, 512, d, seed=n) for n in sizes]
+    c3 = float(np.sum([r["fit_s"] * r["N"] ** 3 for r in runs]) / np.sum([float(r["N"]) ** 6 for r in runs]))
+    civ = float(np.mean([r["ivar_s"] / (r["N"] ** 2 * r["M"]) for r in runs]))
+    big = runs[-1]
+    fair = _fair_chol(32768 if full else 8192, 32768 if full else 2048, d, seed=32768 if full else 8192)
+    return dict(value=(big["N"] + big["M"]) / big["total_s"], unit="points/s", cores=threads, kind="port",
+                sample="reference algorithm (oracle: row-loop fill + pinv + slogdet + per-point variance loop) at N=%s, "
+                       "M=512, d=%d Matern-5/2; value = measured at N=%d (%.1f s); O(N^3): see fit / extrapolated"
+                       % (sizes, d, big["N"], big["total_s"]),
+                cpu_model=model, blas=blas, blas_threads=threads, host_cores=os.cpu_count(), runs=runs,
+                fit="t_fit = c N^3, c = %.3e s (least squares over the measured N)" % c3,
+                extrapolated={"N": 32768, "M": 32768, "fit_s": c3 * 32768.0 ** 3, "ivar_s": civ * 32768.0 ** 2 * 32768,
+                              "note": "EXTRAPOLATED from the fit, not measured (SURVEY.md 8d)"},
+                fair_cpu_chol=dict(fair, note="vectorised fill + LAPACK potrf/potrs + TRSM, the algorithm the GPU runs"),
+                seconds=float(sum(r["total_s"] for r in runs) + fair["total_s"]))
 
 
 def main():
@@ -81,6 +146,8 @@ def main():
     ap.add_argument("--dim", dest="d", type=int, default=8)
     ap.add_argument("--mc-points", dest="m", type=int, default=32768)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", choices=["bounded", "full"], default="bounded",
+                    help="full: SURVEY.md 8d's whole protocol (adds N=8192 and the fair-CPU Cholesky at N=32768; minutes)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -179,10 +246,41 @@ def main():
     dt = reduce_max(dt)
     ll, iv = out
 
+    # GP-fit and IVAR-eval separately (N / t_fit and M / t_IVAR), outside the timed region: inside it the
+    # alpha sweeps run underneath the IVAR GEMMs, so the two phases overlap and do not add up to ms_per_step
+    fit_ms = ivar_ms = None
+    if world == 1 and os.environ.get("GPX_FORCE_DIST") != "1":
+        def fit_only():
+            dev.kfill_into(ctx, spec, X, K, nugget=noise)
+            dev.potrf(ctx, K)
+            dev.potrs_dev(ctx, K, y_dev, alpha_dev)
+            dev.logdet(ctx, K)
+
+        def ivar_only():
+            dev.ivar(ctx, spec, K, X, Z)
+
+        res = []
+        for fn in (fit_only, ivar_only):
+            fn()
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                fn()
+            sync()
+            res.append(1e3 * (time.perf_counter() - t1) / args.steps)
+        fit_ms, ivar_ms = res
+
     if rank == 0:
         ms = 1e3 * dt / args.steps
         g = prof["gemm"]
         kf = prof["kfill"]
+        kc = prof["kcross"]
+
+        def hbm(p):
+            gbs = p["bytes"] / (p["ms"] * 1e-3) / 1e9 if p["ms"] > 0 else 0.0
+            return {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                    "avg_launch_ms": p["ms"] / p["launches"] if p["launches"] else 0.0,
+                    "algorithmic_bytes_per_launch": p["bytes"] / p["launches"] if p["launches"] else 0.0}
         ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
         traffic, traffic_src = None, None
         try:  # PMC counters cannot be read from inside the process: take the committed rocprofv3 --pmc passes of this
@@ -219,10 +317,15 @@ def main():
                          "avg_launch_ms": (g["ms"] / g["launches"]) if g["launches"] else 0.0,
                          "launches_per_step": g["launches"] / args.steps,
                          "kernel_ms_per_step": g["ms"] / args.steps},
-            "kfill": {"bound": "hbm", "achieved": kf["bytes"] / (kf["ms"] * 1e-3) / 1e9 if kf["ms"] > 0 else 0.0,
-                      "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                      "frac": (kf["bytes"] / (kf["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS) if kf["ms"] > 0 else 0.0,
-                      "note": "all kfill launches of the step (square K + N x M cross matrix)"},
+            "roofline_kfill": dict(hbm(kf), kernel="kfill_kernel<SYM> (symmetric N x N assembly, mirror-written)",
+                                   traffic=None),
+            "roofline_kcross": dict(hbm(kc), kernel="kfill_kernel (rectangular N x M cross matrix, every element computed)",
+                                    traffic=None),
+            "fit_ms": fit_ms, "ivar_ms": ivar_ms,
+            "points_per_s_fit": (N / (fit_ms * 1e-3)) if fit_ms else None,
+            "points_per_s_ivar": (M / (ivar_ms * 1e-3)) if ivar_ms else None,
+            "phase_note": "fit_ms (kfill + potrf + potrs + logdet) and ivar_ms are timed separately after the timed region; "
+                          "inside it the alpha sweeps run underneath the IVAR GEMMs",
             "phases_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items() if v["launches"]},
             "phases_note": "HIP-event spans per kernel class; trsv and reduce run on a side stream UNDERNEATH the IVAR GEMMs, "
                            "so their spans include waiting and the classes do not add up to ms_per_step",
@@ -230,7 +333,7 @@ def main():
             "device": info["name"],
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(d, seed=4096)
+            line["cpu_baseline"] = cpu_baseline(d, full=(args.cpu_baseline == "full"))
         print(json.dumps(line), flush=True)
     barrier()
     ctx.close()

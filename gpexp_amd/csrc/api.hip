@@ -226,6 +226,9 @@ int gpx_mat_new(gpx_ctx* ctx, int64_t rows, int64_t cols, int pad, gpx_mat** out
   m->aux_bytes = 0;
   m->factored = 0;
   m->bbox_ok = 0;
+  m->binv = nullptr;
+  m->binv_bytes = 0;
+  m->binv_ib = 0;
   void* p = nullptr;
   int r = gpx_dev_alloc(ctx, m->bytes, &p);
   if (r != 0) {
@@ -414,6 +417,7 @@ int gpx_mat_free(gpx_ctx* ctx, gpx_mat* m) {
   (void)hipDeviceSynchronize();
   gpx_dev_release(ctx, m->p, m->bytes);
   if (m->aux) gpx_dev_release(ctx, m->aux, m->aux_bytes);
+  if (m->binv) gpx_dev_release(ctx, m->binv, m->binv_bytes);
   delete m;
   return 0;
 }
@@ -515,6 +519,7 @@ int gpx_kfill_into(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, c
     (void)hipStreamSynchronize(ctx->stream);
     gpx_dev_release(ctx, d_nug, nug_bytes);
   }
+  K->binv_ib = 0;  // block inverses (chol_potrs) belong to the previous contents
   K->factored = 0;
   return r;
 }
@@ -561,6 +566,7 @@ int gpx_potrf(gpx_ctx* ctx, gpx_mat* K) {
     GPX_TRY(gpx_dev_alloc(ctx, K->aux_bytes, &p));
     K->aux = (double*)p;
   }
+  K->binv_ib = 0;  // block inverses of an earlier factorisation are stale (the buffer itself is reused)
   GPX_TRY(chol_potrf(ctx, K->p, K->ld, K->prows, K->aux, K->rows));
   int info = 0;
   GPX_HIP(hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -673,19 +679,24 @@ int gpx_potrs(gpx_ctx* ctx, const gpx_mat* L, const double* y, double* alpha) {
   GPX_ARG(ctx && y && alpha, "NULL argument");
   GPX_TRY(need_factor(L));
   const int64_t n = L->rows, np = L->prows;
-  void* p;
+  const int64_t sb = chol_potrs_scratch_bytes(np);
+  void *p, *ps;
   GPX_TRY(gpx_dev_alloc(ctx, np * 8, &p));
+  int r = gpx_dev_alloc(ctx, sb, &ps);
+  if (r != 0) {
+    gpx_dev_release(ctx, p, np * 8);
+    return r;
+  }
   double* dv = (double*)p;
-  int r = 0;
   do {
     if (hipMemsetAsync(dv, 0, (size_t)np * 8, ctx->stream) != hipSuccess) { r = -2; break; }
     if (hipMemcpyAsync(dv, y, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { r = -2; break; }
-    if ((r = chol_trsv(ctx, L->p, L->ld, L->aux, dv, np, false)) != 0) break;
-    if ((r = chol_trsv(ctx, L->p, L->ld, L->aux, dv, np, true)) != 0) break;
+    if ((r = chol_potrs(ctx, const_cast<gpx_mat*>(L), dv, (double*)ps)) != 0) break;  // caches the block inverses in L
     if (hipMemcpyAsync(alpha, dv, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { r = -2; break; }
   } while (0);
   (void)hipStreamSynchronize(ctx->stream);
   gpx_dev_release(ctx, dv, np * 8);
+  gpx_dev_release(ctx, ps, sb);
   if (r == -2) gpx_set_error("potrs: HIP copy failed");
   return r;
 }
@@ -696,7 +707,7 @@ int gpx_potrs_dev(gpx_ctx* ctx, const gpx_mat* L, const gpx_mat* y, gpx_mat* alp
   GPX_TRY(need_factor(L));
   const int64_t np = L->prows;
   GPX_ARG(y->bytes >= np * 8 && alpha->bytes >= np * 8, "y / alpha must hold the padded length (zero padded)");
-  const int64_t need = chol_trsv_scratch_bytes(np);
+  const int64_t need = chol_potrs_scratch_bytes(np);
   if (ctx->trsv_scratch_bytes < need) {
     GPX_HIP(hipDeviceSynchronize());  // the old scratch may still be in use on another stream
     if (ctx->trsv_scratch) (void)hipFree(ctx->trsv_scratch);
@@ -707,9 +718,7 @@ int gpx_potrs_dev(gpx_ctx* ctx, const gpx_mat* L, const gpx_mat* y, gpx_mat* alp
   }
   if (alpha->p != y->p)
     GPX_HIP(hipMemcpyAsync(alpha->p, y->p, (size_t)np * 8, hipMemcpyDeviceToDevice, ctx->stream));
-  GPX_TRY(chol_trsv_with_scratch(ctx, L->p, L->ld, L->aux, alpha->p, np, false, nullptr));
-  GPX_TRY(chol_trsv_with_scratch(ctx, L->p, L->ld, L->aux, alpha->p, np, true, ctx->trsv_scratch));
-  return 0;
+  return chol_potrs(ctx, const_cast<gpx_mat*>(L), alpha->p, ctx->trsv_scratch);
 }
 
 int gpx_logdet(gpx_ctx* ctx, const gpx_mat* L, double* out) {

@@ -647,6 +647,61 @@ __global__ __launch_bounds__(256) void logdet_kernel(const double* __restrict__ 
   if (threadIdx.x == 0) out[0] = 2.0 * red[0];
 }
 
+
+// ---- potrs through explicit block inverses ---------------------------------------------------------------------------
+// The sweeps are a chain of N / IB dependent steps; with one workgroup streaming each 512-row diagonal block the chain
+// cost 40-60 us per step (round 1: 10.5 ms at N = 32768, 5 % of the HBM roof).  Here the diagonal blocks of order IB (up
+// to 1024) are INVERTED once per factorisation -- recursively from the 128 x 128 leaf inverses, as batched MFMA products
+// over all blocks at once -- so that a diagonal solve becomes one chip-wide matrix-vector product with the inverse (row-
+// wise for the forward sweep, with the stored transpose for the backward sweep): ~4 us per step instead of ~50.
+
+// binv[b][t*128 + r][t*128 + c] = invd[(b * (IB/128) + t)][r][c], zero elsewhere
+__global__ __launch_bounds__(256) void binv_init_kernel(const double* __restrict__ invd, double* __restrict__ binv,
+                                                        int64_t ib, int64_t n) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one double2 of one IB-wide row of one block
+  const int64_t per_row = ib / 2, row = idx / per_row, c = 2 * (idx % per_row);
+  const int64_t b = row / ib, r = row % ib;
+  if (b * ib + r >= (n + ib - 1) / ib * ib) return;
+  double2 v = double2{0.0, 0.0};
+  const int64_t g = b * ib + r;  // global row
+  if (g < n && (c >> 7) == (r >> 7)) v = *reinterpret_cast<const double2*>(invd + (g >> 7) * NB * NB + (r & 127) * NB + (c & 127));
+  *reinterpret_cast<double2*>(binv + row * ib + c) = v;
+}
+
+// batched transpose of the IB x IB blocks
+__global__ __launch_bounds__(256) void binv_transpose_kernel(const double* __restrict__ in, double* __restrict__ out,
+                                                             int64_t ib) {
+  __shared__ double tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const double* ib_in = in + (int64_t)blockIdx.z * ib * ib;
+  double* ib_out = out + (int64_t)blockIdx.z * ib * ib;
+  const int64_t i0 = (int64_t)blockIdx.y * 32, j0 = (int64_t)blockIdx.x * 32;
+  for (int r = ty; r < 32; r += 8) tile[r][tx] = ib_in[(i0 + r) * ib + j0 + tx];
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) ib_out[(j0 + r) * ib + i0 + tx] = tile[tx][r];
+}
+
+// x[r] = sum_c M[r][c] y[c] over c in [c_lo(r), c_hi(r)): one wave per row; lower != 0: M is lower triangular (columns up
+// to the end of r's 128-block), else upper triangular (columns from the start of r's 128-block)
+__global__ __launch_bounds__(256) void binv_gemv_kernel(const double* __restrict__ M, int64_t ld, int64_t sz,
+                                                        const double* __restrict__ y, double* __restrict__ x, int lower) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+  if (r >= sz) return;
+  const int64_t c0 = lower ? 0 : (r & ~(int64_t)127), c1 = lower ? ((r | 127) + 1) : sz;
+  const double2* mr = reinterpret_cast<const double2*>(M + r * ld);
+  const double2* yr = reinterpret_cast<const double2*>(y);
+  double s0 = 0.0, s1 = 0.0;
+  for (int64_t c = c0 / 2 + lane; c < c1 / 2; c += 64) {
+    const double2 a = mr[c], b = yr[c];
+    s0 = fma(a.x, b.x, s0);
+    s1 = fma(a.y, b.y, s1);
+  }
+  double s = s0 + s1;
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) x[r] = s;
+}
+
 inline int64_t split(int64_t n) { return (n / NB / 2) * NB; }  // n multiple of 128, n > 128
 
 }  // namespace
@@ -819,6 +874,143 @@ static int trsv_bwd_rec(gpx_ctx* ctx, const double* L, int64_t ld, const double*
   // z1 -= L21^T z2 : deterministic column reduction of the (n2 x n1) block against z2, subtracted in its final pass
   GPX_TRY(launch_colreduce(ctx, L + n1 * ld, ld, n2, n1, z + n1, z, part, 1));
   return trsv_bwd_rec(ctx, L, ld, invd, z, n1, tmp, part);
+}
+
+
+// ---- potrs through block inverses: host side -----------------------------------------------------------------------------
+static int64_t potrs_block(int64_t n) {
+  static int64_t forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("GPX_POTRS_IB");  // order of the explicitly inverted diagonal blocks (multiple of 128)
+    forced = e ? atoll(e) : 0;
+  }
+  int64_t ib = forced > 0 ? forced / NB * NB : 1024;
+  if (ib < NB) ib = NB;
+  if (ib > n) ib = n;
+  return ib;
+}
+
+// inverse of the sz x sz diagonal sub-block starting at row/column r0 of every batched block, from the two halves:
+//   [A 0; C B]^-1 = [A^-1 0; -B^-1 C A^-1  B^-1]
+static int binv_build_rec(gpx_ctx* ctx, const double* L, int64_t ld, int64_t sl, double* binv, int64_t ib, int64_t r0,
+                          int64_t sz, double* tmp, int64_t batch) {
+  if (sz <= NB) return 0;
+  const int64_t s1 = split(sz), s2 = sz - s1;
+  GPX_TRY(binv_build_rec(ctx, L, ld, sl, binv, ib, r0, s1, tmp, batch));
+  GPX_TRY(binv_build_rec(ctx, L, ld, sl, binv, ib, r0 + s1, s2, tmp, batch));
+  const double* C = L + (r0 + s1) * ld + r0;
+  const double* Ai = binv + r0 * ib + r0;
+  const double* Bi = binv + (r0 + s1) * ib + r0 + s1;
+  double* R = binv + (r0 + s1) * ib + r0;  // zero so far
+  // T = C A^-1 ; R = 0 - B^-1 T
+  GPX_TRY(launch_gemm_batched(ctx, C, ld, sl, Ai, ib, ib * ib, tmp, s1, ib * ib, s2, s1, s1, false, false, batch));
+  return launch_gemm_batched(ctx, Bi, ib, ib * ib, tmp, s1, ib * ib, R, ib, ib * ib, s2, s1, s2, false, true, batch);
+}
+
+static int binv_ensure(gpx_ctx* ctx, gpx_mat* Lm) {
+  const int64_t n = Lm->prows, ib = potrs_block(n);
+  if (Lm->binv && Lm->binv_ib == ib) return 0;
+  const int64_t nblk = (n + ib - 1) / ib, nfull = n / ib, tail = n - nfull * ib;
+  const int64_t elems = nblk * ib * ib;
+  if (Lm->binv) gpx_dev_release(ctx, Lm->binv, Lm->binv_bytes);
+  Lm->binv = nullptr;
+  void* p;
+  GPX_TRY(gpx_dev_alloc(ctx, 2 * elems * 8, &p));
+  double* binv = (double*)p;
+  void* pt;
+  int r = gpx_dev_alloc(ctx, nblk * ib * ib * 8, &pt);  // products T, one slab per batched block
+  if (r != 0) {
+    gpx_dev_release(ctx, p, 2 * elems * 8);
+    return r;
+  }
+  do {
+    const int64_t rows = nblk * ib;
+    hipLaunchKernelGGL(binv_init_kernel, dim3((unsigned)((rows * (ib / 2) + 255) / 256)), dim3(256), 0, ctx->stream,
+                       Lm->aux, binv, ib, n);
+    if (nfull > 0 && (r = binv_build_rec(ctx, Lm->p, Lm->ld, ib * (Lm->ld + 1), binv, ib, 0, ib, (double*)pt, nfull)) != 0) break;
+    if (tail > 0 && (r = binv_build_rec(ctx, Lm->p + nfull * ib * (Lm->ld + 1), Lm->ld, 0, binv + nfull * ib * ib, ib, 0, tail,
+                                        (double*)pt, 1)) != 0) break;
+    dim3 gt((unsigned)(ib / 32), (unsigned)(ib / 32), (unsigned)nblk);
+    hipLaunchKernelGGL(binv_transpose_kernel, gt, dim3(256), 0, ctx->stream, binv, binv + elems, ib);
+    if (hipGetLastError() != hipSuccess) r = -2;
+  } while (0);
+  (void)hipStreamSynchronize(ctx->stream);  // the product slabs go back to the pool
+  gpx_dev_release(ctx, pt, nblk * ib * ib * 8);
+  if (r != 0) {
+    gpx_dev_release(ctx, p, 2 * elems * 8);
+    if (r == -2) gpx_set_error("potrs: building the block inverses failed");
+    return r;
+  }
+  Lm->binv = binv;
+  Lm->binv_bytes = 2 * elems * 8;
+  Lm->binv_ib = ib;
+  return 0;
+}
+
+struct PotrsPlan {
+  const double* L;
+  int64_t ld, n, ib, nblk;
+  const double* binv;   // [nblk][ib][ib]
+  const double* binvT;
+  double* part;         // colreduce partials
+};
+static inline int64_t blk_off(const PotrsPlan& P, int64_t b) { return b * P.ib < P.n ? b * P.ib : P.n; }
+
+// solve L x = rhs for the diagonal blocks [b0, b1): x (separate vector) receives the solution, rhs is consumed
+static int potrs_fwd(gpx_ctx* ctx, const PotrsPlan& P, int64_t b0, int64_t b1, double* rhs, double* x) {
+  if (b1 - b0 == 1) {
+    const int64_t o = blk_off(P, b0), sz = blk_off(P, b0 + 1) - o;
+    hipLaunchKernelGGL(binv_gemv_kernel, dim3((unsigned)((sz + 3) / 4)), dim3(256), 0, ctx->stream, P.binv + b0 * P.ib * P.ib,
+                       P.ib, sz, rhs + o, x + o, 1);
+    return 0;
+  }
+  const int64_t mid = (b0 + b1) / 2;
+  GPX_TRY(potrs_fwd(ctx, P, b0, mid, rhs, x));
+  const int64_t r0 = blk_off(P, mid), r1 = blk_off(P, b1), c0 = blk_off(P, b0);
+  int64_t wg = (r1 - r0 + 3) / 4;
+  if (wg > 4096) wg = 4096;
+  hipLaunchKernelGGL(gemv_sub_kernel, dim3((unsigned)wg), dim3(256), 0, ctx->stream, P.L + r0 * P.ld + c0, P.ld, r1 - r0, r0 - c0,
+                     x + c0, rhs + r0);
+  return potrs_fwd(ctx, P, mid, b1, rhs, x);
+}
+
+// solve L^T z = rhs
+static int potrs_bwd(gpx_ctx* ctx, const PotrsPlan& P, int64_t b0, int64_t b1, double* rhs, double* z) {
+  if (b1 - b0 == 1) {
+    const int64_t o = blk_off(P, b0), sz = blk_off(P, b0 + 1) - o;
+    hipLaunchKernelGGL(binv_gemv_kernel, dim3((unsigned)((sz + 3) / 4)), dim3(256), 0, ctx->stream, P.binvT + b0 * P.ib * P.ib,
+                       P.ib, sz, rhs + o, z + o, 0);
+    return 0;
+  }
+  const int64_t mid = (b0 + b1) / 2;
+  GPX_TRY(potrs_bwd(ctx, P, mid, b1, rhs, z));
+  const int64_t r0 = blk_off(P, mid), r1 = blk_off(P, b1), c0 = blk_off(P, b0);
+  // rhs[c0 : r0] -= L[r0 : r1, c0 : r0]^T z[r0 : r1]  (deterministic column reduction)
+  GPX_TRY(launch_colreduce(ctx, P.L + r0 * P.ld + c0, P.ld, r1 - r0, r0 - c0, z + r0, rhs + c0, P.part, 1));
+  return potrs_bwd(ctx, P, b0, mid, rhs, z);
+}
+
+int64_t chol_potrs_scratch_bytes(int64_t n) { return n * 8 + colreduce_partial_elems(n, n) * 8 + 64; }
+
+int chol_potrs(gpx_ctx* ctx, gpx_mat* Lm, double* v, double* scratch) {
+  GPX_ARG(Lm && Lm->factored && Lm->aux && v && scratch, "potrs: matrix has not been factored / NULL vector");
+  GPX_ARG(Lm->ld % 2 == 0, "potrs: leading dimension must be even");
+  GPX_TRY(binv_ensure(ctx, Lm));
+  PotrsPlan P;
+  P.L = Lm->p;
+  P.ld = Lm->ld;
+  P.n = Lm->prows;
+  P.ib = Lm->binv_ib;
+  P.nblk = (P.n + P.ib - 1) / P.ib;
+  P.binv = Lm->binv;
+  P.binvT = Lm->binv + P.nblk * P.ib * P.ib;
+  P.part = scratch + P.n;
+  double* x = scratch;
+  ProfScope ps(ctx, GPX_PROF_TRSV, 2.0 * (double)P.n * P.n, 8.0 * (double)P.n * P.n);
+  GPX_TRY(potrs_fwd(ctx, P, 0, P.nblk, v, x));   // v consumed, w = L^-1 y in x
+  GPX_TRY(potrs_bwd(ctx, P, 0, P.nblk, x, v));   // x consumed, alpha in v
+  GPX_HIP(hipGetLastError());
+  return 0;
 }
 
 int64_t chol_trsv_scratch_bytes(int64_t n) { return n * 8 + colreduce_partial_elems(n, n) * 8 + 64; }

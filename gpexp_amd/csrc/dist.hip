@@ -391,6 +391,7 @@ int gpx_dist_kfill(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, c
     (void)hipStreamSynchronize(ctx->stream);
     gpx_dev_release(ctx, d_nug, nug_bytes);
   }
+  K->binv_ib = 0;  // block inverses (chol_potrs) belong to the previous contents
   K->factored = 0;
   return r;
 }
@@ -570,6 +571,7 @@ int gpx_dist2_kfill(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, 
     (void)hipStreamSynchronize(ctx->stream);
     gpx_dev_release(ctx, d_nug, nug_bytes);
   }
+  A->binv_ib = 0;  // block inverses (chol_potrs) belong to the previous contents
   A->factored = 0;
   return r;
 }
@@ -718,6 +720,7 @@ int gpx_dist2_logdet_acc(gpx_ctx* ctx, const gpx_mat* A, int64_t lr, int64_t lc,
 int gpx_dist_finish(gpx_ctx* ctx, gpx_mat* K) {
   GPX_ARG(ctx && K && K->aux, "matrix was not factored by the distributed panel loop");
   GPX_HIP(hipStreamSynchronize(ctx->stream));
+  K->binv_ib = 0;  // block inverses (chol_potrs) belong to the previous contents
   K->factored = 1;
   return 0;
 }

@@ -97,6 +97,7 @@ int factor_in_place(gpx_ctx* ctx, gpx_mat* K, const char* what) {
   int info = 0;
   GPX_HIP(hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   GPX_HIP(hipStreamSynchronize(ctx->stream));
+  K->binv_ib = 0;  // block inverses (chol_potrs) belong to the previous contents
   K->factored = (info == 0);
   if (info != 0) {
     gpx_set_error("fitc: %s is not positive definite (pivot %d <= 0)", what, info);

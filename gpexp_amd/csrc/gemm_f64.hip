@@ -277,6 +277,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64
   gemm_tile<BT, ACC, TE>(sm, A, lda, B, ldb, C, ldc, nk, by, bx);
 }
 
+// Batched form for many small independent products with constant strides (the block inverses of the triangular sweeps,
+// chol.hip): blockIdx.y = batch entry, blockIdx.x = 64x64 tile of that entry's C, row-major.
+template <bool BT, bool ACC>
+__global__ __launch_bounds__(256, 2) void gemm_f64_batched_kernel(const double* A, int64_t lda, int64_t sa,
+                                                                  const double* B, int64_t ldb, int64_t sb, double* C,
+                                                                  int64_t ldc, int64_t sc, int nk, int tiles_n) {
+  __shared__ Smem<BT, 64> sm;
+  const int64_t b = blockIdx.y;
+  const int by = blockIdx.x / tiles_n, bx = blockIdx.x - by * tiles_n;
+  gemm_tile<BT, ACC, 64>(sm, A + b * sa, lda, B + b * sb, ldb, C + b * sc, ldc, nk, by, bx);
+}
+
 // (A persistent per-XCD work-queue variant of this kernel was measured in round 1 and removed: exact XCD placement
 // alone does not bring the L2 hit rate back -- 4096x8192x16384: 51 GB fetched with or without it, 69 GB requested; the
 // first wave of a launch shares panels because it starts in lock-step (70-81 % hit), later tiles drift apart by more
@@ -306,6 +318,31 @@ Plan make_plan(int64_t m, int64_t n, bool lower, int te) {
 }
 
 }  // namespace
+
+// C_b (m x n) = (accumulate ? C_b - A_b*op(B_b) : A_b*op(B_b)) for b = 0..batch-1 with element strides sa, sb, sc between
+// consecutive entries; m, n multiples of 64, k of 16; C_b must not alias A_b or B_b
+int launch_gemm_batched(gpx_ctx* ctx, const double* A, int64_t lda, int64_t sa, const double* B, int64_t ldb, int64_t sb,
+                        double* C, int64_t ldc, int64_t sc, int64_t m, int64_t n, int64_t k, bool bt, bool accumulate,
+                        int64_t batch) {
+  if (m == 0 || n == 0 || batch == 0) return 0;
+  GPX_ARG(m % 64 == 0 && n % 64 == 0 && k % KB == 0 && k > 0, "gemm_batched: m,n must be multiples of 64 and k of 16");
+  GPX_ARG((lda % 2) == 0 && (ldb % 2) == 0 && batch <= 65535, "gemm_batched: even leading dimensions, at most 65535 entries");
+  const int tn = (int)(n / 64);
+  dim3 grid((unsigned)((m / 64) * tn), (unsigned)batch);
+  const int nk = (int)(k / KB);
+  ProfScope ps(ctx, GPX_PROF_GEMM, 2.0 * (double)m * (double)n * (double)k * (double)batch, 0.0);
+#define GPX_B(BT_, ACC_)                                                                                          \
+  hipLaunchKernelGGL((gemm_f64_batched_kernel<BT_, ACC_>), grid, dim3(256), 0, ctx->stream, A, lda, sa, B, ldb, sb, C, \
+                     ldc, sc, nk, tn)
+  if (bt) {
+    if (accumulate) GPX_B(true, true); else GPX_B(true, false);
+  } else {
+    if (accumulate) GPX_B(false, true); else GPX_B(false, false);
+  }
+#undef GPX_B
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
 
 int launch_gemm(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
                 int64_t m, int64_t n, int64_t k, bool bt, bool accumulate, bool lower) {

@@ -82,6 +82,11 @@ struct gpx_mat {
   // bounding box of a point set (cols <= GPX_MAXD), computed on the host at upload (gpx_mat_from_host) or on first use
   int bbox_ok;
   double lo[GPX_MAXD], hi[GPX_MAXD];
+  // explicit inverses of the IB x IB diagonal blocks of the factor (and their transposes), built on the first gpx_potrs
+  // after a factorisation (chol_potrs): ceil(prows / IB) blocks of IB x IB each, twice
+  double* binv;
+  int64_t binv_bytes;
+  int64_t binv_ib;
 };
 
 struct ProfRec {
@@ -163,6 +168,10 @@ int launch_kfill_rows(gpx_ctx* ctx, const KParams& kp, const double* X, int64_t 
 int launch_gemm(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
                 int64_t m, int64_t n, int64_t k, bool bt, bool accumulate, bool lower);
 
+int launch_gemm_batched(gpx_ctx* ctx, const double* A, int64_t lda, int64_t sa, const double* B, int64_t ldb, int64_t sb,
+                        double* C, int64_t ldc, int64_t sc, int64_t m, int64_t n, int64_t k, bool bt, bool accumulate,
+                        int64_t batch);
+
 // chol.hip
 int launch_leaf(gpx_ctx* ctx, double* A, int64_t ld, double* inv, int64_t base_index, int64_t n_valid);
 int chol_potrf(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double* invd, int64_t n_valid);
@@ -183,6 +192,10 @@ int64_t chol_trsv_scratch_bytes(int64_t n);
 int chol_trsv_with_scratch(gpx_ctx* ctx, const double* L, int64_t ld, const double* invd, double* y, int64_t n,
                            bool transposed, double* scratch);
 int launch_logdet(gpx_ctx* ctx, const double* L, int64_t ld, int64_t n, double* d_out);
+// alpha = K^-1 y through explicit inverses of the diagonal blocks (built on first use, kept in L): v (padded n doubles) is
+// overwritten by the solution; scratch >= chol_potrs_scratch_bytes(n).  Asynchronous on the selected stream.
+int64_t chol_potrs_scratch_bytes(int64_t n);
+int chol_potrs(gpx_ctx* ctx, gpx_mat* L, double* v, double* scratch);
 // y[r] -= sum_c A[r][c] x[c] over a rows x cols block (cols a multiple of 2, ld even)
 int launch_gemv_sub(gpx_ctx* ctx, const double* A, int64_t ld, int64_t rows, int64_t cols, const double* x, double* y);
 

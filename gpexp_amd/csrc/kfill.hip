@@ -423,9 +423,10 @@ int launch_kfill(gpx_ctx* ctx, const KParams& kp, const double* A, int64_t na, c
                  int64_t prows, int64_t pcols, int64_t ld) {
   GPX_ARG(prows % TM == 0 && pcols % TN == 0, "kfill: padded shape must be a multiple of 64");
   GPX_ARG(prows / TM <= 65535, "kfill: too many row tiles");
-  ProfScope ps(ctx, GPX_PROF_KFILL, 0.0, 8.0 * (double)prows * (double)pcols + 8.0 * (double)(na + nb) * kp.d);
   // the mirrored (half-compute) path needs a square output whose row and column point sets coincide
   const bool sym = symmetric && prows == pcols && A == B && na == nb;
+  ProfScope ps(ctx, symmetric ? GPX_PROF_KFILL : GPX_PROF_KCROSS, 0.0,
+               8.0 * (double)prows * (double)pcols + 8.0 * (double)(na + nb) * kp.d);
 #define GPX_KIND(K_)                                                                                            \
   (sym ? launch_kind<K_, true>(ctx, kp, A, na, B, nb, 1, d_nugget, nugget_len, nugget_scalar, out, prows, pcols, ld) \
        : launch_kind<K_, false>(ctx, kp, A, na, B, nb, symmetric, d_nugget, nugget_len, nugget_scalar, out, prows,  \

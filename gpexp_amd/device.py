@@ -10,7 +10,7 @@ from . import _lib
 from ._lib import check, as_f64, dptr, c_vp, c_i64
 
 K_SE, K_MATERN32, K_MATERN52, K_MEHLER = 0, 1, 2, 3
-PROF_CLASSES = ["kfill", "gemm", "leaf", "trsv", "reduce", "greedy", "comm"]
+PROF_CLASSES = ["kfill", "gemm", "leaf", "trsv", "reduce", "greedy", "comm", "kcross"]
 
 _ctx = None
 

@@ -46,14 +46,15 @@ enum gpx_kernel_kind { GPX_K_SE = 0, GPX_K_MATERN32 = 1, GPX_K_MATERN52 = 2, GPX
 
 /* names of the timed kernel classes reported by gpx_profile_get */
 enum gpx_prof_class {
-  GPX_PROF_KFILL = 0,   /* covariance assembly (HBM-bound: 8*rows*cols bytes written) */
+  GPX_PROF_KFILL = 0,   /* symmetric covariance assembly K(X,X) (HBM-bound: 8*rows*cols bytes written) */
   GPX_PROF_GEMM = 1,    /* fp64 MFMA GEMM/SYRK/TRSM-update tiles (MFMA-bound: 2*m*n*k flops) */
   GPX_PROF_LEAF = 2,    /* 128x128 diagonal potf2 + trtri */
   GPX_PROF_TRSV = 3,    /* potrs sweeps */
   GPX_PROF_REDUCE = 4,  /* column reductions / logdet */
   GPX_PROF_GREEDY = 5,  /* greedy-design scoring kernels */
   GPX_PROF_COMM = 6,    /* RCCL collectives */
-  GPX_PROF_NCLASS = 7
+  GPX_PROF_KCROSS = 7,  /* rectangular cross-covariance assembly K(X,Z): every element computed (VALU: sqrt + exp) */
+  GPX_PROF_NCLASS = 8
 };
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */
