@@ -573,6 +573,12 @@ int gpx_potrf(gpx_ctx* ctx, gpx_mat* K) {
   GPX_HIP(hipStreamSynchronize(ctx->stream));
   K->factored = (info == 0);
   if (info != 0) gpx_set_error("potrf: matrix is not positive definite (pivot %d <= 0)", info);
+  // explicit inverses of the diagonal blocks for the solves that follow (potrs, posterior / IVAR): built here, on the
+  // factorisation's stream, so that consumers on different streams (the bench runs potrs beside IVAR) find them ready
+  if (info == 0 && K->prows >= 2048) {
+    GPX_TRY(chol_binv_ensure(ctx, K));
+    GPX_HIP(hipStreamSynchronize(ctx->stream));
+  }
   return info;
 }
 
@@ -752,7 +758,9 @@ static int posterior_impl(gpx_ctx* ctx, const KParams& kp, const gpx_mat* L, con
   if (M == 0) return 0;
   const int64_t mcmax = eval_chunk(np);
   const int64_t mc_alloc = gpx_round_up(M < mcmax ? M : mcmax, GPX_TILE);
-  void *pB = nullptr, *pal = nullptr, *pout = nullptr, *ppart = nullptr, *pkd = nullptr;
+  void *pB = nullptr, *pW = nullptr, *pal = nullptr, *pout = nullptr, *ppart = nullptr, *pkd = nullptr;
+  // from 2048 training points the solve goes through the explicit block inverses, out of place (chol_trsm_left_oop)
+  const bool oop = var != nullptr && np >= 2048;
   const int64_t ldb_alloc = gpx_skew_ld(mc_alloc);
   const int64_t bytesB = np * ldb_alloc * 8, bytes_out = mc_alloc * 8;
   const int64_t bytes_part = colreduce_partial_elems(np, mc_alloc) * 8 + 8;
@@ -760,6 +768,7 @@ static int posterior_impl(gpx_ctx* ctx, const KParams& kp, const gpx_mat* L, con
   std::vector<double> hbuf((size_t)mc_alloc), hk((size_t)mc_alloc);
   do {
     if ((r = gpx_dev_alloc(ctx, bytesB, &pB)) != 0) break;
+    if (oop && (r = gpx_dev_alloc(ctx, bytesB, &pW)) != 0) break;
     if ((r = gpx_dev_alloc(ctx, bytes_out, &pout)) != 0) break;
     if ((r = gpx_dev_alloc(ctx, bytes_out, &pkd)) != 0) break;
     if ((r = gpx_dev_alloc(ctx, bytes_part, &ppart)) != 0) break;
@@ -786,8 +795,14 @@ static int posterior_impl(gpx_ctx* ctx, const KParams& kp, const gpx_mat* L, con
         }
       }
       if (var) {
-        if ((r = chol_trsm_left(ctx, L->p, L->ld, L->aux, B, ldb, np, mcp)) != 0) break;
-        if ((r = launch_colreduce(ctx, B, ldb, n, mcp, nullptr, (double*)pout, (double*)ppart)) != 0) break;
+        const double* Wsol = B;
+        if (oop) {
+          if ((r = chol_trsm_left_oop(ctx, const_cast<gpx_mat*>(L), B, ldb, (double*)pW, ldb, mcp)) != 0) break;
+          Wsol = (const double*)pW;
+        } else if ((r = chol_trsm_left(ctx, L->p, L->ld, L->aux, B, ldb, np, mcp)) != 0) {
+          break;
+        }
+        if ((r = launch_colreduce(ctx, Wsol, ldb, n, mcp, nullptr, (double*)pout, (double*)ppart)) != 0) break;
         if ((r = launch_kdiag(ctx, kp, Zc, mc, (double*)pkd)) != 0) break;
         if (hipMemcpyAsync(hbuf.data(), pout, (size_t)mc * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipMemcpyAsync(hk.data(), pkd, (size_t)mc * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
@@ -801,6 +816,7 @@ static int posterior_impl(gpx_ctx* ctx, const KParams& kp, const gpx_mat* L, con
   } while (0);
   (void)hipStreamSynchronize(ctx->stream);
   gpx_dev_release(ctx, pB, bytesB);
+  if (pW) gpx_dev_release(ctx, pW, bytesB);
   gpx_dev_release(ctx, pout, bytes_out);
   gpx_dev_release(ctx, pkd, bytes_out);
   gpx_dev_release(ctx, ppart, bytes_part);

@@ -258,7 +258,7 @@ template <bool BT, bool ACC, bool LOWER, int TE>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64_t lda, const double* B, int64_t ldb,
                                                           double* C, int64_t ldc, int nk, int tiles_m, int tiles_n,
                                                           int sb_cols, int sb_shift, int main_wgs, int tail_m0,
-                                                          int tail_tn) {
+                                                          int tail_tn, int tri) {
   __shared__ Smem<BT, TE> sm;
   const int w = blockIdx.x;
   if (TE == 128 && w >= main_wgs) {
@@ -274,7 +274,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64
   int by, bx;
   if (!tile_of<LOWER>((q >> sbs2) * 8 + xcd, q & ((1 << sbs2) - 1), tiles_m, tiles_n, sb_cols, sb_shift, &by, &bx))
     return;
-  gemm_tile<BT, ACC, TE>(sm, A, lda, B, ldb, C, ldc, nk, by, bx);
+  // triangular operand: tri == 1, A (m x k) is lower triangular -> row tile `by` only needs k < (by+1)*TE; tri == 2, op(B)
+  // comes from a lower-triangular (n x k) matrix used transposed -> column tile `bx` only needs k < (bx+1)*TE.  The zero
+  // half of the product is never multiplied (products with the explicit block inverses, chol.hip).
+  int nkt = nk;
+  if (tri == 1) nkt = min(nk, (by + 1) * (TE / KB));
+  if (tri == 2) nkt = min(nk, (bx + 1) * (TE / KB));
+  gemm_tile<BT, ACC, TE>(sm, A, lda, B, ldb, C, ldc, nkt, by, bx);
 }
 
 // Batched form for many small independent products with constant strides (the block inverses of the triangular sweeps,
@@ -346,7 +352,15 @@ int launch_gemm_batched(gpx_ctx* ctx, const double* A, int64_t lda, int64_t sa, 
 
 int launch_gemm(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
                 int64_t m, int64_t n, int64_t k, bool bt, bool accumulate, bool lower) {
+  return launch_gemm_tri(ctx, A, lda, B, ldb, C, ldc, m, n, k, bt, accumulate, lower, 0);
+}
+
+// tri: 0 = dense operands; 1 = A is lower triangular (k == m); 2 = B is a lower-triangular n x k matrix used transposed
+// (bt, k == n): the structurally zero part of the k range is skipped per tile
+int launch_gemm_tri(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
+                    int64_t m, int64_t n, int64_t k, bool bt, bool accumulate, bool lower, int tri) {
   if (m == 0 || n == 0) return 0;
+  GPX_ARG(tri == 0 || (!lower && ((tri == 1 && k == m) || (tri == 2 && bt && k == n))), "gemm: bad triangular-operand mode");
   GPX_ARG(m % 128 == 0 && n % 128 == 0 && k % KB == 0 && k > 0, "gemm: m,n must be multiples of 128 and k of 16");
   GPX_ARG((lda % 2) == 0 && (ldb % 2) == 0, "gemm: leading dimensions must be even (16-byte loads)");
   GPX_ARG(!lower || m == n, "gemm: lower-only update needs a square C");
@@ -388,10 +402,12 @@ int launch_gemm(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int
   GPX_ARG(p.wgs + tail_wgs < ((int64_t)1 << 31), "gemm: grid too large");
   dim3 grid((unsigned)(p.wgs + tail_wgs));
   const int nk = (int)(k / KB);
-  ProfScope ps(ctx, GPX_PROF_GEMM, 2.0 * tiles128 * 128.0 * 128.0 * (double)k, 0.0);
+  // algorithmic flops: a triangular operand halves the k range on average (+ the diagonal blocks)
+  const double kflops = tri ? 0.5 * (double)k + 64.0 : (double)k;
+  ProfScope ps(ctx, GPX_PROF_GEMM, 2.0 * tiles128 * 128.0 * 128.0 * kflops, 0.0);
 #define GPX_K(BT_, ACC_, LOW_, TE_)                                                                           \
   hipLaunchKernelGGL((gemm_f64_kernel<BT_, ACC_, LOW_, TE_>), grid, dim3(256), 0, ctx->stream, A, lda, B, ldb, C, ldc, \
-                     nk, p.tm, p.tn, p.sbc, p.sb_shift, (int)p.wgs, (int)m_main, (int)tail_tn)
+                     nk, p.tm, p.tn, p.sbc, p.sb_shift, (int)p.wgs, (int)m_main, (int)tail_tn, tri)
 #define GPX_G(BT_, ACC_, LOW_)          \
   do {                                  \
     if (te == 64)                       \

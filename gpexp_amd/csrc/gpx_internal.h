@@ -168,6 +168,8 @@ int launch_kfill_rows(gpx_ctx* ctx, const KParams& kp, const double* X, int64_t 
 int launch_gemm(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
                 int64_t m, int64_t n, int64_t k, bool bt, bool accumulate, bool lower);
 
+int launch_gemm_tri(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
+                    int64_t m, int64_t n, int64_t k, bool bt, bool accumulate, bool lower, int tri);
 int launch_gemm_batched(gpx_ctx* ctx, const double* A, int64_t lda, int64_t sa, const double* B, int64_t ldb, int64_t sb,
                         double* C, int64_t ldc, int64_t sc, int64_t m, int64_t n, int64_t k, bool bt, bool accumulate,
                         int64_t batch);
@@ -194,6 +196,9 @@ int chol_trsv_with_scratch(gpx_ctx* ctx, const double* L, int64_t ld, const doub
 int launch_logdet(gpx_ctx* ctx, const double* L, int64_t ld, int64_t n, double* d_out);
 // alpha = K^-1 y through explicit inverses of the diagonal blocks (built on first use, kept in L): v (padded n doubles) is
 // overwritten by the solution; scratch >= chol_potrs_scratch_bytes(n).  Asynchronous on the selected stream.
+int chol_binv_ensure(gpx_ctx* ctx, gpx_mat* L);  // explicit inverses of L's diagonal blocks (order <= 1024), cached in L
+// W (n x m, separate buffer) = L^-1 B through the block inverses: B is consumed (its lower block rows are updated in place)
+int chol_trsm_left_oop(gpx_ctx* ctx, gpx_mat* L, double* B, int64_t ldb, double* W, int64_t ldw, int64_t m);
 int64_t chol_potrs_scratch_bytes(int64_t n);
 int chol_potrs(gpx_ctx* ctx, gpx_mat* L, double* v, double* scratch);
 // y[r] -= sum_c A[r][c] x[c] over a rows x cols block (cols a multiple of 2, ld even)
