@@ -269,6 +269,9 @@ int gpx_create(int device, gpx_ctx** out) {
   c->Pr = c->Pc = 1;
   c->piv_min = 0.0;
   c->piv_skip = 0;
+  c->pw_binv = c->pw_tmp_build = c->pw_tmp_T = nullptr;
+  c->pw_ib = 0;
+  c->pw_done = 0;
   c->prof_on = 0;
   for (int i = 0; i < GPX_PROF_NCLASS; ++i) {
     c->prof_launches[i] = 0;
@@ -331,6 +334,7 @@ int gpx_destroy(gpx_ctx* ctx) {
   (void)hipFree(ctx->d_scal);
   if (ctx->trsv_scratch) (void)hipFree(ctx->trsv_scratch);
   for (auto ev : ctx->sync_events) (void)hipEventDestroy(ev);
+  for (auto ev : ctx->la_events) (void)hipEventDestroy(ev);
   for (int i = 0; i < 4; ++i) (void)hipStreamDestroy(ctx->streams[i]);
   delete ctx;
   return 0;
@@ -567,16 +571,61 @@ int gpx_potrf(gpx_ctx* ctx, gpx_mat* K) {
     K->aux = (double*)p;
   }
   K->binv_ib = 0;  // block inverses of an earlier factorisation are stale (the buffer itself is reused)
-  GPX_TRY(chol_potrf(ctx, K->p, K->ld, K->prows, K->aux, K->rows));
+  // Large matrices take the blocked look-ahead path, which builds the explicit inverses of the 1024-order diagonal blocks
+  // as it goes (its panel solves use them; potrs and the posterior solves reuse them): give it the storage.
+  const int64_t np = K->prows;
+  const bool blocked = np >= 8192;
+  void *ptb = nullptr, *ptt = nullptr;
+  const int64_t ib = chol_binv_order(np), bbytes = chol_binv_elems(np) * 8;
+  const int64_t tb_bytes = ((np + ib - 1) / ib) * ib * ib * 8, tt_bytes = np * ib * 8;
+  if (blocked) {
+    if (K->binv && K->binv_bytes != bbytes) {
+      gpx_dev_release(ctx, K->binv, K->binv_bytes);
+      K->binv = nullptr;
+    }
+    if (!K->binv) {
+      void* p;
+      GPX_TRY(gpx_dev_alloc(ctx, bbytes, &p));
+      K->binv = (double*)p;
+      K->binv_bytes = bbytes;
+    }
+    GPX_TRY(gpx_dev_alloc(ctx, tb_bytes, &ptb));
+    int ra = gpx_dev_alloc(ctx, tt_bytes, &ptt);
+    if (ra != 0) {
+      gpx_dev_release(ctx, ptb, tb_bytes);
+      return ra;
+    }
+    ctx->pw_binv = K->binv;
+    ctx->pw_ib = ib;
+    ctx->pw_tmp_build = (double*)ptb;
+    ctx->pw_tmp_T = (double*)ptt;
+  }
+  ctx->pw_done = 0;
+  int rc = chol_potrf(ctx, K->p, K->ld, np, K->aux, K->rows);
+  const bool built = ctx->pw_done != 0;
+  ctx->pw_binv = ctx->pw_tmp_build = ctx->pw_tmp_T = nullptr;
+  ctx->pw_ib = 0;
+  ctx->pw_done = 0;
   int info = 0;
-  GPX_HIP(hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  GPX_HIP(hipStreamSynchronize(ctx->stream));
+  if (rc == 0 && hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = -2;
+  if (hipDeviceSynchronize() != hipSuccess && rc == 0) rc = -2;  // the look-ahead path uses three streams
+  if (blocked) {
+    gpx_dev_release(ctx, ptb, tb_bytes);
+    gpx_dev_release(ctx, ptt, tt_bytes);
+  }
+  if (rc != 0) {
+    if (rc == -2) gpx_set_error("potrf: HIP call failed: %s", hipGetErrorString(hipGetLastError()));
+    return rc;
+  }
   K->factored = (info == 0);
   if (info != 0) gpx_set_error("potrf: matrix is not positive definite (pivot %d <= 0)", info);
-  // explicit inverses of the diagonal blocks for the solves that follow (potrs, posterior / IVAR): built here, on the
+  // explicit inverses of the diagonal blocks for the solves that follow (potrs, posterior / IVAR): completed here, on the
   // factorisation's stream, so that consumers on different streams (the bench runs potrs beside IVAR) find them ready
-  if (info == 0 && K->prows >= 2048) {
-    GPX_TRY(chol_binv_ensure(ctx, K));
+  if (info == 0 && np >= 2048) {
+    if (built)
+      GPX_TRY(chol_binv_finish(ctx, K, ib));
+    else
+      GPX_TRY(chol_binv_ensure(ctx, K));
     GPX_HIP(hipStreamSynchronize(ctx->stream));
   }
   return info;

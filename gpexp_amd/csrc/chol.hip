@@ -827,9 +827,133 @@ static int64_t potrf_rl_max() {
   return v;
 }
 
+static int potrf_rec(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double* invd, int64_t base, int64_t n_valid);
+static int binv_build_range(gpx_ctx* ctx, const double* Ld, int64_t ld, const double* invd, double* binv, int64_t ib, int64_t n,
+                            double* tmp);
+
+// X (m x n) <- X L^-T against a diagonal block whose ib-order sub-blocks have explicit inverses (binv, ib x ib each): per
+// sub-block X_b <- X_b Binv_b^T as ONE GEMM (triangular operand: half the k range per column tile; through T, the product
+// cannot be formed in place), between them X[:, later] -= X[:, done] L[later, done]^T with K >= ib.  The leaf-level recursion
+// of chol_trsm_right spends its time in K = 128..512 updates (12-60 TF/s); with 4096-wide panels those were half of the
+// panel solves' 58 ms at N = 32768.
+static int trsm_right_binv_rec(gpx_ctx* ctx, const double* Ld, int64_t ldl, const double* binv, int64_t ib, double* X,
+                               int64_t ldx, int64_t m, int64_t n, int64_t b0, int64_t b1, double* T) {
+  auto off = [&](int64_t b) { return b * ib < n ? b * ib : n; };
+  if (b1 - b0 == 1) {
+    const int64_t o = off(b0), sz = off(b0 + 1) - o;
+    GPX_TRY(launch_gemm_tri(ctx, X + o, ldx, binv + b0 * ib * ib, ib, T, ib, m, sz, sz, true, false, false, 2));
+    return gpx_copy2d(ctx, T, ib, X + o, ldx, m, sz);
+  }
+  const int64_t mid = (b0 + b1) / 2, o0 = off(b0), om = off(mid), o1 = off(b1);
+  GPX_TRY(trsm_right_binv_rec(ctx, Ld, ldl, binv, ib, X, ldx, m, n, b0, mid, T));
+  GPX_TRY(launch_gemm(ctx, X + o0, ldx, Ld + om * ldl + o0, ldl, X + om, ldx, m, o1 - om, om - o0, true, true, false));
+  return trsm_right_binv_rec(ctx, Ld, ldl, binv, ib, X, ldx, m, n, mid, b1, T);
+}
+
+static int64_t env_i64(const char* name, int64_t dflt) {
+  const char* e = getenv(name);
+  return e ? atoll(e) : dflt;
+}
+
+// Blocked right-looking factorisation with panels of width B (4096) and ONE PANEL OF LOOK-AHEAD for large matrices.
+// Per panel k: solve the rows below the diagonal block, then the trailing update A22 -= P P^T with K = B.  The diagonal
+// block of panel k+1 -- a chain of ~100 latency-bound kernels (128-wide leaves, strip multiplies, rank-128 updates: 2.3 ms
+// per 4096 block on an otherwise idle chip, 18 ms per factorisation at N = 32768) -- only needs block column k+1 of that
+// update.  So column k+1 is updated first, the chain moves to the high-priority side stream, and the first `chunk` rows of
+// the remaining update run beside it on the CU-masked stream (a chip-filling kernel starves small kernels on other streams
+// whatever their priority, scripts/cumask_check.hip; the mask leaves 4 CUs per XCD to the chain); the bulk of the update
+// follows on the whole chip once the chain is done.  Measured (profiles/r02_potrf_lookahead.txt): beside the chunk the chain
+// takes 5.5 ms instead of 2.3 (its rank-128 updates have 32 CUs), and a kernel on a CU-masked stream runs ~30 % slower than
+// its CU share explains -- putting ALL large kernels on a masked stream so that the chain never blocks them (tried with 1-4
+// reserved CUs per XCD) costs 226-233 ms against 190.  Main stream only (the streams are the context's).
+static int potrf_blocked(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double* invd, int64_t base, int64_t n_valid,
+                         int64_t B) {
+  static const int64_t la_on = env_i64("GPX_POTRF_LA", 1), chunk_rows = env_i64("GPX_POTRF_LA_CHUNK", 8192) / NB * NB;
+  hipStream_t M = ctx->stream, S = ctx->streams[1], Kq = ctx->streams[3];
+  const bool la = la_on && M == ctx->streams[0];
+  if (la && ctx->la_events.empty()) {
+    for (int i = 0; i < 3; ++i) {
+      hipEvent_t ev;
+      GPX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      ctx->la_events.push_back(ev);
+    }
+  }
+  // explicit inverses of the ib-order diagonal sub-blocks (gpx_potrf provides the storage): built right behind every
+  // diagonal block -- part of the chain -- and used by the panel solves; gpx_potrs / posterior reuse them afterwards
+  const int64_t ib = ctx->pw_ib;
+  const bool bi = ctx->pw_binv != nullptr && ib > 0 && base % ib == 0 && B % ib == 0;
+  auto binv_at = [&](int64_t row) { return ctx->pw_binv + ((base + row) / ib) * ib * ib; };
+  GPX_TRY(potrf_rec(ctx, A, ld, n < B ? n : B, invd, base, n_valid));
+  if (bi) GPX_TRY(binv_build_range(ctx, A, ld, invd, binv_at(0), ib, n < B ? n : B, ctx->pw_tmp_build));
+  for (int64_t j0 = 0; j0 < n; j0 += B) {
+    const int64_t w = (n - j0) < B ? (n - j0) : B, below = n - j0 - w;
+    if (below == 0) break;
+    double* P = A + (j0 + w) * ld + j0;        // below x w panel
+    double* C = A + (j0 + w) * (ld + 1);       // trailing block, below x below
+    if (bi)
+      GPX_TRY(trsm_right_binv_rec(ctx, A + j0 * (ld + 1), ld, binv_at(j0), ib, P, ld, below, w, 0, (w + ib - 1) / ib,
+                                  ctx->pw_tmp_T));
+    else
+      GPX_TRY(chol_trsm_right(ctx, A + j0 * (ld + 1), ld, invd + (j0 / NB) * NB * NB, P, ld, below, w));
+    const int64_t w2 = below < B ? below : B, rest = below - w2;
+    double* invn = invd + ((j0 + w) / NB) * NB * NB;
+    if (!la) {
+      GPX_TRY(launch_gemm(ctx, P, ld, P, ld, C, ld, below, below, w, true, true, true));
+      GPX_TRY(potrf_rec(ctx, C, ld, w2, invn, base + j0 + w, n_valid));
+      if (bi) GPX_TRY(binv_build_range(ctx, C, ld, invn, binv_at(j0 + w), ib, w2, ctx->pw_tmp_build));
+      continue;
+    }
+    hipEvent_t ev_col = ctx->la_events[0], ev_diag = ctx->la_events[1], ev_top = ctx->la_events[2];
+    // block column k+1 of the update first: its diagonal block (lower) and the rows below it
+    GPX_TRY(launch_gemm(ctx, P, ld, P, ld, C, ld, w2, w2, w, true, true, true));
+    if (rest > 0) GPX_TRY(launch_gemm(ctx, P + w2 * ld, ld, P, ld, C + w2 * ld, ld, rest, w2, w, true, true, false));
+    GPX_HIP(hipEventRecord(ev_col, M));
+    // the diagonal chain of panel k+1 (+ its block inverses) on the side stream
+    ctx->stream = S;
+    int r = 0;
+    if (hipStreamWaitEvent(S, ev_col, 0) != hipSuccess) r = -2;
+    if (r == 0) r = potrf_rec(ctx, C, ld, w2, invn, base + j0 + w, n_valid);
+    if (r == 0 && bi) r = binv_build_range(ctx, C, ld, invn, binv_at(j0 + w), ib, w2, ctx->pw_tmp_build);
+    if (r == 0 && hipEventRecord(ev_diag, S) != hipSuccess) r = -2;
+    ctx->stream = M;
+    if (r != 0) {
+      if (r == -2) gpx_set_error("potrf: look-ahead stream plumbing failed");
+      return r;
+    }
+    if (rest > 0) {
+      double* P2 = P + w2 * ld;
+      double* C2 = C + w2 * (ld + 1);
+      const int64_t top = rest < chunk_rows ? rest : chunk_rows;
+      // beside the chain, on the masked stream: the first `top` rows of the remaining update
+      ctx->stream = Kq;
+      if (hipStreamWaitEvent(Kq, ev_col, 0) != hipSuccess) r = -2;
+      if (r == 0) r = launch_gemm(ctx, P2, ld, P2, ld, C2, ld, top, top, w, true, true, true);
+      if (r == 0 && hipEventRecord(ev_top, Kq) != hipSuccess) r = -2;
+      ctx->stream = M;
+      if (r != 0) {
+        if (r == -2) gpx_set_error("potrf: look-ahead stream plumbing failed");
+        return r;
+      }
+      GPX_HIP(hipStreamWaitEvent(M, ev_diag, 0));  // the bulk gets the whole chip: after the chain
+      GPX_HIP(hipStreamWaitEvent(M, ev_top, 0));
+      if (rest > top) {
+        GPX_TRY(launch_gemm(ctx, P2 + top * ld, ld, P2, ld, C2 + top * ld, ld, rest - top, top, w, true, true, false));
+        GPX_TRY(launch_gemm(ctx, P2 + top * ld, ld, P2 + top * ld, ld, C2 + top * (ld + 1), ld, rest - top, rest - top, w, true,
+                            true, true));
+      }
+    } else {
+      GPX_HIP(hipStreamWaitEvent(M, ev_diag, 0));
+    }
+  }
+  if (bi && base == 0) ctx->pw_done = 1;
+  return 0;
+}
+
 static int potrf_rec(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double* invd, int64_t base, int64_t n_valid) {
   if (n == NB) return launch_leaf(ctx, A, ld, invd, base, n_valid);
   if (n <= potrf_rl_max()) return potrf_right_looking(ctx, A, ld, n, invd, base, n_valid);
+  static const int64_t blk = env_i64("GPX_POTRF_BLOCK", 4096) / NB * NB;  // 0: recursive halving at every level (round 1)
+  if (blk >= potrf_rl_max() && n >= 2 * blk) return potrf_blocked(ctx, A, ld, n, invd, base, n_valid, blk);
   const int64_t n1 = split(n), n2 = n - n1;
   GPX_TRY(potrf_rec(ctx, A, ld, n1, invd, base, n_valid));
   double* A21 = A + n1 * ld;
@@ -907,44 +1031,59 @@ static int binv_build_rec(gpx_ctx* ctx, const double* L, int64_t ld, int64_t sl,
   return launch_gemm_batched(ctx, Bi, ib, ib * ib, tmp, s1, ib * ib, R, ib, ib * ib, s2, s1, s2, false, true, batch);
 }
 
+// explicit inverses of the ib-order diagonal blocks covering n rows (a multiple of 128; the last block may be shorter) that
+// start at Ld on the diagonal; invd / binv point at that position too; tmp >= ceil(n / ib) * ib * ib doubles
+static int binv_build_range(gpx_ctx* ctx, const double* Ld, int64_t ld, const double* invd, double* binv, int64_t ib, int64_t n,
+                            double* tmp) {
+  const int64_t nblk = (n + ib - 1) / ib, nfull = n / ib, tail = n - nfull * ib;
+  const int64_t rows = nblk * ib;
+  hipLaunchKernelGGL(binv_init_kernel, dim3((unsigned)((rows * (ib / 2) + 255) / 256)), dim3(256), 0, ctx->stream, invd, binv,
+                     ib, n);
+  if (nfull > 0) GPX_TRY(binv_build_rec(ctx, Ld, ld, ib * (ld + 1), binv, ib, 0, ib, tmp, nfull));
+  if (tail > 0) GPX_TRY(binv_build_rec(ctx, Ld + nfull * ib * (ld + 1), ld, 0, binv + nfull * ib * ib, ib, 0, tail, tmp, 1));
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
+
+int64_t chol_binv_order(int64_t n) { return potrs_block(n); }
+int64_t chol_binv_elems(int64_t n) {  // lower inverses + their transposes
+  const int64_t ib = potrs_block(n);
+  return 2 * ((n + ib - 1) / ib) * ib * ib;
+}
+
+// the transposed copies the backward sweep of potrs multiplies with; marks the cache valid
+int chol_binv_finish(gpx_ctx* ctx, gpx_mat* Lm, int64_t ib) {
+  const int64_t nblk = (Lm->prows + ib - 1) / ib, elems = nblk * ib * ib;
+  dim3 gt((unsigned)(ib / 32), (unsigned)(ib / 32), (unsigned)nblk);
+  hipLaunchKernelGGL(binv_transpose_kernel, gt, dim3(256), 0, ctx->stream, Lm->binv, Lm->binv + elems, ib);
+  GPX_HIP(hipGetLastError());
+  Lm->binv_ib = ib;
+  return 0;
+}
+
 int chol_binv_ensure(gpx_ctx* ctx, gpx_mat* Lm) {
   const int64_t n = Lm->prows, ib = potrs_block(n);
   if (Lm->binv && Lm->binv_ib == ib) return 0;
-  const int64_t nblk = (n + ib - 1) / ib, nfull = n / ib, tail = n - nfull * ib;
-  const int64_t elems = nblk * ib * ib;
-  if (Lm->binv) gpx_dev_release(ctx, Lm->binv, Lm->binv_bytes);
-  Lm->binv = nullptr;
-  void* p;
-  GPX_TRY(gpx_dev_alloc(ctx, 2 * elems * 8, &p));
-  double* binv = (double*)p;
-  void* pt;
-  int r = gpx_dev_alloc(ctx, nblk * ib * ib * 8, &pt);  // products T, one slab per batched block
-  if (r != 0) {
-    gpx_dev_release(ctx, p, 2 * elems * 8);
-    return r;
+  const int64_t nblk = (n + ib - 1) / ib;
+  const int64_t bytes = chol_binv_elems(n) * 8;
+  if (Lm->binv && Lm->binv_bytes != bytes) {
+    gpx_dev_release(ctx, Lm->binv, Lm->binv_bytes);
+    Lm->binv = nullptr;
   }
-  do {
-    const int64_t rows = nblk * ib;
-    hipLaunchKernelGGL(binv_init_kernel, dim3((unsigned)((rows * (ib / 2) + 255) / 256)), dim3(256), 0, ctx->stream,
-                       Lm->aux, binv, ib, n);
-    if (nfull > 0 && (r = binv_build_rec(ctx, Lm->p, Lm->ld, ib * (Lm->ld + 1), binv, ib, 0, ib, (double*)pt, nfull)) != 0) break;
-    if (tail > 0 && (r = binv_build_rec(ctx, Lm->p + nfull * ib * (Lm->ld + 1), Lm->ld, 0, binv + nfull * ib * ib, ib, 0, tail,
-                                        (double*)pt, 1)) != 0) break;
-    dim3 gt((unsigned)(ib / 32), (unsigned)(ib / 32), (unsigned)nblk);
-    hipLaunchKernelGGL(binv_transpose_kernel, gt, dim3(256), 0, ctx->stream, binv, binv + elems, ib);
-    if (hipGetLastError() != hipSuccess) r = -2;
-  } while (0);
+  if (!Lm->binv) {
+    void* p;
+    GPX_TRY(gpx_dev_alloc(ctx, bytes, &p));
+    Lm->binv = (double*)p;
+    Lm->binv_bytes = bytes;
+  }
+  void* pt;
+  GPX_TRY(gpx_dev_alloc(ctx, nblk * ib * ib * 8, &pt));  // products T, one slab per batched block
+  int r = binv_build_range(ctx, Lm->p, Lm->ld, Lm->aux, Lm->binv, ib, n, (double*)pt);
+  if (r == 0) r = chol_binv_finish(ctx, Lm, ib);
   (void)hipStreamSynchronize(ctx->stream);  // the product slabs go back to the pool
   gpx_dev_release(ctx, pt, nblk * ib * ib * 8);
-  if (r != 0) {
-    gpx_dev_release(ctx, p, 2 * elems * 8);
-    if (r == -2) gpx_set_error("potrs: building the block inverses failed");
-    return r;
-  }
-  Lm->binv = binv;
-  Lm->binv_bytes = 2 * elems * 8;
-  Lm->binv_ib = ib;
-  return 0;
+  if (r != 0) Lm->binv_ib = 0;
+  return r;
 }
 
 struct PotrsPlan {

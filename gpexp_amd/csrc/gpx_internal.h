@@ -102,6 +102,14 @@ struct gpx_ctx {
   hipStream_t streams[4];    // 0 = main, 1 = panel (high priority), 2 = communication (high priority),
                              // 3 = background: CU-masked (leaves 4 CUs per XCD to the other streams) when the runtime allows
   std::vector<hipEvent_t> sync_events;  // gpx_event_record / gpx_event_wait ids
+  // work buffers of a blocked factorisation in flight (set by gpx_potrf around chol_potrf, NULL otherwise): storage of the
+  // explicit block inverses being built, order of those blocks, scratch for their build and for the panel solves
+  double* pw_binv;
+  int64_t pw_ib;
+  double* pw_tmp_build;
+  double* pw_tmp_T;
+  int pw_done;   // set by the factorisation when it has built every block inverse into pw_binv
+  std::vector<hipEvent_t> la_events;    // look-ahead factorisation (chol.hip): column ready / chain done / masked chunk done
   int cus;
   // cached device allocations (exact-size reuse)
   std::multimap<int64_t, void*> pool;
@@ -196,7 +204,10 @@ int chol_trsv_with_scratch(gpx_ctx* ctx, const double* L, int64_t ld, const doub
 int launch_logdet(gpx_ctx* ctx, const double* L, int64_t ld, int64_t n, double* d_out);
 // alpha = K^-1 y through explicit inverses of the diagonal blocks (built on first use, kept in L): v (padded n doubles) is
 // overwritten by the solution; scratch >= chol_potrs_scratch_bytes(n).  Asynchronous on the selected stream.
-int chol_binv_ensure(gpx_ctx* ctx, gpx_mat* L);  // explicit inverses of L's diagonal blocks (order <= 1024), cached in L
+int chol_binv_ensure(gpx_ctx* ctx, gpx_mat* L);
+int64_t chol_binv_order(int64_t n);
+int64_t chol_binv_elems(int64_t n);
+int chol_binv_finish(gpx_ctx* ctx, gpx_mat* L, int64_t ib);  // explicit inverses of L's diagonal blocks (order <= 1024), cached in L
 // W (n x m, separate buffer) = L^-1 B through the block inverses: B is consumed (its lower block rows are updated in place)
 int chol_trsm_left_oop(gpx_ctx* ctx, gpx_mat* L, double* B, int64_t ldb, double* W, int64_t ldw, int64_t m);
 int64_t chol_potrs_scratch_bytes(int64_t n);
