@@ -865,7 +865,8 @@ static int64_t env_i64(const char* name, int64_t dflt) {
 // follows on the whole chip once the chain is done.  Measured (profiles/r02_potrf_lookahead.txt): beside the chunk the chain
 // takes 5.5 ms instead of 2.3 (its rank-128 updates have 32 CUs), and a kernel on a CU-masked stream runs ~30 % slower than
 // its CU share explains -- putting ALL large kernels on a masked stream so that the chain never blocks them (tried with 1-4
-// reserved CUs per XCD) costs 226-233 ms against 190.  Main stream only (the streams are the context's).
+// reserved CUs per XCD) costs 226-233 ms against 190; relying on the side stream's priority alone (no mask) leaves the chain
+// behind the whole update (195.8 ms = no look-ahead).  Main stream only (the streams are the context's).
 static int potrf_blocked(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double* invd, int64_t base, int64_t n_valid,
                          int64_t B) {
   static const int64_t la_on = env_i64("GPX_POTRF_LA", 1), chunk_rows = env_i64("GPX_POTRF_LA_CHUNK", 8192) / NB * NB;

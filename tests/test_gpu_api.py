@@ -310,8 +310,8 @@ def test_variance_derivatives_vs_reference(golden):
 def test_demo_flow_config1(golden, capsys):
     """BASELINE config C1: the call sequence of the reference's demo.py (1-D SE GP: log-likelihood,
     hyper-parameter fit by L-BFGS-B, train/evaluate on 1000 points, IVAR design from a greedy-variance start +
-    SLSQP), on the GPU, against what the reference produced for the same inputs.  The optimisers amplify
-    round-off (pinv vs Cholesky at noise=1e-12), hence the looser tolerances on optimiser outputs."""
+    SLSQP), on the GPU, against what the reference produced for the same inputs.  Only the L-BFGS-B hyper-parameter
+    search (numerical gradients at noise = 1e-12) amplifies round-off visibly; everything else agrees to 1e-10 or better."""
     from gpExp.kernels import KernelSquaredExponential
     from gpExp.experimentalDesign import costFunctionGP_IVAR, ExperimentalDesignDerivative, \
         performGreedyVarExperimentalDesign
@@ -331,8 +331,8 @@ def test_demo_flow_config1(golden, capsys):
                             "noise": float(golden(c, "opt_noise"))})
     gpT.train(xTrain, yTrain)
     m, var = gpT.evaluate(np.linspace(-1, 1, 1000).reshape((1000, 1)), compvar=1)
-    assert rel(m, golden(c, "mean1")) <= 1e-7
-    assert np.max(np.abs(var - golden(c, "var1"))) <= 1e-7
+    assert rel(m, golden(c, "mean1")) <= 1e-10
+    assert np.max(np.abs(var - golden(c, "var1"))) <= 1e-10
     mc = golden(c, "mc")
     space = Space(1, lambda size: np.random.rand(size[0], size[1]) * 2.0 - 1.0, lambda p: (np.abs(p) < 1.0) * 0.5)
     cf = costFunctionGP_IVAR(gpT, 8, space, mcPoints=mc)
@@ -340,16 +340,18 @@ def test_demo_flow_config1(golden, capsys):
     start = performGreedyVarExperimentalDesign(gpT.kernel, np.concatenate((xTrain, mc), axis=0), 8, 1,
                                                indKeepStart=keep)
     assert keep == list(golden(c, "greedy_start_idx"))
-    assert cf.evaluate(start) == pytest.approx(float(golden(c, "greedy_start_cost")), rel=1e-7)
-    assert rel(cf.derivative(start), golden(c, "greedy_start_grad")) <= 1e-5
+    assert cf.evaluate(start) == pytest.approx(float(golden(c, "greedy_start_cost")), rel=1e-10)
+    assert rel(cf.derivative(start), golden(c, "greedy_start_grad")) <= 1e-9
     exp = ExperimentalDesignDerivative(cf, 8, 1)
     lb = np.concatenate((xTrain.flatten(), -np.ones(4)))
     ub = np.concatenate((xTrain.flatten(), np.ones(4)))
     design = exp.beginWithVarGreedy(nodesKeep=xTrain, lbounds=lb, rbounds=ub)
     assert design.shape == (8, 1)
     np.testing.assert_allclose(design[:4], xTrain, atol=1e-12)
-    assert cf.evaluate(design) == pytest.approx(float(golden(c, "design_cost")), rel=1e-3)
-    np.testing.assert_allclose(np.sort(design[:, 0]), np.sort(golden(c, "design")[:, 0]), atol=2e-3)
+    # SLSQP follows the reference's iterates: measured 1.3e-12 on the cost and 3.5e-10 on the points (round 1, with the
+    # diagonal jitter: 1e-3 / 2e-3)
+    assert cf.evaluate(design) == pytest.approx(float(golden(c, "design_cost")), rel=1e-8)
+    np.testing.assert_allclose(np.sort(design[:, 0]), np.sort(golden(c, "design")[:, 0]), atol=1e-6)
 
 
 def test_ivar_gradient_on_device_f1(golden):
@@ -376,7 +378,7 @@ def test_ivar_gradient_on_device_f1(golden):
     start = np.concatenate((golden(c, "xTrain"), mc), axis=0)[list(golden(c, "greedy_start_idx"))]
     gp.addNodesAndComputeCovariance(start)
     gd = dev.ivar_grad(ctx, gp.kernel._spec(), gp._L, gp._X, dev.points(ctx, mc))
-    assert rel(gd, golden(c, "greedy_start_grad")) <= 1e-5
+    assert rel(gd, golden(c, "greedy_start_grad")) <= 1e-9
     # finite differences at a larger size
     rng = np.random.default_rng(77)
     n, d, m = 40, 3, 500
