@@ -294,7 +294,9 @@ def main():
         traffic, traffic_src = None, None
         try:  # PMC counters cannot be read from inside the process: take the committed rocprofv3 --pmc passes of this
             # same command (profiles/), per launch like `achieved`; null when the profile is for another config
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pmc = [f for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+                   if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
+            with open(os.path.join(ROOT, "profiles", pmc)) as f:
                 pj = json.load(f)
             if world == 1 and (N, d, M) == (32768, 8, 32768):
                 traffic = (pj["fetch_bytes_per_step_corrected"] + pj["write_bytes_per_step"]) / pj["launches_per_step"]

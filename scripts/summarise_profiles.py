@@ -1,4 +1,5 @@
-"""Turn gpurun_out/final/ (scripts/collect_profiles.sh) into the judged artifacts under profiles/ (round tag r01)."""
+"""Turn gpurun_out/final/ (scripts/collect_profiles.sh) into the judged artifacts under profiles/.
+usage: summarise_profiles.py [gpurun_out/final] [r02]"""
 import csv, glob, json, os, shutil, sys, collections
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/final"
 tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
@@ -26,7 +27,7 @@ shutil.copy(os.path.join(src, "bench.json"), os.path.join(out, tag + "_bench_n1.
 for nm, dst in (("run_kernel_stats.csv", "_kernel_stats.csv"), ("run_domain_stats.csv", "_domain_stats.csv")):
     f = glob.glob(os.path.join(src, "stats", "*" + nm)) or glob.glob(os.path.join(src, "stats", "*", "*" + nm))
     if f: shutil.copy(f[0], os.path.join(out, tag + dst))
-lines = ["# Round 1 -- HBM-side traffic of one bench step (C4, N=32768, d=8, M=32768), rocprofv3 --pmc, separate passes",
+lines = ["# " + tag + " -- HBM-side traffic of one bench step (C4, N=32768, d=8, M=32768), rocprofv3 --pmc, separate passes",
          "# FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); WRITE_SIZE as read; KB -> bytes x1024"]
 res = {}
 for path, counter, mult in (("pmc_fetch", "FETCH_SIZE", 2.0), ("pmc_write", "WRITE_SIZE", 1.0)):
