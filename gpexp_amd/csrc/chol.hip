@@ -1028,6 +1028,10 @@ static int binv_build_rec(gpx_ctx* ctx, const double* L, int64_t ld, int64_t sl,
   const double* Bi = binv + (r0 + s1) * ib + r0 + s1;
   double* R = binv + (r0 + s1) * ib + r0;  // zero so far
   // T = C A^-1 ; R = 0 - B^-1 T
+  if (batch == 1 && s1 >= 1024) {  // one large block (gpx_potri): the tuned kernel, B^-1 as a triangular operand
+    GPX_TRY(launch_gemm(ctx, C, ld, Ai, ib, tmp, s1, s2, s1, s1, false, false, false));
+    return launch_gemm_tri(ctx, Bi, ib, tmp, s1, R, ib, s2, s1, s2, false, true, false, 1);
+  }
   GPX_TRY(launch_gemm_batched(ctx, C, ld, sl, Ai, ib, ib * ib, tmp, s1, ib * ib, s2, s1, s1, false, false, batch));
   return launch_gemm_batched(ctx, Bi, ib, ib * ib, tmp, s1, ib * ib, R, ib, ib * ib, s2, s1, s2, false, true, batch);
 }
@@ -1044,6 +1048,15 @@ static int binv_build_range(gpx_ctx* ctx, const double* Ld, int64_t ld, const do
   if (tail > 0) GPX_TRY(binv_build_rec(ctx, Ld + nfull * ib * (ld + 1), ld, 0, binv + nfull * ib * ib, ib, 0, tail, tmp, 1));
   GPX_HIP(hipGetLastError());
   return 0;
+}
+
+// Linv (n x n, row stride n, zero above the diagonal) = L^-1 for the whole factor, by the same halving recursion: n^3/2
+// flops instead of the n^3 of a triangular solve against a dense identity.  tmp >= (n/2)^2 doubles.
+int chol_trtri(gpx_ctx* ctx, const gpx_mat* Lm, double* Linv, double* tmp) {
+  const int64_t n = Lm->prows;
+  hipLaunchKernelGGL(binv_init_kernel, dim3((unsigned)((n * (n / 2) + 255) / 256)), dim3(256), 0, ctx->stream, Lm->aux, Linv, n, n);
+  GPX_HIP(hipGetLastError());
+  return binv_build_rec(ctx, Lm->p, Lm->ld, 0, Linv, n, 0, n, tmp, 1);
 }
 
 int64_t chol_binv_order(int64_t n) { return potrs_block(n); }

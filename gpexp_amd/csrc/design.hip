@@ -248,25 +248,29 @@ int gpx_posterior_cov(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp
   return 0;
 }
 
-int gpx_potri(gpx_ctx* ctx, const gpx_mat* L, gpx_mat** outP) {
+// K^-1 = L^-T L^-1.  full == 0 (the C ABI's contract: lower triangle valid): L^-1 by the halving recursion (n^3/2 flops,
+// chol_trtri), its transpose U, and the lower tiles of U U^T with the k range of every tile starting at its row block
+// (n^3/3): 0.83 n^3 instead of the 3 n^3 of round 1 (triangular solve against a dense identity + full product).
+// full != 0 (the mutual-information design updates the whole matrix in place): the product fills both triangles.
+int gpx_potri_impl(gpx_ctx* ctx, const gpx_mat* L, gpx_mat** outP, int full) {
   GPX_ARG(ctx && L && outP, "NULL argument");
   GPX_ARG(L->factored && L->aux, "matrix has not been factored by gpx_potrf");
   const int64_t np = L->prows;
   gpx_mat* P = nullptr;
   GPX_TRY(gpx_mat_new(ctx, L->rows, L->cols, 1, &P));
   Scratch sc(ctx);
-  void *pI, *pT;
+  void *pI, *pT, *ptmp;
   int r = 0;
   do {
     if ((r = sc.get(np * np * 8, &pI)) != 0) break;
     if ((r = sc.get(np * np * 8, &pT)) != 0) break;
-    if (hipMemsetAsync(pI, 0, (size_t)(np * np * 8), ctx->stream) != hipSuccess) { r = -2; break; }
-    hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (double*)pI, np, np);
-    if ((r = chol_trsm_left(ctx, L->p, L->ld, L->aux, (double*)pI, np, np, np)) != 0) break;  // L^-1
-    if ((r = launch_transpose(ctx, (double*)pI, np, np, np, (double*)pT, np)) != 0) break;       // L^-T
-    // K^-1 = L^-T L^-1 = T T^T
-    if ((r = launch_gemm(ctx, (double*)pT, np, (double*)pT, np, P->p, P->ld, np, np, np, true, false, false)) != 0) break;
+    if ((r = sc.get((np / 2 + 64) * (np / 2 + 64) * 8, &ptmp)) != 0) break;
+    if ((r = chol_trtri(ctx, L, (double*)pI, (double*)ptmp)) != 0) break;                           // L^-1
+    if ((r = launch_transpose(ctx, (double*)pI, np, np, np, (double*)pT, np)) != 0) break;          // U = L^-T
+    if (full)
+      r = launch_gemm(ctx, (double*)pT, np, (double*)pT, np, P->p, P->ld, np, np, np, true, false, false);
+    else
+      r = launch_gemm_tri(ctx, (double*)pT, np, (double*)pT, np, P->p, P->ld, np, np, np, true, false, true, 3);
   } while (0);
   if (r != 0) {
     gpx_mat_free(ctx, P);
@@ -277,6 +281,8 @@ int gpx_potri(gpx_ctx* ctx, const gpx_mat* L, gpx_mat** outP) {
   *outP = P;
   return 0;
 }
+
+int gpx_potri(gpx_ctx* ctx, const gpx_mat* L, gpx_mat** outP) { return gpx_potri_impl(ctx, L, outP, 0); }
 
 int gpx_greedy_var(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* Cm, const double* w,
                    const int64_t* keep, int64_t nkeep, int64_t nsel, int64_t* out_idx) {

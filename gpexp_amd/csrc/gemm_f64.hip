@@ -265,8 +265,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64
     const int wt = w - main_wgs;
     const int by = wt / tail_tn, bx = wt - by * tail_tn;
     if (LOWER && 64 * bx > tail_m0 + 64 * by + 63) return;  // tile entirely above the diagonal
-    gemm_tile<BT, ACC, 64>(reinterpret_cast<Smem<BT, 64>&>(sm), A + (int64_t)tail_m0 * lda, lda, B, ldb,
-                                 C + (int64_t)tail_m0 * ldc, ldc, nk, by, bx);
+    int64_t k0 = 0;
+    if (tri == 3) k0 = tail_m0 + 64 * by;  // both operands upper triangular: nothing below the row block's first column
+    gemm_tile<BT, ACC, 64>(reinterpret_cast<Smem<BT, 64>&>(sm), A + (int64_t)tail_m0 * lda + k0, lda, B + k0, ldb,
+                                 C + (int64_t)tail_m0 * ldc, ldc, nk - (int)(k0 / KB), by, bx);
     return;
   }
   const int xcd = w & 7, q = w >> 3;
@@ -277,9 +279,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64
   // triangular operand: tri == 1, A (m x k) is lower triangular -> row tile `by` only needs k < (by+1)*TE; tri == 2, op(B)
   // comes from a lower-triangular (n x k) matrix used transposed -> column tile `bx` only needs k < (bx+1)*TE.  The zero
   // half of the product is never multiplied (products with the explicit block inverses, chol.hip).
+  // tri == 3 (lower C = U U^T with U upper triangular, stored as A = B = U, bt): rows of tile `by` are zero left of column
+  // by*TE in BOTH operands (bx <= by), so the k range starts there.
   int nkt = nk;
   if (tri == 1) nkt = min(nk, (by + 1) * (TE / KB));
   if (tri == 2) nkt = min(nk, (bx + 1) * (TE / KB));
+  if (tri == 3) {
+    const int64_t k0 = (int64_t)by * TE;
+    A += k0;
+    B += k0;
+    nkt = nk - by * (TE / KB);
+  }
   gemm_tile<BT, ACC, TE>(sm, A, lda, B, ldb, C, ldc, nkt, by, bx);
 }
 
@@ -356,11 +366,13 @@ int launch_gemm(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int
 }
 
 // tri: 0 = dense operands; 1 = A is lower triangular (k == m); 2 = B is a lower-triangular n x k matrix used transposed
-// (bt, k == n): the structurally zero part of the k range is skipped per tile
+// (bt, k == n); 3 = lower C = U U^T with A = B = U upper triangular (bt, lower): the structurally zero part of the k range
+// is skipped per tile
 int launch_gemm_tri(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
                     int64_t m, int64_t n, int64_t k, bool bt, bool accumulate, bool lower, int tri) {
   if (m == 0 || n == 0) return 0;
-  GPX_ARG(tri == 0 || (!lower && ((tri == 1 && k == m) || (tri == 2 && bt && k == n))), "gemm: bad triangular-operand mode");
+  GPX_ARG(tri == 0 || (!lower && ((tri == 1 && k == m) || (tri == 2 && bt && k == n))) || (tri == 3 && lower && bt && k == m),
+          "gemm: bad triangular-operand mode");
   GPX_ARG(m % 128 == 0 && n % 128 == 0 && k % KB == 0 && k > 0, "gemm: m,n must be multiples of 128 and k of 16");
   GPX_ARG((lda % 2) == 0 && (ldb % 2) == 0, "gemm: leading dimensions must be even (16-byte loads)");
   GPX_ARG(!lower || m == n, "gemm: lower-only update needs a square C");
@@ -403,7 +415,7 @@ int launch_gemm_tri(gpx_ctx* ctx, const double* A, int64_t lda, const double* B,
   dim3 grid((unsigned)(p.wgs + tail_wgs));
   const int nk = (int)(k / KB);
   // algorithmic flops: a triangular operand halves the k range on average (+ the diagonal blocks)
-  const double kflops = tri ? 0.5 * (double)k + 64.0 : (double)k;
+  const double kflops = tri == 3 ? (double)k * (2.0 / 3.0) : (tri ? 0.5 * (double)k + 64.0 : (double)k);
   ProfScope ps(ctx, GPX_PROF_GEMM, 2.0 * tiles128 * 128.0 * 128.0 * kflops, 0.0);
 #define GPX_K(BT_, ACC_, LOW_, TE_)                                                                           \
   hipLaunchKernelGGL((gemm_f64_kernel<BT_, ACC_, LOW_, TE_>), grid, dim3(256), 0, ctx->stream, A, lda, B, ldb, C, ldc, \

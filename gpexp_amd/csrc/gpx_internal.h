@@ -204,6 +204,7 @@ int chol_trsv_with_scratch(gpx_ctx* ctx, const double* L, int64_t ld, const doub
 int launch_logdet(gpx_ctx* ctx, const double* L, int64_t ld, int64_t n, double* d_out);
 // alpha = K^-1 y through explicit inverses of the diagonal blocks (built on first use, kept in L): v (padded n doubles) is
 // overwritten by the solution; scratch >= chol_potrs_scratch_bytes(n).  Asynchronous on the selected stream.
+int chol_trtri(gpx_ctx* ctx, const gpx_mat* L, double* Linv, double* tmp);  // Linv (n x n, ld n) = L^-1; tmp >= (n/2)^2
 int chol_binv_ensure(gpx_ctx* ctx, gpx_mat* L);
 int64_t chol_binv_order(int64_t n);
 int64_t chol_binv_elems(int64_t n);
@@ -225,4 +226,5 @@ int launch_rowreduce(gpx_ctx* ctx, const double* B, int64_t ld, int64_t rows, in
 int launch_sum(gpx_ctx* ctx, const double* x, int64_t n, double* d_out);
 
 // design.hip
+extern "C" int gpx_potri_impl(gpx_ctx* ctx, const gpx_mat* L, gpx_mat** outP, int full);
 int launch_transpose(gpx_ctx* ctx, const double* in, int64_t rows, int64_t cols, int64_t ldi, double* out, int64_t ldo);

@@ -29,6 +29,10 @@ __global__ __launch_bounds__(256) void lmlgrad_kernel(KParams kp, const double* 
   double* red = Bs + TS * d;     // [4] per-wave partials
   const int t = threadIdx.x;
   const int64_t i0 = (int64_t)blockIdx.y * TS, j0 = (int64_t)blockIdx.x * TS;
+  // T and dK are symmetric and only the lower triangle of K^-1 is valid: tiles above the diagonal contribute nothing,
+  // tiles below it count twice, diagonal tiles read the mirrored entry
+  const bool upper = blockIdx.x > blockIdx.y;
+  const double weight = blockIdx.x == blockIdx.y ? 1.0 : 2.0;
   for (int idx = t; idx < TS * d; idx += 256) {
     int p = idx / d, k = idx - p * d;
     int64_t gi = i0 + p, gj = j0 + p;
@@ -48,14 +52,14 @@ __global__ __launch_bounds__(256) void lmlgrad_kernel(KParams kp, const double* 
       const int cc = 2 * tx + c;
       const int64_t gj = j0 + cc;
       double v = 0.0;
-      if (gi < n && gj < n) {
+      if (!upper && gi < n && gj < n) {
         double acc = 0.0;
         for (int k = 0; k < d; ++k) {
           const double e = (As[r * d + k] - Bs[cc * d + k]) * kp.scale[k];
           acc = fma(e, e, acc);
         }
-        const double tij = alpha[gi] * alpha[gj] - P[gi * ld + gj];
-        v = tij * kp.sig * exp(-0.5 * acc);
+        const double tij = alpha[gi] * alpha[gj] - (gi >= gj ? P[gi * ld + gj] : P[gj * ld + gi]);
+        v = weight * tij * kp.sig * exp(-0.5 * acc);
         if (gi == gj) diag += tij;
       }
       tk[a * 2 + c] = v;
@@ -284,7 +288,7 @@ int gpx_mi_greedy(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, co
   GPX_TRY(gpx_kfill(ctx, kind, d, hyp, nhyp, Cm, nullptr, &noise, 1, &S));
   int r = gpx_potrf(ctx, S);
   gpx_mat* P = nullptr;
-  if (r == 0) r = gpx_potri(ctx, S, &P);
+  if (r == 0) r = gpx_potri_impl(ctx, S, &P, 1);  // the down-dates touch both triangles
   gpx_mat_free(ctx, S);
   if (r != 0) return r;
   {

@@ -96,7 +96,7 @@ class GP:
         if self._P_host is None and self._fitc is not None:
             self._P_host = self._fitc.dense(cov=False, prec=True)[1]
         elif self._P_host is None and self._L is not None:
-            self._P_host = _dev.potri(_dev.context(), self._L).to_host()
+            self._P_host = _dev.potri(_dev.context(), self._L).to_host(tri=2)   # lower triangle valid: mirrored
         return self._P_host
 
     @precisionMatrix.setter

@@ -44,7 +44,10 @@ lines.append("MFMA utilisation of the GEMM class over one step (rocprofv3 --pmc 
 lines.append("  SQ_VALU_MFMA_BUSY_CYCLES=%.4e (64 per v_mfma_f64_16x16x4_f64, summed over 1024 SIMDs)  GRBM_GUI_ACTIVE=%.4e (summed over 8 XCDs)  kernel_ms=%.2f" % (busy, gui, ms))
 lines.append("  -> MFMA pipe busy %.1f %% of SIMD cycles (busy / (GUI_ACTIVE/8 * 1024)); clock %.3f GHz (GUI_ACTIVE/8 / kernel time)" % (100.0 * busy / (gui / 8 * 1024), gui / 8 / ms / 1e6))
 open(os.path.join(out, tag + "_pmc_traffic.txt"), "w").write("\n".join(lines) + "\n")
-json.dump({"config": "C4 N=32768 d=8 M=32768, one bench step", "kernel": "gemm class (gemm_f64_kernel variants + leaf_mul kernels)",
+json.dump({"config": "C4 N=32768 d=8 M=32768: the profiled command = bench.py --steps 1 --warmup 0 = one timed step + the fit-only "
+                     "and IVAR-only passes (3 step-equivalents); the *_per_step fields are totals over that command, "
+                     "bench.py divides bytes by launches (per-launch traffic, like roofline.achieved)",
+           "kernel": "gemm class (gemm_f64_kernel variants + leaf_mul kernels)",
            "launches_per_step": res["FETCH_SIZE"][0], "fetch_bytes_per_step_corrected": res["FETCH_SIZE"][1],
            "write_bytes_per_step": res["WRITE_SIZE"][1],
            "correction": "FETCH_SIZE x2 (gfx950 wide coalesced reads), WRITE_SIZE x1, KB x1024; separate --pmc passes",
