@@ -27,6 +27,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -189,8 +191,14 @@ def main():
             runner = dist.DistFitIvar(ctx, comm, spec, Xh, yh, Zh, noise, nb=nb)
             layout = "1-D block-cyclic columns"
         else:
-            runner = dist.DistFitIvar2D(ctx, comm, spec, Xh, yh, Zh, noise, nb=nb)
-            layout = "2-D block-cyclic %dx%d grid, nb=%d" % (runner.geo.Pr, runner.geo.Pc, nb)
+            try:
+                runner = dist.DistFitIvar2D(ctx, comm, spec, Xh, yh, Zh, noise, nb=nb)
+                layout = "2-D block-cyclic %dx%d grid, nb=%d" % (runner.geo.Pr, runner.geo.Pc, nb)
+            except Exception as exc:  # e.g. an RCCL build without ncclCommSplit: every rank fails alike -> 1-D layout
+                print("bench.py: 2-D layout unavailable (%s); falling back to the 1-D block-column layout" % exc,
+                      file=sys.stderr, flush=True)
+                runner = dist.DistFitIvar(ctx, comm, spec, Xh, yh, Zh, noise, nb=nb)
+                layout = "1-D block-cyclic columns (2-D setup failed)"
         step = runner.step
         barrier = comm.barrier
         reduce_max = comm.max_float
