@@ -161,3 +161,54 @@ def test_wide_and_narrow_leaf_multiply_strips_agree(dev, ctx, monkeypatch):
     dev.potrf(ctx, K2)
     a2 = dev.potrs(ctx, K2, y2)
     assert np.max(np.abs(Krows @ a2 - y2[rows])) <= 1e-9 * np.max(np.abs(y2))
+
+
+@pytest.mark.parametrize("n", [2047, 2177, 8200, 9000, 12929])
+def test_round2_solver_paths_at_ragged_sizes(dev, ctx, n):
+    """Sizes that are not multiples of the 1024-order inverse blocks or of the 4096-wide look-ahead panels (padded
+    2048 / 2304 / 8320 / 9088 / 13056): blocked look-ahead factorisation (N >= 8192), block-inverse potrs (ragged last
+    block), out-of-place posterior solve (N >= 2048) -- against LAPACK on the host."""
+    import scipy.linalg as sl
+    rng = np.random.default_rng(n)
+    d = 4
+    X = rng.uniform(-1, 1, (n, d))
+    y = np.sin(X.sum(1)) + 0.1 * rng.standard_normal(n)
+    Z = rng.uniform(-1, 1, (333, d))
+    sp = dev.KernelSpec(dev.K_MATERN52, d, [0.6, 1.1])
+    dX, dZ = dev.points(ctx, X), dev.points(ctx, Z)
+    Kd = dev.kfill(ctx, sp, dX, nugget=0.05)
+    K = Kd.to_host()
+    L = dev.potrf(ctx, Kd)
+    c = sl.cho_factor(K, lower=True, check_finite=False)
+    Lh = L.to_host(tri=1)
+    assert rel(Lh, np.tril(c[0])) <= 1e-12
+    alpha = dev.potrs(ctx, L, y)
+    assert rel(alpha, sl.cho_solve(c, y, check_finite=False)) <= 1e-10
+    assert rel(dev.potrs(ctx, L, y), alpha) == 0.0                      # second solve: cached block inverses, same bits
+    Kxz = dev.kfill(ctx, sp, dX, Z=dZ).to_host()
+    W = sl.solve_triangular(np.tril(c[0]), Kxz, lower=True, check_finite=False)
+    mean, var = dev.posterior(ctx, sp, L, dX, alpha, dZ)
+    assert rel(mean, Kxz.T @ alpha) <= 1e-10
+    assert rel(var, 1.1 - np.sum(W * W, axis=0)) <= 1e-10
+    assert abs(dev.logdet(ctx, L) - 2 * np.sum(np.log(np.diag(c[0])))) <= 1e-11 * n
+    P = dev.potri(ctx, L).to_host(tri=2)                                  # triangular-aware explicit inverse
+    assert rel(P @ K[:, :7], np.eye(n)[:, :7]) <= 1e-9
+    del Kd, L
+    ctx.trim()
+
+
+def test_refactor_in_place_invalidates_block_inverses(dev, ctx):
+    """The bench refills and refactors one matrix every step: the cached block inverses of the previous factor must not
+    leak into the next solve."""
+    rng = np.random.default_rng(99)
+    n, d = 2500, 3
+    X = dev.points(ctx, rng.uniform(-1, 1, (n, d)))
+    y = rng.standard_normal(n)
+    K = dev.DeviceMatrix.zeros(ctx, n, n)
+    out = []
+    for rho in (0.5, 0.9, 0.5):
+        sp = dev.KernelSpec(dev.K_MATERN32, d, [rho, 1.0])
+        dev.kfill_into(ctx, sp, X, K, nugget=0.1)
+        dev.potrf(ctx, K)
+        out.append(dev.potrs(ctx, K, y))
+    assert np.array_equal(out[0], out[2]) and rel(out[1], out[0]) > 1e-3
