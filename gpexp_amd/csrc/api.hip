@@ -979,6 +979,17 @@ int gpx_profile_get(gpx_ctx* ctx, int cls, int64_t* launches, double* ms, double
 }
 
 // ---- test hooks ------------------------------------------------------------------------------------------
+// the triangular-operand modes of the GEMM (launch_gemm_tri): tri = 1 / 2 / 3, see gemm_f64.hip
+int gpx_dbg_gemm_tri(gpx_ctx* ctx, const gpx_mat* A, const gpx_mat* B, gpx_mat* C, int bt, int accumulate, int tri) {
+  GPX_ARG(ctx && A && B && C, "NULL argument");
+  const int64_t m = C->prows, n = C->pcols, k = A->pcols;
+  GPX_ARG(A->prows == m, "A rows");
+  GPX_ARG(bt ? (B->prows == n && B->pcols == k) : (B->prows == k && B->pcols == n), "B shape");
+  GPX_TRY(launch_gemm_tri(ctx, A->p, A->ld, B->p, B->ld, C->p, C->ld, m, n, k, bt != 0, accumulate != 0, tri == 3, tri));
+  GPX_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
 int gpx_dbg_kfill_plan(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* X, const gpx_mat* Z,
                        int* exact, double* center) {
   GPX_ARG(ctx && X && exact && center, "NULL argument");

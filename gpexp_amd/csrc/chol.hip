@@ -829,7 +829,7 @@ static int64_t potrf_rl_max() {
 
 static int potrf_rec(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double* invd, int64_t base, int64_t n_valid);
 static int binv_build_range(gpx_ctx* ctx, const double* Ld, int64_t ld, const double* invd, double* binv, int64_t ib, int64_t n,
-                            double* tmp);
+                            double* tmp, int64_t lo = 0, int64_t hi = INT64_MAX);
 
 // X (m x n) <- X L^-T against a diagonal block whose ib-order sub-blocks have explicit inverses (binv, ib x ib each): per
 // sub-block X_b <- X_b Binv_b^T as ONE GEMM (triangular operand: half the k range per column tile; through T, the product
@@ -884,6 +884,7 @@ static int potrf_blocked(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double*
   const int64_t ib = ctx->pw_ib;
   const bool bi = ctx->pw_binv != nullptr && ib > 0 && base % ib == 0 && B % ib == 0;
   auto binv_at = [&](int64_t row) { return ctx->pw_binv + ((base + row) / ib) * ib * ib; };
+  constexpr int64_t CHAIN_MAX = 1024;  // the chain (few CUs beside the masked chunk) inverts up to this order ...
   GPX_TRY(potrf_rec(ctx, A, ld, n < B ? n : B, invd, base, n_valid));
   if (bi) GPX_TRY(binv_build_range(ctx, A, ld, invd, binv_at(0), ib, n < B ? n : B, ctx->pw_tmp_build));
   for (int64_t j0 = 0; j0 < n; j0 += B) {
@@ -914,7 +915,7 @@ static int potrf_blocked(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double*
     int r = 0;
     if (hipStreamWaitEvent(S, ev_col, 0) != hipSuccess) r = -2;
     if (r == 0) r = potrf_rec(ctx, C, ld, w2, invn, base + j0 + w, n_valid);
-    if (r == 0 && bi) r = binv_build_range(ctx, C, ld, invn, binv_at(j0 + w), ib, w2, ctx->pw_tmp_build);
+    if (r == 0 && bi) r = binv_build_range(ctx, C, ld, invn, binv_at(j0 + w), ib, w2, ctx->pw_tmp_build, 0, CHAIN_MAX);
     if (r == 0 && hipEventRecord(ev_diag, S) != hipSuccess) r = -2;
     ctx->stream = M;
     if (r != 0) {
@@ -945,6 +946,8 @@ static int potrf_blocked(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double*
     } else {
       GPX_HIP(hipStreamWaitEvent(M, ev_diag, 0));
     }
+    // ... and the whole chip completes the inverse of the diagonal block (orders 2048, 4096) behind the chain
+    if (bi) GPX_TRY(binv_build_range(ctx, C, ld, invn, binv_at(j0 + w), ib, w2, ctx->pw_tmp_build, CHAIN_MAX, INT64_MAX));
   }
   if (bi && base == 0) ctx->pw_done = 1;
   return 0;
@@ -1009,6 +1012,9 @@ static int64_t potrs_block(int64_t n) {
     const char* e = getenv("GPX_POTRS_IB");  // order of the explicitly inverted diagonal blocks (multiple of 128)
     forced = e ? atoll(e) : 0;
   }
+  // 1024 minimises build + one solve.  (Order 4096 -- the whole diagonal block of a look-ahead panel, its panel solve then ONE
+  // long-K triangular product, potrs 1.75 ms instead of 2.5 -- was measured too: the factorisation loses 13 ms at N = 32768
+  // and 3 ms at N = 8192, because a triangular product on few rows cannot use its shorter k ranges: 4096^3 gains 1.2x.)
   int64_t ib = forced > 0 ? forced / NB * NB : 1024;
   if (ib < NB) ib = NB;
   if (ib > n) ib = n;
@@ -1017,18 +1023,21 @@ static int64_t potrs_block(int64_t n) {
 
 // inverse of the sz x sz diagonal sub-block starting at row/column r0 of every batched block, from the two halves:
 //   [A 0; C B]^-1 = [A^-1 0; -B^-1 C A^-1  B^-1]
+// Sizes <= lo are taken as already inverted; sizes > hi are only descended into, not combined: the factorisation's chain
+// (few CUs) builds up to hi = 1024, the main stream (whole chip) completes the upper levels with lo = 1024.
 static int binv_build_rec(gpx_ctx* ctx, const double* L, int64_t ld, int64_t sl, double* binv, int64_t ib, int64_t r0,
-                          int64_t sz, double* tmp, int64_t batch) {
-  if (sz <= NB) return 0;
+                          int64_t sz, double* tmp, int64_t batch, int64_t lo = 0, int64_t hi = INT64_MAX) {
+  if (sz <= NB || sz <= lo) return 0;
   const int64_t s1 = split(sz), s2 = sz - s1;
-  GPX_TRY(binv_build_rec(ctx, L, ld, sl, binv, ib, r0, s1, tmp, batch));
-  GPX_TRY(binv_build_rec(ctx, L, ld, sl, binv, ib, r0 + s1, s2, tmp, batch));
+  GPX_TRY(binv_build_rec(ctx, L, ld, sl, binv, ib, r0, s1, tmp, batch, lo, hi));
+  GPX_TRY(binv_build_rec(ctx, L, ld, sl, binv, ib, r0 + s1, s2, tmp, batch, lo, hi));
+  if (sz > hi) return 0;
   const double* C = L + (r0 + s1) * ld + r0;
   const double* Ai = binv + r0 * ib + r0;
   const double* Bi = binv + (r0 + s1) * ib + r0 + s1;
   double* R = binv + (r0 + s1) * ib + r0;  // zero so far
   // T = C A^-1 ; R = 0 - B^-1 T
-  if (batch == 1 && s1 >= 1024) {  // one large block (gpx_potri): the tuned kernel, B^-1 as a triangular operand
+  if (batch == 1 && s1 >= 1024) {  // one large block: the tuned kernel, B^-1 as a triangular operand
     GPX_TRY(launch_gemm(ctx, C, ld, Ai, ib, tmp, s1, s2, s1, s1, false, false, false));
     return launch_gemm_tri(ctx, Bi, ib, tmp, s1, R, ib, s2, s1, s2, false, true, false, 1);
   }
@@ -1037,15 +1046,18 @@ static int binv_build_rec(gpx_ctx* ctx, const double* L, int64_t ld, int64_t sl,
 }
 
 // explicit inverses of the ib-order diagonal blocks covering n rows (a multiple of 128; the last block may be shorter) that
-// start at Ld on the diagonal; invd / binv point at that position too; tmp >= ceil(n / ib) * ib * ib doubles
+// start at Ld on the diagonal; invd / binv point at that position too; tmp >= ceil(n / ib) * ib * ib doubles; (lo, hi): see
+// binv_build_rec
 static int binv_build_range(gpx_ctx* ctx, const double* Ld, int64_t ld, const double* invd, double* binv, int64_t ib, int64_t n,
-                            double* tmp) {
+                            double* tmp, int64_t lo, int64_t hi) {
   const int64_t nblk = (n + ib - 1) / ib, nfull = n / ib, tail = n - nfull * ib;
   const int64_t rows = nblk * ib;
-  hipLaunchKernelGGL(binv_init_kernel, dim3((unsigned)((rows * (ib / 2) + 255) / 256)), dim3(256), 0, ctx->stream, invd, binv,
-                     ib, n);
-  if (nfull > 0) GPX_TRY(binv_build_rec(ctx, Ld, ld, ib * (ld + 1), binv, ib, 0, ib, tmp, nfull));
-  if (tail > 0) GPX_TRY(binv_build_rec(ctx, Ld + nfull * ib * (ld + 1), ld, 0, binv + nfull * ib * ib, ib, 0, tail, tmp, 1));
+  if (lo == 0)
+    hipLaunchKernelGGL(binv_init_kernel, dim3((unsigned)((rows * (ib / 2) + 255) / 256)), dim3(256), 0, ctx->stream, invd, binv,
+                       ib, n);
+  if (nfull > 0) GPX_TRY(binv_build_rec(ctx, Ld, ld, ib * (ld + 1), binv, ib, 0, ib, tmp, nfull, lo, hi));
+  if (tail > 0)
+    GPX_TRY(binv_build_rec(ctx, Ld + nfull * ib * (ld + 1), ld, 0, binv + nfull * ib * ib, ib, 0, tail, tmp, 1, lo, hi));
   GPX_HIP(hipGetLastError());
   return 0;
 }
@@ -1102,19 +1114,26 @@ int chol_binv_ensure(gpx_ctx* ctx, gpx_mat* Lm) {
 
 struct PotrsPlan {
   const double* L;
-  int64_t ld, n, ib, nblk;
-  const double* binv;   // [nblk][ib][ib]
+  int64_t ld, n, ib, nblk;  // ib = order of the diagonal blocks this sweep works with
+  int64_t sib;              // order of the STORED inverses (a multiple of ib; row stride of the storage)
+  const double* binv;       // [ceil(n/sib)][sib][sib]
   const double* binvT;
-  double* part;         // colreduce partials
+  double* part;             // colreduce partials
 };
 static inline int64_t blk_off(const PotrsPlan& P, int64_t b) { return b * P.ib < P.n ? b * P.ib : P.n; }
+// inverse of diagonal block b: the diagonal ib x ib sub-block of the stored sib-order inverse that contains it (the inverse
+// of a block-triangular matrix has the inverses of the diagonal blocks on its diagonal)
+static inline const double* blk_inv(const PotrsPlan& P, const double* base, int64_t b) {
+  const int64_t row = b * P.ib, sb = row / P.sib, within = row - sb * P.sib;
+  return base + sb * P.sib * P.sib + within * P.sib + within;
+}
 
 // solve L x = rhs for the diagonal blocks [b0, b1): x (separate vector) receives the solution, rhs is consumed
 static int potrs_fwd(gpx_ctx* ctx, const PotrsPlan& P, int64_t b0, int64_t b1, double* rhs, double* x) {
   if (b1 - b0 == 1) {
     const int64_t o = blk_off(P, b0), sz = blk_off(P, b0 + 1) - o;
-    hipLaunchKernelGGL(binv_gemv_kernel, dim3((unsigned)((sz + 3) / 4)), dim3(256), 0, ctx->stream, P.binv + b0 * P.ib * P.ib,
-                       P.ib, sz, rhs + o, x + o, 1);
+    hipLaunchKernelGGL(binv_gemv_kernel, dim3((unsigned)((sz + 3) / 4)), dim3(256), 0, ctx->stream, blk_inv(P, P.binv, b0),
+                       P.sib, sz, rhs + o, x + o, 1);
     return 0;
   }
   const int64_t mid = (b0 + b1) / 2;
@@ -1131,8 +1150,8 @@ static int potrs_fwd(gpx_ctx* ctx, const PotrsPlan& P, int64_t b0, int64_t b1, d
 static int potrs_bwd(gpx_ctx* ctx, const PotrsPlan& P, int64_t b0, int64_t b1, double* rhs, double* z) {
   if (b1 - b0 == 1) {
     const int64_t o = blk_off(P, b0), sz = blk_off(P, b0 + 1) - o;
-    hipLaunchKernelGGL(binv_gemv_kernel, dim3((unsigned)((sz + 3) / 4)), dim3(256), 0, ctx->stream, P.binvT + b0 * P.ib * P.ib,
-                       P.ib, sz, rhs + o, z + o, 0);
+    hipLaunchKernelGGL(binv_gemv_kernel, dim3((unsigned)((sz + 3) / 4)), dim3(256), 0, ctx->stream, blk_inv(P, P.binvT, b0),
+                       P.sib, sz, rhs + o, z + o, 0);
     return 0;
   }
   const int64_t mid = (b0 + b1) / 2;
@@ -1150,7 +1169,7 @@ static int trsm_left_oop_rec(gpx_ctx* ctx, const PotrsPlan& P, int64_t b0, int64
                              int64_t ldw, int64_t m) {
   if (b1 - b0 == 1) {
     const int64_t o = blk_off(P, b0), sz = blk_off(P, b0 + 1) - o;
-    return launch_gemm_tri(ctx, P.binv + b0 * P.ib * P.ib, P.ib, B + o * ldb, ldb, W + o * ldw, ldw, sz, m, sz, false, false,
+    return launch_gemm_tri(ctx, blk_inv(P, P.binv, b0), P.sib, B + o * ldb, ldb, W + o * ldw, ldw, sz, m, sz, false, false,
                            false, 1);
   }
   const int64_t mid = (b0 + b1) / 2;
@@ -1169,8 +1188,9 @@ int chol_trsm_left_oop(gpx_ctx* ctx, gpx_mat* Lm, double* B, int64_t ldb, double
   P.L = Lm->p;
   P.ld = Lm->ld;
   P.n = Lm->prows;
-  P.ib = Lm->binv_ib;
-  P.nblk = (P.n + P.ib - 1) / P.ib;
+  P.sib = Lm->binv_ib;
+  P.ib = P.sib < 1024 ? P.sib : 1024;  // the diagonal solves are products with a triangular operand: order 1024 keeps the
+  P.nblk = (P.n + P.ib - 1) / P.ib;    // extra flops (those of the inverse's sub-diagonal part) at 3 % of the solve
   P.binv = Lm->binv;
   P.binvT = nullptr;
   P.part = nullptr;
@@ -1187,7 +1207,7 @@ int chol_potrs(gpx_ctx* ctx, gpx_mat* Lm, double* v, double* scratch) {
   P.L = Lm->p;
   P.ld = Lm->ld;
   P.n = Lm->prows;
-  P.ib = Lm->binv_ib;
+  P.ib = P.sib = Lm->binv_ib;
   P.nblk = (P.n + P.ib - 1) / P.ib;
   P.binv = Lm->binv;
   P.binvT = Lm->binv + P.nblk * P.ib * P.ib;

@@ -45,9 +45,12 @@ struct Smem {
 };
 
 // decode a super-block index + position inside it into tile coordinates; false = nothing to do for this slot
+// rot != 0 (triangular B operand: work grows with the column): the column super-block index is rotated from row to row so
+// that every XCD sees every column class -- super-blocks are dealt to XCDs by index mod 8, so with 4 (or 8, 16) column
+// super-blocks the unrotated map gives each XCD the same columns every time (XCDs 3 and 7 all the heavy ones)
 template <bool LOWER>
 __device__ __forceinline__ bool tile_of(int sblk, int within, int tiles_m, int tiles_n, int sb_cols, int sb_shift,
-                                        int* by, int* bx) {
+                                        int* by, int* bx, int rot = 0) {
   const int sbm = (1 << sb_shift) - 1;
   int sr, sc;
   if (LOWER) {  // sblk-th super-block of the lower triangle, row-major: sr(sr+1)/2 <= sblk
@@ -58,6 +61,12 @@ __device__ __forceinline__ bool tile_of(int sblk, int within, int tiles_m, int t
   } else {
     sr = sblk / sb_cols;
     sc = sblk - sr * sb_cols;
+    if (rot) {
+      if ((8 % sb_cols) == 0)
+        sc = (sc + (sblk >> 3)) % sb_cols;   // a round of 8 super-blocks spans whole rows: rotate per round
+      else if ((sb_cols & 7) == 0)
+        sc = (sc + sr) % sb_cols;            // a row spans whole rounds: rotate per row
+    }
   }
   *by = (sr << sb_shift) + (within >> sb_shift);
   *bx = (sc << sb_shift) + (within & sbm);
@@ -254,11 +263,15 @@ __device__ __forceinline__ void gemm_tile(Smem<BT, TE>& sm, const double* A, int
 // the workgroups with the highest ids, i.e. the ones dispatched last.  All tiles of a launch take the same time, so a
 // launch whose tile count is not a multiple of the resident workgroups ends with a mostly idle round; tiles with a
 // quarter of the work shorten it.
-template <bool BT, bool ACC, bool LOWER, int TE>
+// TRI (triangular-operand modes, see launch_gemm_tri) is a TEMPLATE parameter: the dense instantiations must stay exactly
+// the hand-scheduled kernel -- with `tri` as a run-time argument the IVAR solve lost 2 % (490 -> 500 ms), hipcc's
+// scheduling of the k-loop is that sensitive to what surrounds it.
+template <bool BT, bool ACC, bool LOWER, int TE, int TRI>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64_t lda, const double* B, int64_t ldb,
                                                           double* C, int64_t ldc, int nk, int tiles_m, int tiles_n,
                                                           int sb_cols, int sb_shift, int main_wgs, int tail_m0,
-                                                          int tail_tn, int tri) {
+                                                          int tail_tn) {
+  constexpr int tri = TRI;
   __shared__ Smem<BT, TE> sm;
   const int w = blockIdx.x;
   if (TE == 128 && w >= main_wgs) {
@@ -274,13 +287,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64
   const int xcd = w & 7, q = w >> 3;
   const int sbs2 = 2 * sb_shift;
   int by, bx;
-  if (!tile_of<LOWER>((q >> sbs2) * 8 + xcd, q & ((1 << sbs2) - 1), tiles_m, tiles_n, sb_cols, sb_shift, &by, &bx))
+  if (!tile_of<LOWER>((q >> sbs2) * 8 + xcd, q & ((1 << sbs2) - 1), tiles_m, tiles_n, sb_cols, sb_shift, &by, &bx, tri == 2))
     return;
-  // triangular operand: tri == 1, A (m x k) is lower triangular -> row tile `by` only needs k < (by+1)*TE; tri == 2, op(B)
-  // comes from a lower-triangular (n x k) matrix used transposed -> column tile `bx` only needs k < (bx+1)*TE.  The zero
-  // half of the product is never multiplied (products with the explicit block inverses, chol.hip).
-  // tri == 3 (lower C = U U^T with U upper triangular, stored as A = B = U, bt): rows of tile `by` are zero left of column
-  // by*TE in BOTH operands (bx <= by), so the k range starts there.
+  // (Dealing single tiles of a triangular product to XCDs diagonally balances them too, but gives up the super-blocks'
+  // operand reuse in L2: measured 11.9 ms against 13.1 dense for 28672 x 4096 x 4096 -- fabric-bound.)
   int nkt = nk;
   if (tri == 1) nkt = min(nk, (by + 1) * (TE / KB));
   if (tri == 2) nkt = min(nk, (bx + 1) * (TE / KB));
@@ -417,9 +427,30 @@ int launch_gemm_tri(gpx_ctx* ctx, const double* A, int64_t lda, const double* B,
   // algorithmic flops: a triangular operand halves the k range on average (+ the diagonal blocks)
   const double kflops = tri == 3 ? (double)k * (2.0 / 3.0) : (tri ? 0.5 * (double)k + 64.0 : (double)k);
   ProfScope ps(ctx, GPX_PROF_GEMM, 2.0 * tiles128 * 128.0 * 128.0 * kflops, 0.0);
-#define GPX_K(BT_, ACC_, LOW_, TE_)                                                                           \
-  hipLaunchKernelGGL((gemm_f64_kernel<BT_, ACC_, LOW_, TE_>), grid, dim3(256), 0, ctx->stream, A, lda, B, ldb, C, ldc, \
-                     nk, p.tm, p.tn, p.sbc, p.sb_shift, (int)p.wgs, (int)m_main, (int)tail_tn, tri)
+#define GPX_KT(BT_, ACC_, LOW_, TE_, TRI_)                                                                          \
+  hipLaunchKernelGGL((gemm_f64_kernel<BT_, ACC_, LOW_, TE_, TRI_>), grid, dim3(256), 0, ctx->stream, A, lda, B, ldb, C, \
+                     ldc, nk, p.tm, p.tn, p.sbc, p.sb_shift, (int)p.wgs, (int)m_main, (int)tail_tn)
+  if (tri != 0) {  // the operand forms the explicit inverses use
+#define GPX_GT(BT_, ACC_, LOW_, TRI_)        \
+  do {                                       \
+    if (te == 64)                            \
+      GPX_KT(BT_, ACC_, LOW_, 64, TRI_);     \
+    else                                     \
+      GPX_KT(BT_, ACC_, LOW_, 128, TRI_);    \
+  } while (0)
+    if (tri == 1 && !bt && !accumulate) GPX_GT(false, false, false, 1);
+    else if (tri == 1 && !bt && accumulate) GPX_GT(false, true, false, 1);
+    else if (tri == 2 && !accumulate) GPX_GT(true, false, false, 2);
+    else if (tri == 3 && !accumulate) GPX_GT(true, false, true, 3);
+    else {
+      gpx_set_error("gemm: triangular-operand mode %d is not instantiated for bt=%d accumulate=%d", tri, (int)bt, (int)accumulate);
+      return -1;
+    }
+#undef GPX_GT
+    GPX_HIP(hipGetLastError());
+    return 0;
+  }
+#define GPX_K(BT_, ACC_, LOW_, TE_) GPX_KT(BT_, ACC_, LOW_, TE_, 0)
 #define GPX_G(BT_, ACC_, LOW_)          \
   do {                                  \
     if (te == 64)                       \
@@ -442,6 +473,7 @@ int launch_gemm_tri(gpx_ctx* ctx, const double* A, int64_t lda, const double* B,
   }
 #undef GPX_G
 #undef GPX_K
+#undef GPX_KT
   GPX_HIP(hipGetLastError());
   return 0;
 }

@@ -410,5 +410,9 @@ def kfill_plan(ctx, spec, X, Z=None):
     return bool(ex.value), cen
 
 
+def dbg_gemm_tri(ctx, A, B, Cm, bt, accumulate, tri):
+    check(ctx.lib.gpx_dbg_gemm_tri(ctx.h, A.h, B.h, Cm.h, int(bt), int(accumulate), int(tri)))
+
+
 def dbg_gemm(ctx, A, B, Cm, bt, accumulate, lower=False):
     check(ctx.lib.gpx_dbg_gemm(ctx.h, A.h, B.h, Cm.h, int(bt), int(accumulate), int(lower)))

@@ -308,6 +308,9 @@ int gpx_profile_get(gpx_ctx* ctx, int prof_class, int64_t* launches, double* ms,
 /* C (m x n) = beta*C + alpha*A*op(B); bt != 0: B is (n x k) used transposed; alpha,beta in {(-1,1),(1,0)};
  * lower != 0: only tiles on/below the diagonal are touched */
 int gpx_dbg_gemm(gpx_ctx* ctx, const gpx_mat* A, const gpx_mat* B, gpx_mat* C, int bt, int accumulate, int lower);
+/* triangular-operand GEMM modes: tri = 1 (A lower triangular, k == m), 2 (B lower-triangular n x k used transposed, bt),
+ * 3 (lower C = U U^T with A = B = U upper triangular, bt); the structurally zero part of every tile's k range is skipped */
+int gpx_dbg_gemm_tri(gpx_ctx* ctx, const gpx_mat* A, const gpx_mat* B, gpx_mat* C, int bt, int accumulate, int tri);
 /* what an assembly between X and Z (NULL: X with itself) would do: *exact = 1 when distances are formed from raw
  * coordinate differences on the VALU (wide domain relative to the length scale) instead of the centred expanded MFMA
  * product; center[d] = the origin subtracted before scaling (bounding-box midpoint; 0 for Mehler) */
