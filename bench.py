@@ -213,8 +213,8 @@ def main():
         def step():
             dev.kfill_into(ctx, spec, X, K, nugget=noise)
             dev.potrf(ctx, K)
-            # alpha = K^-1 y is ~1300 latency-bound micro-launches: enqueue it on the high-priority side stream so that it
-            # runs underneath the IVAR GEMMs (both only read L); the results are collected after the device-wide sync
+            # alpha = K^-1 y: a chain of 64 dependent launches -- on the high-priority side stream, underneath the IVAR
+            # GEMMs (both only read L); the results are collected after the device-wide sync
             ctx.stream(1)
             dev.potrs_dev(ctx, K, y_dev, alpha_dev)
             ctx.stream(0)

@@ -55,6 +55,7 @@ _SIGS = {
     "gpx_potri": (C.c_int, [c_vp, c_vp, C.POINTER(c_vp)]),
     "gpx_posterior": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_dp, c_vp, c_dp, c_dp]),
     "gpx_posterior_cov": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_dp]),
+    "gpx_fit_ivar": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_dp]),
     "gpx_ivar": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_dp]),
     "gpx_greedy_var": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_dp, c_ip, c_i64, c_i64, c_ip]),
     "gpx_greedy_ivar_step": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_vp,

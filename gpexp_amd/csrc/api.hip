@@ -272,6 +272,8 @@ int gpx_create(int device, gpx_ctx** out) {
   c->pw_binv = c->pw_tmp_build = c->pw_tmp_T = nullptr;
   c->pw_ib = 0;
   c->pw_done = 0;
+  c->panel_width = 0;
+  c->panel_count = 0;
   c->prof_on = 0;
   for (int i = 0; i < GPX_PROF_NCLASS; ++i) {
     c->prof_launches[i] = 0;
@@ -283,6 +285,7 @@ int gpx_create(int device, gpx_ctx** out) {
     GPX_HIP(hipStreamCreateWithPriority(&c->streams[0], hipStreamNonBlocking, lo));
     GPX_HIP(hipStreamCreateWithPriority(&c->streams[1], hipStreamNonBlocking, hi));
     GPX_HIP(hipStreamCreateWithPriority(&c->streams[2], hipStreamNonBlocking, hi));
+    GPX_HIP(hipStreamCreateWithPriority(&c->streams[4], hipStreamNonBlocking, lo));
     c->stream = c->streams[0];
   }
   hipDeviceProp_t prop;
@@ -335,7 +338,8 @@ int gpx_destroy(gpx_ctx* ctx) {
   if (ctx->trsv_scratch) (void)hipFree(ctx->trsv_scratch);
   for (auto ev : ctx->sync_events) (void)hipEventDestroy(ev);
   for (auto ev : ctx->la_events) (void)hipEventDestroy(ev);
-  for (int i = 0; i < 4; ++i) (void)hipStreamDestroy(ctx->streams[i]);
+  for (int i = 0; i < 5; ++i) (void)hipStreamDestroy(ctx->streams[i]);
+  for (auto ev : ctx->panel_events) (void)hipEventDestroy(ev);
   delete ctx;
   return 0;
 }
@@ -348,7 +352,8 @@ int gpx_sync(gpx_ctx* ctx) {
 }
 
 int gpx_stream_select(gpx_ctx* ctx, int which) {
-  GPX_ARG(ctx && which >= 0 && which < 4, "stream index must be 0 (main), 1 (panel), 2 (communication) or 3 (background)");
+  GPX_ARG(ctx && which >= 0 && which < 5,
+          "stream index must be 0 (main), 1 (panel), 2 (communication), 3 (background, CU-masked) or 4 (evaluation)");
   ctx->stream = ctx->streams[which];
   return 0;
 }
@@ -561,7 +566,17 @@ int gpx_kdiag(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const 
 }
 
 // ---- factorisation and solves ----------------------------------------------------------------------
-int gpx_potrf(gpx_ctx* ctx, gpx_mat* K) {
+// The factorisation in two halves: potrf_begin enqueues everything (nothing blocks: gpx_fit_ivar queues the evaluation
+// solve behind the panel events while the factorisation is still running), potrf_end waits, reads the pivot flag, returns
+// the scratch and completes the block inverses.
+struct PotrfJob {
+  bool blocked, built;
+  void *ptb, *ptt;
+  int64_t ib, tb_bytes, tt_bytes;
+  int rc;
+};
+
+static int potrf_begin(gpx_ctx* ctx, gpx_mat* K, PotrfJob* J, int64_t panel_hook) {
   GPX_ARG(ctx && K, "NULL argument");
   GPX_ARG(K->rows == K->cols && K->prows == K->pcols && K->prows % GPX_TILE == 0, "potrf needs a padded square matrix");
   if (!K->aux) {
@@ -571,14 +586,18 @@ int gpx_potrf(gpx_ctx* ctx, gpx_mat* K) {
     K->aux = (double*)p;
   }
   K->binv_ib = 0;  // block inverses of an earlier factorisation are stale (the buffer itself is reused)
+  K->factored = 0;
   // Large matrices take the blocked look-ahead path, which builds the explicit inverses of the 1024-order diagonal blocks
   // as it goes (its panel solves use them; potrs and the posterior solves reuse them): give it the storage.
   const int64_t np = K->prows;
-  const bool blocked = np >= 8192;
-  void *ptb = nullptr, *ptt = nullptr;
-  const int64_t ib = chol_binv_order(np), bbytes = chol_binv_elems(np) * 8;
-  const int64_t tb_bytes = ((np + ib - 1) / ib) * ib * ib * 8, tt_bytes = np * ib * 8;
-  if (blocked) {
+  J->blocked = np >= 8192;
+  J->built = false;
+  J->ptb = J->ptt = nullptr;
+  J->ib = chol_binv_order(np);
+  const int64_t bbytes = chol_binv_elems(np) * 8;
+  J->tb_bytes = ((np + J->ib - 1) / J->ib) * J->ib * J->ib * 8;
+  J->tt_bytes = np * J->ib * 8;
+  if (J->blocked) {
     if (K->binv && K->binv_bytes != bbytes) {
       gpx_dev_release(ctx, K->binv, K->binv_bytes);
       K->binv = nullptr;
@@ -589,29 +608,36 @@ int gpx_potrf(gpx_ctx* ctx, gpx_mat* K) {
       K->binv = (double*)p;
       K->binv_bytes = bbytes;
     }
-    GPX_TRY(gpx_dev_alloc(ctx, tb_bytes, &ptb));
-    int ra = gpx_dev_alloc(ctx, tt_bytes, &ptt);
+    GPX_TRY(gpx_dev_alloc(ctx, J->tb_bytes, &J->ptb));
+    int ra = gpx_dev_alloc(ctx, J->tt_bytes, &J->ptt);
     if (ra != 0) {
-      gpx_dev_release(ctx, ptb, tb_bytes);
+      gpx_dev_release(ctx, J->ptb, J->tb_bytes);
       return ra;
     }
     ctx->pw_binv = K->binv;
-    ctx->pw_ib = ib;
-    ctx->pw_tmp_build = (double*)ptb;
-    ctx->pw_tmp_T = (double*)ptt;
+    ctx->pw_ib = J->ib;
+    ctx->pw_tmp_build = (double*)J->ptb;
+    ctx->pw_tmp_T = (double*)J->ptt;
   }
   ctx->pw_done = 0;
-  int rc = chol_potrf(ctx, K->p, K->ld, np, K->aux, K->rows);
-  const bool built = ctx->pw_done != 0;
+  ctx->panel_width = panel_hook;
+  ctx->panel_count = 0;
+  J->rc = chol_potrf(ctx, K->p, K->ld, np, K->aux, K->rows);
+  J->built = ctx->pw_done != 0;
   ctx->pw_binv = ctx->pw_tmp_build = ctx->pw_tmp_T = nullptr;
   ctx->pw_ib = 0;
   ctx->pw_done = 0;
-  int info = 0;
+  ctx->panel_width = 0;
+  return 0;
+}
+
+static int potrf_end(gpx_ctx* ctx, gpx_mat* K, PotrfJob* J) {
+  int rc = J->rc, info = 0;
   if (rc == 0 && hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = -2;
   if (hipDeviceSynchronize() != hipSuccess && rc == 0) rc = -2;  // the look-ahead path uses three streams
-  if (blocked) {
-    gpx_dev_release(ctx, ptb, tb_bytes);
-    gpx_dev_release(ctx, ptt, tt_bytes);
+  if (J->blocked) {
+    gpx_dev_release(ctx, J->ptb, J->tb_bytes);
+    gpx_dev_release(ctx, J->ptt, J->tt_bytes);
   }
   if (rc != 0) {
     if (rc == -2) gpx_set_error("potrf: HIP call failed: %s", hipGetErrorString(hipGetLastError()));
@@ -621,14 +647,20 @@ int gpx_potrf(gpx_ctx* ctx, gpx_mat* K) {
   if (info != 0) gpx_set_error("potrf: matrix is not positive definite (pivot %d <= 0)", info);
   // explicit inverses of the diagonal blocks for the solves that follow (potrs, posterior / IVAR): completed here, on the
   // factorisation's stream, so that consumers on different streams (the bench runs potrs beside IVAR) find them ready
-  if (info == 0 && np >= 2048) {
-    if (built)
-      GPX_TRY(chol_binv_finish(ctx, K, ib));
+  if (info == 0 && K->prows >= 2048) {
+    if (J->built)
+      GPX_TRY(chol_binv_finish(ctx, K, J->ib));
     else
       GPX_TRY(chol_binv_ensure(ctx, K));
     GPX_HIP(hipStreamSynchronize(ctx->stream));
   }
   return info;
+}
+
+int gpx_potrf(gpx_ctx* ctx, gpx_mat* K) {
+  PotrfJob J;
+  GPX_TRY(potrf_begin(ctx, K, &J, 0));
+  return potrf_end(ctx, K, &J);
 }
 
 static int need_factor(const gpx_mat* L);
@@ -886,6 +918,17 @@ int gpx_posterior(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, co
   return posterior_impl(ctx, kp, L, X, alpha, Z, mean, var);
 }
 
+// fixed-order pairwise sum / M (deterministic, independent of chunking)
+static double pairwise_mean(std::vector<double>& v, int64_t count) {
+  int64_t m = count;
+  while (m > 1) {
+    int64_t h = (m + 1) / 2;
+    for (int64_t i = 0; i + h < m; ++i) v[(size_t)i] += v[(size_t)(i + h)];
+    m = h;
+  }
+  return v[0] / (double)count;
+}
+
 int gpx_ivar(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
              const gpx_mat* Z, double* out) {
   GPX_ARG(ctx && X && Z && out, "NULL argument");
@@ -897,15 +940,112 @@ int gpx_ivar(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const g
   GPX_TRY(gpx_kparams_sets(ctx, &kp, X, Z));
   std::vector<double> var((size_t)Z->rows);
   GPX_TRY(posterior_impl(ctx, kp, L, X, nullptr, Z, nullptr, var.data()));
-  // fixed-order pairwise sum (deterministic, independent of chunking)
-  int64_t m = Z->rows;
-  std::vector<double>& v = var;
-  while (m > 1) {
-    int64_t h = (m + 1) / 2;
-    for (int64_t i = 0; i + h < m; ++i) v[(size_t)i] += v[(size_t)(i + h)];
-    m = h;
+  *out = pairwise_mean(var, Z->rows);
+  return 0;
+}
+
+// GP fit + IVAR in one call; optionally with the evaluation STREAMED underneath the factorisation (the single-GPU form of
+// the multi-GPU streamed evaluation, gpexp_amd/dist.py).  K holds the assembled covariance and is factored in place, exactly as
+// gpx_potrf does; *out = (1/M) sum_j var_j exactly as gpx_ivar computes it on the finished factor.  What changes is WHEN the
+// N^2 M flops of W = L^-1 K(X,Z) run: the blocked look-ahead factorisation records an event per finished 4096-wide panel of
+// L, and the solve advances panel by panel on a low-priority stream of its own (W_k from the block inverses, then
+// B[below] -= L[below, k] W_k with K = 4096), filling the time the factorisation's main stream spends waiting for its
+// latency-bound diagonal chains (35 of its 192 ms at N = 32768) and overlapping the rest.  Falls back to potrf followed by
+// the ordinary solve when the matrix is too small for the blocked path or Z needs more than one chunk.  Returns the pivot
+// status of gpx_potrf.
+int gpx_fit_ivar(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, gpx_mat* K, const gpx_mat* X, const gpx_mat* Z,
+                 double* out) {
+  GPX_ARG(ctx && K && X && Z && out, "NULL argument");
+  KParams kp;
+  GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
+  GPX_ARG(X->cols == d && X->pcols == d && Z->cols == d && Z->pcols == d, "point sets must be unpadded (n x d)");
+  GPX_ARG(K->rows == X->rows && Z->rows > 0, "K does not match X / IVAR needs at least one integration point");
+  GPX_ARG(ctx->stream == ctx->streams[0], "gpx_fit_ivar runs from the main stream");
+  GPX_TRY(gpx_kparams_sets(ctx, &kp, X, Z));
+  const int64_t n = K->rows, np = K->prows, M = Z->rows, mcp = gpx_round_up(M, GPX_TILE);
+  const int64_t Bw = chol_potrf_panel_width(np), ib = chol_binv_order(np);
+  // Streaming is OPT-IN (GPX_FIT_IVAR_STREAMED=1).  Measured on one MI355X at C4 (one call, bench.py): factor-then-solve
+  // 710 ms per step, streamed 720 (right-looking panel steps) / 739 (left-looking): the factorisation's idle time (35 ms)
+  // is real, but two chip-filling GEMM streams share the CUs at a loss, the chain starves behind the solve's long workgroups,
+  // and the panel-wise solve is ~10 % more work-time than the recursive one.  It pays where the factorisation leaves a GPU
+  // mostly idle -- the multi-GPU panel loop (gpexp_amd/dist.py), which is where the idea comes from.
+  const char* on = getenv("GPX_FIT_IVAR_STREAMED");
+  const bool streamed = Bw > 0 && Bw % ib == 0 && M <= eval_chunk(np) && on && on[0] == '1';
+  PotrfJob J;
+  if (!streamed) {
+    GPX_TRY(potrf_begin(ctx, K, &J, 0));
+    int info = potrf_end(ctx, K, &J);
+    if (info != 0) return info;
+    std::vector<double> var((size_t)M);
+    GPX_TRY(posterior_impl(ctx, kp, K, X, nullptr, Z, nullptr, var.data()));
+    *out = pairwise_mean(var, M);
+    return 0;
   }
-  *out = v[0] / (double)Z->rows;
+  const int64_t ldb = gpx_skew_ld(mcp), bytesB = np * ldb * 8, bytes_out = mcp * 8;
+  const int64_t bytes_part = colreduce_partial_elems(np, mcp) * 8 + 8;
+  void *pB = nullptr, *pW = nullptr, *pout = nullptr, *pkd = nullptr, *ppart = nullptr;
+  int r = 0, info = 0;
+  hipStream_t M0 = ctx->stream, E = ctx->streams[4];
+  std::vector<double> hs((size_t)M), hk((size_t)M);
+  bool begun = false;
+  do {
+    if ((r = gpx_dev_alloc(ctx, bytesB, &pB)) != 0) break;
+    if ((r = gpx_dev_alloc(ctx, bytesB, &pW)) != 0) break;
+    if ((r = gpx_dev_alloc(ctx, bytes_out, &pout)) != 0) break;
+    if ((r = gpx_dev_alloc(ctx, bytes_out, &pkd)) != 0) break;
+    if ((r = gpx_dev_alloc(ctx, bytes_part, &ppart)) != 0) break;
+    // evaluation stream: everything that does not need the factor first
+    ctx->stream = E;
+    r = launch_kfill(ctx, kp, X->p, n, Z->p, M, 0, nullptr, 0, 0.0, (double*)pB, np, mcp, ldb);
+    if (r == 0) r = launch_kdiag(ctx, kp, Z->p, M, (double*)pkd);
+    ctx->stream = M0;
+    if (r != 0) break;
+    // the factorisation, with a panel event per finished look-ahead panel
+    if ((r = potrf_begin(ctx, K, &J, Bw)) != 0) break;
+    begun = true;
+    if (J.rc != 0) break;
+    const int npanel = ctx->panel_count;
+    if (npanel != (int)((np + Bw - 1) / Bw)) {  // the factorisation did not take the hooked path: solve after it
+      info = potrf_end(ctx, K, &J);
+      begun = false;
+      if (info != 0) break;
+      ctx->stream = E;
+      r = chol_trsm_left_oop(ctx, K, (double*)pB, ldb, (double*)pW, ldb, mcp);
+      ctx->stream = M0;
+      if (r != 0) break;
+    } else {
+      ctx->stream = E;
+      for (int k = 0; k < npanel && r == 0; ++k) {
+        const int64_t r0 = (int64_t)k * Bw, r1 = (r0 + Bw) < np ? (r0 + Bw) : np;
+        if (hipStreamWaitEvent(E, ctx->panel_events[(size_t)k], 0) != hipSuccess) { r = -2; break; }
+        r = chol_trsm_left_oop_panel(ctx, K->p, K->ld, np, K->binv, ib, (double*)pB, ldb, (double*)pW, ldb, mcp, r0, r1);
+      }
+      ctx->stream = M0;
+      if (r != 0) break;
+    }
+    ctx->stream = E;
+    r = launch_colreduce(ctx, (const double*)pW, ldb, n, mcp, nullptr, (double*)pout, (double*)ppart);
+    if (r == 0 && (hipMemcpyAsync(hs.data(), pout, (size_t)M * 8, hipMemcpyDeviceToHost, E) != hipSuccess ||
+                   hipMemcpyAsync(hk.data(), pkd, (size_t)M * 8, hipMemcpyDeviceToHost, E) != hipSuccess))
+      r = -2;
+    ctx->stream = M0;
+  } while (0);
+  if (begun) {
+    const int pe = potrf_end(ctx, K, &J);  // device-wide synchronisation
+    if (info == 0) info = pe;
+  } else {
+    (void)hipDeviceSynchronize();
+  }
+  gpx_dev_release(ctx, pB, bytesB);
+  gpx_dev_release(ctx, pW, bytesB);
+  gpx_dev_release(ctx, pout, bytes_out);
+  gpx_dev_release(ctx, pkd, bytes_out);
+  gpx_dev_release(ctx, ppart, bytes_part);
+  if (r == -2) gpx_set_error("fit_ivar: HIP call failed: %s", hipGetErrorString(hipGetLastError()));
+  if (r != 0) return r;
+  if (info != 0) return info;
+  for (int64_t j = 0; j < M; ++j) hk[(size_t)j] -= hs[(size_t)j];
+  *out = pairwise_mean(hk, M);
   return 0;
 }
 

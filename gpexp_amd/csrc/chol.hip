@@ -887,9 +887,25 @@ static int potrf_blocked(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double*
   constexpr int64_t CHAIN_MAX = 1024;  // the chain (few CUs beside the masked chunk) inverts up to this order ...
   GPX_TRY(potrf_rec(ctx, A, ld, n < B ? n : B, invd, base, n_valid));
   if (bi) GPX_TRY(binv_build_range(ctx, A, ld, invd, binv_at(0), ib, n < B ? n : B, ctx->pw_tmp_build));
+  // streamed evaluation hook: panel k of L is final once its rows below the diagonal block are solved
+  const bool hook = ctx->panel_width == B && base == 0;
+  auto panel_done = [&](int64_t k) -> int {
+    if (!hook) return 0;
+    while ((int64_t)ctx->panel_events.size() <= k) {
+      hipEvent_t ev;
+      GPX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      ctx->panel_events.push_back(ev);
+    }
+    GPX_HIP(hipEventRecord(ctx->panel_events[(size_t)k], ctx->stream));
+    ctx->panel_count = (int)k + 1;
+    return 0;
+  };
   for (int64_t j0 = 0; j0 < n; j0 += B) {
     const int64_t w = (n - j0) < B ? (n - j0) : B, below = n - j0 - w;
-    if (below == 0) break;
+    if (below == 0) {
+      GPX_TRY(panel_done(j0 / B));  // the last diagonal block: the main stream has already waited for its chain
+      break;
+    }
     double* P = A + (j0 + w) * ld + j0;        // below x w panel
     double* C = A + (j0 + w) * (ld + 1);       // trailing block, below x below
     if (bi)
@@ -897,6 +913,7 @@ static int potrf_blocked(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double*
                                   ctx->pw_tmp_T));
     else
       GPX_TRY(chol_trsm_right(ctx, A + j0 * (ld + 1), ld, invd + (j0 / NB) * NB * NB, P, ld, below, w));
+    GPX_TRY(panel_done(j0 / B));
     const int64_t w2 = below < B ? below : B, rest = below - w2;
     double* invn = invd + ((j0 + w) / NB) * NB * NB;
     if (!la) {
@@ -951,6 +968,11 @@ static int potrf_blocked(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double*
   }
   if (bi && base == 0) ctx->pw_done = 1;
   return 0;
+}
+
+int64_t chol_potrf_panel_width(int64_t n) {
+  const int64_t blk = env_i64("GPX_POTRF_BLOCK", 4096) / NB * NB;
+  return (blk >= potrf_rl_max() && n >= 2 * blk && n > potrf_rl_max()) ? blk : 0;
 }
 
 static int potrf_rec(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double* invd, int64_t base, int64_t n_valid) {
@@ -1178,6 +1200,29 @@ static int trsm_left_oop_rec(gpx_ctx* ctx, const PotrsPlan& P, int64_t b0, int64
   GPX_TRY(launch_gemm(ctx, P.L + r0 * P.ld + c0, P.ld, W + c0 * ldw, ldw, B + r0 * ldb, ldb, r1 - r0, m, r0 - c0, false, true,
                       false));
   return trsm_left_oop_rec(ctx, P, mid, b1, B, ldb, W, ldw, m);
+}
+
+int chol_trsm_left_oop_panel(gpx_ctx* ctx, const double* L, int64_t ld, int64_t n, const double* binv, int64_t ib, double* B,
+                             int64_t ldb, double* W, int64_t ldw, int64_t m, int64_t r0, int64_t r1) {
+  GPX_ARG(L && binv && B && W && B != W && ib > 0 && r0 % ib == 0 && r0 < r1 && r1 <= n, "trsm panel: bad arguments");
+  if (m == 0) return 0;
+  PotrsPlan P;
+  P.L = L;
+  P.ld = ld;
+  P.n = r1;  // blocks beyond the panel do not exist yet
+  P.ib = P.sib = ib;
+  P.nblk = (r1 + ib - 1) / ib;
+  P.binv = binv;
+  P.binvT = nullptr;
+  P.part = nullptr;
+  // RIGHT-looking across panels (all rows below take this panel's contribution at once, K = r1 - r0): the work sits in the
+  // early panels, which is what an overlap with the factorisation needs.  (Left-looking -- one long-K product per panel, the
+  // shape the GEMM kernel is fastest at -- leaves most of the solve behind the last panel: 739 ms per bench step against
+  // 720 with this form and 710 for factor-then-solve.)
+  GPX_TRY(trsm_left_oop_rec(ctx, P, r0 / ib, P.nblk, B, ldb, W, ldw, m));
+  if (r1 < n)
+    GPX_TRY(launch_gemm(ctx, L + r1 * ld + r0, ld, W + r0 * ldw, ldw, B + r1 * ldb, ldb, n - r1, m, r1 - r0, false, true, false));
+  return 0;
 }
 
 int chol_trsm_left_oop(gpx_ctx* ctx, gpx_mat* Lm, double* B, int64_t ldb, double* W, int64_t ldw, int64_t m) {

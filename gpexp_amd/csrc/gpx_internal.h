@@ -99,7 +99,8 @@ struct ProfRec {
 struct gpx_ctx {
   int device;
   hipStream_t stream;        // currently selected stream (all launches go here)
-  hipStream_t streams[4];    // 0 = main, 1 = panel (high priority), 2 = communication (high priority),
+  hipStream_t streams[5];    // 0 = main, 1 = panel (high priority), 2 = communication (high priority),
+                             // 4 = evaluation (low priority, unmasked): the streamed IVAR solve beside the factorisation,
                              // 3 = background: CU-masked (leaves 4 CUs per XCD to the other streams) when the runtime allows
   std::vector<hipEvent_t> sync_events;  // gpx_event_record / gpx_event_wait ids
   // work buffers of a blocked factorisation in flight (set by gpx_potrf around chol_potrf, NULL otherwise): storage of the
@@ -109,6 +110,11 @@ struct gpx_ctx {
   double* pw_tmp_build;
   double* pw_tmp_T;
   int pw_done;   // set by the factorisation when it has built every block inverse into pw_binv
+  // streamed evaluation (gpx_fit_ivar): the blocked factorisation records panel_events[k] once panel k of L (its diagonal
+  // block, the rows below it and the block inverses) is final; panel_width = its panel width, 0 = no hook
+  std::vector<hipEvent_t> panel_events;
+  int64_t panel_width;
+  int panel_count;
   std::vector<hipEvent_t> la_events;    // look-ahead factorisation (chol.hip): column ready / chain done / masked chunk done
   int cus;
   // cached device allocations (exact-size reuse)
@@ -211,6 +217,11 @@ int64_t chol_binv_elems(int64_t n);
 int chol_binv_finish(gpx_ctx* ctx, gpx_mat* L, int64_t ib);  // explicit inverses of L's diagonal blocks (order <= 1024), cached in L
 // W (n x m, separate buffer) = L^-1 B through the block inverses: B is consumed (its lower block rows are updated in place)
 int chol_trsm_left_oop(gpx_ctx* ctx, gpx_mat* L, double* B, int64_t ldb, double* W, int64_t ldw, int64_t m);
+// one right-looking panel step of that solve with the rows [r0, r1) of the factor only (a finished look-ahead panel): W[r0:r1]
+// from B[r0:r1] through the block inverses at `binv` (order ib, row stride ib), then B[r1:] -= L[r1:, r0:r1] W[r0:r1]
+int chol_trsm_left_oop_panel(gpx_ctx* ctx, const double* L, int64_t ld, int64_t n, const double* binv, int64_t ib, double* B,
+                             int64_t ldb, double* W, int64_t ldw, int64_t m, int64_t r0, int64_t r1);
+int64_t chol_potrf_panel_width(int64_t n);  // width of the look-ahead panels chol_potrf uses for order n (0: not blocked)
 int64_t chol_potrs_scratch_bytes(int64_t n);
 int chol_potrs(gpx_ctx* ctx, gpx_mat* L, double* v, double* scratch);
 // y[r] -= sum_c A[r][c] x[c] over a rows x cols block (cols a multiple of 2, ld even)

@@ -341,6 +341,14 @@ def ivar(ctx, spec, L, X, Z):
     return v.value
 
 
+def fit_ivar(ctx, spec, K, X, Z):
+    """Factor the assembled covariance K in place and return the (signed) IVAR over Z, the evaluation solve streamed
+    underneath the factorisation (gpx_fit_ivar).  Raises NotPositiveDefinite like potrf."""
+    v = C.c_double()
+    check(ctx.lib.gpx_fit_ivar(ctx.h, *spec.args(), K.h, X.h, Z.h, C.byref(v)))
+    return v.value
+
+
 def greedy_var(ctx, spec, Cpts, nsel, keep=(), weights=None):
     keep = np.ascontiguousarray(np.asarray(list(keep), dtype=np.int64))
     out = np.empty(int(nsel), dtype=np.int64)

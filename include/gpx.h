@@ -64,7 +64,8 @@ const char* gpx_last_error(void);
 int gpx_create(int device, gpx_ctx** out);
 int gpx_destroy(gpx_ctx* ctx);
 int gpx_sync(gpx_ctx* ctx);   /* device-wide: every stream of the context */
-/* Three HIP streams per context: 0 main, 1 panel factorisation (high priority), 2 communication (high priority).
+/* HIP streams per context: 0 main, 1 panel factorisation (high priority), 2 communication (high priority), 3 background
+ * (CU-masked: leaves 4 CUs per XCD to the others), 4 evaluation (low priority).
  * All entry points enqueue on the currently selected one; events order work across them (look-ahead pipeline). */
 int gpx_stream_select(gpx_ctx* ctx, int which);
 int gpx_event_record(gpx_ctx* ctx, int id);  /* id in [0, 65536): recorded on the selected stream */
@@ -151,6 +152,14 @@ int gpx_posterior_cov(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp
 /* IVAR = (1/M) sum_j var_j (signed mean; caller applies abs)          experimentalDesign.py:104-117 */
 int gpx_ivar(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp,
              const gpx_mat* L, const gpx_mat* X, const gpx_mat* Z, double* out);
+/* GP fit + IVAR in one call -- what costFunctionGP_IVAR.evaluate (experimentalDesign.py:104-117: refit, then
+ * evaluateVariance over the MC points) amounts to per optimiser evaluation: K (assembled, gpx_kfill) is factored in place
+ * as by gpx_potrf and *out receives what gpx_ivar would return on the finished factor.  With GPX_FIT_IVAR_STREAMED=1 the
+ * evaluation solve is streamed underneath the factorisation (panel events of the blocked look-ahead Cholesky, a
+ * low-priority stream of its own); on one GPU that measured slower than factor-then-solve, so it is opt-in.
+ * Status as gpx_potrf.  Main stream only. */
+int gpx_fit_ivar(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, gpx_mat* K, const gpx_mat* X, const gpx_mat* Z,
+                 double* out);
 /* greedy maximum-posterior-variance selection among M candidates, nugget 0 (experimentalDesign.py:787-845).
  * keep[nkeep] = indices already selected; selects until nsel indices in total; out_idx[nsel] receives
  * keep followed by the new picks; w (host, M) optional weights; first-max tie rule (np.argmax). */

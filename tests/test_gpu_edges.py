@@ -212,3 +212,49 @@ def test_refactor_in_place_invalidates_block_inverses(dev, ctx):
         dev.potrf(ctx, K)
         out.append(dev.potrs(ctx, K, y))
     assert np.array_equal(out[0], out[2]) and rel(out[1], out[0]) > 1e-3
+
+
+@pytest.mark.parametrize("n,m", [(700, 300), (8192, 4096), (9000, 2500), (12929, 1111)])
+def test_fit_ivar_streamed_equals_fit_then_ivar(dev, ctx, n, m, monkeypatch):
+    """gpx_fit_ivar with the evaluation solve streamed underneath the blocked look-ahead factorisation (opt-in; from
+    N = 8192, plain sequence below) against gpx_potrf followed by gpx_ivar on the same inputs: same factor bit for bit,
+    IVAR to 1e-12 (the solve is blocked differently)."""
+    monkeypatch.setenv("GPX_FIT_IVAR_STREAMED", "1")
+    rng = np.random.default_rng(n + m)
+    d = 5
+    X = dev.points(ctx, rng.uniform(-1, 1, (n, d)))
+    Z = dev.points(ctx, rng.uniform(-1, 1, (m, d)))
+    sp = dev.KernelSpec(dev.K_MATERN52, d, [0.6, 1.0])
+    K1 = dev.potrf(ctx, dev.kfill(ctx, sp, X, nugget=0.05))
+    iv1 = dev.ivar(ctx, sp, K1, X, Z)
+    K2 = dev.kfill(ctx, sp, X, nugget=0.05)
+    iv2 = dev.fit_ivar(ctx, sp, K2, X, Z)
+    assert abs(iv2 - iv1) <= 1e-12 * abs(iv1)
+    assert dev.logdet(ctx, K2) == dev.logdet(ctx, K1)
+    y = rng.standard_normal(n)
+    assert np.array_equal(dev.potrs(ctx, K2, y), dev.potrs(ctx, K1, y))    # factor and block inverses identical
+    dev.kfill_into(ctx, sp, X, K2, nugget=0.05)
+    assert dev.fit_ivar(ctx, sp, K2, X, Z) == iv2                           # repeatable bit for bit
+    monkeypatch.setenv("GPX_FIT_IVAR_STREAMED", "0")
+    dev.kfill_into(ctx, sp, X, K2, nugget=0.05)
+    assert abs(dev.fit_ivar(ctx, sp, K2, X, Z) - iv1) <= 1e-13 * abs(iv1)   # default: factor, then the ordinary solve
+    del K1, K2
+    ctx.trim()
+
+
+def test_fit_ivar_reports_non_positive_definite(dev, ctx):
+    from gpexp_amd._lib import NotPositiveDefinite
+    rng = np.random.default_rng(5)
+    n, d = 8300, 3
+    Xh = rng.uniform(-1, 1, (n, d))
+    Xh[8000] = Xh[17]
+    X = dev.points(ctx, Xh)
+    Z = dev.points(ctx, rng.uniform(-1, 1, (256, d)))
+    sp = dev.KernelSpec(dev.K_SE, d, [0.5, 0.5, 0.5, 1.0])
+    K = dev.kfill(ctx, sp, X, nugget=0.0)
+    dev.potrf_policy(ctx, 1e-13, False)
+    try:
+        with pytest.raises(NotPositiveDefinite):
+            dev.fit_ivar(ctx, sp, K, X, Z)
+    finally:
+        dev.potrf_policy(ctx, 0.0, False)
