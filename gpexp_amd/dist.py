@@ -651,10 +651,11 @@ class Grid2D:
         """Global block columns J > k owned by this rank's process column."""
         return [J for J in range(self.pc, self.nblk, self.Pc) if J > k]
 
-    def update_args(self, k, J):
-        """(lr0, m, lc0, n, aoff, boff) of the local trailing update of block column J > k by panel k (this rank)."""
+    def update_args(self, k, J, below_diag=False):
+        """(lr0, m, lc0, n, aoff, boff) of the local trailing update of block column J > k by panel k (this rank);
+        below_diag: only the block rows I > J (the diagonal block of column J is updated by the early path)."""
         nb, pr = self.nb, self.pr
-        liJ = self.blocks_before(pr, self.Pr, J)            # first local block row with I >= J
+        liJ = self.blocks_before(pr, self.Pr, J + (1 if below_diag else 0))   # first local block row with I >= J (> J)
         m = max(self.local_rows(pr) - liJ * nb, 0)
         if m == 0:
             liJ = self.local_rows(pr) // nb                    # nothing below: stay inside the local matrix
@@ -717,43 +718,62 @@ class DeviceOps2D(DeviceOps):
 
 
 # event kinds of the 2-D pipeline (per step k)
-E_COLREADY, E_DFACT, E_DBC, E_PIECE, E_ARRIVED, E_STORED, E_UPD = range(7)
+(E_COLREADY, E_DFACT, E_DBC, E_PIECE, E_ARRIVED, E_STORED, E_UPD, E_DIAGREADY, E_EARLYSOLVED, E_EARLY, E_COL2,
+ E_PANELDONE) = range(12)
 
 
 def _ev2(kind, k):
-    return 8 * (k + 1) + kind
+    return 12 * (k + 1) + kind
 
 
 def dist2_potrf(ops, comm, geo, A, G, L=None, on_stored=None):
     """2-D block-cyclic right-looking Cholesky of the distributed matrix A (in place: A ends as the block-cyclic factor)
-    with one step of look-ahead.  G = two packed panel buffers (geo.buf_elems() doubles) used alternately; L (optional) =
-    full-size matrix that receives every finished panel (replicated factor for the evaluation phase).
+    with look-ahead and a CRITICAL-PATH-FIRST diagonal chain.  G = two packed panel buffers (geo.buf_elems() doubles) used
+    alternately; L (optional) = full-size matrix that receives every finished panel (replicated factor for the evaluation
+    phase).
 
-    Streams per rank: PANEL (diagonal factor, panel solve), COMM (collectives, in step order on every rank, so every
-    communicator sees its operations in the same order everywhere), MAIN (trailing updates; the local part of block column
-    k+1 first, which releases the PANEL stream of its holders for step k+1 underneath the rest of update k), BACK (copies
-    into L, then the streamed-evaluation hook `on_stored(k)`).  A panel buffer is rewritten at step k+2 only after update k
-    and the copy of panel k are done.  Returns 0 or the 1-based index of the first non-positive pivot (agreed by all)."""
+    What serialises a distributed factorisation is the chain diag(k) -> panel(k) -> update of column k+1 -> diag(k+1).  Only
+    ONE nb x nb block of panel k enters diag(k+1): L[k+1, k].  So, per step k,
+      diagonal chain   owner of (k,k) factors it; the holder of block row k+1 solves THAT block first and sends it along its
+                       process row (one small ncclBroadcast on the row sub-communicator); the owner of (k+1,k+1) applies it
+                       to the diagonal block (which got the contributions of the panels before k from the two-ahead column
+                       update below) and can factor at once: potrf(nb) + two small hops per step;
+      panel chain      meanwhile the rest of panel k is solved, every piece goes to every rank over all links
+                       (gpx_comm_panel_bcast), column k+1 is updated below its diagonal block (releases panel k+1's solve);
+      bulk             column k+2 next (its diagonal block is the one the chain needs in two steps), then the other local
+                       block columns.
+    Streams per rank: PANEL (diagonal factor, solves, the early diagonal update), COMM (collectives, enqueued in the same
+    order on every rank of every communicator), MAIN (trailing updates), BACK (copies into L, then the streamed-evaluation
+    hook `on_stored(k)`).  A panel buffer is rewritten at step k+2 only after everything of step k that reads it is done.
+    Returns 0 or the 1-based index of the first non-positive pivot (agreed by all)."""
     nb, Pr, Pc, pr, pc = geo.nb, geo.Pr, geo.Pc, geo.pr, geo.pc
+    nblk = geo.nblk
     ops.stream(MAIN)
     ops.begin()
-    ops.record(_ev2(E_COLREADY, 0))  # the assembly was queued on MAIN
-    for k in range(geo.nblk):
+    ops.record(_ev2(E_DIAGREADY, 0))  # the assembly was queued on MAIN
+    ops.record(_ev2(E_COLREADY, 0))
+    for k in range(nblk):
         kr, kc = k % Pr, k % Pc
         g = G[k & 1]
         w = geo.height(k)
         lr, lc = (k // Pr) * nb, (k // Pc) * nb
         holder = pc == kc
         owner = holder and pr == kr
+        nxt = k + 1 < nblk
+        r1, c1 = (k + 1) % Pr, (k + 1) % Pc        # process row of block row k+1 / column of the next diagonal owner
+        h1 = geo.height(k + 1) if nxt else 0
+        early_off = geo.piece_off(r1) + geo.dsz      # L[k+1, k] is the first block of piece r1
 
         def wait_free():
             if k >= 2:
                 ops.wait(_ev2(E_UPD, k - 2))
                 ops.wait(_ev2(E_STORED, k - 2))
+                ops.wait(_ev2(E_PANELDONE, k - 2))
 
+        # ---- diagonal chain -------------------------------------------------------------------------------------
         if owner:
             ops.stream(PANEL)
-            ops.wait(_ev2(E_COLREADY, k))
+            ops.wait(_ev2(E_DIAGREADY, k))
             wait_free()
             ops.diag_factor(A, lr, lc, w, g, geo.piece_off(kr), nb, k * nb, geo.n)
             ops.record(_ev2(E_DFACT, k))
@@ -768,9 +788,33 @@ def dist2_potrf(ops, comm, geo, A, G, L=None, on_stored=None):
             ops.stream(PANEL)
             ops.wait(_ev2(E_DBC, k))
             ops.wait(_ev2(E_COLREADY, k))
-            ops.panel_trsm(A, geo.row_off(pr, geo.li0(pr, k)), geo.piece_rows(pr, k), lc, w, g, geo.piece_off(kr),
-                           geo.piece_off(pr) + geo.dsz, nb)
+            lr0, m = geo.row_off(pr, geo.li0(pr, k)), geo.piece_rows(pr, k)
+            roff = geo.piece_off(pr) + geo.dsz
+            if nxt and pr == r1:                                         # block row k+1 first: the next diagonal needs it
+                ops.panel_trsm(A, lr0, h1, lc, w, g, geo.piece_off(kr), roff, nb)
+                ops.record(_ev2(E_EARLYSOLVED, k))
+                ops.panel_trsm(A, lr0 + h1, m - h1, lc, w, g, geo.piece_off(kr), roff + h1 * nb, nb)
+            else:
+                ops.panel_trsm(A, lr0, m, lc, w, g, geo.piece_off(kr), roff, nb)
             ops.record(_ev2(E_PIECE, k))
+        if nxt and pr == r1:
+            ops.stream(COMM)
+            if holder:
+                ops.wait(_ev2(E_EARLYSOLVED, k))
+            else:
+                wait_free()
+            comm.bcast_grp(g, early_off, h1 * nb, kc, ROW)               # L[k+1, k] along the process row of block row k+1
+            ops.record(_ev2(E_EARLY, k))
+            if pc == c1:                                                 # owner of the next diagonal block
+                ops.stream(PANEL)
+                ops.wait(_ev2(E_EARLY, k))
+                if k >= 1:
+                    ops.wait(_ev2(E_COL2, k + 1))                        # contributions of the panels before k
+                ops.update(A, ((k + 1) // Pr) * nb, h1, ((k + 1) // Pc) * nb, h1, g, early_off, early_off, w, nb)
+                ops.record(_ev2(E_DIAGREADY, k + 1))
+        ops.stream(PANEL)
+        ops.record(_ev2(E_PANELDONE, k))
+        # ---- panel chain ----------------------------------------------------------------------------------------
         ops.stream(COMM)
         if holder:
             ops.wait(_ev2(E_PIECE, k))
@@ -792,12 +836,18 @@ def dist2_potrf(ops, comm, geo, A, G, L=None, on_stored=None):
         ops.stream(MAIN)
         ops.wait(_ev2(E_ARRIVED, k))
         cols = geo.my_cols_after(k)
-        if cols and cols[0] == k + 1:                                    # look-ahead: the next panel's column first
-            lr0, m, lc0, n, aoff, boff = geo.update_args(k, k + 1)
+        if cols and cols[0] == k + 1:                                    # look-ahead: column k+1 BELOW its diagonal block
+            lr0, m, lc0, n, aoff, boff = geo.update_args(k, k + 1, below_diag=True)
             ops.update(A, lr0, m, lc0, n, g, aoff, boff, w, nb)
             cols = cols[1:]
-        if k + 1 < geo.nblk and (k + 1) % Pc == pc:
+        if nxt and pc == c1:
             ops.record(_ev2(E_COLREADY, k + 1))
+        if cols and cols[0] == k + 2:                                    # two ahead: the diagonal chain needs it next step
+            lr0, m, lc0, n, aoff, boff = geo.update_args(k, k + 2)
+            ops.update(A, lr0, m, lc0, n, g, aoff, boff, w, nb)
+            cols = cols[1:]
+        if k + 2 < nblk and (k + 2) % Pc == pc:
+            ops.record(_ev2(E_COL2, k + 2))
         for J in cols:
             lr0, m, lc0, n, aoff, boff = geo.update_args(k, J)
             ops.update(A, lr0, m, lc0, n, g, aoff, boff, w, nb)
