@@ -299,8 +299,19 @@ int gpx_create(int device, gpx_ctx** out) {
     // stay free for the other streams.
     const int words = (c->cus + 31) / 32;
     std::vector<uint32_t> mask((size_t)words, 0xffffffffu);
-    mask[0] = 0u;
     if (c->cus % 32) mask[(size_t)words - 1] = (1u << (c->cus % 32)) - 1u;
+    const char* rs = getenv("GPX_CUMASK_RESERVE");  // comma-separated CU indices (within every XCD) kept free; default 0-3
+    std::string reserve = rs ? rs : "0,1,2,3";
+    for (size_t pos = 0; pos < reserve.size();) {
+      const int cu = atoi(reserve.c_str() + pos);
+      for (int x = 0; x < 8; ++x) {
+        const int bit = 8 * cu + x;
+        if (cu >= 0 && bit < c->cus) mask[(size_t)bit / 32] &= ~(1u << (bit % 32));
+      }
+      const size_t nx = reserve.find(',', pos);
+      if (nx == std::string::npos) break;
+      pos = nx + 1;
+    }
     if (words < 2 || hipExtStreamCreateWithCUMask(&c->streams[3], (uint32_t)words, mask.data()) != hipSuccess) {
       (void)hipGetLastError();
       int lo = 0, hi = 0;

@@ -872,6 +872,15 @@ static int potrf_blocked(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double*
   static const int64_t la_on = env_i64("GPX_POTRF_LA", 1), chunk_rows = env_i64("GPX_POTRF_LA_CHUNK", 8192) / NB * NB;
   hipStream_t M = ctx->stream, S = ctx->streams[1], Kq = ctx->streams[3];
   const bool la = la_on && M == ctx->streams[0];
+  // GPX_POTRF_TIMING=1 (debug): per-panel phase spans from timing events, printed after a device sync at the end
+  static const int64_t timing = env_i64("GPX_POTRF_TIMING", 0);
+  struct Span { const char* what; int64_t panel; hipEvent_t a, b; };
+  std::vector<Span> spans;
+  auto mark = [&](hipStream_t st) -> hipEvent_t {
+    hipEvent_t e = nullptr;
+    if (timing && base == 0 && hipEventCreate(&e) == hipSuccess) (void)hipEventRecord(e, st);
+    return e;
+  };
   if (la && ctx->la_events.empty()) {
     for (int i = 0; i < 3; ++i) {
       hipEvent_t ev;
@@ -908,11 +917,13 @@ static int potrf_blocked(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double*
     }
     double* P = A + (j0 + w) * ld + j0;        // below x w panel
     double* C = A + (j0 + w) * (ld + 1);       // trailing block, below x below
+    hipEvent_t t0 = mark(M);
     if (bi)
       GPX_TRY(trsm_right_binv_rec(ctx, A + j0 * (ld + 1), ld, binv_at(j0), ib, P, ld, below, w, 0, (w + ib - 1) / ib,
                                   ctx->pw_tmp_T));
     else
       GPX_TRY(chol_trsm_right(ctx, A + j0 * (ld + 1), ld, invd + (j0 / NB) * NB * NB, P, ld, below, w));
+    spans.push_back({"solve", j0 / B, t0, mark(M)});
     GPX_TRY(panel_done(j0 / B));
     const int64_t w2 = below < B ? below : B, rest = below - w2;
     double* invn = invd + ((j0 + w) / NB) * NB * NB;
@@ -924,15 +935,19 @@ static int potrf_blocked(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double*
     }
     hipEvent_t ev_col = ctx->la_events[0], ev_diag = ctx->la_events[1], ev_top = ctx->la_events[2];
     // block column k+1 of the update first: its diagonal block (lower) and the rows below it
+    t0 = mark(M);
     GPX_TRY(launch_gemm(ctx, P, ld, P, ld, C, ld, w2, w2, w, true, true, true));
     if (rest > 0) GPX_TRY(launch_gemm(ctx, P + w2 * ld, ld, P, ld, C + w2 * ld, ld, rest, w2, w, true, true, false));
+    spans.push_back({"column", j0 / B, t0, mark(M)});
     GPX_HIP(hipEventRecord(ev_col, M));
     // the diagonal chain of panel k+1 (+ its block inverses) on the side stream
     ctx->stream = S;
     int r = 0;
     if (hipStreamWaitEvent(S, ev_col, 0) != hipSuccess) r = -2;
+    t0 = mark(S);
     if (r == 0) r = potrf_rec(ctx, C, ld, w2, invn, base + j0 + w, n_valid);
     if (r == 0 && bi) r = binv_build_range(ctx, C, ld, invn, binv_at(j0 + w), ib, w2, ctx->pw_tmp_build, 0, CHAIN_MAX);
+    spans.push_back({"chain", j0 / B, t0, mark(S)});
     if (r == 0 && hipEventRecord(ev_diag, S) != hipSuccess) r = -2;
     ctx->stream = M;
     if (r != 0) {
@@ -946,7 +961,9 @@ static int potrf_blocked(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double*
       // beside the chain, on the masked stream: the first `top` rows of the remaining update
       ctx->stream = Kq;
       if (hipStreamWaitEvent(Kq, ev_col, 0) != hipSuccess) r = -2;
+      t0 = mark(Kq);
       if (r == 0) r = launch_gemm(ctx, P2, ld, P2, ld, C2, ld, top, top, w, true, true, true);
+      spans.push_back({"chunk", j0 / B, t0, mark(Kq)});
       if (r == 0 && hipEventRecord(ev_top, Kq) != hipSuccess) r = -2;
       ctx->stream = M;
       if (r != 0) {
@@ -956,17 +973,34 @@ static int potrf_blocked(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double*
       GPX_HIP(hipStreamWaitEvent(M, ev_diag, 0));  // the bulk gets the whole chip: after the chain
       GPX_HIP(hipStreamWaitEvent(M, ev_top, 0));
       if (rest > top) {
+        t0 = mark(M);
         GPX_TRY(launch_gemm(ctx, P2 + top * ld, ld, P2, ld, C2 + top * ld, ld, rest - top, top, w, true, true, false));
         GPX_TRY(launch_gemm(ctx, P2 + top * ld, ld, P2 + top * ld, ld, C2 + top * (ld + 1), ld, rest - top, rest - top, w, true,
                             true, true));
+        spans.push_back({"bulk", j0 / B, t0, mark(M)});
       }
     } else {
       GPX_HIP(hipStreamWaitEvent(M, ev_diag, 0));
     }
     // ... and the whole chip completes the inverse of the diagonal block (orders 2048, 4096) behind the chain
+    t0 = mark(M);
     if (bi) GPX_TRY(binv_build_range(ctx, C, ld, invn, binv_at(j0 + w), ib, w2, ctx->pw_tmp_build, CHAIN_MAX, INT64_MAX));
+    spans.push_back({"binv-top", j0 / B, t0, mark(M)});
   }
   if (bi && base == 0) ctx->pw_done = 1;
+  if (timing && base == 0 && !spans.empty()) {
+    (void)hipDeviceSynchronize();
+    hipEvent_t first = spans[0].a;
+    for (const Span& sp : spans) {
+      float off = 0.f, len = 0.f;
+      if (sp.a && sp.b && hipEventElapsedTime(&off, first, sp.a) == hipSuccess && hipEventElapsedTime(&len, sp.a, sp.b) == hipSuccess)
+        fprintf(stderr, "potrf-timing panel %lld %-8s at %8.3f ms  len %7.3f ms\n", (long long)sp.panel, sp.what, off, len);
+    }
+    for (const Span& sp : spans) {
+      if (sp.a) (void)hipEventDestroy(sp.a);
+      if (sp.b) (void)hipEventDestroy(sp.b);
+    }
+  }
   return 0;
 }
 

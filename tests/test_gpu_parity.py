@@ -103,6 +103,36 @@ def test_gemm_mfma_vs_numpy(dev, ctx, bt, acc):
     assert rel(dC.to_host(), want) <= 1e-13
 
 
+@pytest.mark.parametrize("tri", [1, 2, 3])
+def test_gemm_triangular_operands(dev, ctx, tri):
+    """The k range of every tile is cut to the operand's non-zero part: same result as the dense product of the
+    explicitly zero-filled operand."""
+    rng = np.random.default_rng(70 + tri)
+    if tri == 1:      # A lower triangular (m x m), C = A B  / C -= A B
+        m, n = 384, 256
+        A = np.tril(rng.standard_normal((m, m))); B = rng.standard_normal((m, n))
+        for acc in (0, 1):
+            C0 = rng.standard_normal((m, n))
+            dC = dev.DeviceMatrix.from_host(ctx, C0, pad=False)
+            dev.dbg_gemm_tri(ctx, dev.DeviceMatrix.from_host(ctx, A, pad=False), dev.DeviceMatrix.from_host(ctx, B, pad=False),
+                             dC, 0, acc, 1)
+            assert rel(dC.to_host(), C0 - A @ B if acc else A @ B) <= 1e-13
+    elif tri == 2:    # B lower triangular (n x n) used transposed, C = A B^T
+        m, n = 640, 384
+        A = rng.standard_normal((m, n)); B = np.tril(rng.standard_normal((n, n)))
+        dC = dev.DeviceMatrix.zeros(ctx, m, n)
+        dev.dbg_gemm_tri(ctx, dev.DeviceMatrix.from_host(ctx, A, pad=False), dev.DeviceMatrix.from_host(ctx, B, pad=False), dC, 1, 0, 2)
+        assert rel(dC.to_host()[:m, :n], A @ B.T) <= 1e-13
+    else:             # lower C = U U^T, U upper triangular
+        m = 512
+        U = np.triu(rng.standard_normal((m, m)))
+        dU = dev.DeviceMatrix.from_host(ctx, U, pad=False)
+        dC = dev.DeviceMatrix.zeros(ctx, m, m)
+        dev.dbg_gemm_tri(ctx, dU, dU, dC, 1, 0, 3)
+        il = np.tril_indices(m)
+        assert rel(dC.to_host()[il], (U @ U.T)[il]) <= 1e-13
+
+
 def test_gemm_lower_only(dev, ctx):
     rng = np.random.default_rng(6)
     A = rng.standard_normal((384, 64))
