@@ -862,11 +862,14 @@ static int64_t env_i64(const char* name, int64_t dflt) {
 // update.  So column k+1 is updated first, the chain moves to the high-priority side stream, and the first `chunk` rows of
 // the remaining update run beside it on the CU-masked stream (a chip-filling kernel starves small kernels on other streams
 // whatever their priority, scripts/cumask_check.hip; the mask leaves 4 CUs per XCD to the chain); the bulk of the update
-// follows on the whole chip once the chain is done.  Measured (profiles/r02_potrf_lookahead.txt): beside the chunk the chain
-// takes 5.5 ms instead of 2.3 (its rank-128 updates have 32 CUs), and a kernel on a CU-masked stream runs ~30 % slower than
-// its CU share explains -- putting ALL large kernels on a masked stream so that the chain never blocks them (tried with 1-4
-// reserved CUs per XCD) costs 226-233 ms against 190; relying on the side stream's priority alone (no mask) leaves the chain
-// behind the whole update (195.8 ms = no look-ahead).  Main stream only (the streams are the context's).
+// follows on the whole chip once the chain is done.  Measured (profiles/r02_potrf_lookahead.txt, r02_potrf_phases.txt):
+// beside the chunk the chain takes 5.5 ms instead of 2.3 (its rank-128 updates have 32 CUs).  A kernel on the masked stream
+// runs at exactly its CU share (0.875) -- the chunk is slow because an 8192^2 lower launch is (2080 tiles = 4.06 rounds of
+// the 512 resident workgroups: 55 TF/s on the whole chip).  Putting ALL large kernels on a masked stream so that the chain
+// never blocks them costs that share all the time (226-233 ms against 190); relying on the side stream's priority alone (no
+// mask) leaves the chain behind the whole update (195.8 ms = no look-ahead); two unmasked streams for the independent
+// launches of one update (+6 %) and one trapezoid launch instead of triangle + rectangle (+2 %) were measured and dropped.
+// Main stream only (the streams are the context's).
 static int potrf_blocked(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double* invd, int64_t base, int64_t n_valid,
                          int64_t B) {
   static const int64_t la_on = env_i64("GPX_POTRF_LA", 1), chunk_rows = env_i64("GPX_POTRF_LA_CHUNK", 8192) / NB * NB;
