@@ -827,6 +827,11 @@ static int64_t potrf_rl_max() {
   return v;
 }
 
+static int64_t env_i64(const char* name, int64_t dflt) {
+  const char* e = getenv(name);
+  return e ? atoll(e) : dflt;
+}
+
 static int potrf_rec(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double* invd, int64_t base, int64_t n_valid);
 static int binv_build_range(gpx_ctx* ctx, const double* Ld, int64_t ld, const double* invd, double* binv, int64_t ib, int64_t n,
                             double* tmp, int64_t lo = 0, int64_t hi = INT64_MAX);
@@ -841,6 +846,8 @@ static int trsm_right_binv_rec(gpx_ctx* ctx, const double* Ld, int64_t ldl, cons
   auto off = [&](int64_t b) { return b * ib < n ? b * ib : n; };
   if (b1 - b0 == 1) {
     const int64_t o = off(b0), sz = off(b0 + 1) - o;
+    static const int64_t strip_min = env_i64("GPX_TRMM_STRIP_MIN", 16384);
+    if (strip_min > 0 && m >= strip_min) return launch_trmm_right_inplace(ctx, X + o, ldx, binv + b0 * ib * ib, ib, m, sz);
     GPX_TRY(launch_gemm_tri(ctx, X + o, ldx, binv + b0 * ib * ib, ib, T, ib, m, sz, sz, true, false, false, 2));
     return gpx_copy2d(ctx, T, ib, X + o, ldx, m, sz);
   }
@@ -848,11 +855,6 @@ static int trsm_right_binv_rec(gpx_ctx* ctx, const double* Ld, int64_t ldl, cons
   GPX_TRY(trsm_right_binv_rec(ctx, Ld, ldl, binv, ib, X, ldx, m, n, b0, mid, T));
   GPX_TRY(launch_gemm(ctx, X + o0, ldx, Ld + om * ldl + o0, ldl, X + om, ldx, m, o1 - om, om - o0, true, true, false));
   return trsm_right_binv_rec(ctx, Ld, ldl, binv, ib, X, ldx, m, n, mid, b1, T);
-}
-
-static int64_t env_i64(const char* name, int64_t dflt) {
-  const char* e = getenv(name);
-  return e ? atoll(e) : dflt;
 }
 
 // Blocked right-looking factorisation with panels of width B (4096) and ONE PANEL OF LOOK-AHEAD for large matrices.

@@ -315,6 +315,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_batched_kernel(const double* 
   gemm_tile<BT, ACC, 64>(sm, A + b * sa, lda, B + b * sb, ldb, C + b * sc, ldc, nk, by, bx);
 }
 
+// X (m x n) <- X Linv^T in place, Linv lower triangular of order n (an explicit block inverse): one workgroup per 128-row
+// strip walks the column tiles from the LAST to the first -- tile j of the result needs columns 0 .. 128(j+1) of X, and no
+// later step reads what an earlier one has written, so neither a second buffer nor a copy back is needed.  A strip is a
+// serial chain of n/128 tiles with k = 128 .. n: this only pays while the strips fill the chip (see launch_trmm_right_inplace).
+__global__ __launch_bounds__(256, 2) void trmm_right_inplace_kernel(double* X, int64_t ldx, const double* Linv, int64_t ldi,
+                                                                    int tiles_n) {
+  __shared__ Smem<true, 128> sm;
+  const int by = blockIdx.x;
+  for (int j = tiles_n - 1; j >= 0; --j) {
+    gemm_tile<true, false, 128>(sm, X, ldx, Linv, ldi, X, ldx, (j + 1) * (128 / KB), by, j);
+    __syncthreads();  // the next tile restages the LDS images
+  }
+}
+
 // (A persistent per-XCD work-queue variant of this kernel was measured in round 1 and removed: exact XCD placement
 // alone does not bring the L2 hit rate back -- 4096x8192x16384: 51 GB fetched with or without it, 69 GB requested; the
 // first wave of a launch shares panels because it starts in lock-step (70-81 % hit), later tiles drift apart by more
@@ -344,6 +358,17 @@ Plan make_plan(int64_t m, int64_t n, bool lower, int te) {
 }
 
 }  // namespace
+
+// X (m x n) <- X Linv^T in place (Linv: n x n lower triangular, row stride ldi); m, n multiples of 128
+int launch_trmm_right_inplace(gpx_ctx* ctx, double* X, int64_t ldx, const double* Linv, int64_t ldi, int64_t m, int64_t n) {
+  if (m == 0 || n == 0) return 0;
+  GPX_ARG(m % 128 == 0 && n % 128 == 0 && (ldx % 2) == 0 && (ldi % 2) == 0, "trmm: m, n multiples of 128, even strides");
+  ProfScope ps(ctx, GPX_PROF_GEMM, (double)m * (double)n * ((double)n + 128.0), 0.0);
+  hipLaunchKernelGGL(trmm_right_inplace_kernel, dim3((unsigned)(m / 128)), dim3(256), 0, ctx->stream, X, ldx, Linv, ldi,
+                     (int)(n / 128));
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
 
 // C_b (m x n) = (accumulate ? C_b - A_b*op(B_b) : A_b*op(B_b)) for b = 0..batch-1 with element strides sa, sb, sc between
 // consecutive entries; m, n multiples of 64, k of 16; C_b must not alias A_b or B_b
