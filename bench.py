@@ -237,10 +237,27 @@ def main():
         # of the process because a second HIP/HSA runtime next to the system RCCL breaks ncclCommInitRank.
         ctx.sync()
 
+    # A collective that never completes (the multi-rank RCCL path has only been rehearsed through a host-staged communicator)
+    # would otherwise hang until the launcher's own limit with nothing on stderr: say where, and leave with an error so that
+    # torch.distributed.run tears the other ranks down.
+    import threading
+    limit_s = float(os.environ.get("GPX_BENCH_WATCHDOG_S", "1500"))
+    progress = {"at": "warm-up"}
+
+    def _expired():
+        print("bench.py: watchdog: rank %d of %d still in %s after %.0f s (layout: %s) -- aborting"
+              % (rank, world, progress["at"], limit_s, layout), file=sys.stderr, flush=True)
+        os._exit(124)
+
+    watchdog = threading.Timer(limit_s, _expired)
+    watchdog.daemon = True
+    watchdog.start()
+
     for _ in range(args.warmup):
         out = step()
     barrier()
     sync()
+    progress["at"] = "the timed steps"
     ctx.profile(True)
     ctx.profile_reset()
     t0 = time.perf_counter()
@@ -252,6 +269,7 @@ def main():
     prof = ctx.profile_get()
     ctx.profile(False)
     dt = reduce_max(dt)
+    watchdog.cancel()
     ll, iv = out
 
     # GP-fit and IVAR-eval separately (N / t_fit and M / t_IVAR), outside the timed region: inside it the
