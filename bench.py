@@ -152,6 +152,12 @@ def main():
                     help="full: SURVEY.md 8d's whole protocol (adds N=8192 and the fair-CPU Cholesky at N=32768; minutes)")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout, and native libraries write there too (RCCL's version banner at init and at
+    # ncclCommSplit, gloo's connection lines in the host-staged rehearsal): fd 1 points at stderr until the line is printed.
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -173,17 +179,7 @@ def main():
 
     if world > 1 or os.environ.get("GPX_FORCE_DIST") == "1":  # GPX_FORCE_DIST: rehearse the RCCL runner on one GPU
         from gpexp_amd import dist
-        # RCCL prints its version banner on stdout during init; the contract is ONE JSON line on stdout, so point fd 1 at
-        # stderr while the communicator comes up
-        sys.stdout.flush()
-        saved_fd = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            comm = dist.init_from_env(ctx)
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_fd, 1)
-            os.close(saved_fd)
+        comm = dist.init_from_env(ctx)
         # default: north_star's 2-D block-cyclic layout (Pr x Pc grid, gpexp_amd/dist.py); GPX_DIST_LAYOUT=1d selects the
         # round-1 block-column layout (every rank holds the full matrix, one ncclBroadcast per panel)
         nb = int(os.environ.get("GPX_DIST_NB", "512"))
@@ -345,7 +341,7 @@ def main():
             "config": {"workload": "C4: N=%d d=%d Matern-5/2 (rho=0.5,s=1,noise=0.1) kfill+potrf+potrs+logdet+"
                                    "IVAR over M=%d MC points" % (N, d, M),
                        "N": N, "d": d, "M": M, "kernel": "matern52", "seed": N,
-                       "parallelism": "1 GPU" if world == 1 else "%d ranks, %s" % (world, layout)},
+                       "parallelism": layout if world == 1 else "%d ranks, %s" % (world, layout)},
             "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel (SYRK/TRSM updates)", "achieved": ach,
                          "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
                          "traffic": traffic, "traffic_unit": "bytes per launch (mean over the step's launches)",
@@ -375,6 +371,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(d, full=(args.cpu_baseline == "full"))
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(line), flush=True)
     barrier()
     ctx.close()
