@@ -264,6 +264,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = ctx.profile_get()
     ctx.profile(False)
+    phases = {k: v["ms"] / args.steps for k, v in prof.items() if v["launches"]}
     dt = reduce_max(dt)
     watchdog.cancel()
     ll, iv = out
@@ -271,6 +272,7 @@ def main():
     # GP-fit and IVAR-eval separately (N / t_fit and M / t_IVAR), outside the timed region: inside it the
     # alpha sweeps run underneath the IVAR GEMMs, so the two phases overlap and do not add up to ms_per_step
     fit_ms = ivar_ms = None
+    in_pass = {}
     if world == 1 and os.environ.get("GPX_FORCE_DIST") != "1":
         def fit_only():
             dev.kfill_into(ctx, spec, X, K, nugget=noise)
@@ -292,11 +294,30 @@ def main():
                 fn()
             sync()
             res.append(1e3 * (time.perf_counter() - t1) / args.steps)
-            # the assembly kernels' own rooflines come from these passes: inside the timed region the N x M fill shares HBM
-            # with the alpha sweeps on the side stream
-            prof[cls] = ctx.profile_get()[cls]
+            in_pass[cls] = ctx.profile_get()[cls]
             ctx.profile(False)
         fit_ms, ivar_ms = res
+
+        # The two assembly kernels by themselves: one launch between two host synchronisations, host clock.  That is the
+        # kernel's duration + ~0.03 ms of launch and completion latency (scripts/probe_event_vs_kernel.py: 1.825 ms against
+        # 1.797 ms in rocprofv3's trace of the same launch).  The HIP-event spans of the passes above are NOT used for these two:
+        # behind a host sync they open up to 0.5 ms before the kernel starts (scripts/probe_event_vs_kernel2.py: spans of
+        # 1.6 -> 2.1 ms over twelve fits whose fill kernels all took 1.57-1.61 ms), and back-to-back launches slow the
+        # rectangular fill itself down (1.65 -> 1.95 ms, rocprofv3), which is not how it occurs in the path.
+        KX = K if M == N else dev.DeviceMatrix.zeros(ctx, N, M)
+        for cls, fill, nbytes in (("kfill", lambda: dev.kfill_into(ctx, spec, X, K, nugget=noise), 8.0 * N * N + 8.0 * N * d),
+                                  ("kcross", lambda: dev.kfill_into(ctx, spec, X, KX, Z=Z), 8.0 * N * M + 8.0 * (N + M) * d)):
+            fill()
+            ts = []
+            for _ in range(5):
+                sync()
+                time.sleep(0.003)  # a fill right behind another fill runs slower (the rectangular one by up to 20 %,
+                t1 = time.perf_counter()  # rocprofv3); in the path it follows the factorisation / a host sync
+                fill()
+                sync()
+                ts.append(1e3 * (time.perf_counter() - t1))
+            prof[cls] = {"launches": 1, "ms": sorted(ts)[len(ts) // 2], "flops": 0.0, "bytes": nbytes}
+        del KX
 
     if rank == 0:
         ms = 1e3 * dt / args.steps
@@ -309,6 +330,10 @@ def main():
             return {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                     "avg_launch_ms": p["ms"] / p["launches"] if p["launches"] else 0.0,
                     "algorithmic_bytes_per_launch": p["bytes"] / p["launches"] if p["launches"] else 0.0}
+        def span_in_pass(cls):
+            p = in_pass.get(cls)
+            return p["ms"] / p["launches"] if p and p["launches"] else None
+
         # The look-ahead factorisation runs GEMMs on three streams at once, so per-class event spans overlap and their sum
         # can exceed the wall time: the roofline divides the class's algorithmic flops by the WALL time of the timed region
         # (which also contains the ~1 % of assembly / reduction kernels) -- overlap cannot inflate it.
@@ -354,16 +379,18 @@ def main():
                          "note": "achieved = class flops / wall time of the timed region; the event sum counts time on "
                                  "concurrent streams twice (look-ahead) and is reported for the rocprofv3 cross-check only"},
             "roofline_kfill": dict(hbm(kf), kernel="kfill_kernel<SYM> (symmetric N x N assembly, mirror-written)",
-                                   traffic=None),
-            "roofline_kcross": dict(hbm(kc), kernel="kfill_kernel (rectangular N x M cross matrix, every element computed)",
-                                    traffic=None),
+                                   traffic=None, event_span_in_fit_ms=span_in_pass("kfill")),
+            "roofline_kcross": dict(hbm(kc), kernel="kfill_rect2_kernel (rectangular N x M cross matrix, every element "
+                                                   "computed)", traffic=None, event_span_in_eval_ms=span_in_pass("kcross")),
             "fit_ms": fit_ms, "ivar_ms": ivar_ms,
             "points_per_s_fit": (N / (fit_ms * 1e-3)) if fit_ms else None,
             "points_per_s_ivar": (M / (ivar_ms * 1e-3)) if ivar_ms else None,
             "phase_note": "fit_ms (kfill + potrf + potrs + logdet) and ivar_ms are timed separately after the timed region "
                           "(inside it the alpha sweeps run underneath the IVAR GEMMs); roofline_kfill / roofline_kcross are "
-                          "HIP-event timings of those passes",
-            "phases_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items() if v["launches"]},
+                          "one isolated launch each between two host syncs, host clock, median of 5 (kernel duration + "
+                          "~0.03 ms); event_span_in_*_ms: the HIP-event span of the same kernel inside those passes, which "
+                          "opens before the kernel starts when the stream was idle",
+            "phases_ms_per_step": phases,
             "phases_note": "HIP-event spans per kernel class; trsv and reduce run on a side stream UNDERNEATH the IVAR GEMMs, "
                            "so their spans include waiting and the classes do not add up to ms_per_step",
             "results": {"loglike": ll, "ivar": iv},

@@ -35,36 +35,59 @@ struct KCyclic { int nbt, Pr, pr, Pc, pc; };  // nbt = block size in tiles; 0 = 
 #ifndef WAVES_PER_EU
 #define WAVES_PER_EU 5
 #endif
+#ifndef WAVES_PER_EU_RECT
+#define WAVES_PER_EU_RECT 6
+#endif
 
-// exp(x) = 2^n * 2^(j/64) * exp(r):  m = rint(x * 64/ln2), n = m >> 6, j = m & 63, r = x - m*ln2/64, |r| <= ln2/128, so
-// a degree-5 polynomial is exact to 3.5e-17; tab[j] = 2^(j/64) sits in LDS.  m comes from the add-and-subtract-1.5*2^52
-// trick: the rounded integer is also the low dword of the shifted sum, so there is no v_rndne / v_cvt.  The reduction
-// uses ONE constant: the fma forms m*C exactly, so the only error is m * (C - ln2/64) <= |x| * 8e-17, below the
-// rounding of the argument itself.  Valid for |x| < 2^31 * ln2/64 (arguments here are <= 0 and far above -2e7).
-// 10 fp64 ops + 4 integer ops.
-constexpr int EXP_TAB = 64;
-__device__ __forceinline__ double fast_exp(double x, const double* __restrict__ tab) {
+// exp(x) = 2^n * 2^(j/256) * exp(r):  m = rint(x * 256/ln2), n = m >> 8, j = m & 255, r = x - m*ln2/256, |r| <= ln2/512, so
+// a degree-4 polynomial is exact to 3.8e-17; tab[j] = 2^(j/256) sits in LDS (2 KB).  m comes from the add-and-subtract-
+// 1.5*2^52 trick: the rounded integer is also the low dword of the shifted sum, so there is no v_rndne / v_cvt.  The
+// reduction uses ONE constant: the fma forms m*C exactly, so the only error is m * (C - ln2/256) <= |x| * 8e-17, below the
+// rounding of the argument itself.  The integer trick holds for |x| < 2^31 * ln2/256 = 5.8e6, so the argument is clamped
+// at -750 first (exp(-750) already underflows to 0; a point pair 1e5 length scales apart must give 0, not garbage from a
+// wrapped exponent).  10 fp64 ops + 4 integer ops.  (Rounds 1-2a used 64 entries and degree 5: one fma more per element --
+// the rectangular Matern fill is VALU-bound, profiles/r02_kfill_valu.txt.)
+constexpr int EXP_TAB = 256;
+__device__ __forceinline__ double vmax1(double a, double b);
+__device__ __forceinline__ double vmax1_neg(double a, double b);
+template <bool NEG = false>  // NEG: exp(-xin), the sign folded into the clamp's source modifier
+__device__ __forceinline__ double fast_exp(double xin, const double* __restrict__ tab) {
   const double SHIFT = 6755399441055744.0;                    // 1.5 * 2^52
-  const double sh = fma(x, 92.33248261689366, SHIFT);         // 64 / ln 2
+  const double x = NEG ? vmax1_neg(xin, -750.0) : vmax1(xin, -750.0);
+  const double sh = fma(x, 369.3299304675746, SHIFT);          // 256 / ln 2
   const int mi = __double2loint(sh);
   const double m = sh - SHIFT;
-  const double r = fma(m, -0.010830424696249145, x);          // ln2 / 64
+  const double r = fma(m, -0.0027076061740622863, x);         // ln2 / 256
   const double tj = tab[mi & (EXP_TAB - 1)];
-  double p = 8.3333333333333332177e-03;                       // 1/120
-  p = fma(p, r, 4.1666666666666664354e-02);                   // 1/24
+  double p = 4.1666666666666664354e-02;                       // 1/24
   p = fma(p, r, 1.6666666666666665741e-01);                   // 1/6
   p = fma(p, r, 0.5);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
-  return ldexp(tj * p, mi >> 6);
+  return ldexp(tj * p, mi >> 8);
 }
 
-__device__ __forceinline__ double fast_sqrt(double xin) {  // xin >= 0 (squared scaled distances)
-  // coincident points give exactly 0: clamp instead of a compare + two selects; sqrt(1e-300) = 1e-150 leaves every
-  // kernel value bit-identical to the r = 0 result (1 + 1e-150 == 1, exp(-1e-150) == 1).
+// max(a, b) as ONE v_max_f64: fmax() compiles to a canonicalising v_max(a, a) in front of the real one (a comes out of the
+// MFMA, the compiler cannot know it is no signalling NaN) -- 2 of the 26 VALU instructions per element of a Matern fill
+__device__ __forceinline__ double vmax1(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b));
+  return r;
+}
+__device__ __forceinline__ double vmax1_neg(double a, double b) {  // max(-a, b)
+  double r;
+  asm("v_max_f64 %0, -%1, %2" : "=v"(r) : "v"(a), "s"(b));
+  return r;
+}
+
+// smallest squared scaled distance the Matern kinds evaluate: coincident points (exactly 0) and the expanded form's negative
+// round-off are clamped to it instead of a compare + two selects; sqrt(1e-300) = 1e-150 leaves every kernel value
+// bit-identical to the r = 0 result (1 + 1e-150 == 1, exp(-1e-150) == 1, 1e-300 * sig/3 vanishes).
+constexpr double DIST2_MIN = 1e-300;
+
+__device__ __forceinline__ double fast_sqrt(double x) {  // DIST2_MIN <= x (clamped by the caller)
   // v_rsq_f64 is good to 2^-23; one coupled (Goldschmidt) step squares that to ~2^-45 and the residual correction
   // g += (x - g*g) * h is a further Newton step for the root itself: < 1 ulp.
-  const double x = fmax(xin, 1e-300);
   const double y = __builtin_amdgcn_rsq(x);
   double g = x * y, h = 0.5 * y;
   const double e = fma(-h, g, 0.5);
@@ -73,37 +96,77 @@ __device__ __forceinline__ double fast_sqrt(double xin) {  // xin >= 0 (squared 
   return fma(d, h, g);
 }
 
-// acc = the exponent argument straight from the MFMA (squared scaled distance, or the Mehler exponent); sig3 = sig/3
+// accin = the exponent argument straight from the MFMA (squared scaled distance, or the Mehler exponent); sig3 = sig/3.
+// The expanded form's round-off can leave a squared distance at -1e-16: harmless under exp (SE), clamped for the root.
 template <int KIND>
-__device__ __forceinline__ double kvalue(double acc, double sig, double sig3, const double* __restrict__ tab) {
+__device__ __forceinline__ double kvalue(double accin, double sig, double sig3, const double* __restrict__ tab) {
   if (KIND == GPX_K_SE) {
-    return sig * fast_exp(-0.5 * acc, tab);
+    return sig * fast_exp(-0.5 * accin, tab);
   } else if (KIND == GPX_K_MATERN32) {
-    const double t = fast_sqrt(acc);
-    return fma(t, sig, sig) * fast_exp(-t, tab);
+    const double t = fast_sqrt(vmax1(accin, DIST2_MIN));
+    return fma(t, sig, sig) * fast_exp<true>(t, tab);
   } else if (KIND == GPX_K_MATERN52) {
+    const double acc = vmax1(accin, DIST2_MIN);
     const double t = fast_sqrt(acc);
-    return fma(acc, sig3, fma(t, sig, sig)) * fast_exp(-t, tab);
+    return fma(acc, sig3, fma(t, sig, sig)) * fast_exp<true>(t, tab);
   } else {  // Mehler
-    return sig * fast_exp(-acc, tab);
+    return sig * fast_exp<true>(accin, tab);
   }
 }
 
-// 2^(j/64), j = 0..63 (correctly rounded)
+// 2^(j/256), j = 0..255 (correctly rounded; generated with 60-digit decimal arithmetic)
 __device__ const double kExp2Tab[EXP_TAB] = {
-    1.0, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284, 1.0442737824274138, 1.0556451783605572,
-    1.0671404006768237, 1.0787607977571199, 1.0905077326652577, 1.102382583307841, 1.1143867425958924,
-    1.1265216186082418, 1.1387886347566916, 1.1511892299529827, 1.1637248587775775, 1.1763969916502812,
-    1.189207115002721, 1.202156731452703, 1.215247359980469, 1.22848053610687, 1.241857812073484, 1.255380757024691,
-    1.2690509571917332, 1.2828700160787783, 1.2968395546510096, 1.3109612115247644, 1.3252366431597413,
-    1.339667524053303, 1.3542555469368927, 1.3690024229745905, 1.383909881963832, 1.3989796725383112,
-    1.4142135623730951, 1.42961333839197, 1.4451808069770467, 1.460917794180647, 1.4768261459394993,
-    1.4929077282912648, 1.5091644275934228, 1.5255981507445384, 1.5422108254079407, 1.559004400237837,
-    1.5759808451078865, 1.593142151342267, 1.6104903319492543, 1.6280274218573478, 1.645755478153965,
-    1.6636765803267364, 1.681792830507429, 1.7001063537185235, 1.718619298122478, 1.7373338352737062,
-    1.7562521603732995, 1.7753764925265212, 1.7947090750031072, 1.8142521755003989, 1.8340080864093424,
-    1.8539791250833855, 1.8741676341103, 1.8945759815869656, 1.9152065613971474, 1.9360617934922943,
-    1.9571441241754002, 1.978456026387951};
+    1.0, 1.0027112750502025, 1.0054299011128027, 1.0081558981184175, 1.0108892860517005, 1.0136300849514894,
+    1.016378314910953, 1.019133996077738, 1.0218971486541166, 1.0246677928971357, 1.0274459491187637,
+    1.030231637686041, 1.0330248790212284, 1.0358256936019572, 1.0386341019613787, 1.041450124688316,
+    1.0442737824274138, 1.0471050958792898, 1.0499440858006872, 1.0527907730046264, 1.0556451783605572,
+    1.0585073227945128, 1.061377227289262, 1.0642549128844645, 1.0671404006768237, 1.0700337118202419,
+    1.0729348675259756, 1.075843889062791, 1.0787607977571199, 1.0816856149932152, 1.0846183622133092,
+    1.0875590609177697, 1.0905077326652577, 1.0934643990728858, 1.0964290818163769, 1.099401802630222,
+    1.102382583307841, 1.1053714457017412, 1.1083684117236787, 1.1113735033448175, 1.1143867425958924,
+    1.1174081515673693, 1.1204377524096067, 1.12347556733302, 1.1265216186082418, 1.129575928566288,
+    1.1326385195987192, 1.1357094141578055, 1.1387886347566916, 1.1418762039695616, 1.1449721444318042,
+    1.148076478840179, 1.1511892299529827, 1.154310420590216, 1.1574400736337511, 1.1605782120274988,
+    1.1637248587775775, 1.1668800369524817, 1.1700437696832502, 1.1732160801636373, 1.1763969916502812,
+    1.1795865274628758, 1.182784710984341, 1.1859915656609938, 1.189207115002721, 1.1924313825831512,
+    1.1956643920398273, 1.1989061670743806, 1.202156731452703, 1.2054161090051239, 1.2086843236265816,
+    1.2119613992768012, 1.215247359980469, 1.2185422298274085, 1.2218460329727576, 1.2251587936371455,
+    1.22848053610687, 1.2318112847340759, 1.2351510639369334, 1.2384998981998165, 1.241857812073484,
+    1.245224830175258, 1.2486009771892048, 1.2519862778663162, 1.255380757024691, 1.2587844395497165,
+    1.2621973503942507, 1.2656195145788063, 1.2690509571917332, 1.2724917033894028, 1.275941778396392,
+    1.2794012075056693, 1.2828700160787783, 1.2863482295460256, 1.2898358734066657, 1.2933329732290895,
+    1.2968395546510096, 1.3003556433796506, 1.3038812651919358, 1.3074164459346773, 1.3109612115247644,
+    1.3145155879493546, 1.318079601266064, 1.3216532776031575, 1.3252366431597413, 1.3288297242059544,
+    1.3324325470831615, 1.3360451382041458, 1.339667524053303, 1.3432997311868353, 1.3469417862329458,
+    1.3505937158920345, 1.3542555469368927, 1.3579273062129011, 1.3616090206382248, 1.365300717204012,
+    1.3690024229745905, 1.3727141650876684, 1.3764359707545302, 1.380167867260238, 1.383909881963832,
+    1.387662042298529, 1.3914243757719262, 1.3951969099662003, 1.3989796725383112, 1.4027726912202048,
+    1.4065759938190154, 1.4103896082172707, 1.4142135623730951, 1.4180478843204152, 1.4218926021691656,
+    1.4257477441054942, 1.42961333839197, 1.433489413367789, 1.4373759974489824, 1.4412731191286257,
+    1.4451808069770467, 1.449099089642035, 1.4530279958490526, 1.4569675544014438, 1.460917794180647,
+    1.4648787441464057, 1.4688504333369818, 1.4728328908693675, 1.4768261459394993, 1.4808302278224719,
+    1.4848451658727524, 1.488870989524397, 1.4929077282912648, 1.4969554117672355, 1.5010140696264256,
+    1.5050837316234065, 1.5091644275934228, 1.5132561874526098, 1.5173590411982147, 1.5214730189088146,
+    1.5255981507445384, 1.529734466947287, 1.533881997840956, 1.5380407738316568, 1.5422108254079407,
+    1.5463921831410214, 1.550584877685, 1.5547889397770887, 1.559004400237837, 1.5632312899713576, 1.567469639965553,
+    1.5717194812923414, 1.5759808451078865, 1.5802537626528246, 1.5845382652524937, 1.588834384317164,
+    1.593142151342267, 1.597461597908627, 1.6017927556826934, 1.606135656416771, 1.6104903319492543,
+    1.6148568142048607, 1.6192351351948637, 1.6236253270173289, 1.6280274218573478, 1.632441451987275,
+    1.6368674497669644, 1.6413054476440063, 1.645755478153965, 1.6502175739206177, 1.6546917676561943,
+    1.6591780921616162, 1.6636765803267364, 1.6681872651305825, 1.6727101796415966, 1.6772453570178785,
+    1.681792830507429, 1.6863526334483934, 1.6909247992693053, 1.6955093614893326, 1.7001063537185235,
+    1.7047158096580513, 1.709337763100463, 1.713972247929926, 1.718619298122478, 1.723278947746274,
+    1.7279512309618377, 1.732636182022311, 1.7373338352737062, 1.7420442251551564, 1.746767386199169,
+    1.7515033530318782, 1.7562521603732995, 1.761013843037584, 1.7657884359332727, 1.7705759740635547,
+    1.7753764925265212, 1.7801900265154245, 1.785016611318935, 1.789856282321401, 1.7947090750031072,
+    1.7995750249405351, 1.804454167806624, 1.809346539371032, 1.8142521755003989, 1.8191711121586085,
+    1.8241033854070534, 1.8290490314048973, 1.8340080864093424, 1.8389805867758937, 1.843966568958626,
+    1.8489660695104508, 1.8539791250833855, 1.8590057724288205, 1.864046048397789, 1.8690999899412386,
+    1.8741676341103, 1.8792490180565602, 1.8843441790323345, 1.8894531543909392, 1.8945759815869656,
+    1.8997126981765553, 1.9048633418176741, 1.9100279502703899, 1.9152065613971474, 1.9203992131630474,
+    1.925605943636125, 1.930826790987627, 1.9360617934922943, 1.9413109895286405, 1.9465744175792332,
+    1.9518521162309783, 1.9571441241754002, 1.9624504802089273, 1.9677712232331759, 1.9731063922552343,
+    1.978456026387951, 1.9838201648502194, 1.9891988469672663, 1.9945921121709402};
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -201,11 +264,7 @@ __device__ __forceinline__ void finish_tile(const d4 (&acc)[2][2], double2 (&val
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      double s0 = acc[mi][0][v], s1 = acc[mi][1][v];
-      if (KIND != GPX_K_MEHLER) {  // squared scaled distance; tiny negative round-off is clamped
-        s0 = fmax(s0, 0.0);
-        s1 = fmax(s1, 0.0);
-      }
+      double s0 = acc[mi][0][v], s1 = acc[mi][1][v];  // squared scaled distance; kvalue deals with negative round-off
       const int64_t gi = i0 + rbase + mi * 16 + 4 * v;
       const int64_t gd = gi + row_shift;  // this row's diagonal column
       if (!INTERIOR && symmetric && KIND != GPX_K_MEHLER) {  // exact zero distance on the diagonal, as the reference has it
@@ -245,7 +304,7 @@ __device__ __forceinline__ void finish_tile(const d4 (&acc)[2][2], double2 (&val
 // K4 = augmented K (d + 2) rounded up to the MFMA step, in units of 4: compile-time so staging holds K4 registers a side.
 // EXACT: distances from raw coordinate differences on the VALU (K4 unused), see exact_dist.
 template <int KIND, bool SYM, int K4, bool EXACT>
-__global__ __launch_bounds__(256, WAVES_PER_EU) void kfill_kernel(KParams kp, const double* __restrict__ A, int64_t na,
+__global__ __launch_bounds__(256, SYM ? WAVES_PER_EU : WAVES_PER_EU_RECT) void kfill_kernel(KParams kp, const double* __restrict__ A, int64_t na,
                                                     const double* __restrict__ B, int64_t nb, int symmetric,
                                                     const double* __restrict__ nugget, int64_t nugget_len,
                                                     double nugget_scalar, double* __restrict__ out, int64_t ld,
@@ -256,7 +315,7 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void kfill_kernel(KParams kp, co
   const int sl = EXACT ? (d | 1) : dpad + 1;  // odd stride
   double* As = sm;
   double* Bs = As + TM * sl;
-  double* tab = Bs + TN * sl;  // 2^(j/64) table
+  double* tab = Bs + TN * sl;  // 2^(j/256) table
   double* Tr = tab + EXP_TAB;  // [32][TP] transpose image (SYM only)
   int ti, tj;
   if (SYM) {
@@ -286,7 +345,7 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void kfill_kernel(KParams kp, co
     stage_points<KIND, true, K4>(kp, d, dpad, sl, A, na, i0, As);
     stage_points<KIND, false, K4>(kp, d, dpad, sl, B, nb, j0, Bs);
   }
-  if (threadIdx.x < EXP_TAB) tab[threadIdx.x] = kExp2Tab[threadIdx.x];
+  tab[threadIdx.x] = kExp2Tab[threadIdx.x];  // EXP_TAB == blockDim.x
   __syncthreads();
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -363,6 +422,154 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void kfill_kernel(KParams kp, co
   }
 }
 
+// Rectangular fills of the Matern kinds: the same tile code, NT = 2 neighbouring column tiles per workgroup.  Those fills are
+// VALU-bound (sqrt + exp for every element, profiles/r02_kfill_valu.txt), so every instruction outside the kernel function
+// counts: the row points are staged once and the workgroup's fixed costs (launch, table, barrier) are paid once per 128
+// columns: 1.94 -> 1.80 ms per 8.6 GB.  The store-bound kinds (SE, Mehler: 1.50-1.58 ms) lose occupancy to it and keep the
+// one-tile kernel.
+template <int KIND, int K4, bool EXACT>
+__global__ __launch_bounds__(256, WAVES_PER_EU_RECT) void kfill_rect2_kernel(KParams kp, const double* __restrict__ A, int64_t na,
+                                                    const double* __restrict__ B, int64_t nb, int symmetric,
+                                                    const double* __restrict__ nugget, int64_t nugget_len,
+                                                    double nugget_scalar, double* __restrict__ out, int64_t ld,
+                                                    int64_t row_shift, KCyclic cyc, int tiles_n) {
+  extern __shared__ double sm[];
+  constexpr bool SYM = false;
+  constexpr int NT = 2;
+  const int d = kp.d;
+  constexpr int dpad = 4 * K4;  // coordinates + the two augmentation slots, padded to the MFMA K step
+  const int sl = EXACT ? (d | 1) : dpad + 1;  // odd stride
+  double* As = sm;
+  double* Bs = As + TM * sl;            // NT images
+  double* tab = Bs + NT * TN * sl;      // 2^(j/256) table
+  double* Tr = tab + EXP_TAB;           // [32][TP] transpose image (SYM only)
+  int ti, tj0;
+  if (SYM) {
+    const int w = blockIdx.x;
+    ti = (int)((sqrtf(8.0f * (float)w + 1.0f) - 1.0f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= w) ++ti;
+    while (ti * (ti + 1) / 2 > w) --ti;
+    tj0 = w - ti * (ti + 1) / 2;
+  } else {
+    ti = blockIdx.y;
+    tj0 = NT * blockIdx.x;
+  }
+  // i0, j0: first point of the tile's row / column set; oi0, oj0: where the tile lands in `out`.  They differ only for the
+  // 2-D block-cyclic local matrices of the multi-GPU path (cyc.nbt > 0): local block (ti / nbt, tj / nbt) holds the global
+  // block (.. * Pr + pr, .. * Pc + pc); tiles strictly above the global diagonal are not needed there.
+  const int64_t oi0 = (int64_t)ti * TM;
+  int64_t i0 = oi0;
+  if (!SYM && cyc.nbt > 0) i0 = ((int64_t)(ti / cyc.nbt) * cyc.Pr + cyc.pr) * cyc.nbt * TM + (int64_t)(ti % cyc.nbt) * TM;
+  int64_t oj0s[NT], j0s[NT];
+  bool live[NT];
+  bool any = false;
+#pragma unroll
+  for (int it = 0; it < NT; ++it) {
+    const int tj = tj0 + it;
+    oj0s[it] = (int64_t)tj * TN;
+    j0s[it] = oj0s[it];
+    live[it] = SYM || tj < tiles_n;
+    if (!SYM && cyc.nbt > 0) {
+      j0s[it] = ((int64_t)(tj / cyc.nbt) * cyc.Pc + cyc.pc) * cyc.nbt * TN + (int64_t)(tj % cyc.nbt) * TN;
+      if (i0 + TM <= j0s[it]) live[it] = false;
+    }
+    any = any || live[it];
+  }
+  if (!any) return;
+  if (EXACT) {
+    stage_raw(d, sl, A, na, i0, As);
+#pragma unroll
+    for (int it = 0; it < NT; ++it)
+      if (live[it]) stage_raw(d, sl, B, nb, j0s[it], Bs + it * TN * sl);
+  } else {
+    stage_points<KIND, true, K4>(kp, d, dpad, sl, A, na, i0, As);
+#pragma unroll
+    for (int it = 0; it < NT; ++it)
+      if (live[it]) stage_points<KIND, false, K4>(kp, d, dpad, sl, B, nb, j0s[it], Bs + it * TN * sl);
+  }
+  tab[threadIdx.x] = kExp2Tab[threadIdx.x];  // EXP_TAB == blockDim.x
+  __syncthreads();
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int g = lane >> 4, q = lane & 15;
+  const int c0 = wn * 32 + 2 * q;
+  // row_shift: the row set starts `row_shift` entries into the column set (row-band refill): diagonal at gj == gi + shift
+  const int64_t is0 = i0 + row_shift;
+
+#pragma unroll
+  for (int it = 0; it < NT; ++it) {
+    if (!live[it]) continue;
+    const int64_t j0 = j0s[it], oj0 = oj0s[it];
+    const double* Bt = Bs + it * TN * sl;
+    d4 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
+    if (EXACT) {
+      exact_dist(kp, d, sl, As, Bt, wm * 32 + g, c0, acc);
+    } else {
+      const double* ap = As + (wm * 32 + q) * sl + g;           // A'[row = mi*16 + q][k = 4s + g]
+      const double* bp = Bt + (wn * 32 + 2 * q) * sl + g;       // B'[col = 2q + ni][k = 4s + g]
+#pragma unroll
+      for (int ks = 0; ks < dpad; ks += 4) {
+        const double a0 = ap[ks], a1 = ap[16 * sl + ks];
+        const double b0 = bp[ks], b1 = bp[sl + ks];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+      }
+    }
+
+    const bool interior = (i0 + TM <= na) && (j0 + TN <= nb) && (!symmetric || (is0 + TM <= j0) || (j0 + TN <= is0));
+    char* const otile = reinterpret_cast<char*>(out + oi0 * ld + oj0);
+    const unsigned ooff = (unsigned)(((wm * 32 + g) * ld + c0) * 8);
+    double2 val[2][4];
+    if (__builtin_amdgcn_readfirstlane((int)interior))
+      finish_tile<KIND, true>(acc, val, kp.sig, tab, i0, j0, na, nb, symmetric, nugget, nugget_len, nugget_scalar, otile,
+                              ooff, ld, wm * 32 + g, c0, false, row_shift);
+    else
+      finish_tile<KIND, false>(acc, val, kp.sig, tab, i0, j0, na, nb, symmetric, nugget, nugget_len, nugget_scalar, otile,
+                               ooff, ld, wm * 32 + g, c0, SYM && ti == tj0, row_shift);
+
+    if (SYM) {
+      // mirror: out[j0 + c][i0 + r] = V[r][c]; the two row halves (wm = 0 / 1) go through the padded image in turn
+      // (the diagonal tile mirrors its strictly-lower part only)
+      const int tx = t & 31, ty = t >> 5;
+      char* const mbase = reinterpret_cast<char*>(out + j0 * ld + i0);
+      const unsigned moff = (unsigned)((ty * ld + tx) * 8);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+        if (wm == half) {
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const int rl = mi * 16 + g + 4 * v;  // row inside the half
+              Tr[rl * TP + c0] = val[mi][v].x;
+              Tr[rl * TP + c0 + 1] = val[mi][v].y;
+            }
+        }
+        __syncthreads();
+        if (ti != tj0) {
+#pragma unroll
+          for (int qq = 0; qq < 8; ++qq)
+            *reinterpret_cast<double*>(mbase + (int64_t)(8 * qq) * ld * 8 + moff + 256 * half) = Tr[tx * TP + ty + 8 * qq];
+        } else {
+#pragma unroll
+          for (int qq = 0; qq < 8; ++qq) {
+            const int c = ty + 8 * qq;
+            if (32 * half + tx > c) out[(j0 + c) * ld + i0 + 32 * half + tx] = Tr[tx * TP + c];
+          }
+        }
+      }
+    }
+  }
+}
+
 template <int KIND>
 __global__ __launch_bounds__(256) void kdiag_kernel(KParams kp, const double* __restrict__ Z, int64_t m,
                                                     double* __restrict__ out) {
@@ -390,7 +597,17 @@ int launch_k4(gpx_ctx* ctx, const KParams& kp, const double* A, int64_t na, cons
   } else {
     grid = dim3((unsigned)(pcols / TN), (unsigned)(prows / TM));
   }
-  const size_t sh = (size_t)(2 * TM * (EXACT ? (kp.d | 1) : 4 * K4 + 1) + EXP_TAB + (SYM ? 32 * TP : 0)) * sizeof(double);
+  static_assert(EXP_TAB == 256, "the exp table is loaded by the 256 threads of the workgroup, one entry each");
+  const size_t img = (size_t)TM * (EXACT ? (kp.d | 1) : 4 * K4 + 1);
+  if (!SYM && (KIND == GPX_K_MATERN32 || KIND == GPX_K_MATERN52)) {
+    grid.x = (grid.x + 1) / 2;  // two column tiles per workgroup
+    hipLaunchKernelGGL((kfill_rect2_kernel<KIND, K4, EXACT>), grid, dim3(256), (3 * img + EXP_TAB) * sizeof(double), ctx->stream,
+                       kp, A, na, B, nb, symmetric, d_nugget, nugget_len, nugget_scalar, out, ld, row_shift, cyc,
+                       (int)(pcols / TN));
+    GPX_HIP(hipGetLastError());
+    return 0;
+  }
+  const size_t sh = (2 * img + EXP_TAB + (SYM ? 32 * TP : 0)) * sizeof(double);
   hipLaunchKernelGGL((kfill_kernel<KIND, SYM, K4, EXACT>), grid, dim3(256), sh, ctx->stream, kp, A, na, B, nb, symmetric,
                      d_nugget, nugget_len, nugget_scalar, out, ld, row_shift, cyc);
   GPX_HIP(hipGetLastError());

@@ -174,3 +174,24 @@ def test_mirror_and_refit_with_offsets(dev, ctx):
     L2 = dev.refit_rows(ctx, spec, dX2, 0.1, L0, 512).to_host(tri=1)
     want = np.linalg.cholesky(orc.cov_matrix(s, X2, 0.1, row_loop=False))
     assert rel(L2, want) <= 1e-12
+
+
+@pytest.mark.parametrize("kind", ["se", "matern32", "matern52"])
+def test_points_many_length_scales_apart_give_zero(dev, ctx, kind):
+    """exp's range reduction keeps the integer part in 32 bits; arguments below -750 are clamped first, so two clusters
+    1e6 length scales apart are uncorrelated (0.0) -- as numpy.exp gives the reference -- instead of a wrapped exponent."""
+    rng = np.random.default_rng(77)
+    d = 3
+    A = rng.uniform(-1, 1, (70, d))
+    X = np.vstack([A, A + 2.0e5])                      # two clusters, 2e5 apart, length scale 0.2
+    if kind == "se":
+        s = {"kind": "se", "d": d, "cl": [0.2] * d, "signalSize": 1.3}
+    else:
+        s = {"kind": kind, "d": d, "rho": 0.2, "signalSize": 1.3}
+    K = dev.kfill(ctx, spec_of(dev, s), dev.points(ctx, X)).to_host()
+    want = orc.cov_matrix(s, X)
+    assert np.all(K[:70, 70:] == 0.0) and np.all(K[70:, :70] == 0.0)
+    assert np.all(want[:70, 70:] == 0.0)
+    assert rel(K, want) <= 1e-13
+    Kc = dev.kfill(ctx, spec_of(dev, s), dev.points(ctx, A), dev.points(ctx, A + 2.0e5)).to_host()
+    assert np.all(Kc == 0.0)
