@@ -307,7 +307,6 @@ def main():
         KX = K if M == N else dev.DeviceMatrix.zeros(ctx, N, M)
         for cls, fill, nbytes in (("kfill", lambda: dev.kfill_into(ctx, spec, X, K, nugget=noise), 8.0 * N * N + 8.0 * N * d),
                                   ("kcross", lambda: dev.kfill_into(ctx, spec, X, KX, Z=Z), 8.0 * N * M + 8.0 * (N + M) * d)):
-            fill()
             ts = []
             for _ in range(5):
                 sync()
