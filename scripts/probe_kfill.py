@@ -16,5 +16,5 @@ for sym in (True, False):
     for it in range(3):
         ctx.profile(True); ctx.profile_reset()
         dev.kfill_into(ctx, sp, X, K, Z=None if sym else Z, nugget=0.1 if sym else 0.0)
-        p = ctx.profile_get()["kfill"]; ctx.profile(False)
+        p = ctx.profile_get()["kfill" if sym else "kcross"]; ctx.profile(False)
     print("kfill kind=%d d=%d N=%d %s: %.3f ms  %.2f TB/s" % (kind, d, N, "symmetric" if sym else "rect", p["ms"], p["bytes"] / p["ms"] / 1e9), flush=True)
