@@ -354,6 +354,58 @@ def test_demo_flow_config1(golden, capsys):
     np.testing.assert_allclose(np.sort(design[:, 0]), np.sort(golden(c, "design")[:, 0]), atol=1e-6)
 
 
+def test_demo2_flow_heteroscedastic(golden):
+    """The call sequence of the reference's demo2.py -- hyper-parameter search under a fixed heteroscedastic noise model
+    (useNoise), train / evaluate with per-point noise (noiseIn), IVAR design whose cost and SLSQP gradient carry
+    space.noiseFunc (experimentalDesign.py:111-112, 168-179), greedy-variance start, final refit -- against what the reference
+    produced for the same inputs (tests/golden/make_golden_r2.py::demo2_flow_case)."""
+    from helpers import NoiseFunc
+    from gpExp.kernels import KernelSquaredExponential
+    from gpExp.experimentalDesign import costFunctionGP_IVAR, ExperimentalDesignDerivative, \
+        performGreedyVarExperimentalDesign
+    from gpExp.gp import GP
+    from gpExp.approximation import Space
+    c = "demo2_flow"
+    nf = NoiseFunc(1)
+    gpT = GP(KernelSquaredExponential([0.3], 1.0, 1), 1e-2)
+    xTrain, yTrain = golden(c, "xTrain"), golden(c, "yTrain")
+    addNoise = nf(xTrain)
+    params, optval = gpT.findOptParamsLogLike(xTrain, yTrain, dict(cl0=1e-1, signalSize=1e0), dict(cl0=1e-2, signalSize=9e-1),
+                                              dict(cl0=1e10, signalSize=2e0), useNoise=addNoise)
+    assert set(params) == {"cl0", "signalSize"}
+    assert params["cl0"] == pytest.approx(float(golden(c, "opt_cl0")), rel=1e-4)
+    assert params["signalSize"] == pytest.approx(float(golden(c, "opt_signalSize")), rel=1e-4)
+    assert optval == pytest.approx(float(golden(c, "opt_value")), rel=1e-6)
+    gpT.updateKernelParams({"cl0": float(golden(c, "opt_cl0")), "signalSize": float(golden(c, "opt_signalSize"))})
+    gpT.train(xTrain, yTrain, noiseIn=addNoise)
+    assert rel(gpT.coeff, golden(c, "coeff1")) <= 1e-10
+    xDemo = np.linspace(-1, 1, 1000).reshape((1000, 1))
+    m, var = gpT.evaluate(xDemo, compvar=1)
+    assert rel(m, golden(c, "mean1")) <= 1e-10
+    assert np.max(np.abs(var - golden(c, "var1"))) <= 1e-10
+    mc = golden(c, "mc")
+    space = Space(1, lambda size: np.random.rand(size[0], size[1]) * 2.0 - 1.0, lambda p: (np.abs(p) < 1.0) * 0.5, noise=nf)
+    cf = costFunctionGP_IVAR(gpT, 8, space, mcPoints=mc)
+    start = performGreedyVarExperimentalDesign(gpT.kernel, np.concatenate((xTrain, mc), axis=0), 8, 1,
+                                               indKeepStart=[0, 1, 2, 3])
+    np.testing.assert_array_equal(start, golden(c, "greedy_start"))      # same candidates picked: index parity
+    assert cf.evaluate(start) == pytest.approx(float(golden(c, "greedy_start_cost")), rel=1e-10)
+    assert rel(cf.derivative(start), golden(c, "greedy_start_grad")) <= 1e-9
+    exp = ExperimentalDesignDerivative(cf, 8, 1)
+    lb = np.concatenate((xTrain.flatten(), -np.ones(4)))
+    ub = np.concatenate((xTrain.flatten(), np.ones(4)))
+    design = exp.beginWithVarGreedy(nodesKeep=xTrain, lbounds=lb, rbounds=ub)
+    np.testing.assert_allclose(design[:4], xTrain, atol=1e-12)
+    assert cf.evaluate(design) == pytest.approx(float(golden(c, "design_cost")), rel=1e-8)
+    np.testing.assert_allclose(np.sort(design[:, 0]), np.sort(golden(c, "design")[:, 0]), atol=1e-6)
+    # final refit on the reference's design (so that the comparison does not inherit the optimiser's last digits)
+    ref_design = golden(c, "design")
+    gpT.train(ref_design, np.sin(2.0 * np.pi * ref_design)[:, 0], noiseIn=nf(ref_design))
+    m2, var2 = gpT.evaluate(xDemo, compvar=1)
+    assert rel(m2, golden(c, "mean2")) <= 1e-10
+    assert np.max(np.abs(var2 - golden(c, "var2"))) <= 1e-10
+
+
 def test_ivar_gradient_on_device_f1(golden):
     """SURVEY 8 f1 on the GPU: d IVAR / d design points (gpx_ivar_grad) against (a) the reference's own vectors
     (evaluateVarianceDerivative summed over the evaluation points; the SLSQP gradient of the demo flow) and (b) central

@@ -72,6 +72,30 @@ def test_point_derivatives_noisefunc(golden):
     assert rel(orc.variance_derivative(spec, m, Z, nf), golden(c, "dvar_dpts")) <= 1e-13
 
 
+def test_demo2_flow_pieces(golden):
+    """The deterministic pieces of the reference's demo2.py flow (make_golden_r2.py::demo2_flow_case) through the oracle:
+    per-point-noise fit and posterior, IVAR cost and gradient with space.noiseFunc, greedy-variance start."""
+    from helpers import NoiseFunc
+    c = "demo2_flow"
+    nf = NoiseFunc(1)
+    spec = dict(kind="se", d=1, cl=[float(golden(c, "opt_cl0"))], signalSize=float(golden(c, "opt_signalSize")))
+    X, y = golden(c, "xTrain"), golden(c, "yTrain")
+    m = orc.fit(spec, X, y, nf(X))
+    assert rel(m["coeff"], golden(c, "coeff1")) <= 1e-12
+    xDemo = np.linspace(-1, 1, 1000).reshape((1000, 1))
+    mean, var = orc.posterior(spec, m, xDemo, compvar=1)
+    assert rel(mean, golden(c, "mean1")) <= 1e-12 and np.max(np.abs(var - golden(c, "var1"))) <= 1e-12
+    mc = golden(c, "mc")
+    cand = np.concatenate((X, mc), axis=0)
+    start = cand[orc.greedy_var(spec, cand, 8, keep_start=[0, 1, 2, 3]), :]
+    assert np.array_equal(start, golden(c, "greedy_start"))
+    assert rel(orc.ivar_grad(spec, start, mc, 1e-2, nf), golden(c, "greedy_start_grad")) <= 1e-11
+    D = golden(c, "design")
+    m2 = orc.fit(spec, D, np.sin(2.0 * np.pi * D)[:, 0], nf(D))
+    mean2, var2 = orc.posterior(spec, m2, xDemo, compvar=1)
+    assert rel(mean2, golden(c, "mean2")) <= 1e-11 and np.max(np.abs(var2 - golden(c, "var2"))) <= 1e-11
+
+
 def test_point_derivatives_mehler1d(golden):
     c = "varderiv_mehler1d"
     spec = golden.index[c]["kernel"]
