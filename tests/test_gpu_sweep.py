@@ -72,3 +72,89 @@ def test_random_configuration_against_oracle(dev, ctx, i):
     assert np.max(np.abs(np.abs(var) - vo)) <= tol * max(1.0, np.max(np.abs(vo)))
     if np.isscalar(noise):
         assert abs(dev.ivar(ctx, spec, L, Xd, Zd)) == pytest.approx(orc.ivar(s, X, Z, noise), rel=tol, abs=tol)
+
+
+def _design_config(i):
+    rng = np.random.default_rng(9500 + i)
+    kind = ["se", "matern32", "matern52"][i % 3]
+    d = int(rng.choice([1, 2, 3, 5]))
+    if kind == "se":
+        s = dict(kind="se", d=d, cl=list(rng.uniform(0.3, 0.7, d) * np.sqrt(d)), signalSize=float(rng.uniform(0.7, 1.5)))
+    else:
+        s = dict(kind=kind, d=d, rho=float(rng.uniform(0.4, 0.9) * np.sqrt(d)), signalSize=float(rng.uniform(0.7, 1.5)))
+    return rng, s, d
+
+
+def _clear_winner(values, pick_max, gap=1e-7):
+    """True when the best candidate beats the runner-up by a relative margin that round-off cannot bridge: only then is
+    the selected INDEX a property of the algorithm rather than of pinv-vs-Cholesky round-off."""
+    v = np.sort(np.asarray(values, dtype=float))
+    if len(v) < 2:
+        return True
+    best, second = (v[-1], v[-2]) if pick_max else (v[0], v[1])
+    return abs(best - second) > gap * max(abs(best), 1e-300)
+
+
+@pytest.mark.parametrize("i", range(12))
+def test_random_greedy_ivar_step_against_oracle(dev, ctx, i):
+    """One step of discrete greedy IVAR on random configurations: all candidate costs to 1e-10 against M actual refits by the
+    oracle; the arg-min index exact whenever the oracle's winner is clear."""
+    from test_gpu_parity import spec_of
+    rng, s, d = _design_config(i)
+    n0, M, nmc = int(rng.choice([3, 8, 20])), int(rng.choice([40, 97, 130])), int(rng.choice([64, 150, 260]))
+    X0, Cn, Z = rng.uniform(-1, 1, (n0, d)), rng.uniform(-1, 1, (M, d)), rng.uniform(-1, 1, (nmc, d))
+    noise = float(rng.choice([1e-3, 1e-2, 0.1]))
+    spec = spec_of(dev, s)
+    Xd = dev.points(ctx, X0)
+    L = dev.potrf(ctx, dev.kfill(ctx, spec, Xd, nugget=noise))
+    best, costs = dev.greedy_ivar_step(ctx, spec, L, Xd, dev.points(ctx, Cn), dev.points(ctx, Z), noise)
+    idx, c1, allc = orc.greedy_ivar(s, X0, Cn, Z, noise, 1)
+    assert rel(costs, allc[0]) <= 1e-10
+    if _clear_winner(allc[0], pick_max=False):
+        assert best == idx[0]
+
+
+@pytest.mark.parametrize("i", range(12))
+def test_random_greedy_variance_against_oracle(dev, ctx, i):
+    """performGreedyVarExperimentalDesign on random candidate sets, with and without weights and a kept prefix: the index
+    sequence is compared step by step while every step so far had a clear winner in the oracle."""
+    from test_gpu_parity import spec_of
+    rng, s, d = _design_config(100 + i)
+    M, nsel = int(rng.choice([50, 128, 300])), int(rng.choice([4, 9, 14]))
+    Cn = rng.uniform(-1, 1, (M, d))
+    w = rng.uniform(0.5, 1.5, M) if i % 2 else None
+    keep = [int(v) for v in rng.choice(M, size=int(rng.choice([0, 1, 3])), replace=False)]
+    got = dev.greedy_var(ctx, spec_of(dev, s), dev.points(ctx, Cn), nsel, keep=keep, weights=w)
+    want = orc.greedy_var(s, Cn, nsel, weights=w, keep_start=keep)
+    for step in range(len(keep), nsel):
+        sel = want[:step]
+        var = orc.kernel_diag(s, Cn)
+        if len(sel) > 0:   # the conditional variance exactly as the selection loop forms it (experimentalDesign.py:834-837)
+            P = np.linalg.pinv(orc.cov_matrix(s, Cn[sel], 0.0))
+            kv = np.stack([orc.kernel_eval(s, Cn, Cn[j:j + 1]) for j in sel])
+            var = var - np.einsum("ij,ik,kj->j", kv, P, kv)
+        score = var * w if w is not None else var
+        if not _clear_winner(score, pick_max=True, gap=1e-6):
+            break
+        assert got[step] == want[step], (step, got, want)
+
+
+@pytest.mark.parametrize("i", range(6))
+def test_random_greedy_mi_against_oracle(dev, ctx, i):
+    from test_gpu_parity import spec_of
+    rng, s, d = _design_config(200 + i)
+    M, nsel = int(rng.choice([24, 40])), int(rng.choice([3, 5]))
+    Cn = rng.uniform(-1, 1, (M, d))
+    noise = float(rng.choice([1e-3, 1e-2]))
+    start = int(rng.integers(0, M))
+    got, ratios = dev.mi_greedy(ctx, spec_of(dev, s), dev.points(ctx, Cn), noise, nsel, start=start)
+    want, wr = orc.greedy_mi(s, Cn, noise, nsel, start=start)
+    keep = [start]
+    for step in range(1, nsel):
+        options = np.setdiff1d(np.arange(M), keep)
+        vals = np.array([orc.mi_evaluate(s, Cn, noise, int(j), keep) for j in options])
+        if not _clear_winner(vals, pick_max=True, gap=1e-6):
+            break
+        assert got[step] == want[step], (step, got, want)
+        assert ratios[step - 1] == pytest.approx(wr[step - 1], rel=1e-7)
+        keep.append(int(want[step]))
