@@ -9,7 +9,10 @@
 
 namespace {
 
-constexpr int ROWS_PER_CHUNK_MIN = 128;
+// Few-row blocks (the transposed products of the backward substitution: 1024 x 1024 .. 4096 x 4096) are latency-bound: with
+// 128-row chunks a 1024-row block was 32 workgroups walking 128 rows each (31 us for 8 MB, profiles/r02_potrs.txt); 16-row
+// chunks make it 256 workgroups.  Large reductions (rows >= 16 * 2048 / column blocks) are not affected.
+constexpr int ROWS_PER_CHUNK_MIN = 16;
 
 __global__ __launch_bounds__(256) void colreduce_kernel(const double* __restrict__ B, int64_t ld, int64_t rows,
                                                         int64_t chunk, const double* __restrict__ v,
@@ -48,8 +51,20 @@ __global__ __launch_bounds__(256) void colreduce_final_kernel(const double* __re
                                                               int64_t pcols, double* __restrict__ out, int subtract) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= pcols) return;
-  double s = 0.0;
-  for (int64_t c = 0; c < nchunk; ++c) s += partial[c * pcols + j];
+  // four interleaved partial sums, combined in a fixed order: the loads of a round are independent (a single running sum
+  // waits for every load in turn: 19 us for 8 partials)
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  const double* p = partial + j;
+  int64_t c = 0;
+  for (; c + 4 <= nchunk; c += 4, p += 4 * pcols) {
+    const double a = p[0], b = p[pcols], d = p[2 * pcols], e = p[3 * pcols];
+    s0 += a;
+    s1 += b;
+    s2 += d;
+    s3 += e;
+  }
+  for (; c < nchunk; ++c, p += pcols) s0 += p[0];
+  const double s = (s0 + s1) + (s2 + s3);
   out[j] = subtract ? out[j] - s : s;
 }
 
@@ -81,16 +96,21 @@ inline void plan(int64_t rows, int64_t pcols, int64_t* chunk, int64_t* nchunk) {
 
 }  // namespace
 
+// Partial sums a reduction of at most `rows` x `pcols` needs.  Callers size ONE buffer for a family of launches (the
+// recursive sweeps reduce sub-blocks of every shape), so this is a bound that is monotone in both arguments, not the exact
+// need of the (rows, pcols) launch: chunks <= 2048 / column blocks and <= rows / ROWS_PER_CHUNK_MIN, columns <= 256 per
+// column block.  (The exact product is NOT monotone: 5120 x 4096 needs more than 9216 x 9216.)
 int64_t colreduce_partial_elems(int64_t rows, int64_t pcols) {
-  int64_t chunk, nchunk;
-  plan(rows, pcols, &chunk, &nchunk);
-  return nchunk * pcols;
+  const int64_t by_rows = ((rows + ROWS_PER_CHUNK_MIN - 1) / ROWS_PER_CHUNK_MIN + 1) * pcols;
+  const int64_t cap = (int64_t)2048 * 256 + pcols;
+  return by_rows < cap ? by_rows : cap;
 }
 
 int launch_colreduce(gpx_ctx* ctx, const double* B, int64_t ld, int64_t rows, int64_t pcols, const double* v,
                      double* out, double* d_partial, int subtract) {
   int64_t chunk, nchunk;
   plan(rows, pcols, &chunk, &nchunk);
+  GPX_ARG(nchunk * pcols <= colreduce_partial_elems(rows, pcols), "colreduce: partial-sum plan exceeds its own bound");
   ProfScope ps(ctx, GPX_PROF_REDUCE, 2.0 * (double)rows * pcols, 8.0 * (double)rows * pcols);
   dim3 grid((unsigned)((pcols + 255) / 256), (unsigned)nchunk);
   hipLaunchKernelGGL(colreduce_kernel, grid, dim3(256), 0, ctx->stream, B, ld, rows, chunk, v, d_partial, pcols);
@@ -159,5 +179,14 @@ int launch_rowreduce(gpx_ctx* ctx, const double* B, int64_t ld, int64_t rows, in
 int launch_sum(gpx_ctx* ctx, const double* x, int64_t n, double* d_out) {
   hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, ctx->stream, x, n, d_out);
   GPX_HIP(hipGetLastError());
+  return 0;
+}
+
+// test hook (host logic only, no device work): chunk count a rows x pcols reduction launches with, and the buffer bound
+extern "C" int gpx_dbg_colreduce_plan(int64_t rows, int64_t pcols, int64_t* nchunk, int64_t* bound_elems) {
+  if (rows < 1 || pcols < 1 || !nchunk || !bound_elems) return -1;
+  int64_t chunk;
+  plan(rows, pcols, &chunk, nchunk);
+  *bound_elems = colreduce_partial_elems(rows, pcols);
   return 0;
 }

@@ -320,6 +320,10 @@ int gpx_dbg_gemm(gpx_ctx* ctx, const gpx_mat* A, const gpx_mat* B, gpx_mat* C, i
 /* triangular-operand GEMM modes: tri = 1 (A lower triangular, k == m), 2 (B lower-triangular n x k used transposed, bt),
  * 3 (lower C = U U^T with A = B = U upper triangular, bt); the structurally zero part of every tile's k range is skipped */
 int gpx_dbg_gemm_tri(gpx_ctx* ctx, const gpx_mat* A, const gpx_mat* B, gpx_mat* C, int bt, int accumulate, int tri);
+/* host logic of the deterministic column reduction: number of row chunks (= partial sums per column) a rows x pcols launch
+ * uses, and the scratch bound callers allocate; the bound is monotone in both arguments (one buffer serves every sub-block
+ * a sweep reduces).  No device work. */
+int gpx_dbg_colreduce_plan(int64_t rows, int64_t pcols, int64_t* nchunk, int64_t* bound_elems);
 /* what an assembly between X and Z (NULL: X with itself) would do: *exact = 1 when distances are formed from raw
  * coordinate differences on the VALU (wide domain relative to the length scale) instead of the centred expanded MFMA
  * product; center[d] = the origin subtracted before scaling (bounding-box midpoint; 0 for Mehler) */

@@ -153,3 +153,29 @@ def test_gpexp_shim_exports_reference_names(built_lib):
     ns = {}
     exec("from gpExp.experimentalDesign import *", ns)  # demo.py:27
     assert "costFunctionGP_IVAR" in ns and "ExperimentalDesignDerivative" in ns
+
+
+def test_column_reduction_scratch_bound_covers_every_sub_block():
+    """One scratch buffer serves all the sub-blocks a triangular sweep reduces, so the bound callers allocate must dominate
+    the need of every smaller launch.  (Sizing it with the exact need of the LARGEST launch did not: a 16640 x 16384 block
+    needs 524288 partial sums, the 33024 x 33024 launch only 495360 -- the sweeps of a 33024-point factor wrote 230 KB past
+    their scratch.)  Host logic only: the library's own planner through its test hook."""
+    import ctypes as C
+    from gpexp_amd import _lib
+    lib = _lib.load()
+    nch, bnd = C.c_int64(), C.c_int64()
+
+    def plan(r, p):
+        assert lib.gpx_dbg_colreduce_plan(r, p, C.byref(nch), C.byref(bnd)) == 0
+        return nch.value, bnd.value
+
+    rng = np.random.default_rng(11)
+    for R, P in [(33024, 33024), (65664, 65664), (9216, 9216), (2176, 2176), (128, 128), (70000, 300)]:
+        _, bound = plan(R, P)
+        for _ in range(3000):
+            r, p = int(rng.integers(1, R + 1)), int(rng.integers(1, P + 1))
+            n, own = plan(r, p)
+            assert n * p <= own <= bound and n <= 2048
+    # the shapes that overflowed
+    assert plan(16640, 16384)[0] * 16384 <= plan(33024, 33024)[1]
+    assert plan(5120, 4096)[0] * 4096 <= plan(9216, 9216)[1]
