@@ -19,25 +19,37 @@ void gpx_set_error(const char* fmt, ...) {
 }
 
 // ---- allocator -------------------------------------------------------------------------------------
+static constexpr int64_t GUARD = 4096;
+
 int gpx_dev_alloc(gpx_ctx* ctx, int64_t bytes, void** out) {
   if (bytes <= 0) bytes = 8;
   bytes = gpx_round_up(bytes, 256);
-  auto it = ctx->pool.find(bytes);
+  const int64_t key = bytes + (ctx->guard ? 2 * GUARD : 0);
+  void* base = nullptr;
+  auto it = ctx->pool.find(key);
   if (it != ctx->pool.end()) {
-    *out = it->second;
+    base = it->second;
     ctx->pool.erase(it);
-    ctx->pool_bytes -= bytes;
-    return 0;
+    ctx->pool_bytes -= key;
+  } else {
+    hipError_t e = hipMalloc(&base, (size_t)key);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      gpx_trim(ctx);
+      e = hipMalloc(&base, (size_t)key);
+    }
+    if (e != hipSuccess) {
+      gpx_set_error("hipMalloc(%lld bytes) failed: %s", (long long)key, hipGetErrorString(e));
+      return -2;
+    }
   }
-  hipError_t e = hipMalloc(out, (size_t)bytes);
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
-    gpx_trim(ctx);
-    e = hipMalloc(out, (size_t)bytes);
-  }
-  if (e != hipSuccess) {
-    gpx_set_error("hipMalloc(%lld bytes) failed: %s", (long long)bytes, hipGetErrorString(e));
-    return -2;
+  if (ctx->guard) {
+    GPX_HIP(hipDeviceSynchronize());
+    GPX_HIP(hipMemset(base, 0xA5, (size_t)GUARD));
+    GPX_HIP(hipMemset((char*)base + GUARD + bytes, 0xA5, (size_t)GUARD));
+    *out = (char*)base + GUARD;
+  } else {
+    *out = base;
   }
   return 0;
 }
@@ -46,8 +58,28 @@ void gpx_dev_release(gpx_ctx* ctx, void* p, int64_t bytes) {
   if (!p) return;
   if (bytes <= 0) bytes = 8;
   bytes = gpx_round_up(bytes, 256);
-  ctx->pool.insert({bytes, p});
-  ctx->pool_bytes += bytes;
+  const int64_t key = bytes + (ctx->guard ? 2 * GUARD : 0);
+  void* base = p;
+  if (ctx->guard) {
+    base = (char*)p - GUARD;
+    std::vector<unsigned char> h((size_t)(2 * GUARD));
+    (void)hipDeviceSynchronize();
+    if (hipMemcpy(h.data(), base, (size_t)GUARD, hipMemcpyDeviceToHost) == hipSuccess &&
+        hipMemcpy(h.data() + GUARD, (char*)p + bytes, (size_t)GUARD, hipMemcpyDeviceToHost) == hipSuccess) {
+      int64_t below = 0, above = 0;
+      for (int64_t i = 0; i < GUARD; ++i) {
+        below += h[(size_t)i] != 0xA5;
+        above += h[(size_t)(GUARD + i)] != 0xA5;
+      }
+      if (below || above) {
+        ctx->guard_violations += 1;
+        fprintf(stderr, "gpx: ALLOCATION GUARD VIOLATED: %lld-byte block, %lld bytes overwritten below, %lld above\n",
+                (long long)bytes, (long long)below, (long long)above);
+      }
+    }
+  }
+  ctx->pool.insert({key, base});
+  ctx->pool_bytes += key;
 }
 
 // ---- profiling -------------------------------------------------------------------------------------
@@ -256,6 +288,8 @@ int gpx_create(int device, gpx_ctx** out) {
   GPX_ARG(device >= 0 && device < ndev, "device ordinal out of range");
   GPX_HIP(hipSetDevice(device));
   gpx_ctx* c = new gpx_ctx();
+  { const char* g = getenv("GPX_ALLOC_GUARD"); c->guard = (g && atoi(g) != 0) ? 1 : 0; }
+  c->guard_violations = 0;
   c->device = device;
   c->pool_bytes = 0;
   c->comm = nullptr;
@@ -326,6 +360,21 @@ int gpx_create(int device, gpx_ctx** out) {
   c->trsv_scratch_bytes = 0;
   *out = c;
   return 0;
+}
+
+int64_t gpx_dbg_guard_violations(gpx_ctx* ctx) { return ctx ? (ctx->guard ? ctx->guard_violations : -1) : -1; }
+
+// writes 16 bytes past a scratch block on purpose and returns 1 if the guard check caught it (the count is restored)
+int gpx_dbg_guard_selftest(gpx_ctx* ctx) {
+  GPX_ARG(ctx && ctx->guard, "guard mode is off");
+  void* p;
+  GPX_TRY(gpx_dev_alloc(ctx, 1024, &p));
+  GPX_HIP(hipMemset((char*)p + 1024, 0, 16));
+  const int64_t before = ctx->guard_violations;
+  gpx_dev_release(ctx, p, 1024);
+  const int caught = ctx->guard_violations == before + 1;
+  ctx->guard_violations = before;
+  return caught;
 }
 
 int gpx_trim(gpx_ctx* ctx) {

@@ -120,6 +120,10 @@ struct gpx_ctx {
   // cached device allocations (exact-size reuse)
   std::multimap<int64_t, void*> pool;
   int64_t pool_bytes;
+  // GPX_ALLOC_GUARD=1 (debug; there is no GPU address sanitizer on this pool): every pooled allocation gets a 4 KiB band of
+  // 0xA5 on either side, checked when it goes back to the pool; violations are counted and reported on stderr
+  int guard;
+  int64_t guard_violations;
   // scalars
   int* d_info;      // [0] first failing pivot (1-based), 0 = ok; [1] pivots dropped in skip mode
   double piv_min;   // pivot policy of the leaf factorisation (gpx_potrf_policy): pivots <= piv_min are bad ...

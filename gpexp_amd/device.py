@@ -37,6 +37,10 @@ class Context:
     def sync(self):
         check(self.lib.gpx_sync(self.h))
 
+    def guard_violations(self):
+        """Pooled blocks found overwritten outside their bounds (GPX_ALLOC_GUARD=1), -1 when the mode is off."""
+        return int(self.lib.gpx_dbg_guard_violations(self.h))
+
     def trim(self):
         check(self.lib.gpx_trim(self.h))
 

@@ -320,6 +320,12 @@ int gpx_dbg_gemm(gpx_ctx* ctx, const gpx_mat* A, const gpx_mat* B, gpx_mat* C, i
 /* triangular-operand GEMM modes: tri = 1 (A lower triangular, k == m), 2 (B lower-triangular n x k used transposed, bt),
  * 3 (lower C = U U^T with A = B = U upper triangular, bt); the structurally zero part of every tile's k range is skipped */
 int gpx_dbg_gemm_tri(gpx_ctx* ctx, const gpx_mat* A, const gpx_mat* B, gpx_mat* C, int bt, int accumulate, int tri);
+/* GPX_ALLOC_GUARD=1 in the environment at gpx_create (debug; this pool has no GPU address sanitizer): every pooled device
+ * allocation carries a 4 KiB band of 0xA5 on either side, checked when the block returns to the pool.  Returns the number of
+ * blocks found overwritten so far (each also reported on stderr), or -1 when the mode is off. */
+int64_t gpx_dbg_guard_violations(gpx_ctx* ctx);
+/* guard mode only: overruns a scratch block by 16 bytes on purpose; 1 if the check caught it, 0 if not, < 0 on error */
+int gpx_dbg_guard_selftest(gpx_ctx* ctx);
 /* host logic of the deterministic column reduction: number of row chunks (= partial sums per column) a rows x pcols launch
  * uses, and the scratch bound callers allocate; the bound is monotone in both arguments (one buffer serves every sub-block
  * a sweep reduces).  No device work. */
