@@ -47,6 +47,9 @@ int gpx_dev_alloc(gpx_ctx* ctx, int64_t bytes, void** out) {
     GPX_HIP(hipDeviceSynchronize());
     GPX_HIP(hipMemset(base, 0xA5, (size_t)GUARD));
     GPX_HIP(hipMemset((char*)base + GUARD + bytes, 0xA5, (size_t)GUARD));
+    if (ctx->guard >= 2) GPX_HIP(hipMemset((char*)base + GUARD, 0xFF, (size_t)bytes));  // poison: every double a NaN
+    GPX_HIP(hipDeviceSynchronize());  // hipMemset on device memory may return before it has run; the context's streams are
+                                      // non-blocking, i.e. not ordered against the null stream it runs on
     *out = (char*)base + GUARD;
   } else {
     *out = base;
@@ -288,7 +291,7 @@ int gpx_create(int device, gpx_ctx** out) {
   GPX_ARG(device >= 0 && device < ndev, "device ordinal out of range");
   GPX_HIP(hipSetDevice(device));
   gpx_ctx* c = new gpx_ctx();
-  { const char* g = getenv("GPX_ALLOC_GUARD"); c->guard = (g && atoi(g) != 0) ? 1 : 0; }
+  { const char* g = getenv("GPX_ALLOC_GUARD"); c->guard = g ? atoi(g) : 0; }
   c->guard_violations = 0;
   c->device = device;
   c->pool_bytes = 0;

@@ -321,7 +321,8 @@ int gpx_dbg_gemm(gpx_ctx* ctx, const gpx_mat* A, const gpx_mat* B, gpx_mat* C, i
  * 3 (lower C = U U^T with A = B = U upper triangular, bt); the structurally zero part of every tile's k range is skipped */
 int gpx_dbg_gemm_tri(gpx_ctx* ctx, const gpx_mat* A, const gpx_mat* B, gpx_mat* C, int bt, int accumulate, int tri);
 /* GPX_ALLOC_GUARD=1 in the environment at gpx_create (debug; this pool has no GPU address sanitizer): every pooled device
- * allocation carries a 4 KiB band of 0xA5 on either side, checked when the block returns to the pool.  Returns the number of
+ * allocation carries a 4 KiB band of 0xA5 on either side, checked when the block returns to the pool; =2 also fills every
+ * block with NaNs when it is handed out (a read of memory nobody wrote then shows in the results).  Returns the number of
  * blocks found overwritten so far (each also reported on stderr), or -1 when the mode is off. */
 int64_t gpx_dbg_guard_violations(gpx_ctx* ctx);
 /* guard mode only: overruns a scratch block by 16 bytes on purpose; 1 if the check caught it, 0 if not, < 0 on error */

@@ -1,6 +1,6 @@
 """Runs last (file name): with GPX_ALLOC_GUARD=1 in the environment every pooled device allocation of the session carried
 guard bands; nothing may have written outside its block.  (How the scratch overflow of the column reduction would have been
-seen; the pool's GPU boxes have no address sanitizer.)  Usage: GPX_ALLOC_GUARD=1 python -m pytest tests -m gpu"""
+seen; the pool's GPU boxes have no address sanitizer.)  Usage: GPX_ALLOC_GUARD=1 python -m pytest tests -m gpu   (=2: blocks are also handed out NaN-filled)"""
 import os
 
 import pytest
