@@ -70,7 +70,7 @@ def test_panel_loop_gloo_cpu(world, n, nb):
 
 
 @pytest.mark.parametrize("world,n,nb,grid", [(2, 700, 128, ""), (4, 1000, 256, ""), (6, 900, 128, ""), (8, 1300, 128, ""),
-                                             (8, 333, 256, ""), (4, 1100, 256, "4x1"), (4, 2100, 256, "")])
+                                             (8, 333, 256, ""), (4, 1100, 256, "4x1"), (4, 2100, 256, ""), (8, 1500, 128, "4x2")])
 def test_panel_loop_2d_gloo_cpu(world, n, nb, grid):
     """North-star layout: Pr x Pc block-cyclic ownership, column-communicator diagonal broadcast, all-rank panel pieces,
     look-ahead order, replicated + distributed factor, distributed substitution (reduce / bcast on sub-groups),
