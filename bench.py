@@ -385,7 +385,7 @@ def main():
                                  "(look-ahead) and is reported for the rocprofv3 cross-check only"},
             "roofline_kfill": dict(hbm(kf), kernel="kfill_kernel<SYM> (symmetric N x N assembly, mirror-written)",
                                    traffic=None),
-            "roofline_kcross": dict(hbm(kc), kernel="kfill_rect2_kernel (rectangular N x M cross matrix, every element "
+            "roofline_kcross": dict(hbm(kc), kernel="kfill_rectn_kernel (rectangular N x M cross matrix, every element "
                                                    "computed)", traffic=None),
             "fit_ms": fit_ms, "ivar_ms": ivar_ms,
             "points_per_s_fit": (N / (fit_ms * 1e-3)) if fit_ms else None,

@@ -111,6 +111,7 @@ _SIGS = {
     "gpx_dbg_colreduce_plan": (C.c_int, [c_i64, c_i64, C.POINTER(c_i64), C.POINTER(c_i64)]),
     "gpx_dbg_guard_violations": (c_i64, [c_vp]),
     "gpx_dbg_guard_selftest": (C.c_int, [c_vp]),
+    "gpx_dbg_spin": (C.c_int, [c_vp, C.c_int]),
 }
 
 _lib = None

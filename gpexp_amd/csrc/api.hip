@@ -365,6 +365,20 @@ int gpx_create(int device, gpx_ctx** out) {
   return 0;
 }
 
+// test hook: one workgroup that spins for about `ms` milliseconds (s_memtime ticks at 100 MHz; capped at 500 ms) on the
+// selected stream -- delays whatever is queued behind it, so that an ordering hole between streams shows deterministically
+__global__ void dbg_spin_kernel(long long ticks) {
+  const long long t0 = __builtin_amdgcn_s_memtime();
+  while (__builtin_amdgcn_s_memtime() - t0 < ticks) {}
+}
+int gpx_dbg_spin(gpx_ctx* ctx, int ms) {
+  GPX_ARG(ctx && ms >= 0 && ms <= 500, "spin: 0..500 ms");
+  if (ms == 0) return 0;
+  hipLaunchKernelGGL(dbg_spin_kernel, dim3(1), dim3(64), 0, ctx->stream, (long long)ms * 100000LL);
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
+
 int64_t gpx_dbg_guard_violations(gpx_ctx* ctx) { return ctx ? (ctx->guard ? ctx->guard_violations : -1) : -1; }
 
 // writes 16 bytes past a scratch block on purpose and returns 1 if the guard check caught it (the count is restored)

@@ -38,6 +38,9 @@ struct KCyclic { int nbt, Pr, pr, Pc, pc; };  // nbt = block size in tiles; 0 = 
 #ifndef WAVES_PER_EU_RECT
 #define WAVES_PER_EU_RECT 6
 #endif
+#ifndef RECT_NT
+#define RECT_NT 4   // column tiles per workgroup of kfill_rectn_kernel (measured 2 / 3 / 4: 1.76 / 1.63 / 1.61 ms, one call)
+#endif
 
 // exp(x) = 2^n * 2^(j/256) * exp(r):  m = rint(x * 256/ln2), n = m >> 8, j = m & 255, r = x - m*ln2/256, |r| <= ln2/512, so
 // a degree-4 polynomial is exact to 3.8e-17; tab[j] = 2^(j/256) sits in LDS (2 KB).  m comes from the add-and-subtract-
@@ -422,20 +425,20 @@ __global__ __launch_bounds__(256, SYM ? WAVES_PER_EU : WAVES_PER_EU_RECT) void k
   }
 }
 
-// Rectangular fills of the Matern kinds: the same tile code, NT = 2 neighbouring column tiles per workgroup.  Those fills are
-// VALU-bound (sqrt + exp for every element, profiles/r02_kfill_valu.txt), so every instruction outside the kernel function
-// counts: the row points are staged once and the workgroup's fixed costs (launch, table, barrier) are paid once per 128
-// columns: 1.94 -> 1.80 ms per 8.6 GB.  The store-bound kinds (SE, Mehler: 1.50-1.58 ms) lose occupancy to it and keep the
-// one-tile kernel.
+// Rectangular fills of the Matern kinds: the same tile code, NT = RECT_NT neighbouring column tiles per workgroup.  Those fills
+// are VALU-bound (sqrt + exp for every element, profiles/r02_kfill_valu.txt), so every instruction outside the kernel function
+// counts: the row points are staged once and the workgroup's fixed costs (launch, table, barrier) are paid once per NT * 64
+// columns: 1.94 ms per 8.6 GB with one tile, 1.76 with two, 1.61 with four.  The store-bound kinds (SE, Mehler: 1.50-1.58 ms)
+// lose occupancy to it and keep the one-tile kernel.
 template <int KIND, int K4, bool EXACT>
-__global__ __launch_bounds__(256, WAVES_PER_EU_RECT) void kfill_rect2_kernel(KParams kp, const double* __restrict__ A, int64_t na,
+__global__ __launch_bounds__(256, WAVES_PER_EU_RECT) void kfill_rectn_kernel(KParams kp, const double* __restrict__ A, int64_t na,
                                                     const double* __restrict__ B, int64_t nb, int symmetric,
                                                     const double* __restrict__ nugget, int64_t nugget_len,
                                                     double nugget_scalar, double* __restrict__ out, int64_t ld,
                                                     int64_t row_shift, KCyclic cyc, int tiles_n) {
   extern __shared__ double sm[];
   constexpr bool SYM = false;
-  constexpr int NT = 2;
+  constexpr int NT = RECT_NT;
   const int d = kp.d;
   constexpr int dpad = 4 * K4;  // coordinates + the two augmentation slots, padded to the MFMA K step
   const int sl = EXACT ? (d | 1) : dpad + 1;  // odd stride
@@ -600,8 +603,8 @@ int launch_k4(gpx_ctx* ctx, const KParams& kp, const double* A, int64_t na, cons
   static_assert(EXP_TAB == 256, "the exp table is loaded by the 256 threads of the workgroup, one entry each");
   const size_t img = (size_t)TM * (EXACT ? (kp.d | 1) : 4 * K4 + 1);
   if (!SYM && (KIND == GPX_K_MATERN32 || KIND == GPX_K_MATERN52)) {
-    grid.x = (grid.x + 1) / 2;  // two column tiles per workgroup
-    hipLaunchKernelGGL((kfill_rect2_kernel<KIND, K4, EXACT>), grid, dim3(256), (3 * img + EXP_TAB) * sizeof(double), ctx->stream,
+    grid.x = (grid.x + RECT_NT - 1) / RECT_NT;  // RECT_NT column tiles per workgroup
+    hipLaunchKernelGGL((kfill_rectn_kernel<KIND, K4, EXACT>), grid, dim3(256), ((1 + RECT_NT) * img + EXP_TAB) * sizeof(double), ctx->stream,
                        kp, A, na, B, nb, symmetric, d_nugget, nugget_len, nugget_scalar, out, ld, row_shift, cyc,
                        (int)(pcols / TN));
     GPX_HIP(hipGetLastError());

@@ -679,6 +679,11 @@ class DeviceOps2D(DeviceOps):
 
     def kfill_local(self, spec, X, A, nugget, geo):
         nug, nlen = _dev._nugget_args(nugget, X.shape[0])
+        # tests: hold the assembly of ONE rank back ("ms@rank"), so that a missing dependency on it shows every time
+        spec_delay = os.environ.get("GPX_TEST_DELAY_FILL", "")
+        delay = int(spec_delay.split("@")[0]) if spec_delay and int(spec_delay.split("@")[1]) == geo.rank else 0
+        if delay:
+            check(self.ctx.lib.gpx_dbg_spin(self.ctx.h, delay))
         check(self.ctx.lib.gpx_dist2_kfill(self.ctx.h, *spec.args(), X.h, dptr(nug), nlen, A.h, geo.nb, geo.Pr, geo.Pc,
                                            geo.pr, geo.pc))
 
@@ -810,6 +815,11 @@ def dist2_potrf(ops, comm, geo, A, G, L=None, on_stored=None):
                 ops.wait(_ev2(E_EARLY, k))
                 if k >= 1:
                     ops.wait(_ev2(E_COL2, k + 1))                        # contributions of the panels before k
+                else:
+                    # k = 0: nothing else orders this stream behind the ASSEMBLY of A (queued on MAIN); without it the
+                    # update could land on the block before the fill wrote it and be overwritten -- seen on the first
+                    # step of a fresh process only, when the fill kernel's first launch is slow (1 run in 12)
+                    ops.wait(_ev2(E_COLREADY, 0))
                 ops.update(A, ((k + 1) // Pr) * nb, h1, ((k + 1) // Pc) * nb, h1, g, early_off, early_off, w, nb)
                 ops.record(_ev2(E_DIAGREADY, k + 1))
         ops.stream(PANEL)

@@ -320,6 +320,9 @@ int gpx_dbg_gemm(gpx_ctx* ctx, const gpx_mat* A, const gpx_mat* B, gpx_mat* C, i
 /* triangular-operand GEMM modes: tri = 1 (A lower triangular, k == m), 2 (B lower-triangular n x k used transposed, bt),
  * 3 (lower C = U U^T with A = B = U upper triangular, bt); the structurally zero part of every tile's k range is skipped */
 int gpx_dbg_gemm_tri(gpx_ctx* ctx, const gpx_mat* A, const gpx_mat* B, gpx_mat* C, int bt, int accumulate, int tri);
+/* queues a kernel that spins for ~ms milliseconds (<= 500) on the selected stream: lets a test hold one stream back so that a
+ * missing cross-stream dependency shows every time instead of once in a dozen runs */
+int gpx_dbg_spin(gpx_ctx* ctx, int ms);
 /* GPX_ALLOC_GUARD=1 in the environment at gpx_create (debug; this pool has no GPU address sanitizer): every pooled device
  * allocation carries a 4 KiB band of 0xA5 on either side, checked when the block returns to the pool; =2 also fills every
  * block with NaNs when it is handed out (a read of memory nobody wrote then shows in the results).  Returns the number of

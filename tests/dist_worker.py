@@ -444,6 +444,71 @@ def run_cpu2d(args):
               flush=True)
 
 
+def _chaos_ops(ctx, seed, rank):
+    """DeviceOps2D whose every primitive is preceded, with probability 1/3, by a kernel that holds the CURRENT stream back for
+    1-40 ms (gpx_dbg_spin): results must not depend on how the streams of a rank -- or the ranks -- drift against each other.
+    A dependency that is only satisfied by luck of timing (the k = 0 early update ran before the assembly once in a dozen
+    fresh processes) fails under some seed instead of once in a blue moon."""
+    from gpexp_amd._lib import check
+    rng = np.random.default_rng(1000 * seed + rank)
+
+    class ChaosOps2D(dist.DeviceOps2D):
+        pass
+
+    def wrap(name):
+        f = getattr(dist.DeviceOps2D, name)
+
+        def g(self, *a, **kw):
+            if rng.random() < 0.4:
+                check(self.ctx.lib.gpx_dbg_spin(self.ctx.h, int(rng.choice([1, 2, 5, 15, 40], p=[0.35, 0.3, 0.2, 0.1, 0.05]))))
+            return f(self, *a, **kw)
+        setattr(ChaosOps2D, name, g)
+    for nm in ("kfill_local", "diag_factor", "panel_trsm", "update", "unpack_rows", "unpack_diag", "cross_fill", "ivar_step",
+               "record"):
+        wrap(nm)
+    return ChaosOps2D(ctx)
+
+
+def run_gpu2d_chaos(args):
+    """First step of a FRESH runner under random per-stream delays, packed buffers and replicated factor pre-filled with NaN
+    (a read of anything that has not arrived yet cannot hide behind zeros or last step's identical data), against the
+    single-GPU path."""
+    from gpexp_amd import device as dev
+    ctx = dev.Context(int(os.environ.get("GPX_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+    dev._ctx = ctx
+    comm = dist.init_from_env(ctx)
+    rng = np.random.default_rng(args.n)
+    d = 4
+    N, M = args.n, args.m
+    Xh = rng.uniform(-1, 1, (N, d))
+    yh = np.sin(2 * np.pi * Xh.sum(1) / d) + 0.3 * rng.standard_normal(N)
+    Zh = rng.uniform(-1, 1, (M, d))
+    spec = dev.KernelSpec(dev.K_MATERN52, d, [0.5, 1.0])
+    grid = tuple(int(v) for v in args.grid.split("x")) if args.grid else None
+    X = dev.points(ctx, Xh)
+    K1 = dev.potrf(ctx, dev.kfill(ctx, spec, X, nugget=0.1))
+    alpha1 = dev.potrs(ctx, K1, yh)
+    ll1 = -0.5 * float(yh @ alpha1) - 0.5 * dev.logdet(ctx, K1) - N / 2.0 * np.log(2 * np.pi)
+    iv1 = abs(dev.ivar(ctx, spec, K1, X, dev.points(ctx, Zh)))
+    for streamed in (True, False):
+        ops = _chaos_ops(ctx, args.chaos, comm.rank)
+        runner = dist.DistFitIvar2D(ctx, comm, spec, Xh, yh, Zh, 0.1, nb=args.nb, streamed=streamed, grid=grid, ops=ops)
+        from gpexp_amd._lib import check, dptr
+        for buf in (runner.G[0], runner.G[1], runner.L):
+            nan = np.full(buf.to_host().size, np.nan)
+            check(ctx.lib.gpx_mat_write(ctx.h, buf.h, 0, nan.size, dptr(nan)))
+        ll, iv = runner.step()
+        assert np.isfinite(ll) and abs(ll - ll1) <= 1e-11 * abs(ll1), (streamed, ll, ll1)
+        assert np.isfinite(iv) and abs(iv - iv1) <= 1e-11 * abs(iv1), (streamed, iv, iv1)
+        del runner
+    comm.barrier()
+    if comm.rank == 0:
+        print("DIST_OK gpu2d-chaos world=%d seed=%d n=%d nb=%d ll=%.12g ivar=%.12g" % (comm.world, args.chaos, N, args.nb, ll, iv),
+              flush=True)
+    comm.close()
+    ctx.close()
+
+
 def run_gpu2d(args):
     """2-D path on the real HIP primitives: ranks share GPU 0 and exchange through the host-staged gloo communicator."""
     from gpexp_amd import device as dev
@@ -556,9 +621,10 @@ if __name__ == "__main__":
     ap.add_argument("--mpts", dest="m", type=int, default=333)
     ap.add_argument("--blk", dest="nb", type=int, default=256)
     ap.add_argument("--grid", default="")
+    ap.add_argument("--chaos", type=int, default=0)
     a = ap.parse_args()
     print("WORKER_UP rank=%s mode=%s" % (os.environ.get("RANK", "0"), a.mode), flush=True)
-    {"cpu": run_cpu, "gpu": run_gpu, "cpu2d": run_cpu2d, "gpu2d": run_gpu2d}[a.mode](a)
+    {"cpu": run_cpu, "gpu": run_gpu, "cpu2d": run_cpu2d, "gpu2d": run_gpu2d, "gpu2d-chaos": run_gpu2d_chaos}[a.mode](a)
     if "torch" in sys.modules:  # orderly gloo teardown: a rank that exits while its peers still hold sub-group
         import torch.distributed as td   # connections aborts in a gloo thread (the RCCL path never imports torch)
         if td.is_initialized():

@@ -121,6 +121,31 @@ def test_distributed_fit_ivar_2d_shared_gpu(world, n, nb, grid):
 
 
 @pytest.mark.gpu
+def test_2d_loop_is_ordered_behind_a_slow_assembly():
+    """The local assembly of A is queued on MAIN; every other stream's first touch of A must be ordered behind it.  At k = 0
+    the early diagonal update (PANEL stream of the owner of block (1,1)) was not: once in a dozen fresh processes -- when the
+    fill kernel's first launch was slow -- the update landed before the fill and was overwritten (wrong factor from block
+    (1,1) on, first step only; later steps re-read identical data).  Here the assembly of that rank alone (rank 3 of the 2 x 2
+    grid) is held back by 40 ms, which makes the unordered version fail every time."""
+    out = launch(4, ["--mode", "gpu2d", "--npts", "2100", "--mpts", "777", "--blk", "256"],
+                 {"GPX_COMM": "host", "GPX_FORCE_DEVICE": "0", "GPX_TEST_DELAY_FILL": "40@3"}, timeout=900)
+    assert "HostStagedComm" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n,nb,grid,seed", [(4, 2100, 256, "", 5), (4, 2100, 256, "", 9), (3, 1900, 128, "", 2),
+                                                  (4, 1500, 256, "4x1", 3), (4, 2100, 128, "1x4", 4)])
+def test_2d_loop_under_random_stream_delays(world, n, nb, grid, seed):
+    """Chaos mode of the worker: every device primitive is preceded, with probability 0.4, by a kernel that holds the current
+    stream back for 1-40 ms; packed buffers and replicated factor start NaN-filled; the FIRST step of a fresh runner (both
+    evaluation schedules) must still equal the single-GPU path.  Seeds 5 and 9 fail on the 2 x 2 grid when the k = 0
+    dependency on the assembly is removed."""
+    out = launch(world, ["--mode", "gpu2d-chaos", "--npts", str(n), "--mpts", "777", "--blk", str(nb), "--grid", grid,
+                         "--chaos", str(seed)], {"GPX_COMM": "host", "GPX_FORCE_DEVICE": "0"}, timeout=900)
+    assert "gpu2d-chaos" in out
+
+
+@pytest.mark.gpu
 def test_rccl_2d_world1():
     """RCCL code path of the 2-D loop at world 1: ncclCommSplit sub-communicators, group broadcasts / reductions, the
     grouped send/recv panel broadcast (degenerate: nothing to send) and the all-reduces."""
