@@ -90,7 +90,19 @@ void gpx_dev_release(gpx_ctx* ctx, void* p, int64_t bytes) {
 // recursive factorisation issues ~2600 launches per step and two event records per launch cost ~15 ms of the timed
 // region.  The 1-2 us launch gaps inside such a run are then counted as kernel time -- a slightly pessimistic
 // `achieved`, within 0.5 % of the rocprofv3 kernel-only total.
+// one workgroup that spins for `ticks` of s_memtime (100 MHz): GPX_CHAOS and gpx_dbg_spin
+__global__ void dbg_spin_kernel(long long ticks) {
+  const long long t0 = __builtin_amdgcn_s_memtime();
+  while (__builtin_amdgcn_s_memtime() - t0 < ticks) {}
+}
+
 ProfScope::ProfScope(gpx_ctx* c, int cls, double flops, double bytes) : ctx(c), idx(-1) {
+  if (c->chaos) {
+    c->chaos = c->chaos * 6364136223846793005ULL + 1442695040888963407ULL;
+    const unsigned r = (unsigned)(c->chaos >> 33);
+    if ((r & 3u) == 0u)  // ticks of s_memtime: 100 MHz -> 1e4 .. 3e5 = 0.1 .. 3 ms
+      hipLaunchKernelGGL(dbg_spin_kernel, dim3(1), dim3(64), 0, c->stream, (long long)(10000 + (r >> 2) % 290000));
+  }
   if (!c->prof_on) return;
   c->prof_launches[cls] += 1;
   c->prof_flops[cls] += flops;
@@ -292,6 +304,7 @@ int gpx_create(int device, gpx_ctx** out) {
   GPX_HIP(hipSetDevice(device));
   gpx_ctx* c = new gpx_ctx();
   { const char* g = getenv("GPX_ALLOC_GUARD"); c->guard = g ? atoi(g) : 0; }
+  { const char* g = getenv("GPX_CHAOS"); c->chaos = g ? (uint64_t)strtoull(g, nullptr, 10) : 0; }
   c->guard_violations = 0;
   c->device = device;
   c->pool_bytes = 0;
@@ -367,10 +380,6 @@ int gpx_create(int device, gpx_ctx** out) {
 
 // test hook: one workgroup that spins for about `ms` milliseconds (s_memtime ticks at 100 MHz; capped at 500 ms) on the
 // selected stream -- delays whatever is queued behind it, so that an ordering hole between streams shows deterministically
-__global__ void dbg_spin_kernel(long long ticks) {
-  const long long t0 = __builtin_amdgcn_s_memtime();
-  while (__builtin_amdgcn_s_memtime() - t0 < ticks) {}
-}
 int gpx_dbg_spin(gpx_ctx* ctx, int ms) {
   GPX_ARG(ctx && ms >= 0 && ms <= 500, "spin: 0..500 ms");
   if (ms == 0) return 0;

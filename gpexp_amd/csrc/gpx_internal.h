@@ -124,6 +124,9 @@ struct gpx_ctx {
   // 0xA5 on either side, checked when it goes back to the pool; violations are counted and reported on stderr
   int guard;
   int64_t guard_violations;
+  // GPX_CHAOS=seed (debug): every profiled launch site holds its stream back by a random 0.1-3 ms with probability 1/4, so
+  // that a missing dependency between the context's streams changes the results instead of hiding behind lucky timing
+  uint64_t chaos;
   // scalars
   int* d_info;      // [0] first failing pivot (1-based), 0 = ok; [1] pivots dropped in skip mode
   double piv_min;   // pivot policy of the leaf factorisation (gpx_potrf_policy): pivots <= piv_min are bad ...
