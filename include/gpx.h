@@ -320,6 +320,8 @@ int gpx_dbg_gemm(gpx_ctx* ctx, const gpx_mat* A, const gpx_mat* B, gpx_mat* C, i
 /* triangular-operand GEMM modes: tri = 1 (A lower triangular, k == m), 2 (B lower-triangular n x k used transposed, bt),
  * 3 (lower C = U U^T with A = B = U upper triangular, bt); the structurally zero part of every tile's k range is skipped */
 int gpx_dbg_gemm_tri(gpx_ctx* ctx, const gpx_mat* A, const gpx_mat* B, gpx_mat* C, int bt, int accumulate, int tri);
+/* GPX_CHAOS=<seed> in the environment at gpx_create (debug): every launch site holds its stream back by a random 0.1-3 ms with
+ * probability 1/4; results must not change (a dependency between the context's streams that is only met by lucky timing would). */
 /* queues a kernel that spins for ~ms milliseconds (<= 500) on the selected stream: lets a test hold one stream back so that a
  * missing cross-stream dependency shows every time instead of once in a dozen runs */
 int gpx_dbg_spin(gpx_ctx* ctx, int ms);
