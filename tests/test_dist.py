@@ -41,6 +41,8 @@ def launch(world, extra, env_extra=None, timeout=600):
         print("launcher retry after rendezvous failure:\n" + r.stderr[-1500:], file=sys.stderr)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "DIST_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    # GPX_ALLOC_GUARD=1 in the environment reaches the workers too: their violations only show on stderr
+    assert "ALLOCATION GUARD VIOLATED" not in r.stderr, r.stderr[-3000:]
     return r.stdout
 
 
