@@ -249,6 +249,72 @@ static int64_t sag_min_elems() {
   return v;
 }
 
+}  // extern "C"
+
+// The schedule itself, separated from RCCL so that a host test can replay it for every rank of a communicator (the multi-rank
+// RCCL path has never run on hardware; tests/test_host_cpu.py checks that the sends and receives of all ranks pair up in
+// order with equal lengths and that every rank ends up with every piece).  op(phase, is_send, piece, off, len, peer): phase 1
+// or 2, element range [off, off+len) of the piece.  Returns whether any piece takes the two-phase route.
+template <class Op>
+static bool panel_bcast_schedule(int W, int me, int64_t small, int npieces, const int64_t* counts, const int* roots, int phase,
+                                 Op op) {
+  // chunk q of a piece: [q*c, min((q+1)*c, count)), c even (16-byte aligned sends); peer index of rank r w.r.t. the root:
+  // r < root ? r : r-1
+  auto chunk = [](int64_t count, int W_, int q, int64_t* off, int64_t* len) {
+    int64_t c = (count + (W_ - 2)) / (W_ - 1);
+    c += c & 1;
+    int64_t a = (int64_t)q * c, b = a + c;
+    if (a > count) a = count;
+    if (b > count) b = count;
+    *off = a;
+    *len = b - a;
+  };
+  bool any = false;
+  for (int i = 0; i < npieces; ++i) any = any || (counts[i] >= small && W > 2);
+  if (phase == 1) {
+    for (int i = 0; i < npieces; ++i) {
+      const int root = roots[i];
+      if (counts[i] == 0) continue;
+      const bool direct = counts[i] < small || W == 2;
+      if (me == root) {
+        for (int r = 0; r < W; ++r) {
+          if (r == root) continue;
+          if (direct) {
+            op(1, true, i, (int64_t)0, counts[i], r);
+          } else {
+            int64_t off, len;
+            chunk(counts[i], W, r < root ? r : r - 1, &off, &len);
+            if (len > 0) op(1, true, i, off, len, r);
+          }
+        }
+      } else if (direct) {
+        op(1, false, i, (int64_t)0, counts[i], root);
+      } else {
+        int64_t off, len;
+        chunk(counts[i], W, me < root ? me : me - 1, &off, &len);
+        if (len > 0) op(1, false, i, off, len, root);
+      }
+    }
+    return any;
+  }
+  for (int i = 0; i < npieces; ++i) {
+    const int root = roots[i];
+    if (counts[i] < small || W == 2 || me == root) continue;
+    int64_t myoff, mylen;
+    chunk(counts[i], W, me < root ? me : me - 1, &myoff, &mylen);
+    for (int r = 0; r < W; ++r) {
+      if (r == root || r == me) continue;
+      int64_t off, len;
+      chunk(counts[i], W, r < root ? r : r - 1, &off, &len);
+      if (mylen > 0) op(2, true, i, myoff, mylen, r);
+      if (len > 0) op(2, false, i, off, len, r);
+    }
+  }
+  return any;
+}
+
+extern "C" {
+
 int gpx_comm_panel_bcast(gpx_ctx* ctx, gpx_mat* buf, const int64_t* offsets, const int64_t* counts, const int* roots,
                          int npieces) {
   GPX_ARG(buf && offsets && counts && roots && npieces >= 0, "NULL argument");
@@ -264,64 +330,45 @@ int gpx_comm_panel_bcast(gpx_ctx* ctx, gpx_mat* buf, const int64_t* offsets, con
   ProfScope ps(ctx, GPX_PROF_COMM, 0.0, total);
   ncclComm_t comm = (ncclComm_t)ctx->comm;
   hipStream_t st = ctx->stream;
-  const int64_t small = sag_min_elems();
-  // chunk q of piece i: [q*c, min((q+1)*c, count)), c even (16-byte aligned sends); peer index of rank r w.r.t. root: r < root ? r : r-1
-  auto chunk = [](int64_t count, int W_, int q, int64_t* off, int64_t* len) {
-    int64_t c = (count + (W_ - 2)) / (W_ - 1);
-    c += c & 1;
-    int64_t a = (int64_t)q * c, b = a + c;
-    if (a > count) a = count;
-    if (b > count) b = count;
-    *off = a;
-    *len = b - a;
+  int rc = 0;
+  auto op = [&](int, bool is_send, int piece, int64_t off, int64_t len, int peer) {
+    if (rc != 0) return;
+    double* p = buf->p + offsets[piece] + off;
+    ncclResult_t r = is_send ? g_rccl.Send(p, (size_t)len, ncclFloat64, peer, comm, st)
+                             : g_rccl.Recv(p, (size_t)len, ncclFloat64, peer, comm, st);
+    if (r != 0) {  // ncclSuccess
+      gpx_set_error("RCCL %s failed: %s", is_send ? "ncclSend" : "ncclRecv", g_rccl.GetErrorString(r));
+      rc = -3;
+    }
   };
-  // phase 1
   GPX_NCCL(g_rccl.GroupStart());
-  for (int i = 0; i < npieces; ++i) {
-    const int root = roots[i];
-    double* base = buf->p + offsets[i];
-    if (counts[i] == 0) continue;
-    const bool direct = counts[i] < small || W == 2;
-    if (me == root) {
-      for (int r = 0; r < W; ++r) {
-        if (r == root) continue;
-        if (direct) {
-          GPX_NCCL(g_rccl.Send(base, (size_t)counts[i], ncclFloat64, r, comm, st));
-        } else {
-          int64_t off, len;
-          chunk(counts[i], W, r < root ? r : r - 1, &off, &len);
-          if (len > 0) GPX_NCCL(g_rccl.Send(base + off, (size_t)len, ncclFloat64, r, comm, st));
-        }
-      }
-    } else if (direct) {
-      GPX_NCCL(g_rccl.Recv(base, (size_t)counts[i], ncclFloat64, root, comm, st));
-    } else {
-      int64_t off, len;
-      chunk(counts[i], W, me < root ? me : me - 1, &off, &len);
-      if (len > 0) GPX_NCCL(g_rccl.Recv(base + off, (size_t)len, ncclFloat64, root, comm, st));
-    }
-  }
+  const bool two_phase = panel_bcast_schedule(W, me, sag_min_elems(), npieces, counts, roots, 1, op);
   GPX_NCCL(g_rccl.GroupEnd());
-  // phase 2
-  bool any = false;
-  for (int i = 0; i < npieces; ++i) any = any || (counts[i] >= small && W > 2);
-  if (!any) return 0;
+  if (rc != 0) return rc;
+  if (!two_phase) return 0;
   GPX_NCCL(g_rccl.GroupStart());
-  for (int i = 0; i < npieces; ++i) {
-    const int root = roots[i];
-    if (counts[i] < small || W == 2 || me == root) continue;
-    double* base = buf->p + offsets[i];
-    int64_t myoff, mylen;
-    chunk(counts[i], W, me < root ? me : me - 1, &myoff, &mylen);
-    for (int r = 0; r < W; ++r) {
-      if (r == root || r == me) continue;
-      int64_t off, len;
-      chunk(counts[i], W, r < root ? r : r - 1, &off, &len);
-      if (mylen > 0) GPX_NCCL(g_rccl.Send(base + myoff, (size_t)mylen, ncclFloat64, r, comm, st));
-      if (len > 0) GPX_NCCL(g_rccl.Recv(base + off, (size_t)len, ncclFloat64, r, comm, st));
-    }
-  }
+  panel_bcast_schedule(W, me, sag_min_elems(), npieces, counts, roots, 2, op);
   GPX_NCCL(g_rccl.GroupEnd());
+  return rc;
+}
+
+// test hook (host logic only): the schedule of rank `me` of a W-rank communicator as rows of 6 int64
+// (phase, is_send, piece, off, len, peer) in issue order; *nops = number of rows (may exceed max_ops: then only max_ops are written)
+int gpx_dbg_panel_bcast_plan(int W, int me, int64_t small, int npieces, const int64_t* counts, const int* roots, int64_t* ops,
+                             int64_t max_ops, int64_t* nops) {
+  if (W < 1 || me < 0 || me >= W || npieces < 0 || !counts || !roots || !nops) return -1;
+  int64_t n = 0;
+  auto op = [&](int phase, bool is_send, int piece, int64_t off, int64_t len, int peer) {
+    if (ops && n < max_ops) {
+      int64_t* r = ops + 6 * n;
+      r[0] = phase; r[1] = is_send ? 1 : 0; r[2] = piece; r[3] = off; r[4] = len; r[5] = peer;
+    }
+    ++n;
+  };
+  if (W > 1) {
+    if (panel_bcast_schedule(W, me, small, npieces, counts, roots, 1, op)) panel_bcast_schedule(W, me, small, npieces, counts, roots, 2, op);
+  }
+  *nops = n;
   return 0;
 }
 

@@ -332,6 +332,11 @@ int gpx_dbg_spin(gpx_ctx* ctx, int ms);
 int64_t gpx_dbg_guard_violations(gpx_ctx* ctx);
 /* guard mode only: overruns a scratch block by 16 bytes on purpose; 1 if the check caught it, 0 if not, < 0 on error */
 int gpx_dbg_guard_selftest(gpx_ctx* ctx);
+/* host logic of gpx_comm_panel_bcast: the ncclSend / ncclRecv schedule of rank `me` in a W-rank communicator, rows of 6 int64
+ * (phase 1|2, is_send, piece, offset within the piece, length, peer) in issue order; *nops = rows needed (at most max_ops are
+ * written).  `small` = the direct-send threshold in doubles.  No device, no RCCL: tests replay it for all ranks. */
+int gpx_dbg_panel_bcast_plan(int W, int me, int64_t small_elems, int npieces, const int64_t* counts, const int* roots,
+                             int64_t* ops, int64_t max_ops, int64_t* nops);
 /* host logic of the deterministic column reduction: number of row chunks (= partial sums per column) a rows x pcols launch
  * uses, and the scratch bound callers allocate; the bound is monotone in both arguments (one buffer serves every sub-block
  * a sweep reduces).  No device work. */

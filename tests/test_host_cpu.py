@@ -179,3 +179,58 @@ def test_column_reduction_scratch_bound_covers_every_sub_block():
     # the shapes that overflowed
     assert plan(16640, 16384)[0] * 16384 <= plan(33024, 33024)[1]
     assert plan(5120, 4096)[0] * 4096 <= plan(9216, 9216)[1]
+
+
+def test_all_link_panel_broadcast_schedule_delivers_every_piece():
+    """gpx_comm_panel_bcast (scatter + all-gather over grouped ncclSend / ncclRecv) has only ever run with one rank on
+    hardware.  Its schedule is host logic: replay it for every rank of communicators of 2..8 ranks with the semantics RCCL
+    gives a group -- the i-th send from a to b pairs with the i-th receive on b from a, lengths must match, all transfers of a
+    group read the state from before the group -- and check that every rank ends up with every piece (root's data), for piece
+    sets like the 2-D loop's (Pr pieces with different roots, ragged and empty ones, both sides of the direct-send threshold)."""
+    import ctypes as C
+    from gpexp_amd import _lib
+    lib = _lib.load()
+
+    def plan(W, me, small, counts, roots):
+        cnt = (C.c_int64 * len(counts))(*counts)
+        rts = (C.c_int * len(roots))(*roots)
+        n = C.c_int64()
+        assert lib.gpx_dbg_panel_bcast_plan(W, me, small, len(counts), cnt, rts, None, 0, C.byref(n)) == 0
+        ops = (C.c_int64 * (6 * max(n.value, 1)))()
+        assert lib.gpx_dbg_panel_bcast_plan(W, me, small, len(counts), cnt, rts, ops, n.value, C.byref(n)) == 0
+        return [tuple(ops[6 * i:6 * i + 6]) for i in range(n.value)]
+
+    rng = np.random.default_rng(5)
+    cases = 0
+    for W in range(2, 9):
+        for trial in range(12):
+            npieces = int(rng.integers(1, 5))
+            counts = [int(rng.choice([0, 2, 130, 4096, 70000, 70001, 262144 + 2 * int(rng.integers(0, 50))])) for _ in range(npieces)]
+            roots = [int(rng.integers(0, W)) for _ in range(npieces)]
+            small = int(rng.choice([1, 65536]))
+            # every rank's buffer: piece i holds (rank, i, index) tagged data only on its root, NaN elsewhere
+            data = [[np.full(c, np.nan) for c in counts] for _ in range(W)]
+            for i, (c, r) in enumerate(zip(counts, roots)):
+                data[r][i] = 1e6 * (i + 1) + np.arange(c, dtype=float)
+            plans = [plan(W, me, small, counts, roots) for me in range(W)]
+            for phase in (1, 2):
+                before = [[a.copy() for a in d] for d in data]
+                sends = {}
+                recvs = {}
+                for me in range(W):
+                    for (ph, is_send, piece, off, ln, peer) in plans[me]:
+                        if ph != phase:
+                            continue
+                        assert 0 <= peer < W and peer != me and ln > 0 and off >= 0 and off + ln <= counts[piece]
+                        (sends if is_send else recvs).setdefault((me, peer) if is_send else (peer, me), []).append((piece, off, ln))
+                assert set(sends) == set(recvs), (W, counts, roots, phase)
+                for key in sends:                      # key = (source, destination)
+                    assert len(sends[key]) == len(recvs[key])
+                    for (sp, so, sl), (rp, ro, rl) in zip(sends[key], recvs[key]):
+                        assert sl == rl                # RCCL pairs them in order; a length mismatch corrupts or hangs
+                        data[key[1]][rp][ro:ro + rl] = before[key[0]][sp][so:so + sl]
+            for me in range(W):
+                for i, c in enumerate(counts):
+                    assert np.array_equal(data[me][i], 1e6 * (i + 1) + np.arange(c, dtype=float)), (W, me, i, counts, roots, small)
+            cases += 1
+    assert cases == 7 * 12
