@@ -234,3 +234,32 @@ def test_all_link_panel_broadcast_schedule_delivers_every_piece():
                     assert np.array_equal(data[me][i], 1e6 * (i + 1) + np.arange(c, dtype=float)), (W, me, i, counts, roots, small)
             cases += 1
     assert cases == 7 * 12
+
+
+def test_file_rendezvous_three_ranks(tmp_path):
+    """The RCCL path exchanges its ncclUniqueId through FileRendezvous (no framework in those processes); only one rank ever
+    used it on hardware.  Three processes with the launcher's environment, rank 0 starting LAST: all end with rank 0's 128
+    bytes, and the file is gone after rank 0's cleanup."""
+    import hashlib
+    import subprocess
+    import sys
+    import time
+    code = ("import os, sys, time, hashlib\n"
+            "sys.path.insert(0, %r)\n"
+            "from gpexp_amd.dist import FileRendezvous\n"
+            "r = FileRendezvous()\n"
+            "if r.rank == 0: time.sleep(0.5)\n"
+            "blob = bytes([7 * i %% 256 for i in range(128)]) if r.rank == 0 else b'x' * 128\n"
+            "got = r.exchange(blob)\n"
+            "print(r.rank, hashlib.sha1(got).hexdigest(), len(got), flush=True)\n"
+            "time.sleep(0.3 if r.rank == 0 else 0.0)\n"
+            "r.cleanup()\n" % ROOT)
+    env = dict(os.environ, WORLD_SIZE="3", MASTER_PORT="45123", TORCHELASTIC_RUN_ID="unit", GPX_RDV_DIR=str(tmp_path))
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, text=True)
+             for r in (2, 1, 0)]
+    outs = [p.communicate(timeout=120)[0].split() for p in procs]
+    assert all(p.returncode == 0 for p in procs)
+    want = hashlib.sha1(bytes([7 * i % 256 for i in range(128)])).hexdigest()
+    assert sorted(o[0] for o in outs) == ["0", "1", "2"] and all(o[1] == want and o[2] == "128" for o in outs)
+    time.sleep(0.1)
+    assert list(tmp_path.iterdir()) == []
