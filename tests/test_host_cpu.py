@@ -263,3 +263,17 @@ def test_file_rendezvous_three_ranks(tmp_path):
     assert sorted(o[0] for o in outs) == ["0", "1", "2"] and all(o[1] == want and o[2] == "128" for o in outs)
     time.sleep(0.1)
     assert list(tmp_path.iterdir()) == []
+
+
+def test_declared_rccl_abi_matches_the_installed_header():
+    """dist.hip binds RCCL through dlopen with hand-declared function types; most of those entry points have never been
+    called with more than one rank.  tests/abi/rccl_abi_check.cpp pins every declared type, constant and size against
+    <rccl/rccl.h> with static_asserts (compile-only, no GPU)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc) or not os.path.exists("/opt/rocm/include/rccl/rccl.h"):
+        pytest.skip("no hipcc / rccl.h on this machine")
+    r = subprocess.run([hipcc, "-std=c++17", "-fsyntax-only", "-x", "hip", "--offload-arch=gfx950", "-I/opt/rocm/include",
+                        os.path.join(ROOT, "tests", "abi", "rccl_abi_check.cpp")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
