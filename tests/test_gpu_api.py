@@ -1,6 +1,7 @@
 """GPU tests (-m gpu) of the GPEXP class API (gpexp_amd / gpExp): same calls a user of the reference makes,
 checked against the golden vectors the reference produced for those calls.  Tolerance 1e-10 relative (fp64)."""
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -506,3 +507,50 @@ def test_ivar_cost_with_heteroscedastic_noise_function(golden):
     k = KernelSquaredExponential(list(ix["kernel"]["cl"]), ix["kernel"]["signalSize"], 2)
     cf = costFunctionGP_IVAR(GP(k, ix["noise"]), len(X), space, mcPoints=mc)
     assert cf.evaluate(X) == pytest.approx(float(golden(c, "ivar")), rel=1e-10)
+
+
+def test_integration_md_stub_binds_and_runs():
+    """INTEGRATION.md section B is what a maintainer of the reference would paste: execute exactly that text (the ctypes stub
+    and the patched addNodesAndComputeCovariance) against the in-tree library and check the result against the oracle -- a
+    documentation example with a wrong prototype would otherwise only fail in somebody else's hands."""
+    import ctypes as C
+    import re
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = [b for b in blocks if b.startswith("# gpExp/_gpx.py")][0]
+    patch = [b for b in blocks if b.startswith("def addNodesAndComputeCovariance")][0]
+    stub = stub.replace('C.CDLL("libgpx_hip.so")', 'C.CDLL(%r)' % os.path.join(root, "gpexp_amd", "libgpx_hip.so"))
+    g = types.ModuleType("_gpx")
+    exec(compile(stub, "INTEGRATION.md:stub", "exec"), g.__dict__)
+    ns = {"np": np, "C": C}
+    exec(compile(patch.replace("from . import _gpx as g", "g = _GPX"), "INTEGRATION.md:patch", "exec"), dict(ns, _GPX=g), ns)
+
+    class K:                       # the reference's kernel object as far as the stub reads it (kernels.py:100-112)
+        dimension = 2
+        hyperParam = {"cl0": 0.4, "cl1": 0.9, "signalSize": 2.0}
+
+    class GPlike:
+        kernel, noise = K(), 1e-3
+    rng = np.random.default_rng(3)
+    X = rng.uniform(-1, 1, (37, 2))
+    y = rng.standard_normal(37)
+    gp = GPlike()
+    ns["addNodesAndComputeCovariance"](gp, X)
+    s = dict(kind="se", d=2, cl=[0.4, 0.9], signalSize=2.0)
+    model = orc.fit(s, X, y, 1e-3)
+    alpha = np.empty(37)
+    assert g.lib.gpx_potrs(g.ctx, gp._L, g.P(y), alpha.ctypes.data_as(g.dp)) == 0
+    assert rel(alpha, model["coeff"]) <= 1e-10
+    ld = C.c_double()
+    assert g.lib.gpx_logdet(g.ctx, gp._L, C.byref(ld)) == 0
+    assert ld.value == pytest.approx(np.linalg.slogdet(orc.cov_matrix(s, X, 1e-3))[1], rel=1e-11)
+    Z = rng.uniform(-1, 1, (11, 2))
+    mean, var = np.empty(11), np.empty(11)
+    kind, d, hyp = g.spec(gp.kernel)
+    Zd = g.upload(Z)
+    assert g.lib.gpx_posterior(g.ctx, kind, d, g.P(hyp), hyp.size, gp._L, gp._X, g.P(alpha), Zd, mean.ctypes.data_as(g.dp),
+                               var.ctypes.data_as(g.dp)) == 0
+    mo, vo = orc.posterior(s, model, Z, compvar=1)
+    assert rel(mean, mo) <= 1e-10 and np.max(np.abs(np.abs(var) - vo)) <= 1e-10
