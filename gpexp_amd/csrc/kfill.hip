@@ -604,7 +604,16 @@ int launch_k4(gpx_ctx* ctx, const KParams& kp, const double* A, int64_t na, cons
   const size_t img = (size_t)TM * (EXACT ? (kp.d | 1) : 4 * K4 + 1);
   if (!SYM && (KIND == GPX_K_MATERN32 || KIND == GPX_K_MATERN52)) {
     grid.x = (grid.x + RECT_NT - 1) / RECT_NT;  // RECT_NT column tiles per workgroup
-    hipLaunchKernelGGL((kfill_rectn_kernel<KIND, K4, EXACT>), grid, dim3(256), ((1 + RECT_NT) * img + EXP_TAB) * sizeof(double), ctx->stream,
+    const size_t shn = ((1 + RECT_NT) * img + EXP_TAB) * sizeof(double);
+    if (shn > 64 * 1024) {  // d >= 19: 97 KB of operand images; say so explicitly rather than rely on the runtime's default
+      static bool raised = false;
+      if (!raised) {
+        GPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfill_rectn_kernel<KIND, K4, EXACT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        raised = true;
+      }
+    }
+    hipLaunchKernelGGL((kfill_rectn_kernel<KIND, K4, EXACT>), grid, dim3(256), shn, ctx->stream,
                        kp, A, na, B, nb, symmetric, d_nugget, nugget_len, nugget_scalar, out, ld, row_shift, cyc,
                        (int)(pcols / TN));
     GPX_HIP(hipGetLastError());

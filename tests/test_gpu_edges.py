@@ -33,7 +33,9 @@ def test_max_dimension_32(dev, ctx):
     for s, sp in [(dict(kind="se", cl=list(1.0 + 0.02 * np.arange(d)), signalSize=0.9, d=d),
                    dev.KernelSpec(dev.K_SE, d, list(1.0 + 0.02 * np.arange(d)) + [0.9])),
                   (dict(kind="mehler", t=list(0.1 + 0.01 * np.arange(d)), d=d),
-                   dev.KernelSpec(dev.K_MEHLER, d, list(0.1 + 0.01 * np.arange(d))))]:
+                   dev.KernelSpec(dev.K_MEHLER, d, list(0.1 + 0.01 * np.arange(d)))),
+                  # Matern: the rectangular fill stages 1 + 4 operand images per workgroup, 97 KB of LDS at d = 32
+                  (dict(kind="matern52", rho=6.0, signalSize=1.1, d=d), dev.KernelSpec(dev.K_MATERN52, d, [6.0, 1.1]))]:
         K = dev.kfill(ctx, sp, dev.points(ctx, X), nugget=0.0).to_host()
         assert rel(K, orc.cov_matrix(s, X, 0.0, row_loop=False)) <= 1e-12
         Kxz = dev.kfill(ctx, sp, dev.points(ctx, X), Z=dev.points(ctx, Z)).to_host()
