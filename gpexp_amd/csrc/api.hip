@@ -904,6 +904,29 @@ int gpx_logdet(gpx_ctx* ctx, const gpx_mat* L, double* out) {
 }
 
 // ---- posterior / IVAR ---------------------------------------------------------------------------------
+// out[j] = a[j] - b[j]: posterior variance k(z,z) - |L^-1 k_z|^2 of a chunk, on the device (round 1 copied both vectors to
+// the host per chunk and subtracted there: a stream sync and two M-length PCIe copies inside every optimiser evaluation)
+__global__ __launch_bounds__(256) static void vec_diff_kernel(const double* __restrict__ a, const double* __restrict__ b,
+                                                              int64_t n, double* __restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j < n) out[j] = a[j] - b[j];
+}
+
+// mean of v[0 .. count) by halving: v[i] += v[i + h], h = ceil(m / 2), m <- h -- the summation ORDER of the host routine this
+// replaces (pairwise_mean), so results do not depend on where the reduction runs or on the chunking.  One workgroup (the
+// levels are separated by workgroup barriers; 32768 values: 15 levels, ~20 us); v is consumed.
+__global__ __launch_bounds__(1024) static void pairwise_mean_kernel(double* __restrict__ v, int64_t count,
+                                                                     double* __restrict__ out) {
+  int64_t m = count;
+  while (m > 1) {
+    const int64_t h = (m + 1) / 2;
+    for (int64_t i = threadIdx.x; i + h < m; i += 1024) v[i] += v[i + h];
+    __syncthreads();
+    m = h;
+  }
+  if (threadIdx.x == 0) out[0] = v[0] / (double)count;
+}
+
 // chunk of evaluation points handled at once: keep the (N x Mc) cross matrix under ~16 GiB
 static int64_t eval_chunk(int64_t np) {
   int64_t budget = (int64_t)16 << 30;
@@ -918,22 +941,29 @@ static int64_t eval_chunk(int64_t np) {
 // mean = B^T alpha (column dots), W = L^-1 B (recursive LEFT triangular solve: NN updates B2 -= L21 W1), var = k(z,z) -
 // colsum(W^2).  Layout measured both ways at C4 after the GEMM schedule change: this N x M form (NN GEMMs, 74 TF/s on
 // large launches) 494.6 ms; the transposed M x N form (right solve, NT GEMMs, 72.9 TF/s) 513.8 ms.
+// var_dev (device, M doubles, nullable): receives the variances when the caller reduces them on the device (IVAR) -- then
+// nothing of length M crosses PCIe.
 static int posterior_impl(gpx_ctx* ctx, const KParams& kp, const gpx_mat* L, const gpx_mat* X, const double* alpha,
-                          const gpx_mat* Z, double* mean, double* var) {
+                          const gpx_mat* Z, double* mean, double* var_host, double* var_dev = nullptr) {
   const int64_t n = L->rows, np = L->prows, M = Z->rows, d = kp.d;
+  const bool var = var_host != nullptr || var_dev != nullptr;
   GPX_ARG(X->rows == n, "X does not match the factor");
   if (M == 0) return 0;
   const int64_t mcmax = eval_chunk(np);
   const int64_t mc_alloc = gpx_round_up(M < mcmax ? M : mcmax, GPX_TILE);
   void *pB = nullptr, *pW = nullptr, *pal = nullptr, *pout = nullptr, *ppart = nullptr, *pkd = nullptr;
   // from 2048 training points the solve goes through the explicit block inverses, out of place (chol_trsm_left_oop)
-  const bool oop = var != nullptr && np >= 2048;
+  const bool oop = var && np >= 2048;
   const int64_t ldb_alloc = gpx_skew_ld(mc_alloc);
   const int64_t bytesB = np * ldb_alloc * 8, bytes_out = mc_alloc * 8;
   const int64_t bytes_part = colreduce_partial_elems(np, mc_alloc) * 8 + 8;
   int r = 0;
-  std::vector<double> hbuf((size_t)mc_alloc), hk((size_t)mc_alloc);
+  void* pvar = nullptr;  // all M variances, device (when the caller did not bring its own)
   do {
+    if (var && !var_dev) {
+      if ((r = gpx_dev_alloc(ctx, M * 8, &pvar)) != 0) break;
+      var_dev = (double*)pvar;
+    }
     if ((r = gpx_dev_alloc(ctx, bytesB, &pB)) != 0) break;
     if (oop && (r = gpx_dev_alloc(ctx, bytesB, &pW)) != 0) break;
     if ((r = gpx_dev_alloc(ctx, bytes_out, &pout)) != 0) break;
@@ -971,17 +1001,16 @@ static int posterior_impl(gpx_ctx* ctx, const KParams& kp, const gpx_mat* L, con
         }
         if ((r = launch_colreduce(ctx, Wsol, ldb, n, mcp, nullptr, (double*)pout, (double*)ppart)) != 0) break;
         if ((r = launch_kdiag(ctx, kp, Zc, mc, (double*)pkd)) != 0) break;
-        if (hipMemcpyAsync(hbuf.data(), pout, (size_t)mc * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipMemcpyAsync(hk.data(), pkd, (size_t)mc * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess) {
-          r = -2;
-          break;
-        }
-        for (int64_t j = 0; j < mc; ++j) var[j0 + j] = hk[(size_t)j] - hbuf[(size_t)j];
+        hipLaunchKernelGGL(vec_diff_kernel, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)pkd,
+                           (const double*)pout, mc, var_dev + j0);
       }
     }
+    if (r == 0 && var_host &&
+        hipMemcpyAsync(var_host, var_dev, (size_t)M * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+      r = -2;
   } while (0);
   (void)hipStreamSynchronize(ctx->stream);
+  if (pvar) gpx_dev_release(ctx, pvar, M * 8);
   gpx_dev_release(ctx, pB, bytesB);
   if (pW) gpx_dev_release(ctx, pW, bytesB);
   gpx_dev_release(ctx, pout, bytes_out);
@@ -1024,10 +1053,17 @@ int gpx_ivar(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const g
   GPX_ARG(X->cols == d && X->pcols == d && Z->cols == d && Z->pcols == d, "point sets must be unpadded (n x d)");
   GPX_ARG(Z->rows > 0, "IVAR needs at least one integration point");
   GPX_TRY(gpx_kparams_sets(ctx, &kp, X, Z));
-  std::vector<double> var((size_t)Z->rows);
-  GPX_TRY(posterior_impl(ctx, kp, L, X, nullptr, Z, nullptr, var.data()));
-  *out = pairwise_mean(var, Z->rows);
-  return 0;
+  void* pv;
+  GPX_TRY(gpx_dev_alloc(ctx, Z->rows * 8, &pv));
+  int r = posterior_impl(ctx, kp, L, X, nullptr, Z, nullptr, nullptr, (double*)pv);
+  if (r == 0) {
+    hipLaunchKernelGGL(pairwise_mean_kernel, dim3(1), dim3(1024), 0, ctx->stream, (double*)pv, Z->rows, ctx->d_scal);
+    if (hipMemcpyAsync(out, ctx->d_scal, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) r = -2;
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  gpx_dev_release(ctx, pv, Z->rows * 8);
+  if (r == -2) gpx_set_error("ivar: HIP copy failed");
+  return r;
 }
 
 // GP fit + IVAR in one call; optionally with the evaluation STREAMED underneath the factorisation (the single-GPU form of
