@@ -148,6 +148,31 @@ def test_2d_loop_under_random_stream_delays(world, n, nb, grid, seed):
 
 
 @pytest.mark.gpu
+def test_bench_c4_full_size_four_ranks_equals_single_gpu():
+    """The headline step at its full size (N = 32768, d = 8, M = 32768) through bench.py exactly as the driver launches it
+    with 4 ranks (2 x 2 grid, streamed evaluation; the ranks share this box's GPU through the host-staged communicator)
+    against the single-GPU run of the same file: log-likelihood and IVAR to 1e-12, one JSON line on stdout each."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    flags = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + flags, env=env, cwd=ROOT, capture_output=True,
+                         text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    ref = json.loads(one.stdout.strip())
+    env.update({"GPX_COMM": "host", "GPX_FORCE_DEVICE": "0", "MASTER_ADDR": "127.0.0.1"})
+    four = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
+                           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"),
+                           "--gpus", "4"] + flags, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert four.returncode == 0, four.stderr[-3000:]
+    lines = [ln for ln in four.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines[:3]
+    got = json.loads(lines[0])
+    assert got["n_gpus"] == 4 and "2x2" in got["config"]["parallelism"]
+    for key in ("loglike", "ivar"):
+        assert got["results"][key] == pytest.approx(ref["results"][key], rel=1e-12)
+
+
+@pytest.mark.gpu
 def test_rccl_2d_world1():
     """RCCL code path of the 2-D loop at world 1: ncclCommSplit sub-communicators, group broadcasts / reductions, the
     grouped send/recv panel broadcast (degenerate: nothing to send) and the all-reduces."""
