@@ -122,10 +122,15 @@ def cpu_baseline(d, full=False):
     measured (the largest measured N), never extrapolated."""
     model, blas, threads = _cpu_info()
     sizes = [2048, 4096] + ([8192] if full else [])
-    runs = [_ref_exact(n, 512, d, seed=n) for n in sizes]
+    runs = []
+    for n in sizes:   # a line per size on stderr: the full protocol runs for minutes, and a silent job looks hung
+        print("bench.py: cpu_baseline: reference algorithm at N=%d ..." % n, file=sys.stderr, flush=True)
+        runs.append(_ref_exact(n, 512, d, seed=n))
+        print("bench.py: cpu_baseline: N=%d took %.1f s" % (n, runs[-1]["total_s"]), file=sys.stderr, flush=True)
     c3 = float(np.sum([r["fit_s"] * r["N"] ** 3 for r in runs]) / np.sum([float(r["N"]) ** 6 for r in runs]))
     civ = float(np.mean([r["ivar_s"] / (r["N"] ** 2 * r["M"]) for r in runs]))
     big = runs[-1]
+    print("bench.py: cpu_baseline: fair-CPU Cholesky at N=%d ..." % (32768 if full else 8192), file=sys.stderr, flush=True)
     fair = _fair_chol(32768 if full else 8192, 32768 if full else 2048, d, seed=32768 if full else 8192)
     return dict(value=(big["N"] + big["M"]) / big["total_s"], unit="points/s", cores=threads, kind="port",
                 sample="reference algorithm (oracle: row-loop fill + pinv + slogdet + per-point variance loop) at N=%s, "
