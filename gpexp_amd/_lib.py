@@ -42,6 +42,7 @@ _SIGS = {
     "gpx_potrs": (C.c_int, [c_vp, c_vp, c_dp, c_dp]),
     "gpx_col_sumsq": (C.c_int, [c_vp, c_vp, c_i64, c_dp]),
     "gpx_dist_ivar_step": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "gpx_dist_ivar_group": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]),
     "gpx_matvec": (C.c_int, [c_vp, c_vp, c_dp, c_dp]),
     "gpx_fitc_fit": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, C.c_double, C.POINTER(c_vp)]),
     "gpx_fitc_free": (C.c_int, [c_vp, c_vp]),
@@ -85,11 +86,17 @@ _SIGS = {
     "gpx_comm_allreduce_host": (C.c_int, [c_vp, c_dp, c_i64]),
     "gpx_comm_panel_bcast": (C.c_int, [c_vp, c_vp, c_ip, c_ip, C.POINTER(C.c_int), C.c_int]),
     "gpx_dist2_diag_elems": (c_i64, [c_i64]),
+    "gpx_dist2_row_stride": (c_i64, [c_i64]),
     "gpx_dist2_kfill": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_dp, c_i64, c_vp, c_i64, C.c_int, C.c_int,
                                   C.c_int, C.c_int]),
     "gpx_dist2_diag_factor": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64]),
     "gpx_dist2_panel_trsm": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64]),
     "gpx_dist2_update": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64]),
+    "gpx_dist2_update_multi": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_i64,
+                                         C.c_int, C.POINTER(c_vp), c_ip, C.c_int]),
+    "gpx_dist2_pack_rows": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64]),
+    "gpx_dist2_pack_diag": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64]),
+    "gpx_program_run": (C.c_int, [c_vp, c_ip, c_i64, c_ip, c_i64, c_dp]),
     "gpx_dist2_unpack_rows": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64]),
     "gpx_dist2_unpack_diag": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64]),
     "gpx_dist2_trsv_diag": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, C.c_int]),

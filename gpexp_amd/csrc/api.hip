@@ -362,11 +362,15 @@ int gpx_create(int device, gpx_ctx** out) {
       if (nx == std::string::npos) break;
       pos = nx + 1;
     }
-    if (words < 2 || hipExtStreamCreateWithCUMask(&c->streams[3], (uint32_t)words, mask.data()) != hipSuccess) {
-      (void)hipGetLastError();
-      int lo = 0, hi = 0;
-      GPX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-      GPX_HIP(hipStreamCreateWithPriority(&c->streams[3], hipStreamNonBlocking, lo));
+    // two streams with that mask: 3 = background (copies into the replicated factor, streamed evaluation), 5 = bulk (the
+    // aggregated trailing updates of the 2-D distributed factorisation: long chip-filling launches beside the diagonal chain)
+    for (int si : {3, 5}) {
+      if (words < 2 || hipExtStreamCreateWithCUMask(&c->streams[si], (uint32_t)words, mask.data()) != hipSuccess) {
+        (void)hipGetLastError();
+        int lo = 0, hi = 0;
+        GPX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        GPX_HIP(hipStreamCreateWithPriority(&c->streams[si], hipStreamNonBlocking, lo));
+      }
     }
   }
   GPX_HIP(hipMalloc((void**)&c->d_info, 256));
@@ -374,6 +378,8 @@ int gpx_create(int device, gpx_ctx** out) {
   GPX_HIP(hipMemset(c->d_info, 0, 256));
   c->trsv_scratch = nullptr;
   c->trsv_scratch_bytes = 0;
+  c->d2_scratch = nullptr;
+  c->d2_scratch_bytes = 0;
   *out = c;
   return 0;
 }
@@ -422,9 +428,10 @@ int gpx_destroy(gpx_ctx* ctx) {
   (void)hipFree(ctx->d_info);
   (void)hipFree(ctx->d_scal);
   if (ctx->trsv_scratch) (void)hipFree(ctx->trsv_scratch);
+  if (ctx->d2_scratch) (void)hipFree(ctx->d2_scratch);
   for (auto ev : ctx->sync_events) (void)hipEventDestroy(ev);
   for (auto ev : ctx->la_events) (void)hipEventDestroy(ev);
-  for (int i = 0; i < 5; ++i) (void)hipStreamDestroy(ctx->streams[i]);
+  for (int i = 0; i < GPX_NSTREAMS; ++i) (void)hipStreamDestroy(ctx->streams[i]);
   for (auto ev : ctx->panel_events) (void)hipEventDestroy(ev);
   delete ctx;
   return 0;
@@ -438,8 +445,9 @@ int gpx_sync(gpx_ctx* ctx) {
 }
 
 int gpx_stream_select(gpx_ctx* ctx, int which) {
-  GPX_ARG(ctx && which >= 0 && which < 5,
-          "stream index must be 0 (main), 1 (panel), 2 (communication), 3 (background, CU-masked) or 4 (evaluation)");
+  GPX_ARG(ctx && which >= 0 && which < GPX_NSTREAMS,
+          "stream index must be 0 (main), 1 (panel), 2 (communication), 3 (background, CU-masked), 4 (evaluation) or 5 (bulk, "
+          "CU-masked)");
   ctx->stream = ctx->streams[which];
   return 0;
 }

@@ -36,15 +36,24 @@ __device__ __forceinline__ double readlane_d(double v, int srclane) {
 }
 
 constexpr int LB = 16;          // block edge
-constexpr int TS17 = LB + 1;    // stride of the T blocks
+constexpr int TS17 = LB + 1;    // row stride inside a 16 x 16 block (odd: conflict-free fragment reads)
+constexpr int BSZ = LB * TS17;  // doubles per stored block
+
+// LDS image of the leaf (round 3): only the 36 blocks on / below the diagonal, block (I, J) at sb_off(I, J), element (r, c)
+// at r * 17 + c -- 78 336 bytes instead of the 149 KB of the full 128 x 129 image + 8 inverse blocks.  That is what lets
+// the leaf START beside a chip-filling GEMM: a GEMM workgroup holds 68 KB of the CU's 160 KB of LDS, so a kernel that needs
+// less than ~90 KB gets a slot whenever ONE GEMM workgroup retires (every microsecond somewhere on the chip), while the old
+// leaf needed a whole CU and waited for the END of the big kernel (scripts/dispatch_check2.hip: 89 KB runs as if alone, 92 KB
+// waits for the end) -- which is why round 2 reserved four CUs per XCD for the diagonal chain.  The diagonal block (p, p)
+// holds A_pp until it is factored; L_pp then goes straight to global memory and the slot is reused for T_p = L_pp^-1.
+__device__ __forceinline__ constexpr int sb_off(int I, int J) { return (I * (I + 1) / 2 + J) * BSZ; }
 
 // one block column K of X = L^-1, entirely in registers; rows of blocks I = K..7
 template <int K>
-__device__ __forceinline__ void leaf_inverse_column(const double* S, const double (*T)[LB * TS17],
-                                                    double* __restrict__ inv, int g, int q) {
+__device__ __forceinline__ void leaf_inverse_column(const double* S, double* __restrict__ inv, int g, int q) {
   d4 xb[8 - K];
 #pragma unroll
-  for (int v = 0; v < 4; ++v) xb[0][v] = T[K][(g + 4 * v) * TS17 + q];
+  for (int v = 0; v < 4; ++v) xb[0][v] = S[sb_off(K, K) + (g + 4 * v) * TS17 + q];
 #pragma unroll
   for (int v = 0; v < 4; ++v) inv[(LB * K + g + 4 * v) * NB + LB * K + q] = xb[0][v];
 #pragma unroll
@@ -54,14 +63,14 @@ __device__ __forceinline__ void leaf_inverse_column(const double* S, const doubl
     for (int J = K; J < I; ++J) {
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
-        const double a = S[(LB * I + q) * LS + LB * J + 4 * s4 + g];
+        const double a = S[sb_off(I, J) + q * TS17 + 4 * s4 + g];
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xb[J - K][s4], acc, 0, 0, 0);
       }
     }
     d4 r = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
-      const double a = -T[I][q * TS17 + 4 * s4 + g];
+      const double a = -S[sb_off(I, I) + q * TS17 + 4 * s4 + g];
       r = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[s4], r, 0, 0, 0);
     }
     xb[I - K] = r;
@@ -96,29 +105,32 @@ __device__ __forceinline__ double row_bcast_n(double v, int n) {  // n is a cons
   }
 }
 
-// (1) of the leaf: factor the 16x16 diagonal block at (c0, c0) of S and invert the factor, one wave, in registers.
-// Lane q of every 16-lane row owns row q of the block and column q of the inverse (the four rows of the wave work
+// (1) of the leaf: factor the 16x16 diagonal block p (LDS block D = S + sb_off(p, p)) and invert the factor, one wave, in
+// registers.  Lane q of every 16-lane row owns row q of the block and column q of the inverse (the four rows of the wave work
 // redundantly); L[c][j] reaches the other lanes through a DPP row broadcast, and one broadcast feeds both the
 // right-looking update of the factor and the forward substitution of the inverse.  sqrt and 1/sqrt of the pivot come from
 // v_rsq_f64 + two coupled Goldschmidt steps + a residual correction: 8 dependent fp64 ops instead of sqrt + division.
+// Column j of L_pp is final after step j: it goes straight to global memory (Ag = the block's first element there, zeros
+// above the diagonal), and row j of the inverse T_p replaces the block in LDS -- every lane has read its row of A_pp into
+// registers before the first store.
 //
 // Pivot policy (piv_min, skip): a pivot <= piv_min is "bad".  skip == 0: it is replaced by 1.0 and its global index is
 // reported (first one wins) -- the caller sees a non-positive-definite matrix.  skip != 0 (the rank-deficient retry of
 // GP._factor): the point is DROPPED -- L_jj = 1, the rest of column j and row j of the inverse are 0, so every solve
 // against the factor returns 0 in that component, exactly as if the point were not in the training set; this is what
 // numpy.linalg.pinv (gp.py:181) makes of an exactly duplicated point.  Dropped pivots are counted in info[1].
-__device__ __forceinline__ void leaf_diag(double* __restrict__ S, double* __restrict__ Tp, int c0, int q, int lane,
+__device__ __forceinline__ void leaf_diag(double* __restrict__ D, double* __restrict__ Ag, int64_t ld, int c0, int q, int lane,
                                           int64_t base_index, int64_t n_valid, int* __restrict__ info, double piv_min,
                                           int skip) {
   double a[LB], sacc[LB];
 #pragma unroll
   for (int c = 0; c < LB; ++c) {
-    a[c] = (c <= q) ? S[(c0 + q) * LS + c0 + c] : 0.0;
+    a[c] = (c <= q) ? D[q * TS17 + c] : 0.0;
     sacc[c] = (c == q) ? 1.0 : 0.0;
   }
   int first_bad = LB;  // first column with a non-positive (or NaN) pivot; wave-uniform
   int nbad = 0;
-  double* const srow = S + (c0 + q) * LS + c0;
+  double* const grow = Ag + (int64_t)q * ld;
 #pragma unroll
   for (int j = 0; j < LB; ++j) {
     double piv = row_bcast_n(a[j], j);
@@ -145,10 +157,10 @@ __device__ __forceinline__ void leaf_diag(double* __restrict__ S, double* __rest
       a[c] = fma(l, naj, a[c]);
       sacc[c] = fma(l, nxj, sacc[c]);
     }
-    // column j of the factor and row j of the inverse are final: to LDS now, their registers are free
+    // column j of the factor and row j of the inverse are final: out now, their registers are free
     if (lane < LB) {
-      srow[j] = (j <= q) ? aj : 0.0;
-      Tp[j * TS17 + q] = xj;
+      grow[j] = (j <= q) ? aj : 0.0;
+      D[j * TS17 + q] = xj;
     }
   }
   if (first_bad < LB && lane == 0 && base_index + c0 + first_bad < n_valid) {
@@ -177,17 +189,17 @@ constexpr int leaf_first_slot(int W, int kmin) {  // first slot of wave W whose 
   return s;
 }
 
-// C(slot) -= B_I B_K^T for slots [S0, S1) of wave W, from the scaled block column at c0; the MFMAs of different slots
+// C(slot) -= B_I B_K^T for slots [S0, S1) of wave W, from the scaled block column P; the MFMAs of different slots
 // interleave (independent accumulators)
-template <int W, int S0, int S1, int NS>
-__device__ __forceinline__ void leaf_update(const double* __restrict__ S, d4 (&blk)[NS], int c0, int g, int q) {
+template <int W, int P, int S0, int S1, int NS>
+__device__ __forceinline__ void leaf_update(const double* __restrict__ S, d4 (&blk)[NS], int g, int q) {
 #pragma unroll
   for (int s4 = 0; s4 < 4; ++s4) {
 #pragma unroll
     for (int s = S0; s < S1; ++s) {
       const LeafBlk bk = leaf_blk(3 * s + (W - 1));
-      const double a = -S[(LB * bk.I + q) * LS + c0 + 4 * s4 + g];
-      const double b = S[(LB * bk.K + q) * LS + c0 + 4 * s4 + g];
+      const double a = -S[sb_off(bk.I, P) + q * TS17 + 4 * s4 + g];
+      const double b = S[sb_off(bk.K, P) + q * TS17 + 4 * s4 + g];
       blk[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, blk[s], 0, 0, 0);
     }
   }
@@ -198,32 +210,32 @@ __device__ __forceinline__ void leaf_update(const double* __restrict__ S, d4 (&b
 template <int W, int P, int NS>
 __device__ __forceinline__ void leaf_update_priority(double* __restrict__ S, d4 (&blk)[NS], int g, int q) {
   constexpr int S0 = leaf_first_slot(W, P + 1), S1 = leaf_first_slot(W, P + 2);
-  leaf_update<W, S0, S1, NS>(S, blk, LB * P, g, q);
+  leaf_update<W, P, S0, S1, NS>(S, blk, g, q);
 #pragma unroll
   for (int s = S0; s < S1; ++s) {  // column P+1 becomes current: back to LDS for the diagonal factor and the scaling
     const LeafBlk bk = leaf_blk(3 * s + (W - 1));
 #pragma unroll
-    for (int v = 0; v < 4; ++v) S[(LB * bk.I + g + 4 * v) * LS + LB * bk.K + q] = blk[s][v];
+    for (int v = 0; v < 4; ++v) S[sb_off(bk.I, bk.K) + (g + 4 * v) * TS17 + q] = blk[s][v];
   }
 }
 template <int W, int P, int NS>
 __device__ __forceinline__ void leaf_update_deferred(const double* __restrict__ S, d4 (&blk)[NS], int g, int q) {
-  leaf_update<W, leaf_first_slot(W, P + 2), NS, NS>(S, blk, LB * P, g, q);
+  leaf_update<W, P, leaf_first_slot(W, P + 2), NS, NS>(S, blk, g, q);
 }
 
 // (2) of a step: the blocks below the diagonal of column p are multiplied by T[p]^T (all four waves)
-__device__ __forceinline__ void leaf_scale(double* __restrict__ S, const double* __restrict__ Tp, int p, int wave, int g,
-                                           int q) {
-  const int c0 = LB * p;
+__device__ __forceinline__ void leaf_scale(double* __restrict__ S, int p, int wave, int g, int q) {
+  const double* Tp = S + sb_off(p, p);
   for (int I = p + 1 + wave; I < 8; I += 4) {
+    double* B = S + sb_off(I, p);
     double af[4];
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) af[s4] = S[(LB * I + q) * LS + c0 + 4 * s4 + g];
+    for (int s4 = 0; s4 < 4; ++s4) af[s4] = B[q * TS17 + 4 * s4 + g];
     d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s4], Tp[q * TS17 + 4 * s4 + g], acc, 0, 0, 0);
 #pragma unroll
-    for (int v = 0; v < 4; ++v) S[(LB * I + g + 4 * v) * LS + c0 + q] = acc[v];
+    for (int v = 0; v < 4; ++v) B[(g + 4 * v) * TS17 + q] = acc[v];
   }
 }
 
@@ -232,21 +244,20 @@ __device__ __forceinline__ void leaf_scale(double* __restrict__ S, const double*
 //   [B] T[p] ready                all: scale the blocks below the diagonal
 //   [C] column p scaled           waves 1..3: PRIORITY part of update p (column p+1 -> LDS)
 template <int W>
-__device__ __forceinline__ void leaf_factor(double* __restrict__ S, double (*T)[LB * TS17], int g, int q, int lane,
-                                            int64_t base_index, int64_t n_valid, int* __restrict__ info) {
+__device__ __forceinline__ void leaf_factor(double* __restrict__ S, int g, int q) {
   constexpr int NS = leaf_nslots(W);
   d4 blk[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const LeafBlk bk = leaf_blk(3 * s + (W - 1));
 #pragma unroll
-    for (int v = 0; v < 4; ++v) blk[s][v] = S[(LB * bk.I + g + 4 * v) * LS + LB * bk.K + q];
+    for (int v = 0; v < 4; ++v) blk[s][v] = S[sb_off(bk.I, bk.K) + (g + 4 * v) * TS17 + q];
   }
 #define GPX_LEAF_STEP(P_)                                                     \
   do {                                                                        \
     if (P_ > 0) leaf_update_deferred<W, (P_ > 0 ? P_ - 1 : 0), NS>(S, blk, g, q); \
     __syncthreads(); /* [B] */                                                \
-    leaf_scale(S, T[P_], P_, W, g, q);                                        \
+    leaf_scale(S, P_, W, g, q);                                               \
     __syncthreads(); /* [C] */                                                \
     if (P_ < 7) leaf_update_priority<W, (P_ < 7 ? P_ : 6), NS>(S, blk, g, q);  \
     __syncthreads(); /* [A] of the next step */                               \
@@ -263,77 +274,84 @@ __device__ __forceinline__ void leaf_factor(double* __restrict__ S, double (*T)[
 }
 
 // wave 0: the diagonal blocks
-__device__ __forceinline__ void leaf_panel_wave(double* __restrict__ S, double (*T)[LB * TS17], int g, int q, int lane,
-                                                int64_t base_index, int64_t n_valid, int* __restrict__ info,
+__device__ __forceinline__ void leaf_panel_wave(double* __restrict__ S, double* __restrict__ A, int64_t ld, int g, int q,
+                                                int lane, int64_t base_index, int64_t n_valid, int* __restrict__ info,
                                                 double piv_min, int skip) {
   for (int p = 0; p < 8; ++p) {
-    leaf_diag(S, T[p], LB * p, q, lane, base_index, n_valid, info, piv_min, skip);
+    leaf_diag(S + sb_off(p, p), A + (int64_t)(LB * p) * ld + LB * p, ld, LB * p, q, lane, base_index, n_valid, info, piv_min, skip);
     __syncthreads();  // [B]
-    leaf_scale(S, T[p], p, 0, g, q);
+    leaf_scale(S, p, 0, g, q);
     __syncthreads();  // [C]
     __syncthreads();  // [A] of the next step
   }
 }
 
-__global__ __launch_bounds__(256) void leaf_kernel(double* __restrict__ A, int64_t ld, double* __restrict__ inv,
+__global__ __launch_bounds__(256, 2) void leaf_kernel(double* __restrict__ A, int64_t ld, double* __restrict__ inv,
                                                    int64_t base_index, int64_t n_valid, int* __restrict__ info,
                                                    double piv_min, int skip) {
-  __shared__ double S[NB * LS];
-  __shared__ double T[8][LB * TS17];
+  __shared__ double S[36 * BSZ];
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int g = lane >> 4, q = lane & 15;
-  // global -> LDS in two batches of 16 loads per thread: two round trips to memory instead of 64
+  // global -> LDS in two batches of 16 loads per thread (two round trips to memory instead of 64); blocks above the diagonal
+  // are neither loaded nor stored
   {
-    const int r0 = t >> 6, c = 2 * (t & 63);
+    const int r0 = t >> 6, c = 2 * (t & 63), J = c >> 4, cc = c & 15;
     const double* ap = A + (int64_t)r0 * ld + c;
-    double* sp = S + r0 * LS + c;
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
       double2 v[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] = *reinterpret_cast<const double2*>(ap + (int64_t)(4 * i) * ld);
+      for (int i = 0; i < 16; ++i) {
+        const int r = 64 * h + r0 + 4 * i;
+        v[i] = double2{0.0, 0.0};
+        if (J <= (r >> 4)) v[i] = *reinterpret_cast<const double2*>(ap + (int64_t)(4 * i) * ld);
+      }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        sp[(4 * i) * LS] = v[i].x;
-        sp[(4 * i) * LS + 1] = v[i].y;
+        const int r = 64 * h + r0 + 4 * i, I = r >> 4;
+        if (J <= I) {
+          double* sp = S + sb_off(I, J) + (r & 15) * TS17 + cc;
+          sp[0] = v[i].x;
+          sp[1] = v[i].y;
+        }
       }
       ap += 64 * ld;
-      sp += 64 * LS;
     }
   }
   __syncthreads();
   switch (wave) {
-    case 0: leaf_panel_wave(S, T, g, q, lane, base_index, n_valid, info, piv_min, skip); break;
-    case 1: leaf_factor<1>(S, T, g, q, lane, base_index, n_valid, info); break;
-    case 2: leaf_factor<2>(S, T, g, q, lane, base_index, n_valid, info); break;
-    default: leaf_factor<3>(S, T, g, q, lane, base_index, n_valid, info); break;
+    case 0: leaf_panel_wave(S, A, ld, g, q, lane, base_index, n_valid, info, piv_min, skip); break;
+    case 1: leaf_factor<1>(S, g, q); break;
+    case 2: leaf_factor<2>(S, g, q); break;
+    default: leaf_factor<3>(S, g, q); break;
   }
-  // write L back (zero above the diagonal) and zero the upper blocks of the inverse; the other blocks are written below
+  // write the off-diagonal blocks of L back (the diagonal blocks went out of leaf_diag), zero above the diagonal blocks, and
+  // zero the upper blocks of the inverse; the other blocks of the inverse are written below
   {
-    const int r0 = t >> 6, c = 2 * (t & 63);
+    const int r0 = t >> 6, c = 2 * (t & 63), J = c >> 4, cc = c & 15;
     double* ap = A + (int64_t)r0 * ld + c;
     double* ip = inv + r0 * NB + c;
-    const double* sp = S + r0 * LS + c;
 #pragma unroll 4
     for (int i = 0; i < 32; ++i) {
-      const int r = r0 + 4 * i;
-      double2 o;
-      o.x = (c <= r) ? sp[0] : 0.0;
-      o.y = (c + 1 <= r) ? sp[1] : 0.0;
-      *reinterpret_cast<double2*>(ap) = o;
-      if ((c >> 4) > (r >> 4)) *reinterpret_cast<double2*>(ip) = double2{0.0, 0.0};
+      const int r = r0 + 4 * i, I = r >> 4;
+      if (J < I) {
+        const double* sp = S + sb_off(I, J) + (r & 15) * TS17 + cc;
+        *reinterpret_cast<double2*>(ap) = double2{sp[0], sp[1]};
+      } else if (J > I) {
+        *reinterpret_cast<double2*>(ap) = double2{0.0, 0.0};
+        *reinterpret_cast<double2*>(ip) = double2{0.0, 0.0};
+      }
       ap += 4 * ld;
       ip += 4 * NB;
-      sp += 4 * LS;
     }
   }
   // inverse: wave w builds block columns w and 7-w (balanced: 140+4 / 108+12 / 80+24 / 56+40 MFMAs)
   switch (wave) {
-    case 0: leaf_inverse_column<0>(S, T, inv, g, q); leaf_inverse_column<7>(S, T, inv, g, q); break;
-    case 1: leaf_inverse_column<1>(S, T, inv, g, q); leaf_inverse_column<6>(S, T, inv, g, q); break;
-    case 2: leaf_inverse_column<2>(S, T, inv, g, q); leaf_inverse_column<5>(S, T, inv, g, q); break;
-    default: leaf_inverse_column<3>(S, T, inv, g, q); leaf_inverse_column<4>(S, T, inv, g, q); break;
+    case 0: leaf_inverse_column<0>(S, inv, g, q); leaf_inverse_column<7>(S, inv, g, q); break;
+    case 1: leaf_inverse_column<1>(S, inv, g, q); leaf_inverse_column<6>(S, inv, g, q); break;
+    case 2: leaf_inverse_column<2>(S, inv, g, q); leaf_inverse_column<5>(S, inv, g, q); break;
+    default: leaf_inverse_column<3>(S, inv, g, q); leaf_inverse_column<4>(S, inv, g, q); break;
   }
 }
 
@@ -341,51 +359,27 @@ __global__ __launch_bounds__(256) void leaf_kernel(double* __restrict__ A, int64
 // The triangular solves against a 128x128 diagonal block are products with its inverse.  As 128x128x128 GEMM tiles they
 // are bound by the serial MFMA chain and eight k-steps of load latency (21 us however few rows there are, 1024 of them in
 // a C4 factorisation).  Here a workgroup owns a strip of ST rows (right) / ST columns (left) over the WHOLE 128-wide
-// leaf -- so the in-place update is race-free by construction --, brings the strip and the block-lower part of the
-// inverse into LDS in ONE round trip, and each wave multiplies the block pair (w, 7-w) of the inverse's block rows, whose
-// k-extents 16(w+1) + 16(8-w) always add up to 144: the zero upper blocks are never multiplied (36/64 of the MFMAs).
-constexpr int kInvRowOff(int cb) { return 16 * (8 * cb * (cb + 1) + cb); }  // doubles before block row cb: 16 rows x (16(b+1)+1)
-constexpr int INV_LDS = kInvRowOff(8);                                      // 9344 doubles (73 KiB)
-
-// inverse (row-major 128x128, ld 128) -> LDS, block row cb stored with row stride 16(cb+1)+1 (odd: conflict-free)
-__device__ __forceinline__ void leaf_stage_inverse(const double* __restrict__ inv, double* __restrict__ Is) {
-  const int t = threadIdx.x;
-  double2 v[32];
+// leaf -- so the in-place update is race-free by construction --, and each wave multiplies the block pair (w, 7-w) of the
+// inverse's block rows, whose k-extents 16(w+1) + 16(8-w) always add up to 144: the zero upper blocks are never
+// multiplied (36/64 of the MFMAs).
+// Round 3: the 36 fragments of the inverse a wave needs go from global memory (L2: every strip reads the same 73 KB) straight
+// into REGISTERS, all in flight at once, instead of through a 73 KB LDS image -- one round trip less, and the kernel's LDS
+// shrinks to the strip (33 / 66 KB): like the leaf it now co-schedules beside resident GEMM workgroups instead of waiting for a
+// whole CU (scripts/dispatch_check2.hip).
+template <int ST, int W>
+__device__ __forceinline__ void leaf_mul_right_wave(double* __restrict__ Xs, double* __restrict__ Xg, int64_t ldx,
+                                                    const double* __restrict__ inv, const double2 (&xv)[ST / 4], int t,
+                                                    int g, int q) {
+  constexpr int CA = W, CB = 7 - W, SA_ = 4 * (CA + 1), SB_ = 4 * (CB + 1), RB = ST / 16, NX = ST / 4;
+  double fa[SA_], fb[SB_];  // B operands: inv[16 cb + q][4 s + g]
+  {
+    const double* ia = inv + (16 * CA + q) * NB + g;
+    const double* ib = inv + (16 * CB + q) * NB + g;
 #pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    const int idx = t + 256 * i, r = idx >> 6, c = 2 * (idx & 63);
-    v[i] = double2{0.0, 0.0};
-    if (c < 16 * ((r >> 4) + 1)) v[i] = *reinterpret_cast<const double2*>(inv + r * NB + c);
-  }
+    for (int s = 0; s < SA_; ++s) fa[s] = ia[4 * s];
 #pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    const int idx = t + 256 * i, r = idx >> 6, c = 2 * (idx & 63);
-    const int cb = r >> 4, len = 16 * (cb + 1);
-    if (c < len) {
-      double* d = Is + 16 * (8 * cb * (cb + 1) + cb) + (r & 15) * (len + 1) + c;
-      d[0] = v[i].x;
-      d[1] = v[i].y;
-    }
+    for (int s = 0; s < SB_; ++s) fb[s] = ib[4 * s];
   }
-}
-
-// X (m x 128, ld ldx) <- X * inv^T.  grid = m / ST workgroups.
-template <int ST>
-__global__ __launch_bounds__(256) void leaf_mul_right_kernel(double* __restrict__ X, int64_t ldx,
-                                                             const double* __restrict__ inv) {
-  extern __shared__ double lsm[];
-  double* Is = lsm;
-  double* Xs = lsm + INV_LDS;  // [ST][129]
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, q = lane & 15;
-  double* Xg = X + (int64_t)blockIdx.x * ST * ldx;
-  constexpr int NX = ST * 64 / 256;  // 16-byte loads per thread for the strip
-  double2 xv[NX];
-#pragma unroll
-  for (int i = 0; i < NX; ++i) {
-    const int idx = t + 256 * i, r = idx >> 6, c = 2 * (idx & 63);
-    xv[i] = *reinterpret_cast<const double2*>(Xg + (int64_t)r * ldx + c);
-  }
-  leaf_stage_inverse(inv, Is);
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
     const int idx = t + 256 * i, r = idx >> 6, c = 2 * (idx & 63);
@@ -393,53 +387,118 @@ __global__ __launch_bounds__(256) void leaf_mul_right_kernel(double* __restrict_
     Xs[r * LS + c + 1] = xv[i].y;
   }
   __syncthreads();  // every read of the strip is done: the stores below cannot race with another workgroup's rows
-  constexpr int RB = ST / 16;
-  const int cbA = wave, cbB = 7 - wave;
-  const int lenA = 16 * (cbA + 1), lenB = 16 * (cbB + 1);
-  const double* ia = Is + 16 * (8 * cbA * (cbA + 1) + cbA) + q * (lenA + 1) + g;  // inv[16cbA + q][4s + g]
-  const double* ib = Is + 16 * (8 * cbB * (cbB + 1) + cbB) + q * (lenB + 1) + g;
   d4 accA[RB], accB[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) accA[rb] = accB[rb] = (d4){0.0, 0.0, 0.0, 0.0};
   const double* xs = Xs + q * LS + g;  // X[16rb + q][4s + g]
   // both column blocks share the strip's A fragments while s is inside the shorter extent
-  const int sA = lenA / 4, sB = lenB / 4;  // sA <= sB (cbA = wave <= 3)
-  for (int s = 0; s < sA; ++s) {
-    const double ba = ia[4 * s], bb = ib[4 * s];
+#pragma unroll
+  for (int s = 0; s < SA_; ++s) {
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
       const double a = xs[(16 * rb) * LS + 4 * s];
-      accA[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, ba, accA[rb], 0, 0, 0);
-      accB[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, accB[rb], 0, 0, 0);
+      accA[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fa[s], accA[rb], 0, 0, 0);
+      accB[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fb[s], accB[rb], 0, 0, 0);
     }
   }
-  for (int s = sA; s < sB; ++s) {
-    const double bb = ib[4 * s];
+#pragma unroll
+  for (int s = SA_; s < SB_; ++s) {
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
-      accB[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(xs[(16 * rb) * LS + 4 * s], bb, accB[rb], 0, 0, 0);
+      accB[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(xs[(16 * rb) * LS + 4 * s], fb[s], accB[rb], 0, 0, 0);
   }
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       double* row = Xg + (int64_t)(16 * rb + g + 4 * v) * ldx + q;
-      row[16 * cbA] = accA[rb][v];
-      row[16 * cbB] = accB[rb][v];
+      row[16 * CA] = accA[rb][v];
+      row[16 * CB] = accB[rb][v];
+    }
+}
+
+// X (m x 128, ld ldx) <- X * inv^T.  grid = m / ST workgroups.
+template <int ST>
+__global__ __launch_bounds__(256, 2) void leaf_mul_right_kernel(double* __restrict__ X, int64_t ldx,
+                                                                const double* __restrict__ inv) {
+  extern __shared__ double lsm[];
+  double* Xs = lsm;  // [ST][129]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, q = lane & 15;
+  double* Xg = X + (int64_t)blockIdx.x * ST * ldx;
+  constexpr int NX = ST / 4;  // 16-byte loads per thread for the strip
+  double2 xv[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int idx = t + 256 * i, r = idx >> 6, c = 2 * (idx & 63);
+    xv[i] = *reinterpret_cast<const double2*>(Xg + (int64_t)r * ldx + c);
+  }
+  switch (wave) {
+    case 0: leaf_mul_right_wave<ST, 0>(Xs, Xg, ldx, inv, xv, t, g, q); break;
+    case 1: leaf_mul_right_wave<ST, 1>(Xs, Xg, ldx, inv, xv, t, g, q); break;
+    case 2: leaf_mul_right_wave<ST, 2>(Xs, Xg, ldx, inv, xv, t, g, q); break;
+    default: leaf_mul_right_wave<ST, 3>(Xs, Xg, ldx, inv, xv, t, g, q); break;
+  }
+}
+
+template <int ST, int W>
+__device__ __forceinline__ void leaf_mul_left_wave(double* __restrict__ Bs, double* __restrict__ Bg, int64_t ldb,
+                                                   const double* __restrict__ inv, const double2 (&bv)[ST / 4], int t, int g,
+                                                   int q) {
+  constexpr int RA = W, RBK = 7 - W, SA_ = 4 * (RA + 1), SB_ = 4 * (RBK + 1), CB = ST / 16, NBV = ST / 4, CPR = ST / 2,
+                SBS = ST + 1;
+  double fa[SA_], fb[SB_];  // A operands: inv[16 rb + q][4 s + g]
+  {
+    const double* ia = inv + (16 * RA + q) * NB + g;
+    const double* ib = inv + (16 * RBK + q) * NB + g;
+#pragma unroll
+    for (int s = 0; s < SA_; ++s) fa[s] = ia[4 * s];
+#pragma unroll
+    for (int s = 0; s < SB_; ++s) fb[s] = ib[4 * s];
+  }
+#pragma unroll
+  for (int i = 0; i < NBV; ++i) {
+    const int idx = t + 256 * i, r = idx / CPR, c = 2 * (idx % CPR);
+    Bs[r * SBS + c] = bv[i].x;
+    Bs[r * SBS + c + 1] = bv[i].y;
+  }
+  __syncthreads();
+  d4 accA[CB], accB[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) accA[cb] = accB[cb] = (d4){0.0, 0.0, 0.0, 0.0};
+  const double* bs = Bs + g * SBS + q;  // B operand: strip[4s + g][16cb + q]
+#pragma unroll
+  for (int s = 0; s < SA_; ++s) {
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      const double b = bs[(4 * s) * SBS + 16 * cb];
+      accA[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[s], b, accA[cb], 0, 0, 0);
+      accB[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[s], b, accB[cb], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int s = SA_; s < SB_; ++s) {
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+      accB[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[s], bs[(4 * s) * SBS + 16 * cb], accB[cb], 0, 0, 0);
+  }
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      Bg[(int64_t)(16 * RA + g + 4 * v) * ldb + 16 * cb + q] = accA[cb][v];
+      Bg[(int64_t)(16 * RBK + g + 4 * v) * ldb + 16 * cb + q] = accB[cb][v];
     }
 }
 
 // B (128 x m, ld ldb) <- inv * B.  grid = m / ST workgroups (ST columns each).
 template <int ST>
-__global__ __launch_bounds__(256) void leaf_mul_left_kernel(double* __restrict__ B, int64_t ldb,
-                                                            const double* __restrict__ inv) {
+__global__ __launch_bounds__(256, 2) void leaf_mul_left_kernel(double* __restrict__ B, int64_t ldb,
+                                                               const double* __restrict__ inv) {
   extern __shared__ double lsm[];
-  double* Is = lsm;
-  double* Bs = lsm + INV_LDS;  // [128][ST + 1]
-  constexpr int SB = ST + 1;
+  double* Bs = lsm;  // [128][ST + 1]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, q = lane & 15;
   double* Bg = B + (int64_t)blockIdx.x * ST;
-  constexpr int NBV = 128 * ST / 2 / 256;  // 16-byte loads per thread for the strip
+  constexpr int NBV = 128 * ST / 2 / 256;  // 16-byte loads per thread for the strip (= ST / 4)
   constexpr int CPR = ST / 2;              // 16-byte chunks per strip row
   double2 bv[NBV];
 #pragma unroll
@@ -447,46 +506,12 @@ __global__ __launch_bounds__(256) void leaf_mul_left_kernel(double* __restrict__
     const int idx = t + 256 * i, r = idx / CPR, c = 2 * (idx % CPR);
     bv[i] = *reinterpret_cast<const double2*>(Bg + (int64_t)r * ldb + c);
   }
-  leaf_stage_inverse(inv, Is);
-#pragma unroll
-  for (int i = 0; i < NBV; ++i) {
-    const int idx = t + 256 * i, r = idx / CPR, c = 2 * (idx % CPR);
-    Bs[r * SB + c] = bv[i].x;
-    Bs[r * SB + c + 1] = bv[i].y;
+  switch (wave) {
+    case 0: leaf_mul_left_wave<ST, 0>(Bs, Bg, ldb, inv, bv, t, g, q); break;
+    case 1: leaf_mul_left_wave<ST, 1>(Bs, Bg, ldb, inv, bv, t, g, q); break;
+    case 2: leaf_mul_left_wave<ST, 2>(Bs, Bg, ldb, inv, bv, t, g, q); break;
+    default: leaf_mul_left_wave<ST, 3>(Bs, Bg, ldb, inv, bv, t, g, q); break;
   }
-  __syncthreads();
-  constexpr int CB = ST / 16;
-  const int rbA = wave, rbB = 7 - wave;
-  const int lenA = 16 * (rbA + 1), lenB = 16 * (rbB + 1);
-  const double* ia = Is + 16 * (8 * rbA * (rbA + 1) + rbA) + q * (lenA + 1) + g;  // A operand: inv[16rb + q][4s + g]
-  const double* ib = Is + 16 * (8 * rbB * (rbB + 1) + rbB) + q * (lenB + 1) + g;
-  d4 accA[CB], accB[CB];
-#pragma unroll
-  for (int cb = 0; cb < CB; ++cb) accA[cb] = accB[cb] = (d4){0.0, 0.0, 0.0, 0.0};
-  const double* bs = Bs + g * SB + q;  // B operand: strip[4s + g][16cb + q]
-  const int sA = lenA / 4, sB = lenB / 4;
-  for (int s = 0; s < sA; ++s) {
-    const double aa = ia[4 * s], ab = ib[4 * s];
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-      const double b = bs[(4 * s) * SB + 16 * cb];
-      accA[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aa, b, accA[cb], 0, 0, 0);
-      accB[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ab, b, accB[cb], 0, 0, 0);
-    }
-  }
-  for (int s = sA; s < sB; ++s) {
-    const double ab = ib[4 * s];
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb)
-      accB[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ab, bs[(4 * s) * SB + 16 * cb], accB[cb], 0, 0, 0);
-  }
-#pragma unroll
-  for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      Bg[(int64_t)(16 * rbA + g + 4 * v) * ldb + 16 * cb + q] = accA[cb][v];
-      Bg[(int64_t)(16 * rbB + g + 4 * v) * ldb + 16 * cb + q] = accB[cb][v];
-    }
 }
 
 // ---- TRSV pieces (potrs) ---------------------------------------------------------------------------
@@ -706,7 +731,7 @@ inline int64_t split(int64_t n) { return (n / NB / 2) * NB; }  // n multiple of 
 
 }  // namespace
 
-// the strips + the staged inverse need more than the default 64 KiB of dynamic LDS
+// the 64-row / 64-column strips need more than the default 64 KiB of dynamic LDS
 template <class K>
 static int leaf_mul_allow_lds(K kernel, size_t bytes) {
   GPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -720,13 +745,13 @@ static int launch_leaf_mul_right(gpx_ctx* ctx, double* X, int64_t ldx, const dou
   // 32-row strips while they fill the chip once, 64-row strips (half the copies of the inverse) beyond that
   if (m <= 32 * (int64_t)ctx->cus) {
     constexpr int ST = 32;
-    const size_t sh = (size_t)(INV_LDS + ST * LS) * sizeof(double);
+    const size_t sh = (size_t)(ST * LS) * sizeof(double);
     static bool once = false;
     if (!once) { GPX_TRY(leaf_mul_allow_lds(leaf_mul_right_kernel<ST>, sh)); once = true; }
     hipLaunchKernelGGL(leaf_mul_right_kernel<ST>, dim3((unsigned)(m / ST)), dim3(256), sh, ctx->stream, X, ldx, inv);
   } else {
     constexpr int ST = 64;
-    const size_t sh = (size_t)(INV_LDS + ST * LS) * sizeof(double);
+    const size_t sh = (size_t)(ST * LS) * sizeof(double);
     static bool once = false;
     if (!once) { GPX_TRY(leaf_mul_allow_lds(leaf_mul_right_kernel<ST>, sh)); once = true; }
     hipLaunchKernelGGL(leaf_mul_right_kernel<ST>, dim3((unsigned)(m / ST)), dim3(256), sh, ctx->stream, X, ldx, inv);
@@ -741,13 +766,13 @@ static int launch_leaf_mul_left(gpx_ctx* ctx, double* B, int64_t ldb, const doub
   ProfScope ps(ctx, GPX_PROF_GEMM, 2.0 * (double)m * NB * NB, 0.0);
   if (m <= 32 * (int64_t)ctx->cus) {
     constexpr int ST = 32;
-    const size_t sh = (size_t)(INV_LDS + NB * (ST + 1)) * sizeof(double);
+    const size_t sh = (size_t)(NB * (ST + 1)) * sizeof(double);
     static bool once = false;
     if (!once) { GPX_TRY(leaf_mul_allow_lds(leaf_mul_left_kernel<ST>, sh)); once = true; }
     hipLaunchKernelGGL(leaf_mul_left_kernel<ST>, dim3((unsigned)(m / ST)), dim3(256), sh, ctx->stream, B, ldb, inv);
   } else {
     constexpr int ST = 64;
-    const size_t sh = (size_t)(INV_LDS + NB * (ST + 1)) * sizeof(double);
+    const size_t sh = (size_t)(NB * (ST + 1)) * sizeof(double);
     static bool once = false;
     if (!once) { GPX_TRY(leaf_mul_allow_lds(leaf_mul_left_kernel<ST>, sh)); once = true; }
     hipLaunchKernelGGL(leaf_mul_left_kernel<ST>, dim3((unsigned)(m / ST)), dim3(256), sh, ctx->stream, B, ldb, inv);
@@ -959,7 +984,19 @@ static int potrf_blocked(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double*
       if (r == -2) gpx_set_error("potrf: look-ahead stream plumbing failed");
       return r;
     }
-    if (rest > 0) {
+    static const int64_t la_mode = env_i64("GPX_POTRF_LA_MODE", 1);
+    if (rest > 0 && la_mode == 1) {
+      // Round 3: the chain's kernels now fit beside resident GEMM workgroups (leaf 78 KB / 240 VGPRs, strip multiplies 33-66
+      // KB; scripts/dispatch_check2.hip), so they get a slot whenever one GEMM workgroup retires -- no reserved CUs, no
+      // masked chunk: the WHOLE remaining update runs on the main stream, all CUs, with the chain of the next diagonal block
+      // underneath it on the high-priority side stream.
+      double* P2 = P + w2 * ld;
+      double* C2 = C + w2 * (ld + 1);
+      t0 = mark(M);
+      GPX_TRY(launch_gemm(ctx, P2, ld, P2, ld, C2, ld, rest, rest, w, true, true, true));
+      spans.push_back({"bulk", j0 / B, t0, mark(M)});
+      GPX_HIP(hipStreamWaitEvent(M, ev_diag, 0));
+    } else if (rest > 0) {
       double* P2 = P + w2 * ld;
       double* C2 = C + w2 * (ld + 1);
       const int64_t top = rest < chunk_rows ? rest : chunk_rows;
@@ -1121,6 +1158,15 @@ static int binv_build_range(gpx_ctx* ctx, const double* Ld, int64_t ld, const do
     GPX_TRY(binv_build_rec(ctx, Ld + nfull * ib * (ld + 1), ld, 0, binv + nfull * ib * ib, ib, 0, tail, tmp, 1, lo, hi));
   GPX_HIP(hipGetLastError());
   return 0;
+}
+
+// inv (w x w, row stride w, zero above the diagonal) = D^-1 for ONE factored diagonal block D (w x w, row stride ldd, leaf
+// inverses at invd): the panel solve of the 2-D distributed factorisation multiplies with it instead of walking the
+// leaf-level recursion (4 strip kernels + 3 short-K products per 512 columns: 56 ms per C4 factorisation on one rank).
+// tmp >= w * w doubles.  Asynchronous on the selected stream.
+int chol_block_inverse(gpx_ctx* ctx, const double* D, int64_t ldd, const double* invd, double* inv, int64_t w, double* tmp) {
+  GPX_ARG(w > 0 && w % NB == 0, "block inverse: order must be a positive multiple of 128");
+  return binv_build_range(ctx, D, ldd, invd, inv, w, w, tmp);
 }
 
 // Linv (n x n, row stride n, zero above the diagonal) = L^-1 for the whole factor, by the same halving recursion: n^3/2

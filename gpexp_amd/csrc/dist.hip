@@ -541,13 +541,30 @@ int gpx_dist_ivar_step(gpx_ctx* ctx, const gpx_mat* K, int64_t k, int64_t nb, gp
   return 0;
 }
 
+// Streamed evaluation, GROUP form: the panels k0 .. k1 of the factor are stored.  With r0 = k0 nb, r1 = min((k1 + 1) nb, np):
+//   B[r0:r1] <- L[r0:r1, r0:r1]^-1 B[r0:r1];   B[r1:, :] -= L[r1:, r0:r1] B[r0:r1]
+// i.e. (k1 - k0 + 1) steps of gpx_dist_ivar_step at once: the update below the group runs with K = r1 - r0 (2048 at nb = 512,
+// four panels) instead of one K = nb product per panel -- the same aggregation as the factorisation's trailing updates.
+int gpx_dist_ivar_group(gpx_ctx* ctx, const gpx_mat* K, int64_t k0, int64_t k1, int64_t nb, gpx_mat* B) {
+  GPX_ARG(ctx && K && B && K->aux, "NULL argument / no stored panel yet");
+  const int64_t np = K->prows, r0 = k0 * nb;
+  GPX_ARG(nb % GPX_TILE == 0 && k0 >= 0 && k1 >= k0 && r0 < np && B->prows == np, "bad panel range / B does not match the factor");
+  const int64_t r1 = (k1 + 1) * nb < np ? (k1 + 1) * nb : np, w = r1 - r0, below = np - r1, mcp = B->pcols;
+  double* Bk = B->p + r0 * B->ld;
+  GPX_TRY(chol_trsm_left(ctx, K->p + r0 * K->ld + r0, K->ld, K->aux + (r0 / GPX_TILE) * GPX_TILE * GPX_TILE, Bk, B->ld, w, mcp));
+  if (below > 0)
+    GPX_TRY(launch_gemm(ctx, K->p + r1 * K->ld + r0, K->ld, Bk, B->ld, B->p + r1 * B->ld, B->ld, below, mcp, w, false, true, false));
+  return 0;
+}
+
 // =====================================================================================================================
 // 2-D block-cyclic distributed Cholesky (north_star).  Process grid Pr x Pc, rank (pr, pc) = (rank / Pc,
 // rank % Pc); global block (I, J) of the padded matrix (block size nb, the last block may be shorter) lives on rank
 // (I % Pr, J % Pc) at local block (I / Pr, J / Pc) of that rank's LOCAL matrix -- each rank allocates only its
 // ~N^2 / (Pr Pc) share.  gpexp_amd/dist.py drives the panel loop; the pieces below are its device primitives.  A panel
 // step k moves data through ONE packed buffer G per rank with Pr "pieces", piece p = what process row p contributes:
-//     [ D: nb x nb factored diagonal block (row stride nb) | nb/128 inverted 128x128 leaves | rows: m_p x nb ]
+//     [ D: nb x nb factored diagonal block (row stride nb) | nb/128 inverted 128x128 leaves | rows: m_p x nb, row stride
+//       gpx_dist2_row_stride(nb) ]
 // where rows = the blocks L_Ik, I > k, I % Pr == p, in ascending I (D is only meaningful in piece k % Pr).
 // =====================================================================================================================
 namespace {
@@ -561,6 +578,65 @@ __global__ __launch_bounds__(256) void copy_cyclic_rows_kernel(const double* __r
   if (c2 >= cols || r >= rows) return;
   const int64_t gr = ((r / nb) * stride + first) * nb + r % nb;
   *reinterpret_cast<double2*>(dst + gr * ldd + c2) = *reinterpret_cast<const double2*>(src + r * lds_ + c2);
+}
+
+// src[((r / nb) * stride + first) * nb + r % nb][c] -> dst[r][c]: the inverse of copy_cyclic_rows_kernel (rows of a
+// full-size factor -> packed piece rows; the single-rank REPLAY of the distributed loop stages "received" pieces with it)
+__global__ __launch_bounds__(256) void gather_cyclic_rows_kernel(const double* __restrict__ src, int64_t lds_,
+                                                                 double* __restrict__ dst, int64_t ldd, int64_t rows,
+                                                                 int64_t cols, int64_t nb, int64_t first, int64_t stride) {
+  const int64_t c2 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+  const int64_t r = blockIdx.y;
+  if (c2 >= cols || r >= rows) return;
+  const int64_t gr = ((r / nb) * stride + first) * nb + r % nb;
+  *reinterpret_cast<double2*>(dst + r * ldd + c2) = *reinterpret_cast<const double2*>(src + gr * lds_ + c2);
+}
+
+// acc[c] -= sum_r A[r][c] x[r] over an m x w block (row stride ld), m a multiple of 4: a workgroup owns 128 columns (64
+// column pairs x 4 row groups), every row group walks its quarter of the rows with coalesced 16-byte loads, the four
+// partial sums meet in LDS in a fixed order -- deterministic, no scratch, no host synchronisation (the column reduction
+// this replaces allocated its partial sums from the pool and synchronised the stream on every block of the back
+// substitution: 64 host round trips per solve at C4)
+__global__ __launch_bounds__(256) void gemv_t_sub_kernel(const double* __restrict__ A, int64_t ld, int64_t m, int64_t w,
+                                                         const double* __restrict__ x, double* __restrict__ acc) {
+  __shared__ double2 part[4][64];
+  const int cp = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 128 + 2 * cp;
+  const int64_t rows_per = (m + 3) / 4, r0 = rg * rows_per, r1 = (r0 + rows_per) < m ? (r0 + rows_per) : m;
+  double s0 = 0.0, s1 = 0.0;
+  if (c < w) {
+    const double* ap = A + r0 * ld + c;
+    int64_t r = r0;
+    for (; r + 8 <= r1; r += 8) {
+      double2 v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const double2*>(ap + (int64_t)i * ld);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const double xv = x[r + i];
+        s0 = fma(v[i].x, xv, s0);
+        s1 = fma(v[i].y, xv, s1);
+      }
+      ap += 8 * ld;
+    }
+    for (; r < r1; ++r) {
+      const double2 v = *reinterpret_cast<const double2*>(ap);
+      const double xv = x[r];
+      s0 = fma(v.x, xv, s0);
+      s1 = fma(v.y, xv, s1);
+      ap += ld;
+    }
+  }
+  part[rg][cp] = double2{s0, s1};
+  __syncthreads();
+  if (rg == 0 && c < w) {
+    const double t0 = (part[0][cp].x + part[1][cp].x) + (part[2][cp].x + part[3][cp].x);
+    const double t1 = (part[0][cp].y + part[1][cp].y) + (part[2][cp].y + part[3][cp].y);
+    double2 a = *reinterpret_cast<double2*>(acc + c);
+    a.x -= t0;
+    a.y -= t1;
+    *reinterpret_cast<double2*>(acc + c) = a;
+  }
 }
 
 // out[0] += 2 * sum_i log(L[i][i]) over a w x w diagonal block (deterministic: one workgroup, fixed tree)
@@ -588,6 +664,8 @@ static int check_local(const gpx_mat* A, int64_t lr, int64_t m, int64_t lc, int6
 }
 
 int64_t gpx_dist2_diag_elems(int64_t nb) { return nb * nb + (nb / GPX_TILE) * GPX_TILE * GPX_TILE; }
+// row stride (doubles) of the rows region of a packed piece (see gpx_g_ld); the host side checks its constant against it
+int64_t gpx_dist2_row_stride(int64_t nb) { return gpx_g_ld(nb); }
 
 // assemble the local part of K(X) + nugget on rank (pr, pc): A is the local (rows_local x cols_local) matrix
 int gpx_dist2_kfill(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* X, const double* nugget,
@@ -648,19 +726,46 @@ int gpx_dist2_diag_factor(gpx_ctx* ctx, gpx_mat* A, int64_t lr, int64_t lc, int6
   return 0;
 }
 
-// holders of block column k (ranks with pc == k % Pc): X = A[lr0 : lr0+m, lc : lc+w] <- X L_kk^-T in place (L_kk and its
-// leaf inverses from the D region at doff), then packed (row stride nb) into G at roff.  Asynchronous.
+// holders of block column k (ranks with pc == k % Pc): X = A[lr0 : lr0+m, lc : lc+w] <- X L_kk^-T (L_kk and its leaf
+// inverses from the D region at doff), packed (row stride nb) into G at roff AND kept in A.  Asynchronous.
+// Tall pieces (m >= GPX_DIST2_INV_MIN rows, default 2 nb) multiply with the EXPLICIT inverse of L_kk -- built here from the
+// leaf inverses by four batched MFMA products (every holder builds its own copy: nothing more to broadcast, and it is off the
+// diagonal chain, which solves its one early block through the leaves) -- as one triangular-operand GEMM straight into the
+// packed buffer; the leaf-level recursion (4 strip kernels + 3 short-K products per 512 columns) cost 56 ms per C4
+// factorisation on one rank against 190 ms for everything else (profiles/r03_dist_w1_before.txt).  The inverse lives in a
+// context-owned scratch: calls must be issued in order on ONE stream (the PANEL stream of the panel loop).
 int gpx_dist2_panel_trsm(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t lc, int64_t w, gpx_mat* G, int64_t doff,
                          int64_t roff, int64_t nb) {
   GPX_ARG(ctx && G, "NULL argument");
   GPX_TRY(check_local(A, lr0, m, lc, w));
+  const int64_t gld = gpx_g_ld(nb);
   GPX_ARG(w <= nb && doff >= 0 && roff >= 0 && (doff + gpx_dist2_diag_elems(nb)) * 8 <= G->bytes &&
-              (roff + m * nb) * 8 <= G->bytes, "region outside G");
+              (roff + m * gld) * 8 <= G->bytes, "region outside G");
   if (m == 0) return 0;
   const double* D = G->p + doff;
   double* X = A->p + lr0 * A->ld + lc;
+  static int64_t inv_min = -1;
+  if (inv_min < 0) {
+    const char* e = getenv("GPX_DIST2_INV_MIN");  // rows from which the explicit inverse is used, in units of nb; 0 = never
+    inv_min = e ? atoll(e) : 2;
+  }
+  if (inv_min > 0 && m >= inv_min * nb && w == nb && w > GPX_TILE) {
+    const int64_t need = 2 * nb * nb * 8;
+    if (ctx->d2_scratch_bytes < need) {
+      GPX_HIP(hipDeviceSynchronize());
+      if (ctx->d2_scratch) (void)hipFree(ctx->d2_scratch);
+      ctx->d2_scratch = nullptr;
+      ctx->d2_scratch_bytes = 0;
+      GPX_HIP(hipMalloc((void**)&ctx->d2_scratch, (size_t)need));
+      ctx->d2_scratch_bytes = need;
+    }
+    double* inv = ctx->d2_scratch;
+    GPX_TRY(chol_block_inverse(ctx, D, nb, D + nb * nb, inv, w, inv + nb * nb));
+    GPX_TRY(launch_gemm_tri(ctx, X, A->ld, inv, w, G->p + roff, gld, m, w, w, true, false, false, 2));
+    return gpx_copy2d(ctx, G->p + roff, gld, X, A->ld, m, w);
+  }
   GPX_TRY(chol_trsm_right(ctx, D, nb, D + nb * nb, X, A->ld, m, w));
-  return gpx_copy2d(ctx, X, A->ld, G->p + roff, nb, m, w);
+  return gpx_copy2d(ctx, X, A->ld, G->p + roff, gld, m, w);
 }
 
 // A[lr0 : lr0+m, lc0 : lc0+n] -= G[aoff](m x w, stride nb) * G[boff](n x w, stride nb)^T   (trailing update of one local
@@ -669,10 +774,76 @@ int gpx_dist2_update(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t l
                      int64_t aoff, int64_t boff, int64_t w, int64_t nb) {
   GPX_ARG(ctx && G, "NULL argument");
   GPX_TRY(check_local(A, lr0, m, lc0, n));
-  GPX_ARG(w > 0 && w <= nb && w % 16 == 0 && aoff >= 0 && boff >= 0 && (aoff + m * nb) * 8 <= G->bytes &&
-              (boff + n * nb) * 8 <= G->bytes, "operand outside G");
+  const int64_t gld = gpx_g_ld(nb);
+  GPX_ARG(w > 0 && w <= nb && w % 16 == 0 && aoff >= 0 && boff >= 0 && (aoff + m * gld) * 8 <= G->bytes &&
+              (boff + n * gld) * 8 <= G->bytes, "operand outside G");
   if (m == 0 || n == 0) return 0;
-  return launch_gemm(ctx, G->p + aoff, nb, G->p + boff, nb, A->p + lr0 * A->ld + lc0, A->ld, m, n, w, true, true, false);
+  return launch_gemm(ctx, G->p + aoff, gld, G->p + boff, gld, A->p + lr0 * A->ld + lc0, A->ld, m, n, w, true, true, false);
+}
+
+// A[lr0 : lr0+m, lc0 : lc0+n] -= the contributions of nseg panels at once, for the local blocks on / below (below_diag != 0:
+// strictly below) the global diagonal: panel ks[s] sits in the packed buffer G[s] (piece layout above; piece_stride doubles per
+// piece).  One launch over the whole local trailing matrix with K = nseg * nb -- see dist2_update_kernel (gemm_f64.hip).
+int gpx_dist2_update_multi(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t lc0, int64_t n, int64_t nb, int Pr, int Pc,
+                           int pr, int pc, int64_t piece_stride, int nseg, const gpx_mat* const* G, const int64_t* ks,
+                           int below_diag) {
+  GPX_ARG(ctx && G && ks, "NULL argument");
+  GPX_TRY(check_local(A, lr0, m, lc0, n));
+  GPX_ARG(nb > 0 && nb % GPX_TILE == 0 && Pr >= 1 && Pr <= GPX_MAX_PR && Pc >= 1 && pr >= 0 && pr < Pr && pc >= 0 && pc < Pc &&
+              nseg >= 0 && nseg <= GPX_SEG_MAX, "bad grid / segment count");
+  GPX_ARG(lr0 % nb == 0 && lc0 % nb == 0, "the updated block must start on a block boundary");
+  if (m == 0 || n == 0 || nseg == 0) return 0;
+  const int64_t dsz = gpx_dist2_diag_elems(nb);
+  GPX_ARG(piece_stride >= dsz, "piece stride smaller than a diagonal region");
+  const double* g[GPX_SEG_MAX];
+  const int64_t li_first = lr0 / nb, li_last = (lr0 + m - 1) / nb, lj_first = lc0 / nb, lj_last = (lc0 + n - 1) / nb;
+  for (int s = 0; s < nseg; ++s) {
+    GPX_ARG(G[s] != nullptr && ks[s] >= 0, "NULL panel buffer / negative panel index");
+    GPX_ARG(Pr * piece_stride * 8 <= G[s]->bytes, "panel buffer smaller than Pr pieces");
+    g[s] = G[s]->p;
+    // every operand row must lie inside its piece: rows of local block li are block (li - li0(pr, k)) of piece pr, rows of
+    // global block J are block (J / Pr - li0(J % Pr, k)) of piece J % Pr, li0(p, k) = #{I' <= k : I' % Pr == p}
+    auto li0 = [&](int64_t p) { return ks[s] + 1 <= p ? (int64_t)0 : (ks[s] - p) / Pr + 1; };
+    GPX_ARG(li_first * Pr + pr > ks[s] && lj_first * Pc + pc > ks[s], "update touches blocks that are not behind the panel");
+    GPX_ARG(dsz + ((li_last - li0(pr)) * nb + (lr0 + m - li_last * nb)) * gpx_g_ld(nb) <= piece_stride, "A rows beyond the piece");
+    for (int64_t lj = lj_first; lj <= lj_last; ++lj) {
+      const int64_t J = lj * Pc + pc, p = J % Pr;
+      const int64_t cw = (lc0 + n - lj * nb) < nb ? (lc0 + n - lj * nb) : nb;
+      GPX_ARG(J / Pr >= li0(p) && dsz + ((J / Pr - li0(p)) * nb + cw) * gpx_g_ld(nb) <= piece_stride, "B rows beyond the piece");
+    }
+  }
+  return launch_dist2_update(ctx, A->p, A->ld, lr0, m, lc0, n, nb, Pr, Pc, pr, pc, piece_stride, dsz, nseg, g, ks, below_diag);
+}
+
+// single-rank REPLAY of the distributed loop (gpexp_amd/dist.py ReplayComm): what a collective would have delivered is
+// copied -- same byte count, device to device -- out of a complete factor L that is resident on this GPU.
+// rows: the inverse of gpx_dist2_unpack_rows; diag: the inverse of gpx_dist2_unpack_diag (block + its leaf inverses)
+int gpx_dist2_pack_rows(gpx_ctx* ctx, const gpx_mat* L, int64_t first_block, int64_t stride, int64_t col0, gpx_mat* G,
+                        int64_t roff, int64_t m, int64_t w, int64_t nb) {
+  GPX_ARG(ctx && G && L, "NULL argument");
+  const int64_t gld = gpx_g_ld(nb);
+  GPX_ARG(roff >= 0 && m >= 0 && (roff + m * gld) * 8 <= G->bytes && w % 2 == 0 && col0 + w <= L->pcols, "bad piece");
+  if (m == 0) return 0;
+  const int64_t last = ((m - 1) / nb * stride + first_block) * nb + (m - 1) % nb;
+  GPX_ARG(last < L->prows, "piece rows fall outside the factor");
+  for (int64_t r0 = 0; r0 < m; r0 += 65535 / nb * nb) {
+    int64_t rr = m - r0;
+    if (rr > 65535 / nb * nb) rr = 65535 / nb * nb;
+    dim3 grid((unsigned)((w / 2 + 255) / 256), (unsigned)rr);
+    hipLaunchKernelGGL(gather_cyclic_rows_kernel, grid, dim3(256), 0, ctx->stream, L->p + col0, L->ld, G->p + roff + r0 * gld, gld,
+                       rr, w, nb, first_block + (r0 / nb) * stride, stride);
+  }
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
+
+int gpx_dist2_pack_diag(gpx_ctx* ctx, const gpx_mat* L, int64_t r0, int64_t w, int64_t nb, gpx_mat* G, int64_t doff) {
+  GPX_ARG(ctx && G && L && L->aux, "NULL argument / factor without leaf inverses");
+  GPX_ARG(doff >= 0 && (doff + gpx_dist2_diag_elems(nb)) * 8 <= G->bytes && r0 + w <= L->prows && w <= nb, "bad D region");
+  GPX_TRY(gpx_copy2d(ctx, L->p + r0 * L->ld + r0, L->ld, G->p + doff, nb, w, w));
+  GPX_HIP(hipMemcpyAsync(G->p + doff + nb * nb, L->aux + (r0 / GPX_TILE) * GPX_TILE * GPX_TILE,
+                         (size_t)((w / GPX_TILE) * GPX_TILE * GPX_TILE * 8), hipMemcpyDeviceToDevice, ctx->stream));
+  return 0;
 }
 
 // replicated factor: the m x w rows of a piece (blocks first, first+stride, ... in ascending order) -> rows of block
@@ -680,7 +851,8 @@ int gpx_dist2_update(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t l
 int gpx_dist2_unpack_rows(gpx_ctx* ctx, const gpx_mat* G, int64_t roff, int64_t m, int64_t w, int64_t nb, gpx_mat* L,
                           int64_t first_block, int64_t stride, int64_t col0) {
   GPX_ARG(ctx && G && L, "NULL argument");
-  GPX_ARG(roff >= 0 && m >= 0 && (roff + m * nb) * 8 <= G->bytes && w % 2 == 0 && col0 + w <= L->pcols, "bad piece");
+  const int64_t gld = gpx_g_ld(nb);
+  GPX_ARG(roff >= 0 && m >= 0 && (roff + m * gld) * 8 <= G->bytes && w % 2 == 0 && col0 + w <= L->pcols, "bad piece");
   if (m == 0) return 0;
   const int64_t last = ((m - 1) / nb * stride + first_block) * nb + (m - 1) % nb;
   GPX_ARG(last < L->prows, "piece rows fall outside the replicated factor");
@@ -688,7 +860,7 @@ int gpx_dist2_unpack_rows(gpx_ctx* ctx, const gpx_mat* G, int64_t roff, int64_t 
     int64_t rr = m - r0;
     if (rr > 65535 / nb * nb) rr = 65535 / nb * nb;
     dim3 grid((unsigned)((w / 2 + 255) / 256), (unsigned)rr);
-    hipLaunchKernelGGL(copy_cyclic_rows_kernel, grid, dim3(256), 0, ctx->stream, G->p + roff + r0 * nb, nb,
+    hipLaunchKernelGGL(copy_cyclic_rows_kernel, grid, dim3(256), 0, ctx->stream, G->p + roff + r0 * gld, gld,
                        L->p + col0, L->ld, rr, w, nb, first_block + (r0 / nb) * stride, stride);
   }
   GPX_HIP(hipGetLastError());
@@ -744,14 +916,13 @@ int gpx_dist2_gemv(gpx_ctx* ctx, const gpx_mat* A, int64_t lr0, int64_t m, int64
     GPX_ARG((xoff + w) * 8 <= x->bytes && (aoff + m) * 8 <= acc->bytes && xoff % 2 == 0, "vector segment out of range");
     return launch_gemv_sub(ctx, Ab, A->ld, m, w, x->p + xoff, acc->p + aoff);
   }
-  GPX_ARG((xoff + m) * 8 <= x->bytes && (aoff + w) * 8 <= acc->bytes, "vector segment out of range");
-  const int64_t pe = colreduce_partial_elems(m, w);
-  void* pp;
-  GPX_TRY(gpx_dev_alloc(ctx, pe * 8 + 8, &pp));
-  int r = launch_colreduce(ctx, Ab, A->ld, m, w, x->p + xoff, acc->p + aoff, (double*)pp, 1);
-  (void)hipStreamSynchronize(ctx->stream);  // the partials go back to the pool
-  gpx_dev_release(ctx, pp, pe * 8 + 8);
-  return r;
+  GPX_ARG((xoff + m) * 8 <= x->bytes && (aoff + w) * 8 <= acc->bytes && aoff % 2 == 0 && A->ld % 2 == 0,
+          "vector segment out of range / misaligned");
+  ProfScope ps(ctx, GPX_PROF_TRSV, 2.0 * (double)m * w, 8.0 * (double)m * w);
+  hipLaunchKernelGGL(gemv_t_sub_kernel, dim3((unsigned)((w + 127) / 128)), dim3(256), 0, ctx->stream, Ab, A->ld, m, w,
+                     x->p + xoff, acc->p + aoff);
+  GPX_HIP(hipGetLastError());
+  return 0;
 }
 
 // acc += 2 sum log diag of the w x w block at local (lr, lc); acc is a device scalar (>= 1 double), zero it first
@@ -769,6 +940,99 @@ int gpx_dist_finish(gpx_ctx* ctx, gpx_mat* K) {
   GPX_HIP(hipStreamSynchronize(ctx->stream));
   K->binv_ib = 0;  // block inverses (chol_potrs) belong to the previous contents
   K->factored = 1;
+  return 0;
+}
+
+}  // extern "C"
+
+// =====================================================================================================================
+// Recorded programs.  The panel loop of the 2-D factorisation is Python on purpose (gpexp_amd/dist.py: the same loop drives
+// the NumPy device double of the CPU tests), but its ~60 C-ABI calls per step cost more host time than an 8-rank step leaves
+// (0.45 ms of GPU work per step at C4).  The loop is therefore RUN ONCE against a recorder, which turns every primitive and
+// collective into a row of 16 int64 -- [opcode, handle0..2, a0..a11] -- and the rows are replayed here, natively, on every
+// step: no Python, no ctypes marshalling, identical call sequence.  Variable-length arguments (piece lists, segment lists) live
+// in the `extra` pool and are referenced by offset.  The direct (unrecorded) mode of the Python side executes the very same
+// rows one at a time, so there is one dispatch table, not two.
+// =====================================================================================================================
+#include <chrono>
+
+extern "C" {
+
+int gpx_program_run(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const int64_t* extra, int64_t nextra, double* host_ms) {
+  GPX_ARG(ctx && (ops || nops == 0) && nops >= 0 && nextra >= 0, "bad program");
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int64_t i = 0; i < nops; ++i) {
+    const int64_t* o = ops + 16 * i;
+    gpx_mat* h0 = reinterpret_cast<gpx_mat*>((uintptr_t)o[1]);
+    gpx_mat* h1 = reinterpret_cast<gpx_mat*>((uintptr_t)o[2]);
+    gpx_mat* h2 = reinterpret_cast<gpx_mat*>((uintptr_t)o[3]);
+    const int64_t* a = o + 4;
+    int r = 0;
+    switch ((int)o[0]) {
+      case GPX_OP_STREAM: r = gpx_stream_select(ctx, (int)a[0]); break;
+      case GPX_OP_RECORD: r = gpx_event_record(ctx, (int)a[0]); break;
+      case GPX_OP_WAIT: r = gpx_event_wait(ctx, (int)a[0]); break;
+      case GPX_OP_BEGIN: r = gpx_dist_begin(ctx); break;
+      case GPX_OP_DIAG_FACTOR: r = gpx_dist2_diag_factor(ctx, h0, a[0], a[1], a[2], h1, a[3], a[4], a[5], a[6]); break;
+      case GPX_OP_PANEL_TRSM: r = gpx_dist2_panel_trsm(ctx, h0, a[0], a[1], a[2], a[3], h1, a[4], a[5], a[6]); break;
+      case GPX_OP_UPDATE: r = gpx_dist2_update(ctx, h0, a[0], a[1], a[2], a[3], h1, a[4], a[5], a[6], a[7]); break;
+      case GPX_OP_UPDATE_MULTI: {
+        // a: lr0, m, lc0, n, nb, Pr, Pc, pr, pc, piece_stride, nseg | below_diag << 8, extra offset of [G handles..., ks...]
+        const int nseg = (int)(a[10] & 0xff), below = (int)(a[10] >> 8);
+        if (nseg < 0 || nseg > GPX_SEG_MAX || a[11] < 0 || a[11] + 2 * nseg > nextra) {
+          gpx_set_error("program op %lld: segment list outside the extra pool", (long long)i);
+          return -1;
+        }
+        const gpx_mat* G[GPX_SEG_MAX];
+        for (int s = 0; s < nseg; ++s) G[s] = reinterpret_cast<const gpx_mat*>((uintptr_t)extra[a[11] + s]);
+        r = gpx_dist2_update_multi(ctx, h0, a[0], a[1], a[2], a[3], a[4], (int)a[5], (int)a[6], (int)a[7], (int)a[8], a[9], nseg,
+                                   G, extra + a[11] + nseg, below);
+        break;
+      }
+      case GPX_OP_UNPACK_ROWS: r = gpx_dist2_unpack_rows(ctx, h0, a[0], a[1], a[2], a[3], h1, a[4], a[5], a[6]); break;
+      case GPX_OP_UNPACK_DIAG: r = gpx_dist2_unpack_diag(ctx, h0, a[0], a[1], a[2], h1, a[3]); break;
+      case GPX_OP_PACK_ROWS: r = gpx_dist2_pack_rows(ctx, h0, a[0], a[1], a[2], h1, a[3], a[4], a[5], a[6]); break;
+      case GPX_OP_PACK_DIAG: r = gpx_dist2_pack_diag(ctx, h0, a[0], a[1], a[2], h1, a[3]); break;
+      case GPX_OP_BCAST_GRP: r = gpx_comm_bcast_grp(ctx, h0, a[0], a[1], (int)a[2], (int)a[3]); break;
+      case GPX_OP_REDUCE_GRP: r = gpx_comm_reduce_grp(ctx, h0, a[0], a[1], (int)a[2], (int)a[3]); break;
+      case GPX_OP_ALLREDUCE: r = gpx_comm_allreduce(ctx, h0, a[0], a[1]); break;
+      case GPX_OP_PANEL_BCAST: {
+        // a: npieces, extra offset of [offsets..., counts..., roots...]
+        const int64_t np_ = a[0];
+        if (np_ < 0 || np_ > 64 || a[1] < 0 || a[1] + 3 * np_ > nextra) {
+          gpx_set_error("program op %lld: piece list outside the extra pool", (long long)i);
+          return -1;
+        }
+        int roots[64];
+        for (int64_t q = 0; q < np_; ++q) roots[q] = (int)extra[a[1] + 2 * np_ + q];
+        r = gpx_comm_panel_bcast(ctx, h0, extra + a[1], extra + a[1] + np_, roots, (int)np_);
+        break;
+      }
+      case GPX_OP_IVAR_STEP: r = gpx_dist_ivar_step(ctx, h0, a[0], a[1], h1); break;
+      case GPX_OP_IVAR_GROUP: r = gpx_dist_ivar_group(ctx, h0, a[0], a[1], a[2], h1); break;
+      case GPX_OP_TRSV_DIAG: r = gpx_dist2_trsv_diag(ctx, h0, a[0], a[1], a[2], h1, a[3], (int)a[4]); break;
+      case GPX_OP_GEMV: r = gpx_dist2_gemv(ctx, h0, a[0], a[1], a[2], a[3], h1, a[4], h2, a[5], (int)a[6]); break;
+      case GPX_OP_LOGDET_ACC: r = gpx_dist2_logdet_acc(ctx, h0, a[0], a[1], a[2], a[3], h1); break;
+      case GPX_OP_VEC_OP: r = gpx_vec_op(ctx, h0, a[0], h1, a[1], a[2], (int)a[3]); break;
+      case GPX_OP_SPIN: r = gpx_dbg_spin(ctx, (int)a[0]); break;
+      case GPX_OP_COPY: {  // h0[a0 : a0+a2] <- h1[a1 : a1+a2], device to device (replay stand-in for a point-to-point transfer)
+        if (!h0 || !h1 || a[0] < 0 || a[1] < 0 || a[2] < 0 || (a[0] + a[2]) * 8 > h0->bytes || (a[1] + a[2]) * 8 > h1->bytes) {
+          gpx_set_error("program op %lld: copy outside its buffers", (long long)i);
+          return -1;
+        }
+        if (a[2] > 0 && hipMemcpyAsync(h0->p + a[0], h1->p + a[1], (size_t)a[2] * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+          gpx_set_error("program op %lld: hipMemcpyAsync failed", (long long)i);
+          return -2;
+        }
+        break;
+      }
+      default:
+        gpx_set_error("program op %lld: unknown opcode %lld", (long long)i, (long long)o[0]);
+        return -1;
+    }
+    if (r != 0) return r;
+  }
+  if (host_ms) *host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return 0;
 }
 

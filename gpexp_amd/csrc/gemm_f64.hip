@@ -75,10 +75,19 @@ __device__ __forceinline__ bool tile_of(int sblk, int within, int tiles_m, int t
   return true;
 }
 
+// SEGMENTED k range (SEGF::on): the k range is a concatenation of nseg segments of seg_nk k-steps each, segment s with its
+// own operand base pointers segf.a(s) / segf.b(s) (the tile's first row of each operand; uniform scalars).  This is how the
+// distributed factorisation applies several received panels -- which live in separate packed buffers -- in ONE pass over C
+// (K = nseg * nb instead of nb: the C read-modify-write and the tile prologue / epilogue are paid once, not per panel).
+// The dense instantiations (NoSeg) compile to exactly the code they had before: every use is behind `if constexpr`.
+struct NoSeg {
+  static constexpr bool on = false;
+};
+
 // (Variants measured and dropped: a 2-deep register prefetch; reading only two k-substeps' fragments at a time.)
-template <bool BT, bool ACC, int TE>
+template <bool BT, bool ACC, int TE, class SEGF = NoSeg>
 __device__ __forceinline__ void gemm_tile(Smem<BT, TE>& sm, const double* A, int64_t lda, const double* B, int64_t ldb,
-                                          double* C, int64_t ldc, int nk, int by, int bx) {
+                                          double* C, int64_t ldc, int nk, int by, int bx, const SEGF& segf = SEGF()) {
   constexpr int SBN = TE + 16;     // row stride of the [k][n] image
   constexpr int FI = TE / 32;      // MFMA tiles per wave and dimension
   constexpr int NL = TE / 32;      // 16-byte staging loads per thread and operand
@@ -108,11 +117,36 @@ __device__ __forceinline__ void gemm_tile(Smem<BT, TE>& sm, const double* A, int
   // array form compiles to a measurably slower NN loop (IVAR 551 vs 534 ms at C4) -- hipcc scheduling lottery.
   double2 Pa0, Pa1, Pa2, Pa3, Pb0, Pb1, Pb2, Pb3;
   const int64_t b_rs2 = 2 * b_rs, b_rs3 = 3 * b_rs, a_rs2 = 2 * a_rs, a_rs3 = 3 * a_rs;
+  // segmented mode: running pointers to the NEXT k-step to load (advanced right after every load is issued)
+  const char* seg_ap = nullptr;
+  const char* seg_bp = nullptr;
+  int seg_k = 0, seg_s = 0;
+  if constexpr (SEGF::on) {
+    seg_ap = reinterpret_cast<const char*>(segf.a(0));
+    seg_bp = reinterpret_cast<const char*>(segf.b(0));
+  }
 #define GPX_LD16(base_, voff_) (*reinterpret_cast<const double2*>((base_) + (voff_)))
 #define GPX_GLOAD(S_, kt_)                                                                            \
   do {                                                                                                \
-    const char* ap_ = Abase + (int64_t)(kt_) * a_ks;                                                  \
-    const char* bp_ = Bbase + (int64_t)(kt_) * b_ks;                                                  \
+    const char* ap_;                                                                                  \
+    const char* bp_;                                                                                  \
+    if constexpr (SEGF::on) {                                                                         \
+      ap_ = seg_ap;                                                                                   \
+      bp_ = seg_bp;                                                                                   \
+      if (++seg_k == segf.seg_nk) {                                                                   \
+        seg_k = 0;                                                                                    \
+        if (++seg_s < segf.nseg) {                                                                    \
+          seg_ap = reinterpret_cast<const char*>(segf.a(seg_s));                                      \
+          seg_bp = reinterpret_cast<const char*>(segf.b(seg_s));                                      \
+        }                                                                                             \
+      } else {                                                                                        \
+        seg_ap += a_ks;                                                                               \
+        seg_bp += b_ks;                                                                               \
+      }                                                                                               \
+    } else {                                                                                          \
+      ap_ = Abase + (int64_t)(kt_) * a_ks;                                                            \
+      bp_ = Bbase + (int64_t)(kt_) * b_ks;                                                            \
+    }                                                                                                 \
     S_##a0 = GPX_LD16(ap_, voff_a);                                                                    \
     S_##a1 = GPX_LD16(ap_ + a_rs, voff_a);                                                             \
     if (NL == 4) {                                                                                    \
@@ -193,6 +227,17 @@ __device__ __forceinline__ void gemm_tile(Smem<BT, TE>& sm, const double* A, int
     // memory operations cannot cross this, and it consumes the accumulator every k-substep updates last: the LDS store
     // and the barrier stay behind the third substep's MFMAs, the fourth substep stays behind the barrier
 #define GPX_PIN() asm volatile("" : "+v"(acc[FI - 1][FI - 1]) : : "memory")
+    // segmented instantiations only: hipcc hoists most of the fourth substep's MFMAs above the barrier there (3 of 16 stayed
+    // behind it: nothing left to cover the fragment reads, 60 instead of 72 TF/s) -- consuming EVERY accumulator keeps all 16
+    // behind the pin.  The dense kernels keep their single-operand pin (their schedule is right as it is).
+#define GPX_PIN_ALL()                                                                                            \
+  do {                                                                                                           \
+    if constexpr (SEGF::on && FI == 4)                                                                           \
+      asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]),    \
+                        "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]), "+v"(acc[2][0]), "+v"(acc[2][1]),    \
+                        "+v"(acc[2][2]), "+v"(acc[2][3]), "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(acc[3][2]),    \
+                        "+v"(acc[3][3]) : : "memory");                                                          \
+  } while (0)
     static_assert(KB == 16, "the hand schedule below is written for four k-substeps");
     double fa0[FI], fa1[FI], fa2[FI], fa3[FI], fb0[FI], fb1[FI], fb2[FI], fb3[FI];  // one slot per k-substep
     GPX_GLOAD(P, 0);
@@ -219,6 +264,7 @@ __device__ __forceinline__ void gemm_tile(Smem<BT, TE>& sm, const double* A, int
       GPX_FRAGS(buf ^ 1, 1, 1);
       GPX_FRAGS(buf ^ 1, 2, 2);
       GPX_PIN();  // the reads above are issued BEFORE the last 16 MFMAs (hipcc would sink most of them below)
+      GPX_PIN_ALL();
       GPX_MFMAS(3);
       GPX_FRAGS(buf ^ 1, 3, 3);
     }
@@ -230,6 +276,7 @@ __device__ __forceinline__ void gemm_tile(Smem<BT, TE>& sm, const double* A, int
 #undef GPX_FRAGS
 #undef GPX_MFMAS
 #undef GPX_PIN
+#undef GPX_PIN_ALL
   }
 #undef GPX_GLOAD
 #undef GPX_LD16
@@ -327,6 +374,78 @@ __global__ __launch_bounds__(256, 2) void trmm_right_inplace_kernel(double* X, i
     gemm_tile<true, false, 128>(sm, X, ldx, Linv, ldi, X, ldx, (j + 1) * (128 / KB), by, j);
     __syncthreads();  // the next tile restages the LDS images
   }
+}
+
+// ---- trailing update of the 2-D block-cyclic factorisation (dist.hip / gpexp_amd/dist.py) ------------------------------------
+// C = the local matrix of rank (pr, pc) from local block (li_first, lj_first) on; local block (li, lj) is global block
+// (I, J) = (li Pr + pr, lj Pc + pc).  For every tile with I > J (or I >= J), in ONE launch,
+//     C_tile -= sum over segments s of  Arows_s(tile rows) * Brows_s(tile columns)^T
+// where segment s is panel k_s in its packed buffer g[s] (layout: dist.hip, "piece p = [D | leaf inverses | rows]"):
+//     rows of local block li      = block (li - li0[s][pr]) of piece pr            (contiguous over li)
+//     rows of global block J      = block (J / Pr - li0[s][J % Pr]) of piece J % Pr
+// with li0[s][p] = number of blocks I' <= k_s with I' % Pr == p.  Replaces one launch per panel and block column (K = nb,
+// 64-tiles: 39 TF/s at C4 on one rank, profiles/r03_dist_w1_before.txt) by one launch per GROUP of panels over the whole
+// local trailing matrix (K = nseg * nb).
+constexpr int GPX_SC_MAX = 128;  // super-block columns (8 tiles each) one launch may span
+struct Dist2Upd {
+  const double* g[GPX_SEG_MAX];
+  int li0[GPX_SEG_MAX][GPX_MAX_PR];
+  int nseg, seg_nk;
+  int Pr, Pc, pr, pc;
+  int nb, gld;   // block size; row stride of the packed rows (gpx_g_ld)
+  int li_first, lj_first;
+  int below_diag;
+  int64_t piece_stride, dsz;
+  // Workgroup -> tile map.  The active tiles form a trapezoid (local block (li, lj) is active iff its global block row is on /
+  // below its global block column); enumerating the enclosing rectangle and letting the rest exit deals the XCDs very unequal
+  // shares -- super-blocks go to XCDs round-robin, and with 8 super-block columns each XCD owns ONE column of a staircase
+  // (2 x 4 grid, rank 0: 992 tiles on XCD 0, 96 on XCD 7; measured 60 against 66 TF/s even on the 1 x 1 triangle).  So only the
+  // super-blocks (8 x 8 tiles) that contain an active tile are enumerated, column by column: super-block column sc holds
+  // rows sr_min[sc] .. nsr-1 and starts at index prefix[sc]; index s goes to XCD class s % 8.
+  int nsc, nsr;
+  int sr_min[GPX_SC_MAX];
+  int prefix[GPX_SC_MAX + 1];
+};
+
+template <int TE>
+struct Dist2Seg {
+  static constexpr bool on = true;
+  const Dist2Upd& u;
+  int nseg, seg_nk;
+  int64_t arow;  // (li_first * nb + tile row) : row index inside piece pr counted from local block 0
+  int pj;        // piece of this tile's column block
+  int64_t brow;  // (J / Pr) * nb + column offset inside the block
+  __device__ __forceinline__ const double* a(int s) const {
+    return u.g[s] + (int64_t)u.pr * u.piece_stride + u.dsz + (arow - (int64_t)u.li0[s][u.pr] * u.nb) * u.gld;
+  }
+  __device__ __forceinline__ const double* b(int s) const {
+    return u.g[s] + (int64_t)pj * u.piece_stride + u.dsz + (brow - (int64_t)u.li0[s][pj] * u.nb) * u.gld;
+  }
+};
+
+template <int TE>
+__global__ __launch_bounds__(256, 2) void dist2_update_kernel(const Dist2Upd u, double* C, int64_t ldc, int tiles_m,
+                                                              int tiles_n) {
+  __shared__ Smem<true, TE> sm;
+  const int w = blockIdx.x;
+  const int xcd = w & 7, q = w >> 3;
+  const int s = (q >> 6) * 8 + xcd, within = q & 63;  // s-th active super-block, tile `within` of its 8 x 8
+  if (s >= u.prefix[u.nsc]) return;
+  int lo = 0, hi = u.nsc - 1;  // last column with prefix[sc] <= s  (uniform: scalar loads)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (u.prefix[mid] <= s) lo = mid; else hi = mid - 1;
+  }
+  const int sc = lo, sr = u.sr_min[sc] + (s - u.prefix[sc]);
+  const int by = sr * 8 + (within >> 3), bx = sc * 8 + (within & 7);
+  if (by >= tiles_m || bx >= tiles_n) return;
+  const int tpb = u.nb / TE;  // tiles per block edge
+  const int li = u.li_first + by / tpb, lj = u.lj_first + bx / tpb;
+  const int I = li * u.Pr + u.pr, J = lj * u.Pc + u.pc;
+  if (I < J || (u.below_diag && I == J)) return;
+  Dist2Seg<TE> sg{u, u.nseg, u.seg_nk, (int64_t)u.li_first * u.nb + (int64_t)by * TE, J % u.Pr,
+                  (int64_t)(J / u.Pr) * u.nb + (int64_t)(bx % tpb) * TE};
+  gemm_tile<true, true, TE, Dist2Seg<TE>>(sm, nullptr, u.gld, nullptr, u.gld, C, ldc, u.nseg * u.seg_nk, by, bx, sg);
 }
 
 // (A persistent per-XCD work-queue variant of this kernel was measured in round 1 and removed: exact XCD placement
@@ -499,6 +618,81 @@ int launch_gemm_tri(gpx_ctx* ctx, const double* A, int64_t lda, const double* B,
 #undef GPX_G
 #undef GPX_K
 #undef GPX_KT
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
+
+// A[lr0 : lr0+m, lc0 : lc0+n] (local matrix, rank (pr, pc) of a Pr x Pc grid, block size nb) -= the contributions of the nseg
+// panels ks[s] held in the packed buffers g[s], for the local blocks on / below (below_diag: strictly below) the global
+// diagonal.  See dist2_update_kernel.  m, n multiples of 128, lr0 and lc0 multiples of nb.
+int launch_dist2_update(gpx_ctx* ctx, double* C, int64_t ldc, int64_t lr0, int64_t m, int64_t lc0, int64_t n, int64_t nb, int Pr,
+                        int Pc, int pr, int pc, int64_t piece_stride, int64_t dsz, int nseg, const double* const* g,
+                        const int64_t* ks, int below_diag) {
+  if (m == 0 || n == 0 || nseg == 0) return 0;
+  GPX_ARG(nseg > 0 && nseg <= GPX_SEG_MAX && Pr >= 1 && Pr <= GPX_MAX_PR && Pc >= 1, "dist2 update: too many segments / grid rows");
+  GPX_ARG(m % 128 == 0 && n % 128 == 0 && nb % 128 == 0 && lr0 % nb == 0 && lc0 % nb == 0 && (ldc % 2) == 0, "dist2 update: alignment");
+  Dist2Upd u;
+  for (int s = 0; s < nseg; ++s) {
+    u.g[s] = g[s];
+    for (int p = 0; p < Pr; ++p) u.li0[s][p] = (int)(ks[s] + 1 <= p ? 0 : (ks[s] - p) / Pr + 1);  // blocks I' <= k with I' % Pr == p
+  }
+  u.nseg = nseg;
+  u.seg_nk = (int)(nb / KB);
+  u.Pr = Pr; u.Pc = Pc; u.pr = pr; u.pc = pc;
+  u.nb = (int)nb;
+  u.gld = (int)gpx_g_ld(nb);
+  u.li_first = (int)(lr0 / nb);
+  u.lj_first = (int)(lc0 / nb);
+  u.below_diag = below_diag;
+  u.piece_stride = piece_stride;
+  u.dsz = dsz;
+  // work estimate (tiles on / below the diagonal) for the tile-size choice and the profile
+  double tiles128 = 0.0;
+  for (int64_t lj = lc0 / nb; lj * nb < lc0 + n; ++lj) {
+    const int64_t J = lj * Pc + pc;
+    const int64_t cw = (lc0 + n - lj * nb) < nb ? (lc0 + n - lj * nb) : nb;
+    for (int64_t li = lr0 / nb; li * nb < lr0 + m; ++li) {
+      const int64_t I = li * Pr + pr;
+      if (I < J || (below_diag && I == J)) continue;
+      const int64_t rh = (lr0 + m - li * nb) < nb ? (lr0 + m - li * nb) : nb;
+      tiles128 += (double)(rh / 128) * (double)(cw / 128);
+    }
+  }
+  if (tiles128 == 0.0) return 0;
+  static int small_max = -1;
+  if (small_max < 0) {
+    const char* e3 = getenv("GPX_DIST2_SMALL_MAX");  // 64-tiles while fewer 128-tiles than this have work
+    small_max = e3 ? atoi(e3) : 512;
+  }
+  const int te = tiles128 < (double)small_max ? 64 : 128;
+  const int tm = (int)(m / te), tn = (int)(n / te), tpb = (int)(nb / te);
+  u.nsc = (tn + 7) / 8;
+  u.nsr = (tm + 7) / 8;
+  GPX_ARG(u.nsc <= GPX_SC_MAX, "dist2 update: too many column super-blocks in one launch");
+  int64_t nsb = 0;
+  for (int sc = 0; sc < u.nsc; ++sc) {
+    // first active local block row of this super-block column: the column's LEFTMOST block has the lowest global index
+    const int64_t lj = lc0 / nb + (8 * sc) / tpb, J = lj * Pc + pc;
+    int64_t li_min = (J + (below_diag ? 1 : 0) - pr + Pr - 1) / Pr;  // smallest li with li Pr + pr >= J (+1)
+    if (J + (below_diag ? 1 : 0) - pr < 0) li_min = 0;
+    int64_t by_min = (li_min - lr0 / nb) * tpb;   // first tile row (relative to the launch) that can be active
+    if (by_min < 0) by_min = 0;
+    int srm = (int)(by_min / 8);
+    if (srm > u.nsr) srm = u.nsr;
+    u.sr_min[sc] = srm;
+    u.prefix[sc] = (int)nsb;
+    nsb += u.nsr - srm;
+  }
+  u.prefix[u.nsc] = (int)nsb;
+  if (nsb == 0) return 0;
+  const int64_t wgs = (nsb + 7) / 8 * 8 * 64;
+  GPX_ARG(wgs < ((int64_t)1 << 31), "dist2 update: grid too large");
+  ProfScope ps(ctx, GPX_PROF_GEMM, 2.0 * tiles128 * 128.0 * 128.0 * (double)nb * nseg, 0.0);
+  double* Cb = C + lr0 * ldc + lc0;
+  if (te == 64)
+    hipLaunchKernelGGL(dist2_update_kernel<64>, dim3((unsigned)wgs), dim3(256), 0, ctx->stream, u, Cb, ldc, tm, tn);
+  else
+    hipLaunchKernelGGL(dist2_update_kernel<128>, dim3((unsigned)wgs), dim3(256), 0, ctx->stream, u, Cb, ldc, tm, tn);
   GPX_HIP(hipGetLastError());
   return 0;
 }

@@ -9,6 +9,12 @@
 
 #define GPX_TILE 128          // padding / GEMM tile / Cholesky leaf size
 #define GPX_MAXD GPX_MAX_DIM
+#define GPX_NSTREAMS 6
+#define GPX_SEG_MAX 8         // panels one trailing update of the 2-D distributed factorisation can apply at once
+#ifndef GPX_G_SKEW
+#define GPX_G_SKEW 0          // doubles added to the row stride of the packed panel pieces of the 2-D distributed loop (see gpx_g_ld)
+#endif
+#define GPX_MAX_PR 4          // process rows of the 2-D grid the segmented update supports (grids up to 4 x Pc)
 
 // ---- error plumbing ---------------------------------------------------------------------------
 void gpx_set_error(const char* fmt, ...);
@@ -38,6 +44,12 @@ static inline int64_t gpx_round_up(int64_t v, int64_t m) { return (v + m - 1) / 
 // be a large power of two (N = 32768 -> 256 KiB).  Measured NEUTRAL on MI355X (GEMM 66.98 vs 66.97 TF/s: the L2 /
 // channel address hashing already spreads such strides); kept because it decouples ld from the padded width.
 static inline int64_t gpx_skew_ld(int64_t cols) { return (cols >= 1024 && cols % 256 == 0) ? cols + 16 : cols; }
+
+// Row stride of the rows region of a packed panel piece (dist.hip): nb + GPX_G_SKEW doubles.  At nb = 512 a stride of nb is
+// exactly 4 KiB, the textbook channel-conflict stride; measured on MI355X it makes NO difference (66.0 TF/s with skew 0, 65.9
+// with 16: scripts/probe_update_multi.py -- like gpx_skew_ld, the address hashing already spreads it), so the skew is 0 and the
+// pieces travel without 3 % of padding.  The stride stays a separate quantity (gpexp_amd/dist.py Grid2D.gld mirrors it).
+static inline int64_t gpx_g_ld(int64_t nb) { return nb + GPX_G_SKEW; }
 
 // ---- covariance-function parameters, passed to kernels by value ---------------------------------
 // Coordinates are pre-multiplied by `scale` when staged into LDS so that
@@ -99,9 +111,9 @@ struct ProfRec {
 struct gpx_ctx {
   int device;
   hipStream_t stream;        // currently selected stream (all launches go here)
-  hipStream_t streams[5];    // 0 = main, 1 = panel (high priority), 2 = communication (high priority),
+  hipStream_t streams[GPX_NSTREAMS];  // 0 = main, 1 = panel (high priority), 2 = communication (high priority),
                              // 4 = evaluation (low priority, unmasked): the streamed IVAR solve beside the factorisation,
-                             // 3 = background: CU-masked (leaves 4 CUs per XCD to the other streams) when the runtime allows
+                             // 3 = background, 5 = bulk: CU-masked (leave 4 CUs per XCD to the other streams) when the runtime allows
   std::vector<hipEvent_t> sync_events;  // gpx_event_record / gpx_event_wait ids
   // work buffers of a blocked factorisation in flight (set by gpx_potrf around chol_potrf, NULL otherwise): storage of the
   // explicit block inverses being built, order of those blocks, scratch for their build and for the panel solves
@@ -134,6 +146,8 @@ struct gpx_ctx {
   double* d_scal;   // small scalar workspace (>= 64 doubles)
   double* trsv_scratch;      // grown on demand, kept until gpx_destroy (lets gpx_potrs_dev stay asynchronous)
   int64_t trsv_scratch_bytes;
+  double* d2_scratch;        // 2-D distributed panel solve: explicit inverse of the current diagonal block + build scratch
+  int64_t d2_scratch_bytes;  // (2 nb^2 doubles; used on the PANEL stream only, in step order)
   // multi-GPU (RCCL communicator, opaque here; see dist.hip)
   void* comm;
   int rank, world;
@@ -196,6 +210,10 @@ int launch_gemm_batched(gpx_ctx* ctx, const double* A, int64_t lda, int64_t sa, 
                         double* C, int64_t ldc, int64_t sc, int64_t m, int64_t n, int64_t k, bool bt, bool accumulate,
                         int64_t batch);
 
+int launch_dist2_update(gpx_ctx* ctx, double* C, int64_t ldc, int64_t lr0, int64_t m, int64_t lc0, int64_t n, int64_t nb, int Pr,
+                        int Pc, int pr, int pc, int64_t piece_stride, int64_t dsz, int nseg, const double* const* g,
+                        const int64_t* ks, int below_diag);
+
 // chol.hip
 int launch_leaf(gpx_ctx* ctx, double* A, int64_t ld, double* inv, int64_t base_index, int64_t n_valid);
 int chol_potrf(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double* invd, int64_t n_valid);
@@ -220,6 +238,7 @@ int launch_logdet(gpx_ctx* ctx, const double* L, int64_t ld, int64_t n, double* 
 // overwritten by the solution; scratch >= chol_potrs_scratch_bytes(n).  Asynchronous on the selected stream.
 int chol_trtri(gpx_ctx* ctx, const gpx_mat* L, double* Linv, double* tmp);  // Linv (n x n, ld n) = L^-1; tmp >= (n/2)^2
 int chol_binv_ensure(gpx_ctx* ctx, gpx_mat* L);
+int chol_block_inverse(gpx_ctx* ctx, const double* D, int64_t ldd, const double* invd, double* inv, int64_t w, double* tmp);
 int64_t chol_binv_order(int64_t n);
 int64_t chol_binv_elems(int64_t n);
 int chol_binv_finish(gpx_ctx* ctx, gpx_mat* L, int64_t ib);  // explicit inverses of L's diagonal blocks (order <= 1024), cached in L

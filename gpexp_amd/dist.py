@@ -4,22 +4,32 @@ This replaces the reference's only parallel backend -- `parallelizeMcForLoop`, a
 slices the evaluation points row-wise over CPU processes (parallel_utilities.py:26-80, used at gp.py:258) -- by
 two shardings:
 
-  fit   the covariance matrix is distributed by block columns (width `nb`, owner = block index mod world).
-        Assembly is communication-free; the right-looking Cholesky broadcasts one factored panel per step
-        (`gpx_comm_bcast` -> ncclBroadcast) and every rank updates the block columns it owns.  Every rank also
-        KEEPS each received panel, so at the end each GPU holds the complete factor L.
+  fit   2-D BLOCK-CYCLIC (the default, `DistFitIvar2D` / `dist2_potrf`): process grid Pr x Pc (8 -> 2x4, 4 -> 2x2,
+        2 -> 1x2), global block (I, J) of size nb on rank (I % Pr, J % Pc); assembly is communication-free; the
+        right-looking Cholesky factors the diagonal block on its owner, broadcasts it down the process column
+        (ncclCommSplit sub-communicator), the column's ranks solve their rows of the panel, every piece of the panel
+        reaches every rank over all xGMI links (grouped ncclSend / ncclRecv scatter + all-gather), and every rank
+        updates its local blocks -- the next two block columns at once (look-ahead: they gate the diagonal chain),
+        everything else in GROUPS of `agg` panels (one launch over the whole local trailing matrix with K = agg * nb).
+        Every rank also keeps each finished panel in a replicated copy of L for the evaluation phase.
+        (`DistFitIvar` / `dist_potrf`: round 1's 1-D block-column layout, GPX_DIST_LAYOUT=1d.)
   eval  posterior / IVAR evaluation points are split in contiguous slices [r*M/W, (r+1)*M/W), exactly the
         chunking the reference's helper intends (parallel_utilities.py:46-60); each rank solves against its own
         copy of L and the only exchange is an all-gather of one partial sum per rank (summed in rank order, so
         the result does not depend on arrival order).
 
-The panel loop lives here, in Python, on top of three C-ABI primitives (gpx_dist_panel_factor /
-gpx_comm_bcast / gpx_dist_panel_store + gpx_dist_panel_update); per step that is a handful of ctypes calls against ~10^10 flops of GPU
-work.  The communicator is an object with `bcast_panel`, `allgather`, `barrier`, `max_float`:
-  RcclComm      device-to-device over RCCL (the product path; no torch in the process, see FileRendezvous);
-  HostStagedComm  device -> host -> torch.distributed(gloo) -> device, for the world_size>1 tests that share one
-                GPU (RCCL refuses two ranks on one device) -- test infrastructure, never used by bench.py.
-The index arithmetic (ownership, slices, panel sizes) is plain Python and is unit-tested on CPU with gloo.
+The panel loops are Python on top of C-ABI primitives (gpx_dist2_*), so that the very same loop also drives the NumPy
+device double of the CPU tests (tests/dist_worker.py).  On the device the loop is not interpreted per step: it runs ONCE
+against a recorder (`Program`), and the recorded rows are replayed natively by gpx_program_run on every step -- same call
+sequence, no interpreter and no ctypes marshalling in the issue path.  Communicators (`bcast_grp`, `reduce_grp`,
+`allreduce`, `panel_bcast`, `allgather`, `barrier`, `max_float`):
+  RcclComm    device-to-device over RCCL (the product path; no torch in the process, see FileRendezvous);
+  ReplayComm  ONE process plays rank (pr, pc) of a larger grid: every receive becomes a device copy of the same bytes
+              out of a complete factor resident on the GPU -- measures a rank's GPU time and host issue time without
+              the other GPUs (scripts/dist_replay.py);
+  tests/dist_testcomm.py holds the host-staged gloo communicator of the shared-GPU tests (RCCL refuses two ranks on
+              one device); GPX_COMM=host selects it, nothing in this package imports torch.
+The index arithmetic (ownership, slices, piece offsets, update ranges) is plain Python and unit-tested on CPU with gloo.
 """
 import ctypes as C
 import os
@@ -79,80 +89,65 @@ def merge_argmin(values, indices):
     return best
 
 
-# ---- communicators -----------------------------------------------------------------------------------------
-class _TorchGroup:
-    """Thin wrapper over torch.distributed (gloo, CPU tensors) for rendezvous-level exchanges."""
+# ---- recorded programs (include/gpx.h: gpx_program_run) -----------------------------------------------------------
+OP = dict(STREAM=1, RECORD=2, WAIT=3, BEGIN=4, DIAG_FACTOR=5, PANEL_TRSM=6, UPDATE=7, UPDATE_MULTI=8, UNPACK_ROWS=9,
+          UNPACK_DIAG=10, PACK_ROWS=11, PACK_DIAG=12, BCAST_GRP=13, REDUCE_GRP=14, ALLREDUCE=15, PANEL_BCAST=16, IVAR_STEP=17,
+          TRSV_DIAG=18, GEMV=19, LOGDET_ACC=20, VEC_OP=21, SPIN=22, COPY=23, IVAR_GROUP=24)
+
+
+class Program:
+    """Rows of 16 int64 [opcode, handle0..2, a0..a11] + a pool of variable-length arguments; replayed by gpx_program_run."""
 
     def __init__(self):
-        import torch
-        import torch.distributed as td
-        self.torch = torch
-        self.td = td
-        if not td.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            td.init_process_group(backend="gloo")
-        self.rank = td.get_rank()
-        self.world = td.get_world_size()
+        self.rows, self.extra, self.keep = [], [], []
+        self._frozen = None
+        self.host_ms = 0.0   # host time of the last run (issue only: every op is asynchronous)
 
-    def bcast_bytes(self, b, root=0):
-        t = self.torch.zeros(len(b), dtype=self.torch.uint8)
-        if self.rank == root:
-            t = self.torch.tensor(list(b), dtype=self.torch.uint8)
-        self.td.broadcast(t, src=root)
-        return bytes(t.tolist())
+    def emit(self, op, handles=(), args=(), extra=None):
+        row = [int(op), 0, 0, 0] + [0] * 12
+        for i, h in enumerate(handles):
+            if h is not None:
+                row[1 + i] = int(h.h.value)
+                self.keep.append(h)          # the matrix must outlive the program
+        args = [int(a) for a in args]
+        if extra is not None:
+            args = args + [len(self.extra)]
+            self.extra.extend(int(e) for e in extra)
+        assert len(args) <= 12, (op, args)
+        row[4:4 + len(args)] = args
+        self.rows.append(row)
+        self._frozen = None
 
-    def bcast_array(self, a, root):
-        t = self.torch.from_numpy(a)
-        self.td.broadcast(t, src=root)
-        return a
+    def __len__(self):
+        return len(self.rows)
 
-    def make_grid(self, Pr, Pc):
-        """Process-row / process-column groups (every rank creates every group, in the same order)."""
-        self.rows = [self.td.new_group([p * Pc + q for q in range(Pc)]) for p in range(Pr)]
-        self.cols = [self.td.new_group([p * Pc + q for p in range(Pr)]) for q in range(Pc)]
-        self.Pr, self.Pc = Pr, Pc
-
-    def _group(self, grp):
-        """(process group, world ranks of its members) for WORLD / ROW / COL of this rank."""
-        pr, pc = self.rank // self.Pc, self.rank % self.Pc
-        if grp == 1:
-            return self.rows[pr], [pr * self.Pc + q for q in range(self.Pc)]
-        if grp == 2:
-            return self.cols[pc], [p * self.Pc + pc for p in range(self.Pr)]
-        return None, list(range(self.world))
-
-    def bcast_array_grp(self, a, root, grp):
-        g, members = self._group(grp)
-        self.td.broadcast(self.torch.from_numpy(a), src=members[root], group=g)
-        return a
-
-    def reduce_array_grp(self, a, root, grp):
-        g, members = self._group(grp)
-        t = self.torch.from_numpy(a.copy())
-        self.td.reduce(t, dst=members[root], op=self.td.ReduceOp.SUM, group=g)
-        if self.rank == members[root]:
-            a[:] = t.numpy()
-        return a
-
-    def allreduce_array(self, a):
-        self.td.all_reduce(self.torch.from_numpy(a), op=self.td.ReduceOp.SUM)
-        return a
-
-    def allgather(self, vec):
-        vec = np.ascontiguousarray(vec, dtype=np.float64)
-        outs = [self.torch.zeros(vec.size, dtype=self.torch.float64) for _ in range(self.world)]
-        self.td.all_gather(outs, self.torch.from_numpy(vec.copy()))
-        return np.stack([o.numpy() for o in outs])
-
-    def barrier(self):
-        self.td.barrier()
-
-    def max_float(self, v):
-        t = self.torch.tensor([float(v)], dtype=self.torch.float64)
-        self.td.all_reduce(t, op=self.td.ReduceOp.MAX)
-        return float(t[0])
+    def run(self, ctx):
+        if self._frozen is None:
+            self._frozen = (np.ascontiguousarray(np.array(self.rows, dtype=np.int64).reshape(-1, 16)),
+                            np.ascontiguousarray(np.array(self.extra + [0], dtype=np.int64)))
+        ops, extra = self._frozen
+        ms = C.c_double(0.0)
+        check(ctx.lib.gpx_program_run(ctx.h, ops.ctypes.data_as(C.POINTER(c_i64)), ops.shape[0],
+                                      extra.ctypes.data_as(C.POINTER(c_i64)), extra.size, C.byref(ms)))
+        self.host_ms = ms.value
+        return ms.value
 
 
+class Emitter:
+    """Mixin of the device-primitive and communicator objects: every call becomes a program row, appended to `self.prog`
+    while a program is being recorded, executed at once (a one-row program: the same native dispatch) otherwise."""
+    prog = None
+
+    def _emit(self, op, handles=(), args=(), extra=None):
+        if self.prog is not None:
+            self.prog.emit(op, handles, args, extra)
+            return
+        one = Program()
+        one.emit(op, handles, args, extra)
+        one.run(self.ctx)
+
+
+# ---- communicators -----------------------------------------------------------------------------------------
 class FileRendezvous:
     """Single-node exchange of the 128-byte ncclUniqueId without any framework in the process: rank 0 writes it
     atomically to a file keyed by the launcher's (MASTER_PORT, run id, launcher pid); the others poll for it.
@@ -190,8 +185,10 @@ class FileRendezvous:
                 pass
 
 
-class RcclComm:
-    """Device-side collectives over RCCL; barriers and the timing max are RCCL all-gathers of one double."""
+class RcclComm(Emitter):
+    """Device-side collectives over RCCL; barriers and the timing max are RCCL all-gathers of one double.  The stream-ordered
+    collectives (bcast_grp, reduce_grp, allreduce, panel_bcast) are recordable (Emitter)."""
+    recordable = True
 
     def __init__(self, ctx, rendezvous=None):
         self.ctx = ctx
@@ -215,25 +212,22 @@ class RcclComm:
             self.grid = (Pr, Pc)
 
     def bcast_grp(self, buf, offset, count, root, grp):
-        check(self.ctx.lib.gpx_comm_bcast_grp(self.ctx.h, buf.h, int(offset), int(count), int(root), int(grp)))
+        self._emit(OP["BCAST_GRP"], (buf,), (offset, count, root, grp))
 
     def reduce_grp(self, buf, offset, count, root, grp):
-        check(self.ctx.lib.gpx_comm_reduce_grp(self.ctx.h, buf.h, int(offset), int(count), int(root), int(grp)))
+        self._emit(OP["REDUCE_GRP"], (buf,), (offset, count, root, grp))
 
     def allreduce(self, buf, offset, count):
-        check(self.ctx.lib.gpx_comm_allreduce(self.ctx.h, buf.h, int(offset), int(count)))
+        self._emit(OP["ALLREDUCE"], (buf,), (offset, count))
+
+    def panel_bcast(self, buf, pieces):
+        self._emit(OP["PANEL_BCAST"], (buf,), (len(pieces),),
+                   extra=[p[0] for p in pieces] + [p[1] for p in pieces] + [p[2] for p in pieces])
 
     def allreduce_host(self, vec):
         vec = as_f64(np.atleast_1d(vec)).copy()
         check(self.ctx.lib.gpx_comm_allreduce_host(self.ctx.h, dptr(vec), vec.size))
         return vec
-
-    def panel_bcast(self, buf, pieces):
-        n = len(pieces)
-        offs = (c_i64 * n)(*[int(p[0]) for p in pieces])
-        cnts = (c_i64 * n)(*[int(p[1]) for p in pieces])
-        roots = (C.c_int * n)(*[int(p[2]) for p in pieces])
-        check(self.ctx.lib.gpx_comm_panel_bcast(self.ctx.h, buf.h, offs, cnts, roots, n))
 
     def allgather(self, vec):
         vec = as_f64(np.atleast_1d(vec))
@@ -252,81 +246,24 @@ class RcclComm:
         self.ctx.lib.gpx_comm_destroy(self.ctx.h)
 
 
-class HostStagedComm:
-    """Test-only communicator: panels bounce through host memory and gloo (several ranks may share one GPU)."""
-
-    def __init__(self, ctx, group=None):
-        self.ctx = ctx
-        self.group = group or _TorchGroup()
-        self.rank, self.world = self.group.rank, self.group.world
-
-    def bcast_panel(self, P, count, root):
-        buf = np.empty(int(count))
-        if self.rank == root:
-            check(self.ctx.lib.gpx_mat_read(self.ctx.h, P.h, 0, int(count), dptr(buf)))
-        self.group.bcast_array(buf, root)
-        if self.rank != root:
-            check(self.ctx.lib.gpx_mat_write(self.ctx.h, P.h, 0, int(count), dptr(buf)))
-
-    # ---- 2-D path (same interface as RcclComm) ----
-    def set_grid(self, Pr, Pc):
-        if getattr(self, "grid", None) != (Pr, Pc):
-            self.group.make_grid(Pr, Pc)
-            self.grid = (Pr, Pc)
-
-    def _read(self, buf, offset, count):
-        a = np.empty(int(count))
-        check(self.ctx.lib.gpx_mat_read(self.ctx.h, buf.h, int(offset), int(count), dptr(a)))
-        return a
-
-    def _write(self, buf, offset, a):
-        check(self.ctx.lib.gpx_mat_write(self.ctx.h, buf.h, int(offset), a.size, dptr(a)))
-
-    def bcast_grp(self, buf, offset, count, root, grp):
-        if count == 0:
-            return
-        self._write(buf, offset, self.group.bcast_array_grp(self._read(buf, offset, count), root, grp))
-
-    def reduce_grp(self, buf, offset, count, root, grp):
-        if count == 0:
-            return
-        self._write(buf, offset, self.group.reduce_array_grp(self._read(buf, offset, count), root, grp))
-
-    def allreduce(self, buf, offset, count):
-        self._write(buf, offset, self.group.allreduce_array(self._read(buf, offset, count)))
-
-    def allreduce_host(self, vec):
-        return self.group.allreduce_array(np.array(np.atleast_1d(vec), dtype=np.float64))
-
-    def panel_bcast(self, buf, pieces):
-        for off, cnt, root in pieces:
-            a = self._read(buf, off, cnt)
-            self.group.bcast_array(a, root)
-            if self.rank != root:
-                self._write(buf, off, a)
-
-    def allgather(self, vec):
-        return self.group.allgather(np.atleast_1d(vec))
-
-    def barrier(self):
-        self.ctx.sync()
-        self.group.barrier()
-
-    def max_float(self, v):
-        return self.group.max_float(v)
-
-    def close(self):
-        pass
-
-
 def init_from_env(ctx):
-    """Communicator for the process group the launcher created (RANK / WORLD_SIZE / MASTER_* in the environment)."""
+    """Communicator for the process group the launcher created (RANK / WORLD_SIZE / MASTER_* in the environment).
+    GPX_COMM=host selects the TEST communicator (tests/dist_testcomm.py: device -> host -> gloo -> device, several ranks
+    sharing one GPU); it is test infrastructure and is imported from the tests directory, never shipped in this package."""
     kind = os.environ.get("GPX_COMM", "rccl")
-    return HostStagedComm(ctx) if kind == "host" else RcclComm(ctx)
+    if kind == "host":
+        import sys
+        tests = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")
+        if tests not in sys.path:
+            sys.path.insert(0, tests)
+        from dist_testcomm import HostStagedComm   # noqa: E402  (test-only)
+        return HostStagedComm(ctx)
+    return RcclComm(ctx)
 
 
 # ---- distributed operations -----------------------------------------------------------------------------------
-MAIN, PANEL, COMM, BACK = 0, 1, 2, 3  # stream indices of the context (gpx_stream_select); BACK = CU-masked background
+MAIN, PANEL, COMM, BACK, EVAL, BULK = 0, 1, 2, 3, 4, 5  # stream indices of the context (gpx_stream_select); BACK and BULK are
+                                                         # CU-masked (4 CUs per XCD stay free for the diagonal chain)
 
 
 class DeviceOps:
@@ -577,6 +514,8 @@ def dist_greedy_var(ctx, comm, spec, cand_host, nsel, keep=()):
 # exchange (and stream, see DistFitIvar); alpha / logdet come from the block-cyclic factor by distributed forward / back
 # substitution (reduce along process rows, broadcast down process columns) and ncclAllReduce.
 WORLD, ROW, COL = 0, 1, 2   # communicator groups (gpx_comm_grid)
+G_SKEW = 0                  # packed panel rows have stride nb + G_SKEW doubles (= gpx_dist2_row_stride(nb) - nb; a skew of 16
+                            # was measured and made no difference on MI355X)
 
 
 def choose_grid(world):
@@ -598,7 +537,8 @@ class Grid2D:
         self.np = padded(n)
         self.nblk = num_blocks(n, nb)
         self.dsz = nb * nb + (nb // TILE) * TILE * TILE
-        self.piece_stride = self.dsz + max(self.local_rows(p) for p in range(Pr)) * nb
+        self.gld = nb + G_SKEW               # row stride of the packed rows (the D region keeps stride nb)
+        self.piece_stride = self.dsz + max(self.local_rows(p) for p in range(Pr)) * self.gld
 
     def height(self, I):
         return min(self.nb, self.np - I * self.nb)
@@ -642,9 +582,9 @@ class Grid2D:
         for p in range(self.Pr):
             m = self.piece_rows(p, k)
             if p == kr:
-                out.append((self.piece_off(p), self.dsz + m * self.nb, p * self.Pc + kc))
+                out.append((self.piece_off(p), self.dsz + m * self.gld, p * self.Pc + kc))
             elif m > 0:
-                out.append((self.piece_off(p) + self.dsz, m * self.nb, p * self.Pc + kc))
+                out.append((self.piece_off(p) + self.dsz, m * self.gld, p * self.Pc + kc))
         return out
 
     def my_cols_after(self, k):
@@ -659,14 +599,15 @@ class Grid2D:
         m = max(self.local_rows(pr) - liJ * nb, 0)
         if m == 0:
             liJ = self.local_rows(pr) // nb                    # nothing below: stay inside the local matrix
-        aoff = self.piece_off(pr) + self.dsz + (liJ - self.li0(pr, k)) * nb * nb
+        aoff = self.piece_off(pr) + self.dsz + (liJ - self.li0(pr, k)) * nb * self.gld
         pj = J % self.Pr
-        boff = self.piece_off(pj) + self.dsz + (J // self.Pr - self.li0(pj, k)) * nb * nb
+        boff = self.piece_off(pj) + self.dsz + (J // self.Pr - self.li0(pj, k)) * nb * self.gld
         return self.row_off(pr, liJ), m, (J // self.Pc) * nb, self.height(J), aoff, boff
 
 
-class DeviceOps2D(DeviceOps):
-    """Device primitives of the 2-D panel loop (gpx_dist2_*); the tests substitute a NumPy double."""
+class DeviceOps2D(Emitter, DeviceOps):
+    """Device primitives of the 2-D panel loop (gpx_dist2_*); the tests substitute a NumPy double.  Everything the loop
+    enqueues goes through the Emitter, so the loop can be recorded once and replayed natively (Program)."""
 
     def alloc_local(self, geo):
         return _dev.DeviceMatrix.zeros(self.ctx, max(geo.local_rows(geo.pr), 1), max(geo.local_cols(geo.pc), 1))
@@ -687,32 +628,64 @@ class DeviceOps2D(DeviceOps):
         check(self.ctx.lib.gpx_dist2_kfill(self.ctx.h, *spec.args(), X.h, dptr(nug), nlen, A.h, geo.nb, geo.Pr, geo.Pc,
                                            geo.pr, geo.pc))
 
+    # stream / event plumbing
+    def stream(self, which):
+        self._emit(OP["STREAM"], (), (which,))
+
+    def record(self, ev):
+        self._emit(OP["RECORD"], (), (ev,))
+
+    def wait(self, ev):
+        self._emit(OP["WAIT"], (), (ev,))
+
+    def begin(self):
+        self._emit(OP["BEGIN"])
+
     def diag_factor(self, A, lr, lc, w, G, doff, nb, base, n_valid):
-        check(self.ctx.lib.gpx_dist2_diag_factor(self.ctx.h, A.h, lr, lc, w, G.h, doff, nb, base, n_valid))
+        self._emit(OP["DIAG_FACTOR"], (A, G), (lr, lc, w, doff, nb, base, n_valid))
 
     def panel_trsm(self, A, lr0, m, lc, w, G, doff, roff, nb):
-        check(self.ctx.lib.gpx_dist2_panel_trsm(self.ctx.h, A.h, lr0, m, lc, w, G.h, doff, roff, nb))
+        self._emit(OP["PANEL_TRSM"], (A, G), (lr0, m, lc, w, doff, roff, nb))
 
     def update(self, A, lr0, m, lc0, n, G, aoff, boff, w, nb):
-        check(self.ctx.lib.gpx_dist2_update(self.ctx.h, A.h, lr0, m, lc0, n, G.h, aoff, boff, w, nb))
+        self._emit(OP["UPDATE"], (A, G), (lr0, m, lc0, n, aoff, boff, w, nb))
+
+    def update_multi(self, A, lr0, m, lc0, n, geo, Gs, ks, below_diag):
+        """A[lr0:lr0+m, lc0:lc0+n] -= contributions of the panels ks (packed buffers Gs) on / below the global diagonal."""
+        if m <= 0 or n <= 0 or not ks:
+            return
+        self._emit(OP["UPDATE_MULTI"], (A,),
+                   (lr0, m, lc0, n, geo.nb, geo.Pr, geo.Pc, geo.pr, geo.pc, geo.piece_stride, len(ks) | (int(bool(below_diag)) << 8)),
+                   extra=[int(g.h.value) for g in Gs] + list(ks))
+        if self.prog is not None:
+            self.prog.keep.extend(Gs)
 
     def unpack_rows(self, G, roff, m, w, nb, L, first_block, stride, col0):
-        check(self.ctx.lib.gpx_dist2_unpack_rows(self.ctx.h, G.h, roff, m, w, nb, L.h, first_block, stride, col0))
+        self._emit(OP["UNPACK_ROWS"], (G, L), (roff, m, w, nb, first_block, stride, col0))
 
     def unpack_diag(self, G, doff, w, nb, L, r0):
-        check(self.ctx.lib.gpx_dist2_unpack_diag(self.ctx.h, G.h, doff, w, nb, L.h, r0))
+        self._emit(OP["UNPACK_DIAG"], (G, L), (doff, w, nb, r0))
+
+    def ivar_step(self, K, k, nb, B):
+        self._emit(OP["IVAR_STEP"], (K, B), (k, nb))
+
+    def ivar_group(self, K, k0, k1, nb, B):
+        self._emit(OP["IVAR_GROUP"], (K, B), (k0, k1, nb))
 
     def trsv_diag(self, A, lr, lc, w, v, voff, transposed):
-        check(self.ctx.lib.gpx_dist2_trsv_diag(self.ctx.h, A.h, lr, lc, w, v.h, voff, int(transposed)))
+        self._emit(OP["TRSV_DIAG"], (A, v), (lr, lc, w, voff, int(transposed)))
 
     def gemv(self, A, lr0, m, lc, w, x, xoff, acc, aoff, transposed):
-        check(self.ctx.lib.gpx_dist2_gemv(self.ctx.h, A.h, lr0, m, lc, w, x.h, xoff, acc.h, aoff, int(transposed)))
+        self._emit(OP["GEMV"], (A, x, acc), (lr0, m, lc, w, xoff, aoff, int(transposed)))
 
     def logdet_acc(self, A, lr, lc, w, n_valid, acc):
-        check(self.ctx.lib.gpx_dist2_logdet_acc(self.ctx.h, A.h, lr, lc, w, n_valid, acc.h))
+        self._emit(OP["LOGDET_ACC"], (A, acc), (lr, lc, w, n_valid))
 
     def vec_op(self, dst, doff, src, soff, n, mode):
-        check(self.ctx.lib.gpx_vec_op(self.ctx.h, dst.h, doff, src.h if src is not None else None, soff, n, mode))
+        self._emit(OP["VEC_OP"], (dst, src), (doff, soff, n, mode))
+
+    def spin(self, ms):
+        self._emit(OP["SPIN"], (), (ms,))
 
     def vec_to_host(self, v, n):
         return v.to_host()[:n, 0]
@@ -724,42 +697,105 @@ class DeviceOps2D(DeviceOps):
 
 # event kinds of the 2-D pipeline (per step k)
 (E_COLREADY, E_DFACT, E_DBC, E_PIECE, E_ARRIVED, E_STORED, E_UPD, E_DIAGREADY, E_EARLYSOLVED, E_EARLY, E_COL2,
- E_PANELDONE) = range(12)
+ E_PANELDONE, E_BULK) = range(13)
 
 
 def _ev2(kind, k):
-    return 12 * (k + 1) + kind
+    return 13 * (k + 1) + kind
 
 
-def dist2_potrf(ops, comm, geo, A, G, L=None, on_stored=None):
+def default_agg():
+    """Panels per aggregated trailing update (GPX_DIST_AGG; K = agg * nb per launch).  4 -> K = 2048 at nb = 512."""
+    return max(1, min(8, int(os.environ.get("GPX_DIST_AGG", "4"))))
+
+
+def ring_size(agg):
+    """Packed panel buffers the loop cycles through: a panel's buffer is read until the bulk update of ITS group has run,
+    which may finish one group late (it runs beside the next group's chain) -- two groups of buffers."""
+    return 2 * agg
+
+
+def dist2_potrf(ops, comm, geo, A, G, L=None, on_stored=None, agg=None):
     """2-D block-cyclic right-looking Cholesky of the distributed matrix A (in place: A ends as the block-cyclic factor)
-    with look-ahead and a CRITICAL-PATH-FIRST diagonal chain.  G = two packed panel buffers (geo.buf_elems() doubles) used
-    alternately; L (optional) = full-size matrix that receives every finished panel (replicated factor for the evaluation
-    phase).
+    with look-ahead, a CRITICAL-PATH-FIRST diagonal chain and AGGREGATED trailing updates.  G = ring of packed panel
+    buffers (geo.buf_elems() doubles each, len(G) >= ring_size(agg), or 2 with agg = 1); L (optional) = full-size matrix
+    that receives every finished panel (replicated factor for the evaluation phase).
 
     What serialises a distributed factorisation is the chain diag(k) -> panel(k) -> update of column k+1 -> diag(k+1).  Only
     ONE nb x nb block of panel k enters diag(k+1): L[k+1, k].  So, per step k,
       diagonal chain   owner of (k,k) factors it; the holder of block row k+1 solves THAT block first and sends it along its
                        process row (one small ncclBroadcast on the row sub-communicator); the owner of (k+1,k+1) applies it
-                       to the diagonal block (which got the contributions of the panels before k from the two-ahead column
-                       update below) and can factor at once: potrf(nb) + two small hops per step;
+                       to the diagonal block (already up to date through panel k-1, see "near" below) and can factor at
+                       once: potrf(nb) + two small hops per step;
       panel chain      meanwhile the rest of panel k is solved, every piece goes to every rank over all links
-                       (gpx_comm_panel_bcast), column k+1 is updated below its diagonal block (releases panel k+1's solve);
-      bulk             column k+2 next (its diagonal block is the one the chain needs in two steps), then the other local
-                       block columns.
+                       (gpx_comm_panel_bcast);
+      near updates     (MAIN) column k+1 below its diagonal block gets panel k (releases panel k+1's solve); column k+2 is
+                       brought up to date through panel k in one launch over the panels of the current group;
+      group end        every `agg` steps: the next `agg` block columns (the ones that become "near" during the next group)
+                       get the whole group at once (MAIN, K = agg nb), and everything to the right of them gets it on the
+                       CU-masked BULK stream -- ONE launch over the whole local trailing matrix, beside the next group's
+                       chain.  (Round 2 applied every panel to every block column separately: K = nb, one launch per block
+                       column, 39 TF/s at C4 on one rank; profiles/r03_dist_w1_before.txt.)
     Streams per rank: PANEL (diagonal factor, solves, the early diagonal update), COMM (collectives, enqueued in the same
-    order on every rank of every communicator), MAIN (trailing updates), BACK (copies into L, then the streamed-evaluation
-    hook `on_stored(k)`).  A panel buffer is rewritten at step k+2 only after everything of step k that reads it is done.
+    order on every rank of every communicator), MAIN (near updates), BULK (aggregated updates), BACK (copies into L, then the
+    streamed-evaluation hook `on_stored(k)`).  A panel buffer is rewritten one ring later, after everything that reads it.
     Returns 0 or the 1-based index of the first non-positive pivot (agreed by all)."""
+    dist2_potrf_enqueue(ops, comm, geo, A, G, L=L, on_stored=on_stored, agg=agg)
+    return dist2_potrf_finish(ops, comm, L)
+
+
+def dist2_potrf_finish(ops, comm, L=None):
+    info = ops.info()  # synchronises every stream
+    if L is not None:
+        ops.finish(L)
+    allinfo = comm.allgather(np.array([float(info)]))[:, 0]
+    bad = [int(v) for v in allinfo if v > 0]
+    return min(bad) if bad else 0
+
+
+def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None):
+    """The asynchronous part of dist2_potrf: pure enqueue, no host read -- recordable (Program)."""
     nb, Pr, Pc, pr, pc = geo.nb, geo.Pr, geo.Pc, geo.pr, geo.pc
     nblk = geo.nblk
+    q = default_agg() if agg is None else int(agg)
+    R = len(G)
+    assert R >= (ring_size(q) if q > 1 else 2), "panel-buffer ring too short for the aggregation depth"
+    bulk_stream = {"bulk": BULK, "eval": EVAL, "main": MAIN}[os.environ.get("GPX_DIST_BULK_STREAM", "bulk")]
+    at_step = getattr(comm, "at_step", None)
+
+    def group_end(k):
+        return min((k // q + 1) * q - 1, nblk - 1)
+
+    def my_col_range(Ja, Jb):
+        """(lc0, n, first J) of this rank's local block columns with global index in [Ja, Jb]."""
+        Jb = min(Jb, nblk - 1)
+        if Ja > Jb:
+            return 0, 0, None
+        lja = 0 if Ja <= pc else (Ja - pc + Pc - 1) // Pc
+        ljb = (Jb - pc) // Pc if Jb >= pc else -1
+        if ljb < lja:
+            return 0, 0, None
+        n = sum(geo.height(lj * Pc + pc) for lj in range(lja, ljb + 1))
+        return lja * nb, n, lja * Pc + pc
+
+    def update_cols(Ja, Jb, ks, below_diag=False):
+        lc0, n, J0 = my_col_range(Ja, Jb)
+        if n == 0:
+            return
+        li = geo.blocks_before(pr, Pr, J0 + (1 if below_diag else 0))   # first local block row with I >= J0 (> J0)
+        lr0 = geo.row_off(pr, li)
+        m = geo.local_rows(pr) - lr0
+        if m > 0:
+            ops.update_multi(A, lr0, m, lc0, n, geo, [G[kk % R] for kk in ks], list(ks), below_diag)
+
+    bulk_recorded = set()
     ops.stream(MAIN)
     ops.begin()
     ops.record(_ev2(E_DIAGREADY, 0))  # the assembly was queued on MAIN
     ops.record(_ev2(E_COLREADY, 0))
     for k in range(nblk):
         kr, kc = k % Pr, k % Pc
-        g = G[k & 1]
+        g = G[k % R]
         w = geo.height(k)
         lr, lc = (k // Pr) * nb, (k // Pc) * nb
         holder = pc == kc
@@ -768,12 +804,20 @@ def dist2_potrf(ops, comm, geo, A, G, L=None, on_stored=None):
         r1, c1 = (k + 1) % Pr, (k + 1) % Pc        # process row of block row k+1 / column of the next diagonal owner
         h1 = geo.height(k + 1) if nxt else 0
         early_off = geo.piece_off(r1) + geo.dsz      # L[k+1, k] is the first block of piece r1
+        if at_step is not None:
+            at_step(geo, k)
 
         def wait_free():
-            if k >= 2:
-                ops.wait(_ev2(E_UPD, k - 2))
-                ops.wait(_ev2(E_STORED, k - 2))
-                ops.wait(_ev2(E_PANELDONE, k - 2))
+            """everything that read this buffer one ring ago is done (near updates + group-end updates of that panel's group,
+            the copy into L, the panel stream's solves)"""
+            old = k - R
+            if old >= 0:
+                ge = group_end(old)
+                ops.wait(_ev2(E_UPD, ge))
+                if ge in bulk_recorded:
+                    ops.wait(_ev2(E_BULK, ge))
+                ops.wait(_ev2(E_STORED, old))
+                ops.wait(_ev2(E_PANELDONE, old))
 
         # ---- diagonal chain -------------------------------------------------------------------------------------
         if owner:
@@ -798,7 +842,7 @@ def dist2_potrf(ops, comm, geo, A, G, L=None, on_stored=None):
             if nxt and pr == r1:                                         # block row k+1 first: the next diagonal needs it
                 ops.panel_trsm(A, lr0, h1, lc, w, g, geo.piece_off(kr), roff, nb)
                 ops.record(_ev2(E_EARLYSOLVED, k))
-                ops.panel_trsm(A, lr0 + h1, m - h1, lc, w, g, geo.piece_off(kr), roff + h1 * nb, nb)
+                ops.panel_trsm(A, lr0 + h1, m - h1, lc, w, g, geo.piece_off(kr), roff + h1 * geo.gld, nb)
             else:
                 ops.panel_trsm(A, lr0, m, lc, w, g, geo.piece_off(kr), roff, nb)
             ops.record(_ev2(E_PIECE, k))
@@ -808,7 +852,7 @@ def dist2_potrf(ops, comm, geo, A, G, L=None, on_stored=None):
                 ops.wait(_ev2(E_EARLYSOLVED, k))
             else:
                 wait_free()
-            comm.bcast_grp(g, early_off, h1 * nb, kc, ROW)               # L[k+1, k] along the process row of block row k+1
+            comm.bcast_grp(g, early_off, h1 * geo.gld, kc, ROW)          # L[k+1, k] along the process row of block row k+1
             ops.record(_ev2(E_EARLY, k))
             if pc == c1:                                                 # owner of the next diagonal block
                 ops.stream(PANEL)
@@ -830,6 +874,11 @@ def dist2_potrf(ops, comm, geo, A, G, L=None, on_stored=None):
             ops.wait(_ev2(E_PIECE, k))
         else:
             wait_free()
+        # Ranks of process row r1 that are no column holders already HAVE L[k+1, k] (row broadcast above) and their PANEL
+        # stream may be reading it (early diagonal update) while the panel broadcast lands the same bytes on it again:
+        # order the overwrite behind that read instead of relying on the bytes being identical.
+        if nxt and pr == r1 and pc == c1 and not holder:
+            ops.wait(_ev2(E_DIAGREADY, k + 1))
         comm.panel_bcast(g, geo.pieces(k))                               # every piece to every rank, all links
         ops.record(_ev2(E_ARRIVED, k))
         ops.stream(BACK)
@@ -843,32 +892,36 @@ def dist2_potrf(ops, comm, geo, A, G, L=None, on_stored=None):
         ops.record(_ev2(E_STORED, k))
         if on_stored is not None:
             on_stored(k)
+        # ---- trailing updates -----------------------------------------------------------------------------------
         ops.stream(MAIN)
         ops.wait(_ev2(E_ARRIVED, k))
-        cols = geo.my_cols_after(k)
-        if cols and cols[0] == k + 1:                                    # look-ahead: column k+1 BELOW its diagonal block
-            lr0, m, lc0, n, aoff, boff = geo.update_args(k, k + 1, below_diag=True)
-            ops.update(A, lr0, m, lc0, n, g, aoff, boff, w, nb)
-            cols = cols[1:]
+        g0 = (k // q) * q
+        update_cols(k + 1, k + 1, [k], below_diag=True)                  # look-ahead: releases panel k+1's solve
         if nxt and pc == c1:
             ops.record(_ev2(E_COLREADY, k + 1))
-        if cols and cols[0] == k + 2:                                    # two ahead: the diagonal chain needs it next step
-            lr0, m, lc0, n, aoff, boff = geo.update_args(k, k + 2)
-            ops.update(A, lr0, m, lc0, n, g, aoff, boff, w, nb)
-            cols = cols[1:]
+        update_cols(k + 2, k + 2, list(range(g0, k + 1)))                # two ahead: up to date through panel k
         if k + 2 < nblk and (k + 2) % Pc == pc:
             ops.record(_ev2(E_COL2, k + 2))
-        for J in cols:
-            lr0, m, lc0, n, aoff, boff = geo.update_args(k, J)
-            ops.update(A, lr0, m, lc0, n, g, aoff, boff, w, nb)
+        if k == group_end(k):
+            ks = list(range(g0, k + 1))
+            if k + 3 < nblk:
+                # the block columns that turn "near" during the next group: here, ahead of everything else.  They were last
+                # written by the previous group's bulk update (other stream).
+                prev = g0 - 1
+                if prev in bulk_recorded:
+                    ops.wait(_ev2(E_BULK, prev))
+                update_cols(k + 3, k + 2 + q, ks)
+            if k + 3 + q < nblk:
+                ops.stream(bulk_stream)
+                if bulk_stream != MAIN:
+                    ops.wait(_ev2(E_COLREADY, 0))                        # this rank's own assembly of A (queued on MAIN)
+                    ops.wait(_ev2(E_ARRIVED, k))                         # COMM is in order: implies the group's earlier panels
+                update_cols(k + 3 + q, nblk - 1, ks)
+                ops.record(_ev2(E_BULK, k))
+                bulk_recorded.add(k)
+                ops.stream(MAIN)
         ops.record(_ev2(E_UPD, k))
     ops.stream(MAIN)
-    info = ops.info()  # synchronises every stream
-    if L is not None:
-        ops.finish(L)
-    allinfo = comm.allgather(np.array([float(info)]))[:, 0]
-    bad = [int(v) for v in allinfo if v > 0]
-    return min(bad) if bad else 0
 
 
 def dist2_potrs(ops, comm, geo, A, yv, acc_r, acc_c, out):
@@ -876,7 +929,7 @@ def dist2_potrs(ops, comm, geo, A, yv, acc_r, acc_c, out):
     row of the diagonal owner, the solved block broadcast down its process column), then the transposed sweep with the
     roles of rows and columns exchanged; the blocks of alpha (one per diagonal owner) are assembled on every rank by one
     ncclAllReduce.  yv: device vector (padded N) holding y on every rank -- overwritten; acc_r / acc_c: scratch vectors
-    of local_rows / local_cols doubles; out: device vector (padded N) that receives alpha everywhere."""
+    of local_rows / local_cols doubles; out: device vector (padded N) that receives alpha everywhere.  Pure enqueue."""
     nb, Pr, Pc, pr, pc = geo.nb, geo.Pr, geo.Pc, geo.pr, geo.pc
     ops.stream(MAIN)
     ops.vec_op(acc_r, 0, None, 0, max(geo.local_rows(pr), 1), 2)
@@ -913,70 +966,214 @@ def dist2_potrs(ops, comm, geo, A, yv, acc_r, acc_c, out):
     return out
 
 
-def dist2_logdet(ops, comm, geo, A, scal):
-    """log det K = 2 sum log L_ii: every diagonal owner adds its blocks, one ncclAllReduce of a scalar."""
+def dist2_logdet_enqueue(ops, geo, A, scal):
     ops.stream(MAIN)
     ops.vec_op(scal, 0, None, 0, 1, 2)
     for k in range(geo.nblk):
         if k % geo.Pr == geo.pr and k % geo.Pc == geo.pc:
             ops.logdet_acc(A, (k // geo.Pr) * geo.nb, (k // geo.Pc) * geo.nb, geo.height(k), geo.height(k), scal)
+
+
+def dist2_logdet(ops, comm, geo, A, scal):
+    """log det K = 2 sum log L_ii: every diagonal owner adds its blocks, one ncclAllReduce of a scalar."""
+    dist2_logdet_enqueue(ops, geo, A, scal)
     return float(comm.allreduce_host(np.array([ops.vec_to_host(scal, 1)[0]]))[0])
+
+
+class ReplayComm(Emitter):
+    """ONE process plays rank `rank` of a `world`-rank grid on one GPU: every receive of the panel loop becomes a device copy
+    of the same bytes out of the complete factor `Lref` resident on this GPU (gpx_dist2_pack_*), sends cost nothing (the
+    sender's data is its own), and nothing waits for a peer.  What it measures: the rank's kernel sequence, its GPU time per
+    strand and the host issue time -- not xGMI.  Only the factorisation + streamed evaluation are replayable (the substitution
+    sweeps need the peers' partial sums)."""
+    recordable = True
+
+    def __init__(self, ctx, world, rank, Lref):
+        self.ctx, self.world, self.rank, self.Lref = ctx, int(world), int(rank), Lref
+        self.k = None
+        self.bytes_in = 0     # bytes the collectives would have delivered to this rank (per recording)
+
+    def set_grid(self, Pr, Pc):
+        assert Pr * Pc == self.world
+        self.grid = (Pr, Pc)
+
+    def at_step(self, geo, k):
+        self.geo, self.k = geo, k
+
+    def _rows(self, buf, off, m, first_block, stride, k):
+        geo = self.geo
+        self._emit(OP["PACK_ROWS"], (self.Lref, buf), (first_block, stride, k * geo.nb, off, m, geo.height(k), geo.nb))
+        self.bytes_in += 8 * m * geo.gld
+
+    def _diag(self, buf, off, k):
+        geo = self.geo
+        self._emit(OP["PACK_DIAG"], (self.Lref, buf), (k * geo.nb, geo.height(k), geo.nb, off))
+        self.bytes_in += 8 * geo.dsz
+
+    def bcast_grp(self, buf, offset, count, root, grp):
+        geo, k = self.geo, self.k
+        mine = geo.pc if grp == ROW else geo.pr
+        if count == 0 or mine == root:
+            return
+        if grp == COL:
+            assert offset == geo.piece_off(k % geo.Pr) and count == geo.dsz
+            self._diag(buf, offset, k)
+        else:
+            assert grp == ROW and count == geo.height(k + 1) * geo.gld
+            self._rows(buf, offset, geo.height(k + 1), k + 1, 1, k)
+
+    def panel_bcast(self, buf, pieces):
+        geo, k = self.geo, self.k
+        for off, cnt, root in pieces:
+            if root == self.rank or cnt == 0:
+                continue
+            p = root // geo.Pc
+            m = geo.piece_rows(p, k)
+            if p == k % geo.Pr:
+                assert off == geo.piece_off(p) and cnt == geo.dsz + m * geo.gld
+                self._diag(buf, off, k)
+                off += geo.dsz
+            else:
+                assert off == geo.piece_off(p) + geo.dsz and cnt == m * geo.gld
+            if m > 0:
+                self._rows(buf, off, m, p + geo.li0(p, k) * geo.Pr, geo.Pr, k)
+
+    def reduce_grp(self, *a):
+        raise NotImplementedError("the substitution sweeps are not replayable on one rank")
+
+    allreduce = reduce_grp
+
+    def allgather(self, vec):
+        return np.tile(as_f64(np.atleast_1d(vec)), (self.world, 1))
+
+    def barrier(self):
+        self.ctx.sync()
+
+    def max_float(self, v):
+        return float(v)
+
+    def close(self):
+        pass
 
 
 class DistFitIvar2D:
     """bench.py's multi-GPU step on the 2-D block-cyclic layout: distributed fit (local assembly + dist2_potrf), alpha
     by distributed substitution, logdet / y^T alpha through all-reduce, IVAR with the evaluation points sharded over the
-    ranks against the replicated factor (streamed underneath the factorisation from 4 ranks)."""
+    ranks against the replicated factor (streamed underneath the factorisation from 4 ranks).
 
-    def __init__(self, ctx, comm, spec, Xh, yh, Zh, noise, nb=512, ops=None, streamed=None, grid=None):
+    Memory per rank: the local share of the working matrix (N^2 / W), the ring of packed panel buffers (2 agg x N x nb) --
+    and a REPLICATED copy of the finished factor (N^2: 8.6 GB at C4, 34 GB at C5 of the 288 GB), which is what makes the
+    evaluation phase communication-free.  The 2-D layout distributes the factorisation's work and traffic, not its result."""
+
+    def __init__(self, ctx, comm, spec, Xh, yh, Zh, noise, nb=512, ops=None, streamed=None, grid=None, agg=None,
+                 fit_only=False):
         self.ctx, self.comm, self.spec = ctx, comm, spec
         self.ops = ops or DeviceOps2D(ctx)
         Pr, Pc = grid or choose_grid(comm.world)
         comm.set_grid(Pr, Pc)
         self.n, self.noise = Xh.shape[0], float(noise)
         self.geo = Grid2D(self.n, nb, Pr, Pc, comm.rank)
+        self.agg = default_agg() if agg is None else int(agg)
         env = os.environ.get("GPX_DIST_STREAM_IVAR")
         self.streamed = (comm.world >= 4) if streamed is None else bool(streamed)
         if env is not None:
             self.streamed = env == "1"
+        self.fit_only = bool(fit_only)       # replay: factorisation (+ streamed evaluation) only
         self.yh = np.ascontiguousarray(yh, dtype=np.float64)
         self.m = Zh.shape[0]
         self.X = self.ops.points(Xh)
         lo, hi = eval_slice(self.m, comm.rank, comm.world)
         self.Zloc = self.ops.points(Zh[lo:hi]) if hi > lo else None
         self.A = self.ops.alloc_local(self.geo)
-        self.G = [self.ops.alloc_buf(self.geo), self.ops.alloc_buf(self.geo)]
+        self.G = [self.ops.alloc_buf(self.geo) for _ in range(ring_size(self.agg) if self.agg > 1 else 2)]
         self.L = self.ops.alloc_matrix(self.n)
         self.yv = self.ops.alloc_vec(self.geo.np)
+        self.y0 = self.ops.alloc_vec(self.geo.np)
+        ypad = np.zeros(self.geo.np)
+        ypad[:self.n] = self.yh
+        self.ops.vec_from_host(self.y0, ypad)
         self.alpha = self.ops.alloc_vec(self.geo.np)
         self.acc_r = self.ops.alloc_vec(self.geo.local_rows(self.geo.pr))
         self.acc_c = self.ops.alloc_vec(self.geo.local_cols(self.geo.pc))
         self.scal = self.ops.alloc_vec(8)
         self.B = self.ops.alloc_cross(self.n, hi - lo) if (self.streamed and hi > lo) else None
+        # recorded programs (device ops + a recordable communicator only; GPX_DIST_RECORD=0 interprets every step)
+        self.programs = None
+        self.recordable = (type(self.ops) is DeviceOps2D and getattr(comm, "recordable", False)
+                           and os.environ.get("GPX_DIST_RECORD", "1") == "1")
+        self.host_ms = {}
+
+    # the three asynchronous phases of a step, written once, either executed directly or recorded
+    def _hook(self):
+        if self.B is None:
+            return None
+        ops, geo = self.ops, self.geo
+
+        q, last = self.agg, geo.nblk - 1
+        ivar_stream = EVAL if os.environ.get("GPX_DIST_IVAR_STREAM", "back") == "eval" else BACK
+
+        def hook(k):
+            # one right-looking solve step per GROUP of stored panels (K = agg * nb updates), behind the copy of the group's
+            # last panel into L
+            if k % q == q - 1 or k == last:
+                if ivar_stream != BACK:
+                    ops.stream(ivar_stream)
+                    ops.wait(_ev2(E_STORED, k))
+                else:
+                    ops.stream(BACK)                            # same stream as the copies: already ordered
+                ops.ivar_group(self.L, (k // q) * q, k, geo.nb, self.B)
+        return hook
+
+    def _enqueue_factor(self):
+        dist2_potrf_enqueue(self.ops, self.comm, self.geo, self.A, self.G, L=self.L, on_stored=self._hook(), agg=self.agg)
+
+    def _enqueue_solve(self):
+        ops, geo = self.ops, self.geo
+        ops.stream(MAIN)
+        ops.vec_op(self.yv, 0, self.y0, 0, geo.np, 0)
+        dist2_potrs(ops, self.comm, geo, self.A, self.yv, self.acc_r, self.acc_c, self.alpha)
+        dist2_logdet_enqueue(ops, geo, self.A, self.scal)
+
+    def _record(self):
+        progs = {}
+        for name, fn in (("factor", self._enqueue_factor), ("solve", self._enqueue_solve)):
+            if name == "solve" and self.fit_only:
+                continue
+            prog = Program()
+            self.ops.prog = self.comm.prog = prog
+            try:
+                fn()
+            finally:
+                self.ops.prog = self.comm.prog = None
+            progs[name] = prog
+        self.programs = progs
+
+    def _run(self, name, fn):
+        if self.recordable:
+            if self.programs is None:
+                self._record()
+            self.host_ms[name] = self.programs[name].run(self.ctx)
+        else:
+            fn()
 
     def step(self):
         ops, comm, geo = self.ops, self.comm, self.geo
         ops.stream(MAIN)
         ops.kfill_local(self.spec, self.X, self.A, self.noise, geo)
-        hook = None
         if self.B is not None:
             ops.stream(BACK)
             ops.cross_fill(self.spec, self.X, self.Zloc, self.B)   # independent of the factorisation
             ops.stream(MAIN)
-
-            def hook(k):
-                ops.stream(BACK)                                    # behind the copy of panel k into L (same stream)
-                ops.ivar_step(self.L, k, geo.nb, self.B)
-
-        info = dist2_potrf(ops, comm, geo, self.A, self.G, L=self.L, on_stored=hook)
+        self._run("factor", self._enqueue_factor)
+        info = dist2_potrf_finish(ops, comm, self.L)
         if info:
             from ._lib import NotPositiveDefinite
             raise NotPositiveDefinite(info)
-        ypad = np.zeros(geo.np)
-        ypad[:self.n] = self.yh
-        ops.vec_from_host(self.yv, ypad)
-        dist2_potrs(ops, comm, geo, self.A, self.yv, self.acc_r, self.acc_c, self.alpha)
-        logdet = dist2_logdet(ops, comm, geo, self.A, self.scal)
+        if self.fit_only:
+            part = float(np.sum(ops.variances(self.spec, self.Zloc, self.B, self.n))) if self.B is not None else 0.0
+            return 0.0, part
+        self._run("solve", self._enqueue_solve)
+        logdet = float(comm.allreduce_host(np.array([ops.vec_to_host(self.scal, 1)[0]]))[0])
         part = 0.0
         if self.B is not None:     # the solve finished with the last panel (dist2_potrf synchronised every stream)
             part = float(np.sum(ops.variances(self.spec, self.Zloc, self.B, self.n)))

@@ -65,7 +65,8 @@ int gpx_create(int device, gpx_ctx** out);
 int gpx_destroy(gpx_ctx* ctx);
 int gpx_sync(gpx_ctx* ctx);   /* device-wide: every stream of the context */
 /* HIP streams per context: 0 main, 1 panel factorisation (high priority), 2 communication (high priority), 3 background
- * (CU-masked: leaves 4 CUs per XCD to the others), 4 evaluation (low priority).
+ * (CU-masked: leaves 4 CUs per XCD to the others), 4 evaluation (low priority), 5 bulk (CU-masked like 3: the aggregated
+ * trailing updates of the distributed factorisation).
  * All entry points enqueue on the currently selected one; events order work across them (look-ahead pipeline). */
 int gpx_stream_select(gpx_ctx* ctx, int which);
 int gpx_event_record(gpx_ctx* ctx, int id);  /* id in [0, 65536): recorded on the selected stream */
@@ -237,6 +238,8 @@ int gpx_dist_panel_update(gpx_ctx* ctx, gpx_mat* K, int64_t k, int64_t nb, const
 /* streamed evaluation (multi-GPU): step k of a right-looking left solve of B = K(X, Z_local) (padded N x m) against block
  * column k of the factor, valid as soon as gpx_dist_panel_store(k) has run; asynchronous on the selected stream */
 int gpx_dist_ivar_step(gpx_ctx* ctx, const gpx_mat* K, int64_t k, int64_t nb, gpx_mat* B);
+/* the same for the panels k0 .. k1 at once (the update below the group runs with K = (k1 - k0 + 1) nb) */
+int gpx_dist_ivar_group(gpx_ctx* ctx, const gpx_mat* K, int64_t k0, int64_t k1, int64_t nb, gpx_mat* B);
 int gpx_dist_finish(gpx_ctx* ctx, gpx_mat* K);
 
 /* ---- multi-GPU, 2-D block-cyclic (north_star) ---------------------------------------------------------
@@ -259,6 +262,8 @@ int gpx_comm_panel_bcast(gpx_ctx* ctx, gpx_mat* buf, const int64_t* offsets, con
                          int npieces);
 /* doubles of a packed diagonal block: nb x nb factor + nb/128 inverted 128 x 128 leaves */
 int64_t gpx_dist2_diag_elems(int64_t nb);
+/* row stride (doubles) of the packed panel rows (nb + a build-time skew, 0 by default) */
+int64_t gpx_dist2_row_stride(int64_t nb);
 /* local part of K(X) + nugget on rank (pr, pc)   (gp_kernel_utilities.py:34-68, communication-free) */
 int gpx_dist2_kfill(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* X, const double* nugget,
                     int64_t nugget_len, gpx_mat* A, int64_t nb, int Pr, int Pc, int pr, int pc);
@@ -271,6 +276,17 @@ int gpx_dist2_panel_trsm(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64
 /* A[lr0:lr0+m, lc0:lc0+n] -= G[aoff] (m x w) * G[boff] (n x w)^T : trailing update of one local block column */
 int gpx_dist2_update(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t lc0, int64_t n, const gpx_mat* G,
                      int64_t aoff, int64_t boff, int64_t w, int64_t nb);
+/* trailing update by SEVERAL panels at once over the whole local trailing matrix (one launch, K = nseg * nb): panel ks[s]
+ * sits in the packed buffer G[s] (Pr pieces of piece_stride doubles); only local blocks on / below (below_diag != 0:
+ * strictly below) the global diagonal are touched.  nseg <= 8, Pr <= 4. */
+int gpx_dist2_update_multi(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t lc0, int64_t n, int64_t nb, int Pr, int Pc,
+                           int pr, int pc, int64_t piece_stride, int nseg, const gpx_mat* const* G, const int64_t* ks,
+                           int below_diag);
+/* single-rank replay of the distributed loop: stage what a collective would have delivered out of a complete factor L
+ * resident on this GPU (inverse of the two unpack calls below; same bytes, device to device) */
+int gpx_dist2_pack_rows(gpx_ctx* ctx, const gpx_mat* L, int64_t first_block, int64_t stride, int64_t col0, gpx_mat* G,
+                        int64_t roff, int64_t m, int64_t w, int64_t nb);
+int gpx_dist2_pack_diag(gpx_ctx* ctx, const gpx_mat* L, int64_t r0, int64_t w, int64_t nb, gpx_mat* G, int64_t doff);
 /* replicated factor for the evaluation phase: piece rows / diagonal block of panel k into the full-size matrix L */
 int gpx_dist2_unpack_rows(gpx_ctx* ctx, const gpx_mat* G, int64_t roff, int64_t m, int64_t w, int64_t nb, gpx_mat* L,
                           int64_t first_block, int64_t stride, int64_t col0);
@@ -281,6 +297,18 @@ int gpx_dist2_trsv_diag(gpx_ctx* ctx, const gpx_mat* A, int64_t lr, int64_t lc, 
 int gpx_dist2_gemv(gpx_ctx* ctx, const gpx_mat* A, int64_t lr0, int64_t m, int64_t lc, int64_t w, const gpx_mat* x,
                    int64_t xoff, gpx_mat* acc, int64_t aoff, int transposed);
 int gpx_dist2_logdet_acc(gpx_ctx* ctx, const gpx_mat* A, int64_t lr, int64_t lc, int64_t w, int64_t n_valid, gpx_mat* acc);
+
+/* Recorded programs: the Python panel loop (gpexp_amd/dist.py) runs once against a recorder; its primitives and collectives
+ * become rows of 16 int64 [opcode, handle0, handle1, handle2, a0 .. a11] (variable-length lists in `extra`, referenced by
+ * offset) and are replayed natively on every step -- same call sequence, no interpreter in the issue path.  *host_ms
+ * (nullable) = host time spent issuing.  Opcodes: */
+enum {
+  GPX_OP_STREAM = 1, GPX_OP_RECORD, GPX_OP_WAIT, GPX_OP_BEGIN, GPX_OP_DIAG_FACTOR, GPX_OP_PANEL_TRSM, GPX_OP_UPDATE,
+  GPX_OP_UPDATE_MULTI, GPX_OP_UNPACK_ROWS, GPX_OP_UNPACK_DIAG, GPX_OP_PACK_ROWS, GPX_OP_PACK_DIAG, GPX_OP_BCAST_GRP,
+  GPX_OP_REDUCE_GRP, GPX_OP_ALLREDUCE, GPX_OP_PANEL_BCAST, GPX_OP_IVAR_STEP, GPX_OP_TRSV_DIAG, GPX_OP_GEMV, GPX_OP_LOGDET_ACC,
+  GPX_OP_VEC_OP, GPX_OP_SPIN, GPX_OP_COPY, GPX_OP_IVAR_GROUP
+};
+int gpx_program_run(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const int64_t* extra, int64_t nextra, double* host_ms);
 
 /* out[j] = sum over the first `rows` rows of B[i][j]^2 (host out[B->cols]): variance reduction of a solved cross matrix */
 int gpx_col_sumsq(gpx_ctx* ctx, const gpx_mat* B, int64_t rows, double* out);

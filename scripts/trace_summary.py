@@ -1,17 +1,57 @@
-"""Summarise a rocprofv3 kernel_trace.csv: per kernel name x grid size -> calls, total ms, avg us."""
-import csv, sys, collections
-rows = collections.defaultdict(lambda: [0, 0.0])
-with open(sys.argv[1]) as f:
-    for r in csv.DictReader(f):
-        name = r["Kernel_Name"].split("(")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
-        if "<" in r["Kernel_Name"]:
-            name = r["Kernel_Name"].split("(anonymous namespace)::")[-1].split("(")[0]
-        key = (name, int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1), int(r["Grid_Size_Y"]))
-        d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-        rows[key][0] += 1
-        rows[key][1] += d
-tot = sum(v[1] for v in rows.values())
-lim = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-print("total kernel ms %.2f" % tot)
-for k, v in sorted(rows.items(), key=lambda kv: -kv[1][1])[:lim]:
-    print("%-40s grid=(%5d,%5d) calls=%5d total=%9.3f ms avg=%9.1f us  %.1f%%" % (k[0][:40], k[1], k[2], v[0], v[1], 1e3 * v[1] / v[0], 100 * v[1] / tot))
+#!/usr/bin/env python3
+"""Per-kernel and per-stream summary of a rocprofv3 --kernel-trace database (rocpd .db).
+usage: trace_summary.py results.db [t0_ms t1_ms]   -- window in ms relative to the first kernel (default: everything)"""
+import re
+import sqlite3
+import sys
+
+db = sqlite3.connect(sys.argv[1])
+c = db.cursor()
+rows = list(c.execute("select name, start, end, stream_id, queue_id, grid_x, workgroup_x from kernels order by start"))
+t00 = rows[0][1]
+lo = float(sys.argv[2]) if len(sys.argv) > 2 else -1e30
+hi = float(sys.argv[3]) if len(sys.argv) > 3 else 1e30
+rows = [r for r in rows if lo <= (r[1] - t00) / 1e6 <= hi]
+
+
+def short(n):
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = re.sub(r"^void ", "", n)
+    return n.split("(")[0][:60]
+
+
+agg = {}
+for n, s, e, st, q, gx, wx in rows:
+    a = agg.setdefault(short(n), [0, 0.0, 0.0])
+    a[0] += 1
+    a[1] += (e - s) / 1e6
+    a[2] = max(a[2], (e - s) / 1e3)
+print("window %.1f .. %.1f ms, %d kernels" % ((rows[0][1] - t00) / 1e6, (rows[-1][2] - t00) / 1e6, len(rows)))
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
+    print("%-62s n=%6d tot=%9.2f ms avg=%8.1f us max=%9.1f us" % (k, v[0], v[1], 1e3 * v[1] / v[0], v[2]))
+# per stream: busy time (union of intervals) and span
+by = {}
+for n, s, e, st, q, gx, wx in rows:
+    by.setdefault(st, []).append((s, e))
+print("\nper stream: kernels, busy (union) ms, first..last ms")
+for st, iv in sorted(by.items()):
+    iv.sort()
+    busy, cs, ce = 0, iv[0][0], iv[0][1]
+    for s, e in iv[1:]:
+        if s > ce:
+            busy += ce - cs
+            cs, ce = s, e
+        else:
+            ce = max(ce, e)
+    busy += ce - cs
+    print("stream %3s  n=%6d busy=%9.2f  %9.2f .. %9.2f" % (st, len(iv), busy / 1e6, (iv[0][0] - t00) / 1e6, (iv[-1][1] - t00) / 1e6))
+allv = sorted((s, e) for _, s, e, *_ in rows)
+busy, cs, ce = 0, allv[0][0], allv[0][1]
+for s, e in allv[1:]:
+    if s > ce:
+        busy += ce - cs
+        cs, ce = s, e
+    else:
+        ce = max(ce, e)
+busy += ce - cs
+print("device busy (union over streams) %.2f ms of %.2f ms" % (busy / 1e6, (allv[-1][1] - allv[0][0]) / 1e6))

@@ -1,0 +1,159 @@
+"""TEST-ONLY communicators for the multi-rank tests (moved out of gpexp_amd/ in round 3: the product package imports no torch).
+
+  _TorchGroup     thin wrapper over torch.distributed (gloo, CPU tensors): rendezvous-level exchanges and sub-groups
+  HostStagedComm  device -> host -> gloo -> device: lets 2..6 ranks SHARE one GPU (RCCL refuses two ranks on one device),
+                  so the real HIP primitives of the distributed loops run at world > 1 on a one-GPU box
+
+Same interface as gpexp_amd.dist.RcclComm.  Selected with GPX_COMM=host (gpexp_amd.dist.init_from_env imports it from here).
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from gpexp_amd._lib import check, dptr  # noqa: E402
+
+
+class _TorchGroup:
+    """Thin wrapper over torch.distributed (gloo, CPU tensors) for rendezvous-level exchanges."""
+
+    def __init__(self):
+        import torch
+        import torch.distributed as td
+        self.torch = torch
+        self.td = td
+        if not td.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            td.init_process_group(backend="gloo")
+        self.rank = td.get_rank()
+        self.world = td.get_world_size()
+
+    def bcast_bytes(self, b, root=0):
+        t = self.torch.zeros(len(b), dtype=self.torch.uint8)
+        if self.rank == root:
+            t = self.torch.tensor(list(b), dtype=self.torch.uint8)
+        self.td.broadcast(t, src=root)
+        return bytes(t.tolist())
+
+    def bcast_array(self, a, root):
+        t = self.torch.from_numpy(a)
+        self.td.broadcast(t, src=root)
+        return a
+
+    def make_grid(self, Pr, Pc):
+        """Process-row / process-column groups (every rank creates every group, in the same order)."""
+        self.rows = [self.td.new_group([p * Pc + q for q in range(Pc)]) for p in range(Pr)]
+        self.cols = [self.td.new_group([p * Pc + q for p in range(Pr)]) for q in range(Pc)]
+        self.Pr, self.Pc = Pr, Pc
+
+    def _group(self, grp):
+        """(process group, world ranks of its members) for WORLD / ROW / COL of this rank."""
+        pr, pc = self.rank // self.Pc, self.rank % self.Pc
+        if grp == 1:
+            return self.rows[pr], [pr * self.Pc + q for q in range(self.Pc)]
+        if grp == 2:
+            return self.cols[pc], [p * self.Pc + pc for p in range(self.Pr)]
+        return None, list(range(self.world))
+
+    def bcast_array_grp(self, a, root, grp):
+        g, members = self._group(grp)
+        self.td.broadcast(self.torch.from_numpy(a), src=members[root], group=g)
+        return a
+
+    def reduce_array_grp(self, a, root, grp):
+        g, members = self._group(grp)
+        t = self.torch.from_numpy(a.copy())
+        self.td.reduce(t, dst=members[root], op=self.td.ReduceOp.SUM, group=g)
+        if self.rank == members[root]:
+            a[:] = t.numpy()
+        return a
+
+    def allreduce_array(self, a):
+        self.td.all_reduce(self.torch.from_numpy(a), op=self.td.ReduceOp.SUM)
+        return a
+
+    def allgather(self, vec):
+        vec = np.ascontiguousarray(vec, dtype=np.float64)
+        outs = [self.torch.zeros(vec.size, dtype=self.torch.float64) for _ in range(self.world)]
+        self.td.all_gather(outs, self.torch.from_numpy(vec.copy()))
+        return np.stack([o.numpy() for o in outs])
+
+    def barrier(self):
+        self.td.barrier()
+
+    def max_float(self, v):
+        t = self.torch.tensor([float(v)], dtype=self.torch.float64)
+        self.td.all_reduce(t, op=self.td.ReduceOp.MAX)
+        return float(t[0])
+
+
+
+class HostStagedComm:
+    """Test-only communicator: panels bounce through host memory and gloo (several ranks may share one GPU)."""
+
+    def __init__(self, ctx, group=None):
+        self.ctx = ctx
+        self.group = group or _TorchGroup()
+        self.rank, self.world = self.group.rank, self.group.world
+
+    def bcast_panel(self, P, count, root):
+        buf = np.empty(int(count))
+        if self.rank == root:
+            check(self.ctx.lib.gpx_mat_read(self.ctx.h, P.h, 0, int(count), dptr(buf)))
+        self.group.bcast_array(buf, root)
+        if self.rank != root:
+            check(self.ctx.lib.gpx_mat_write(self.ctx.h, P.h, 0, int(count), dptr(buf)))
+
+    # ---- 2-D path (same interface as RcclComm) ----
+    def set_grid(self, Pr, Pc):
+        if getattr(self, "grid", None) != (Pr, Pc):
+            self.group.make_grid(Pr, Pc)
+            self.grid = (Pr, Pc)
+
+    def _read(self, buf, offset, count):
+        a = np.empty(int(count))
+        check(self.ctx.lib.gpx_mat_read(self.ctx.h, buf.h, int(offset), int(count), dptr(a)))
+        return a
+
+    def _write(self, buf, offset, a):
+        check(self.ctx.lib.gpx_mat_write(self.ctx.h, buf.h, int(offset), a.size, dptr(a)))
+
+    def bcast_grp(self, buf, offset, count, root, grp):
+        if count == 0:
+            return
+        self._write(buf, offset, self.group.bcast_array_grp(self._read(buf, offset, count), root, grp))
+
+    def reduce_grp(self, buf, offset, count, root, grp):
+        if count == 0:
+            return
+        self._write(buf, offset, self.group.reduce_array_grp(self._read(buf, offset, count), root, grp))
+
+    def allreduce(self, buf, offset, count):
+        self._write(buf, offset, self.group.allreduce_array(self._read(buf, offset, count)))
+
+    def allreduce_host(self, vec):
+        return self.group.allreduce_array(np.array(np.atleast_1d(vec), dtype=np.float64))
+
+    def panel_bcast(self, buf, pieces):
+        for off, cnt, root in pieces:
+            a = self._read(buf, off, cnt)
+            self.group.bcast_array(a, root)
+            if self.rank != root:
+                self._write(buf, off, a)
+
+    def allgather(self, vec):
+        return self.group.allgather(np.atleast_1d(vec))
+
+    def barrier(self):
+        self.ctx.sync()
+        self.group.barrier()
+
+    def max_float(self, v):
+        return self.group.max_float(v)
+
+    def close(self):
+        pass

@@ -17,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from gpexp_amd import dist  # noqa: E402
+import dist_testcomm  # noqa: E402  (tests/: the gloo communicators)
 
 
 class NumpyMat:
@@ -128,6 +129,10 @@ class NumpyOps:
         if r0 + w < np_:
             B.a[r0 + w:] -= K.a[r0 + w:, r0:r0 + w] @ B.a[r0:r0 + w]
 
+    def ivar_group(self, K, k0, k1, nb, B):
+        for k in range(k0, k1 + 1):
+            self.ivar_step(K, k, nb, B)
+
     def variances(self, spec, Z, B, n):
         return self.orc.kernel_diag(self.spec, Z) - np.sum(B.a[:n] ** 2, axis=0)
 
@@ -200,22 +205,61 @@ class NumpyOps2D(NumpyOps):
         X = A.a[lr0:lr0 + m, lc:lc + w]
         assert not self.poison or not np.isnan(X).any(), "holder solves rows it never assembled/updated"
         X[:] = np.linalg.solve(L11, X.T).T
-        rows = G.a[roff:roff + m * nb].reshape(m, nb)
+        gld = nb + dist.G_SKEW
+        rows = G.a[roff:roff + m * gld].reshape(m, gld)[:, :nb]   # the 16 pad doubles of a row are never read or written
         rows[:] = 0.0
         rows[:, :w] = X
 
     def update(self, A, lr0, m, lc0, n, G, aoff, boff, w, nb):
         self._inside(A, lr0, m, lc0, n)
-        assert aoff + m * nb <= G.a.size and boff + n * nb <= G.a.size
+        gld = nb + dist.G_SKEW
+        assert aoff + m * gld <= G.a.size and boff + n * gld <= G.a.size
         if m == 0 or n == 0:
             return
-        a = G.a[aoff:aoff + m * nb].reshape(m, nb)[:, :w]
-        b = G.a[boff:boff + n * nb].reshape(n, nb)[:, :w]
+        a = G.a[aoff:aoff + m * gld].reshape(m, gld)[:, :w]
+        b = G.a[boff:boff + n * gld].reshape(n, gld)[:, :w]
         assert not self.poison or not (np.isnan(a).any() or np.isnan(b).any()), "update reads a piece that never arrived"
         A.a[lr0:lr0 + m, lc0:lc0 + n] -= a @ b.T
 
+    def update_multi(self, A, lr0, m, lc0, n, geo, Gs, ks, below_diag):
+        """Same semantics as gpx_dist2_update_multi: every local block (li, lj) of the range with global I > J (I >= J
+        unless below_diag) gets minus the sum over the panels ks of  rows_I(panel) rows_J(panel)^T, the operands taken
+        from the packed buffers exactly where the device kernel reads them."""
+        self._inside(A, lr0, m, lc0, n)
+        nb, Pr, Pc, pr, pc = geo.nb, geo.Pr, geo.Pc, geo.pr, geo.pc
+        assert lr0 % nb == 0 and lc0 % nb == 0 and len(Gs) == len(ks) <= 8 and Pr <= 4
+        for lj in range(lc0 // nb, (lc0 + n + nb - 1) // nb):
+            J = lj * Pc + pc
+            cw = min(nb, lc0 + n - lj * nb)
+            for li in range(lr0 // nb, (lr0 + m + nb - 1) // nb):
+                I = li * Pr + pr
+                if I < J or (below_diag and I == J):
+                    continue
+                rh = min(nb, lr0 + m - li * nb)
+                acc = np.zeros((rh, cw))
+                for G, k in zip(Gs, ks):
+                    assert I > k and J > k, "update touches blocks that are not behind the panel"
+                    gld = geo.gld
+                    aoff = geo.piece_off(pr) + geo.dsz + (li - geo.li0(pr, k)) * nb * gld
+                    pj = J % Pr
+                    boff = geo.piece_off(pj) + geo.dsz + (J // Pr - geo.li0(pj, k)) * nb * gld
+                    assert aoff + rh * gld <= geo.piece_off(pr) + geo.piece_stride
+                    assert boff + cw * gld <= geo.piece_off(pj) + geo.piece_stride
+                    a = G.a[aoff:aoff + rh * gld].reshape(rh, gld)[:, :nb]
+                    b = G.a[boff:boff + cw * gld].reshape(cw, gld)[:, :nb]
+                    assert not self.poison or not (np.isnan(a).any() or np.isnan(b).any()), \
+                        "update reads a piece that never arrived (panel %d, block %d,%d)" % (k, I, J)
+                    acc += a @ b.T
+                blk = A.a[li * nb:li * nb + rh, lj * nb:lj * nb + cw]
+                assert not self.poison or I == J or not np.isnan(blk).any(), "update of a block that was never assembled"
+                blk -= acc
+
+    def spin(self, ms):
+        pass
+
     def unpack_rows(self, G, roff, m, w, nb, L, first_block, stride, col0):
-        rows = G.a[roff:roff + m * nb].reshape(m, nb)[:, :w]
+        gld = nb + dist.G_SKEW
+        rows = G.a[roff:roff + m * gld].reshape(m, gld)[:, :w]
         for t in range((m + nb - 1) // nb):
             h = min(nb, m - t * nb)
             g0 = (first_block + t * stride) * nb
@@ -272,7 +316,7 @@ class NumpyOps2D(NumpyOps):
 
 class NumpyComm:
     def __init__(self):
-        self.group = dist._TorchGroup()
+        self.group = dist_testcomm._TorchGroup()
         self.rank, self.world = self.group.rank, self.group.world
 
     # 2-D path: same interface as gpexp_amd.dist.RcclComm, on host arrays over gloo
@@ -397,15 +441,15 @@ def run_cpu2d(args):
         assert (geo.Pr, geo.Pc) == grid and geo.Pr * geo.Pc == comm.world
         seen = []
         if streamed:
-            orig = ops.ivar_step
+            orig = ops.ivar_group
 
-            def spy(K, k, nb_, B):
-                seen.append(k)
-                orig(K, k, nb_, B)
-            ops.ivar_step = spy
+            def spy(K, k0, k1, nb_, B):
+                seen.extend(range(k0, k1 + 1))
+                orig(K, k0, k1, nb_, B)
+            ops.ivar_group = spy
         ll, iv = run.step()
         if streamed:
-            ops.ivar_step = orig
+            ops.ivar_group = orig
             if run.B is not None:
                 assert seen == list(range(geo.nblk)), seen
         # replicated factor on every rank
@@ -463,7 +507,7 @@ def _chaos_ops(ctx, seed, rank):
                 check(self.ctx.lib.gpx_dbg_spin(self.ctx.h, int(rng.choice([1, 2, 5, 15, 40], p=[0.35, 0.3, 0.2, 0.1, 0.05]))))
             return f(self, *a, **kw)
         setattr(ChaosOps2D, name, g)
-    for nm in ("kfill_local", "diag_factor", "panel_trsm", "update", "unpack_rows", "unpack_diag", "cross_fill", "ivar_step",
+    for nm in ("kfill_local", "diag_factor", "panel_trsm", "update", "update_multi", "unpack_rows", "unpack_diag", "cross_fill", "ivar_group",
                "record"):
         wrap(nm)
     return ChaosOps2D(ctx)
