@@ -68,12 +68,12 @@ def _cpu_info():
     return model, blas, int(threads)
 
 
-def _ref_exact(n, m, d, seed):
+def _ref_exact(n, m, d, seed, kind="matern52"):
     """One pass of the REFERENCE ALGORITHM (the oracle's restatement) at N=n: row-loop assembly
     (gp_kernel_utilities.py:56-60) + pinv (gp.py:181) + slogdet (gp.py:434) + per-point variance loop (gp.py:246-256)."""
     from oracle import gpexp_oracle as orc
     X, y, Z, noise = workload(n, d, m, seed)
-    spec = dict(kind="matern52", rho=0.5, signalSize=1.0, d=d)
+    spec = dict(kind=kind, rho=0.5, signalSize=1.0, d=d)
     t0 = time.perf_counter()
     K = orc.cov_matrix(spec, X, noise, row_loop=True)
     t_fill = time.perf_counter() - t0
@@ -88,17 +88,24 @@ def _ref_exact(n, m, d, seed):
                 ivar=float(abs(var.mean())))
 
 
-def _fair_chol(n, m, d, seed):
+def _fair_chol(n, m, d, seed, kind="matern52"):
     """The "fair CPU" line of SURVEY.md 8d: the algorithm the GPU runs (vectorised fill + LAPACK Cholesky + triangular
     solves) on the host cores."""
     import scipy.linalg as sl
     from oracle import gpexp_oracle as orc
     X, y, Z, noise = workload(n, d, m, seed)
-    spec = dict(kind="matern52", rho=0.5, signalSize=1.0, d=d)
+    spec = dict(kind=kind, rho=0.5, signalSize=1.0, d=d)
+
+    def kern(r2):
+        if kind == "matern52":
+            t = np.sqrt(5.0 * r2) / 0.5
+            return (1.0 + t + t * t / 3.0) * np.exp(-t)
+        t = np.sqrt(3.0 * r2) / 0.5          # Matern-3/2, kernels.py:85-89
+        return (1.0 + t) * np.exp(-t)
+
     t0 = time.perf_counter()
     r2 = np.maximum(((X * X).sum(1)[:, None] + (X * X).sum(1)[None, :] - 2.0 * X @ X.T), 0.0)
-    t = np.sqrt(5.0 * r2) / 0.5
-    K = (1.0 + t + t * t / 3.0) * np.exp(-t)
+    K = kern(r2)
     K[np.diag_indices(n)] += noise
     c = sl.cho_factor(K, lower=True, overwrite_a=True, check_finite=False)
     alpha = sl.cho_solve(c, y, check_finite=False)
@@ -107,15 +114,14 @@ def _fair_chol(n, m, d, seed):
     kz = orc.cross_matrix(spec, Z, X).T if m <= 4096 else None
     if kz is None:
         r2 = np.maximum(((X * X).sum(1)[:, None] + (Z * Z).sum(1)[None, :] - 2.0 * X @ Z.T), 0.0)
-        t = np.sqrt(5.0 * r2) / 0.5
-        kz = (1.0 + t + t * t / 3.0) * np.exp(-t)
+        kz = kern(r2)
     W = sl.solve_triangular(c[0], kz, lower=True, check_finite=False, overwrite_b=True)
     iv = abs(np.mean(1.0 - np.sum(W * W, axis=0)))
     t_all = time.perf_counter() - t0
     return dict(N=n, M=m, fit_s=t_fit, ivar_s=t_all - t_fit, total_s=t_all, loglike=float(ll), ivar=float(iv))
 
 
-def cpu_baseline(d, full=False):
+def cpu_baseline(d, full=False, kind="matern52"):
     """SURVEY.md 8d protocol, bounded by default: the reference algorithm at N = 2048 and 4096 (M = 512 evaluation points;
     `--cpu-baseline full` adds N = 8192 and the fair-CPU Cholesky line at the full N = 32768), a least-squares fit of
     t = c N^3 through the measured fits, and the EXTRAPOLATED reference time at N = 32768 -- labelled as such.  `value` is
@@ -125,23 +131,59 @@ def cpu_baseline(d, full=False):
     runs = []
     for n in sizes:   # a line per size on stderr: the full protocol runs for minutes, and a silent job looks hung
         print("bench.py: cpu_baseline: reference algorithm at N=%d ..." % n, file=sys.stderr, flush=True)
-        runs.append(_ref_exact(n, 512, d, seed=n))
+        runs.append(_ref_exact(n, 512, d, seed=n, kind=kind))
         print("bench.py: cpu_baseline: N=%d took %.1f s" % (n, runs[-1]["total_s"]), file=sys.stderr, flush=True)
     c3 = float(np.sum([r["fit_s"] * r["N"] ** 3 for r in runs]) / np.sum([float(r["N"]) ** 6 for r in runs]))
     civ = float(np.mean([r["ivar_s"] / (r["N"] ** 2 * r["M"]) for r in runs]))
     big = runs[-1]
     print("bench.py: cpu_baseline: fair-CPU Cholesky at N=%d ..." % (32768 if full else 8192), file=sys.stderr, flush=True)
-    fair = _fair_chol(32768 if full else 8192, 32768 if full else 2048, d, seed=32768 if full else 8192)
+    fair = _fair_chol(32768 if full else 8192, 32768 if full else 2048, d, seed=32768 if full else 8192, kind=kind)
     return dict(value=(big["N"] + big["M"]) / big["total_s"], unit="points/s", cores=threads, kind="port",
                 sample="reference algorithm (oracle: row-loop fill + pinv + slogdet + per-point variance loop) at N=%s, "
-                       "M=512, d=%d Matern-5/2; value = measured at N=%d (%.1f s); O(N^3): see fit / extrapolated"
-                       % (sizes, d, big["N"], big["total_s"]),
+                       "M=512, d=%d %s; value = measured at N=%d (%.1f s); O(N^3): see fit / extrapolated"
+                       % (sizes, d, kind, big["N"], big["total_s"]),
                 cpu_model=model, blas=blas, blas_threads=threads, host_cores=os.cpu_count(), runs=runs,
                 fit="t_fit = c N^3, c = %.3e s (least squares over the measured N)" % c3,
                 extrapolated={"N": 32768, "M": 32768, "fit_s": c3 * 32768.0 ** 3, "ivar_s": civ * 32768.0 ** 2 * 32768,
                               "note": "EXTRAPOLATED from the fit, not measured (SURVEY.md 8d)"},
                 fair_cpu_chol=dict(fair, note="vectorised fill + LAPACK potrf/potrs + TRSM, the algorithm the GPU runs"),
                 seconds=float(sum(r["total_s"] for r in runs) + fair["total_s"]))
+
+
+def dist_preflight(ctx, comm, dist, dev, spec, d, nb=256, two_d=True, n=2048, m=512):
+    """One small distributed step (N = 2048, M = 512, the bench's kernel) against the single-GPU path on the same inputs:
+    log-likelihood and IVAR to 1e-10, and -- 2-D layout -- the replicated factor block by block.  Returns a dict with
+    `ok`; on a mismatch `first_bad_block` = (I, J) of the first nb-block of L that differs by more than 1e-10."""
+    Xh, yh, Zh, noise = workload(n, d, m, seed=12345)
+    t0 = time.perf_counter()
+    if two_d:
+        run = dist.DistFitIvar2D(ctx, comm, spec, Xh, yh, Zh, noise, nb=nb)
+    else:
+        run = dist.DistFitIvar(ctx, comm, spec, Xh, yh, Zh, noise, nb=nb)
+    ll, iv = run.step()
+    X = dev.points(ctx, Xh)
+    K1 = dev.potrf(ctx, dev.kfill(ctx, spec, X, nugget=noise))
+    a1 = dev.potrs(ctx, K1, yh)
+    ll1 = -0.5 * float(yh @ a1) - 0.5 * dev.logdet(ctx, K1) - n / 2.0 * np.log(2 * np.pi)
+    iv1 = abs(dev.ivar(ctx, spec, K1, X, dev.points(ctx, Zh)))
+    out = {"N": n, "M": m, "nb": nb, "layout": "2d" if two_d else "1d", "loglike": ll, "ivar": iv,
+           "rel_err_loglike": abs(ll - ll1) / abs(ll1) if (two_d or comm.rank == 0) else 0.0,
+           "rel_err_ivar": abs(iv - iv1) / abs(iv1)}
+    ok = out["rel_err_loglike"] <= 1e-10 and out["rel_err_ivar"] <= 1e-10
+    Ld = (run.L if two_d else run.K).to_host(tri=1)
+    L1 = K1.to_host(tri=1)
+    scale = float(np.max(np.abs(L1)))
+    diff = np.abs(Ld - L1)
+    out["max_err_L"] = float(diff.max() / scale)
+    if not (diff.max() <= 1e-10 * scale):
+        ok = False
+        bad = np.argwhere(~(diff <= 1e-10 * scale))
+        i, j = min(((int(a) // nb, int(b) // nb) for a, b in bad), key=lambda t: (t[1], t[0]))
+        out["first_bad_block"] = [i, j]
+    out["ok"] = bool(ok)
+    out["seconds"] = time.perf_counter() - t0
+    del run
+    return out
 
 
 def main():
@@ -152,6 +194,9 @@ def main():
     ap.add_argument("--train-points", dest="n", type=int, default=32768)
     ap.add_argument("--dim", dest="d", type=int, default=8)
     ap.add_argument("--mc-points", dest="m", type=int, default=32768)
+    ap.add_argument("--kernel", choices=["matern52", "matern32"], default="matern52",
+                    help="matern52 = BASELINE config C4; matern32 = the only Matern the reference itself can evaluate "
+                         "(kernels.py:85-89), same workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", choices=["bounded", "full"], default="bounded",
                     help="full: SURVEY.md 8d's whole protocol (adds N=8192 and the fair-CPU Cholesky at N=32768; minutes)")
@@ -180,7 +225,8 @@ def main():
 
     N, d, M = args.n, args.d, args.m
     Xh, yh, Zh, noise = workload(N, d, M, seed=N)
-    spec = dev.KernelSpec(dev.K_MATERN52, d, [0.5, 1.0])
+    spec = dev.KernelSpec(dev.K_MATERN52 if args.kernel == "matern52" else dev.K_MATERN32, d, [0.5, 1.0])
+    preflight = None
 
     if world > 1 or os.environ.get("GPX_FORCE_DIST") == "1":  # GPX_FORCE_DIST: rehearse the RCCL runner on one GPU
         from gpexp_amd import dist
@@ -188,18 +234,39 @@ def main():
         # default: north_star's 2-D block-cyclic layout (Pr x Pc grid, gpexp_amd/dist.py); GPX_DIST_LAYOUT=1d selects the
         # round-1 block-column layout (every rank holds the full matrix, one ncclBroadcast per panel)
         nb = int(os.environ.get("GPX_DIST_NB", "512"))
-        if os.environ.get("GPX_DIST_LAYOUT", "2d") == "1d":
-            runner = dist.DistFitIvar(ctx, comm, spec, Xh, yh, Zh, noise, nb=nb)
-            layout = "1-D block-cyclic columns"
-        else:
+        want_2d = os.environ.get("GPX_DIST_LAYOUT", "2d") != "1d"
+        runner, err = None, ""
+        if want_2d:
             try:
                 runner = dist.DistFitIvar2D(ctx, comm, spec, Xh, yh, Zh, noise, nb=nb)
-                layout = "2-D block-cyclic %dx%d grid, nb=%d" % (runner.geo.Pr, runner.geo.Pc, nb)
-            except Exception as exc:  # e.g. an RCCL build without ncclCommSplit: every rank fails alike -> 1-D layout
-                print("bench.py: 2-D layout unavailable (%s); falling back to the 1-D block-column layout" % exc,
+            except Exception as exc:   # ncclCommSplit missing / failed, out of memory, ...
+                err = "%s: %s" % (type(exc).__name__, exc)
+        # The layout is agreed on COLLECTIVELY: a rank that could not build the 2-D runner (while others could) would
+        # otherwise issue the 1-D path's collectives against its peers' 2-D ones and hang until the watchdog.
+        ok_all = comm.allgather(np.array([1.0 if (runner is not None or not want_2d) else 0.0]))[:, 0]
+        if want_2d and ok_all.min() < 1.0:
+            print("bench.py: rank %d: 2-D layout unavailable on rank(s) %s%s; ALL ranks fall back to the 1-D block-column layout"
+                  % (rank, [i for i, v in enumerate(ok_all) if v < 1.0], (" (here: %s)" % err) if err else ""),
+                  file=sys.stderr, flush=True)
+            runner = None
+            want_2d = False
+        if runner is None:
+            runner = dist.DistFitIvar(ctx, comm, spec, Xh, yh, Zh, noise, nb=nb)
+            layout = "1-D block-cyclic columns" + ("" if os.environ.get("GPX_DIST_LAYOUT") == "1d" else " (2-D setup failed)")
+        else:
+            layout = "2-D block-cyclic %dx%d grid, nb=%d, %d panels per trailing update" % (runner.geo.Pr, runner.geo.Pc, nb, runner.agg)
+        # First contact (RCCL with more than one rank has never run on the build's hardware): one SMALL step of the same
+        # runner class, checked on every rank against the single-GPU path before anything is timed.  A mismatch names the
+        # first block of the replicated factor that differs; the bench then stops instead of timing garbage.
+        if world > 1 or os.environ.get("GPX_BENCH_PREFLIGHT") == "1":
+            preflight = dist_preflight(ctx, comm, dist, dev, spec, d, nb=min(nb, 256), two_d=want_2d)
+            print("bench.py: preflight rank %d: %s" % (rank, json.dumps(preflight)), file=sys.stderr, flush=True)
+            bad = comm.allgather(np.array([0.0 if preflight["ok"] else 1.0]))[:, 0]
+            if bad.max() > 0:
+                print("bench.py: preflight FAILED on rank(s) %s -- not timing a wrong result" % [i for i, v in enumerate(bad) if v > 0],
                       file=sys.stderr, flush=True)
-                runner = dist.DistFitIvar(ctx, comm, spec, Xh, yh, Zh, noise, nb=nb)
-                layout = "1-D block-cyclic columns (2-D setup failed)"
+                comm.barrier()
+                os._exit(3)
         step = runner.step
         barrier = comm.barrier
         reduce_max = comm.max_float
@@ -344,15 +411,19 @@ def main():
         # The look-ahead factorisation runs GEMMs on three streams at once, so per-class event spans overlap and their sum
         # can exceed the wall time: the roofline divides the class's algorithmic flops by the WALL time of the timed region
         # (which also contains the ~1 % of assembly / reduction kernels) -- overlap cannot inflate it.
-        ach = g["flops"] / dt / 1e12 if dt > 0 else 0.0
+        # ALGORITHMIC flops of a step: N^3/3 (factorisation) + N^2 M (evaluation solve), SURVEY.md 8d.  The launched count of
+        # the GEMM class (g["flops"]: adds the block-inverse builds and the padding of the triangular products, ~0.6 %) is
+        # reported beside it, never used for `achieved`.
+        algo_flops = float(N) ** 3 / 3.0 + float(N) ** 2 * float(M)
+        ach = algo_flops * args.steps / dt / 1e12 if dt > 0 else 0.0
         traffic, traffic_src = None, None
         try:  # PMC counters cannot be read from inside the process: take the committed rocprofv3 --pmc passes of this
             # same command (profiles/), per launch like `achieved`; null when the profile is for another config
-            pmc = [f for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+            pmc = [f for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
                    if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
             with open(os.path.join(ROOT, "profiles", pmc)) as f:
                 pj = json.load(f)
-            if world == 1 and (N, d, M) == (32768, 8, 32768):
+            if world == 1 and (N, d, M) == (32768, 8, 32768) and args.kernel == "matern52":
                 traffic = (pj["fetch_bytes_per_step_corrected"] + pj["write_bytes_per_step"]) / pj["launches_per_step"]
                 traffic_src = pj["source"]
         except (OSError, KeyError, ValueError):
@@ -370,21 +441,22 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "C4: N=%d d=%d Matern-5/2 (rho=0.5,s=1,noise=0.1) kfill+potrf+potrs+logdet+"
-                                   "IVAR over M=%d MC points" % (N, d, M),
-                       "N": N, "d": d, "M": M, "kernel": "matern52", "seed": N,
+            "config": {"workload": "C4: N=%d d=%d Matern-%s (rho=0.5,s=1,noise=0.1) kfill+potrf+potrs+logdet+"
+                                   "IVAR over M=%d MC points" % (N, d, "5/2" if args.kernel == "matern52" else "3/2", M),
+                       "N": N, "d": d, "M": M, "kernel": args.kernel, "seed": N,
                        "parallelism": layout if world == 1 else "%d ranks, %s" % (world, layout)},
             "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel (SYRK/TRSM updates)", "achieved": ach,
                          "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
                          "traffic": traffic, "traffic_unit": "bytes per launch (mean over the step's launches)",
                          "traffic_source": traffic_src,
-                         "algorithmic_flop_per_launch": (g["flops"] / g["launches"]) if g["launches"] else 0.0,
+                         "algorithmic_flop_per_step": algo_flops,
+                         "algorithmic_flop_per_launch": (algo_flops * args.steps / g["launches"]) if g["launches"] else 0.0,
+                         "launched_flop_per_step": g["flops"] / args.steps,
                          "avg_launch_ms": (g["ms"] / g["launches"]) if g["launches"] else 0.0,
                          "launches_per_step": g["launches"] / args.steps,
-                         "algorithmic_flop_per_step": g["flops"] / args.steps,
                          "event_ms_per_step_summed_over_streams": g["ms"] / args.steps,
                          "ms_per_step_instrumented": 1e3 * dt_instr / args.steps,
-                         "note": "achieved = class flops / wall time of the timed region (no profiler events inside it); the "
+                         "note": "achieved = algorithmic flops (N^3/3 + N^2 M) / wall time of the timed region (no profiler events inside it); the "
                                  "per-launch figures are HIP-event spans from an identical instrumented repeat of the same "
                                  "steps (bit-identical results, asserted); their sum counts time on concurrent streams twice "
                                  "(look-ahead) and is reported for the rocprofv3 cross-check only"},
@@ -405,8 +477,28 @@ def main():
             "results": {"loglike": ll, "ivar": iv},
             "device": info["name"],
         }
+        if preflight is not None:
+            line["preflight"] = preflight
+        if world > 1 or os.environ.get("GPX_FORCE_DIST") == "1":
+            line["host_issue_ms_per_step"] = dict(getattr(runner, "host_ms", {}) or {})
+            line["comm_note"] = ("phases_ms_per_step.comm = HIP-event spans around the collectives on the communication stream "
+                                 "(includes waiting for the peers); gemm / leaf = the compute strands")
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(d, full=(args.cpu_baseline == "full"))
+            line["cpu_baseline"] = cpu_baseline(d, full=(args.cpu_baseline == "full"), kind=args.kernel)
+            ref = os.path.join(ROOT, "profiles", "r02_bench_n1_cpu_full.json")
+            if os.path.exists(ref):   # the WHOLE SURVEY 8d protocol takes ~5 minutes of CPU: a builder-run record, quoted here
+                try:
+                    with open(ref) as f:
+                        full = json.load(f)["cpu_baseline"]
+                    line["cpu_baseline"]["full_protocol_ref"] = {
+                        "provenance": "profiles/r02_bench_n1_cpu_full.json: `bench.py --cpu-baseline full`, run by the builder on "
+                                      "a gpurun MI355X box in round 2 (not re-measured by this run)",
+                        "cpu_model": full.get("cpu_model"), "blas_threads": full.get("blas_threads"),
+                        "reference_algorithm_runs": [{k: r[k] for k in ("N", "M", "total_s")} for r in full.get("runs", [])],
+                        "fit": full.get("fit"), "extrapolated": full.get("extrapolated"),
+                        "fair_cpu_chol_full_size": {k: full["fair_cpu_chol"][k] for k in ("N", "M", "fit_s", "ivar_s", "total_s")}}
+                except (OSError, KeyError, ValueError):
+                    pass
         sys.stdout.flush()
         os.dup2(stdout_fd, 1)
         print(json.dumps(line), flush=True)

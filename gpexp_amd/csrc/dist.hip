@@ -1,15 +1,16 @@
-// Multi-GPU pieces: RCCL communicator (dlopen'ed, so single-GPU use never touches librccl) and the panel
-// primitives of the 1-D block-cyclic distributed Cholesky.  One process per GPU; the Python side
-// (gpexp_amd/dist.py) drives the panel loop and owns the rendezvous (the 128-byte ncclUniqueId travels over
-// whatever the launcher provides -- torch.distributed/gloo under torchrun).
+// Multi-GPU pieces: the RCCL communicator (dlopen'ed, so single-GPU use never touches librccl) and the device primitives of
+// the distributed Cholesky.  One process per GPU; gpexp_amd/dist.py drives the panel loops and owns the rendezvous (the
+// 128-byte ncclUniqueId travels through a file keyed by the launcher's port, see FileRendezvous).
 //
-// Layout: every rank holds a full-size padded matrix.  Block column j (width nb, a multiple of 128) is OWNED
-// by rank j % world: only the owner assembles and updates it.  At step k the owner packs its panel
-// (rows >= k*nb of block column k) into a contiguous buffer, factors it there (diagonal block: recursive
-// potrf; rows below: TRSM against it), appends the inverted 128x128 diagonal leaves, and broadcasts the
-// buffer.  Every rank then (a) stores the panel and the leaf inverses into its own matrix -- so that at the
-// end each rank holds the complete factor, which lets posterior/IVAR evaluation shard the evaluation points
-// with no further exchange of L -- and (b) applies  C_j -= P_j.. P_j^T  to each owned block column j > k.
+//   2-D block-cyclic (the default; second half of this file, "gpx_dist2_*"): process grid Pr x Pc, global block (I, J) on rank
+//   (I % Pr, J % Pc); ncclCommSplit row / column sub-communicators; diagonal block broadcast down the process column, every
+//   piece of a panel to every rank over all xGMI links (grouped ncclSend / ncclRecv scatter + all-gather), trailing updates by
+//   groups of panels in one segmented launch; every rank keeps the finished panels in a replicated copy of L for the
+//   evaluation phase.  The recorded-program executor (gpx_program_run) is at the end.
+//
+//   1-D block columns (round 1, GPX_DIST_LAYOUT=1d; first half, "gpx_dist_*"): every rank holds a full-size matrix, block
+//   column j is owned by rank j % world; the owner packs + factors the panel and ncclBroadcast's it, every rank stores it and
+//   updates the block columns it owns.
 #include "gpx_internal.h"
 #include <dlfcn.h>
 #include <string.h>
@@ -62,17 +63,29 @@ static int rccl_load() {
   GPX_SYM(Broadcast, "ncclBroadcast");
   GPX_SYM(AllReduce, "ncclAllReduce");
   GPX_SYM(AllGather, "ncclAllGather");
-  GPX_SYM(Reduce, "ncclReduce");
-  GPX_SYM(CommSplit, "ncclCommSplit");
-  GPX_SYM(Send, "ncclSend");
-  GPX_SYM(Recv, "ncclRecv");
-  GPX_SYM(GroupStart, "ncclGroupStart");
-  GPX_SYM(GroupEnd, "ncclGroupEnd");
   GPX_SYM(GetErrorString, "ncclGetErrorString");
 #undef GPX_SYM
+  // what only the 2-D layout needs is optional: a build of librccl without it still serves the 1-D layout (GPX_DIST_LAYOUT=1d),
+  // and the entry points that need a missing symbol say so (need_sym below)
+#define GPX_OPT(field, name) *(void**)(&g_rccl.field) = dlsym(h, name)
+  GPX_OPT(Reduce, "ncclReduce");
+  GPX_OPT(CommSplit, "ncclCommSplit");
+  GPX_OPT(Send, "ncclSend");
+  GPX_OPT(Recv, "ncclRecv");
+  GPX_OPT(GroupStart, "ncclGroupStart");
+  GPX_OPT(GroupEnd, "ncclGroupEnd");
+#undef GPX_OPT
   g_rccl.h = h;
   return 0;
 }
+
+#define GPX_NEED_SYM(field, name)                                                                       \
+  do {                                                                                                  \
+    if (!g_rccl.field) {                                                                                \
+      gpx_set_error("librccl.so lacks %s: the 2-D block-cyclic layout is unavailable (GPX_DIST_LAYOUT=1d)", name); \
+      return -3;                                                                                        \
+    }                                                                                                   \
+  } while (0)
 
 #define GPX_NCCL(call)                                                                     \
   do {                                                                                     \
@@ -161,10 +174,23 @@ int gpx_comm_grid(gpx_ctx* ctx, int Pr, int Pc) {
   GPX_ARG(ctx && ctx->comm, "communicator not initialised");
   GPX_ARG(Pr >= 1 && Pc >= 1 && Pr * Pc == ctx->world, "grid does not match the communicator size");
   GPX_ARG(ctx->grp[1] == nullptr && ctx->grp[2] == nullptr, "process grid already set");
+  GPX_NEED_SYM(CommSplit, "ncclCommSplit");
+  GPX_NEED_SYM(Send, "ncclSend");
+  GPX_NEED_SYM(Recv, "ncclRecv");
+  GPX_NEED_SYM(GroupStart, "ncclGroupStart");
+  GPX_NEED_SYM(GroupEnd, "ncclGroupEnd");
+  GPX_NEED_SYM(Reduce, "ncclReduce");
   const int pr = ctx->rank / Pc, pc = ctx->rank % Pc;
   ncclComm_t row = nullptr, col = nullptr;
   GPX_NCCL(g_rccl.CommSplit((ncclComm_t)ctx->comm, /*color*/ pr, /*key*/ pc, &row, nullptr));
-  GPX_NCCL(g_rccl.CommSplit((ncclComm_t)ctx->comm, /*color*/ Pr + pc, /*key*/ pr, &col, nullptr));
+  {
+    const ncclResult_t r2 = g_rccl.CommSplit((ncclComm_t)ctx->comm, /*color*/ Pr + pc, /*key*/ pr, &col, nullptr);
+    if (r2 != 0) {  // no half-built grid: the row communicator goes back
+      if (row) g_rccl.CommDestroy(row);
+      gpx_set_error("%s:%d ncclCommSplit (process column) -> %s", __FILE__, __LINE__, g_rccl.GetErrorString(r2));
+      return -3;
+    }
+  }
   ctx->grp[1] = row;
   ctx->grp_size[1] = Pc;
   ctx->grp_rank[1] = pc;

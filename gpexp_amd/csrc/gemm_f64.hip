@@ -117,36 +117,9 @@ __device__ __forceinline__ void gemm_tile(Smem<BT, TE>& sm, const double* A, int
   // array form compiles to a measurably slower NN loop (IVAR 551 vs 534 ms at C4) -- hipcc scheduling lottery.
   double2 Pa0, Pa1, Pa2, Pa3, Pb0, Pb1, Pb2, Pb3;
   const int64_t b_rs2 = 2 * b_rs, b_rs3 = 3 * b_rs, a_rs2 = 2 * a_rs, a_rs3 = 3 * a_rs;
-  // segmented mode: running pointers to the NEXT k-step to load (advanced right after every load is issued)
-  const char* seg_ap = nullptr;
-  const char* seg_bp = nullptr;
-  int seg_k = 0, seg_s = 0;
-  if constexpr (SEGF::on) {
-    seg_ap = reinterpret_cast<const char*>(segf.a(0));
-    seg_bp = reinterpret_cast<const char*>(segf.b(0));
-  }
 #define GPX_LD16(base_, voff_) (*reinterpret_cast<const double2*>((base_) + (voff_)))
-#define GPX_GLOAD(S_, kt_)                                                                            \
+#define GPX_GLOAD_AT(S_, ap_, bp_)                                                                    \
   do {                                                                                                \
-    const char* ap_;                                                                                  \
-    const char* bp_;                                                                                  \
-    if constexpr (SEGF::on) {                                                                         \
-      ap_ = seg_ap;                                                                                   \
-      bp_ = seg_bp;                                                                                   \
-      if (++seg_k == segf.seg_nk) {                                                                   \
-        seg_k = 0;                                                                                    \
-        if (++seg_s < segf.nseg) {                                                                    \
-          seg_ap = reinterpret_cast<const char*>(segf.a(seg_s));                                      \
-          seg_bp = reinterpret_cast<const char*>(segf.b(seg_s));                                      \
-        }                                                                                             \
-      } else {                                                                                        \
-        seg_ap += a_ks;                                                                               \
-        seg_bp += b_ks;                                                                               \
-      }                                                                                               \
-    } else {                                                                                          \
-      ap_ = Abase + (int64_t)(kt_) * a_ks;                                                            \
-      bp_ = Bbase + (int64_t)(kt_) * b_ks;                                                            \
-    }                                                                                                 \
     S_##a0 = GPX_LD16(ap_, voff_a);                                                                    \
     S_##a1 = GPX_LD16(ap_ + a_rs, voff_a);                                                             \
     if (NL == 4) {                                                                                    \
@@ -159,6 +132,12 @@ __device__ __forceinline__ void gemm_tile(Smem<BT, TE>& sm, const double* A, int
       S_##b2 = GPX_LD16(bp_ + b_rs2, voff_b);                                                          \
       S_##b3 = GPX_LD16(bp_ + b_rs3, voff_b);                                                          \
     }                                                                                                 \
+  } while (0)
+#define GPX_GLOAD(S_, kt_)                                                                            \
+  do {                                                                                                \
+    const char* ap_ = Abase + (int64_t)(kt_) * a_ks;                                                  \
+    const char* bp_ = Bbase + (int64_t)(kt_) * b_ks;                                                  \
+    GPX_GLOAD_AT(S_, ap_, bp_);                                                                        \
   } while (0)
 
   double* const sa_w = &sm.a[0][ar * SA + ac];
@@ -240,6 +219,57 @@ __device__ __forceinline__ void gemm_tile(Smem<BT, TE>& sm, const double* A, int
   } while (0)
     static_assert(KB == 16, "the hand schedule below is written for four k-substeps");
     double fa0[FI], fa1[FI], fa2[FI], fa3[FI], fb0[FI], fb1[FI], fb2[FI], fb3[FI];  // one slot per k-substep
+    // one steady-state step: the loads of the NEXT step first, 48 of this step's MFMAs, LDS store + barrier, the fragment
+    // reads of the next step underneath the remaining 16 MFMAs
+#define GPX_STEP(LOADS_, buf_)                                                                        \
+  do {                                                                                                \
+    LOADS_;                                                                                           \
+    GPX_MFMAS(0);                                                                                     \
+    GPX_MFMAS(1);                                                                                     \
+    GPX_MFMAS(2);                                                                                     \
+    GPX_PIN();                                                                                        \
+    GPX_SSTORE(P, (buf_) ^ 1);                                                                        \
+    __syncthreads();                                                                                  \
+    GPX_PIN();                                                                                        \
+    GPX_FRAGS((buf_) ^ 1, 0, 0);                                                                      \
+    GPX_FRAGS((buf_) ^ 1, 1, 1);                                                                      \
+    GPX_FRAGS((buf_) ^ 1, 2, 2);                                                                      \
+    GPX_PIN(); /* the reads above are issued BEFORE the last 16 MFMAs (hipcc would sink most of them below) */ \
+    GPX_PIN_ALL();                                                                                    \
+    GPX_MFMAS(3);                                                                                     \
+    GPX_FRAGS((buf_) ^ 1, 3, 3);                                                                      \
+  } while (0)
+    if constexpr (SEGF::on) {
+      // Segmented k range as a TWO-LEVEL loop: the inner loop over the k-steps of one segment is the dense loop (one basic
+      // block, pointers advance by a constant), and the step that crosses into the next segment is the same step body once
+      // more with the next segment's base pointers -- the software pipeline never drains between segments.  (With the
+      // switch folded into ONE loop as a conditional, hipcc split the loop into several blocks and the kernel ran at 66
+      // instead of 72 TF/s: twice the share of parked wave cycles in SQ_WAIT_ANY.)
+      const char* ap = reinterpret_cast<const char*>(segf.a(0));
+      const char* bp = reinterpret_cast<const char*>(segf.b(0));
+      GPX_GLOAD_AT(P, ap, bp);
+      GPX_SSTORE(P, 0);
+      __syncthreads();
+      GPX_FRAGS(0, 0, 0);
+      GPX_FRAGS(0, 1, 1);
+      GPX_FRAGS(0, 2, 2);
+      GPX_FRAGS(0, 3, 3);
+      int buf = 0;
+      for (int sgi = 0; sgi < segf.nseg; ++sgi) {
+        for (int j = 1; j < segf.seg_nk; ++j) {
+          ap += a_ks;
+          bp += b_ks;
+          GPX_STEP(GPX_GLOAD_AT(P, ap, bp), buf);
+          buf ^= 1;
+        }
+        if (sgi + 1 < segf.nseg) {
+          ap = reinterpret_cast<const char*>(segf.a(sgi + 1));
+          bp = reinterpret_cast<const char*>(segf.b(sgi + 1));
+          GPX_STEP(GPX_GLOAD_AT(P, ap, bp), buf);
+          buf ^= 1;
+        }
+      }
+    } else {
     GPX_GLOAD(P, 0);
     GPX_SSTORE(P, 0);
     __syncthreads();
@@ -264,21 +294,23 @@ __device__ __forceinline__ void gemm_tile(Smem<BT, TE>& sm, const double* A, int
       GPX_FRAGS(buf ^ 1, 1, 1);
       GPX_FRAGS(buf ^ 1, 2, 2);
       GPX_PIN();  // the reads above are issued BEFORE the last 16 MFMAs (hipcc would sink most of them below)
-      GPX_PIN_ALL();
       GPX_MFMAS(3);
       GPX_FRAGS(buf ^ 1, 3, 3);
+    }
     }
     // last step: its fragments are loaded
     GPX_MFMAS(0);
     GPX_MFMAS(1);
     GPX_MFMAS(2);
     GPX_MFMAS(3);
+#undef GPX_STEP
 #undef GPX_FRAGS
 #undef GPX_MFMAS
 #undef GPX_PIN
 #undef GPX_PIN_ALL
   }
 #undef GPX_GLOAD
+#undef GPX_GLOAD_AT
 #undef GPX_LD16
 #undef GPX_SSTORE
 #undef GPX_ST2

@@ -760,7 +760,18 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None):
     q = default_agg() if agg is None else int(agg)
     R = len(G)
     assert R >= (ring_size(q) if q > 1 else 2), "panel-buffer ring too short for the aggregation depth"
-    bulk_stream = {"bulk": BULK, "eval": EVAL, "main": MAIN}[os.environ.get("GPX_DIST_BULK_STREAM", "bulk")]
+    # Where the group-end bulk update runs (GPX_DIST_BULK: chunks | eval | bulk | main):
+    #   eval    (default) whole, on the low-priority unmasked stream beside the next group's chain and near updates: MAIN stays
+    #           free for the near updates that gate the panel chain.
+    #   chunks  on MAIN, cut into `q` column ranges of equal work that are issued one per step BEHIND the near updates of the
+    #           following steps -- one GEMM stream, the big launches never share the chip with each other.  Expected to win
+    #           where the GPU is the bound (1-2 ranks); measured it does not (the thin near updates -- 2 to 4 rounds of tiles,
+    #           42-57 TF/s -- then run alone instead of underneath a bulk launch).
+    #   bulk    the same on the CU-masked stream (round 2's reserved CUs; the chain no longer needs them); main: whole, on MAIN.
+    mode = os.environ.get("GPX_DIST_BULK", "eval")   # measured (replay, C4): eval 213 / 119 / 192 / 103 ms at 1 / 2 / 4 / 8 ranks,
+                                                     # chunks 225 / 124 / 191 / 103 (profiles/r03_dist_replay.txt)
+    bulk_stream = {"bulk": BULK, "eval": EVAL, "main": MAIN, "chunks": MAIN}[mode]
+    chunked = mode == "chunks"
     at_step = getattr(comm, "at_step", None)
 
     def group_end(k):
@@ -788,7 +799,25 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None):
         if m > 0:
             ops.update_multi(A, lr0, m, lc0, n, geo, [G[kk % R] for kk in ks], list(ks), below_diag)
 
+    def split_cols(Ja, Jb, parts):
+        """[Ja, Jb] cut into <= parts consecutive ranges of about equal trailing-update work (block column J costs ~ the
+        number of block rows below it)."""
+        Jb = min(Jb, nblk - 1)
+        cols = list(range(Ja, Jb + 1))
+        if not cols:
+            return []
+        wts = [nblk - J for J in cols]
+        total, out, acc, start = float(sum(wts)), [], 0.0, 0
+        for i, wgt in enumerate(wts):
+            acc += wgt
+            if acc >= total * (len(out) + 1) / parts or i == len(cols) - 1:
+                out.append((cols[start], cols[i]))
+                start = i + 1
+        return [r for r in out if r[0] <= r[1]]
+
     bulk_recorded = set()
+    pending = []                 # chunks of the last group's bulk update still to be issued (chunked mode)
+    last_chunk_step = {}         # group end -> step at which its last chunk was issued
     ops.stream(MAIN)
     ops.begin()
     ops.record(_ev2(E_DIAGREADY, 0))  # the assembly was queued on MAIN
@@ -813,7 +842,7 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None):
             old = k - R
             if old >= 0:
                 ge = group_end(old)
-                ops.wait(_ev2(E_UPD, ge))
+                ops.wait(_ev2(E_UPD, last_chunk_step.get(ge, ge)))
                 if ge in bulk_recorded:
                     ops.wait(_ev2(E_BULK, ge))
                 ops.wait(_ev2(E_STORED, old))
@@ -902,7 +931,15 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None):
         update_cols(k + 2, k + 2, list(range(g0, k + 1)))                # two ahead: up to date through panel k
         if k + 2 < nblk and (k + 2) % Pc == pc:
             ops.record(_ev2(E_COL2, k + 2))
+        if pending and k != group_end(k):                                # chunked bulk of the previous group, one per step
+            Ja, Jb, pks, pge = pending.pop(0)
+            update_cols(Ja, Jb, pks)
+            last_chunk_step[pge] = k
         if k == group_end(k):
+            while pending:                                               # (only a short last group leaves any)
+                Ja, Jb, pks, pge = pending.pop(0)
+                update_cols(Ja, Jb, pks)
+                last_chunk_step[pge] = k
             ks = list(range(g0, k + 1))
             if k + 3 < nblk:
                 # the block columns that turn "near" during the next group: here, ahead of everything else.  They were last
@@ -911,7 +948,12 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None):
                 if prev in bulk_recorded:
                     ops.wait(_ev2(E_BULK, prev))
                 update_cols(k + 3, k + 2 + q, ks)
-            if k + 3 + q < nblk:
+            if k + 3 + q < nblk and chunked:
+                pending = [(Ja, Jb, ks, k) for Ja, Jb in split_cols(k + 3 + q, nblk - 1, q)]
+                Ja, Jb, pks, pge = pending.pop(0)
+                update_cols(Ja, Jb, pks)
+                last_chunk_step[k] = k
+            elif k + 3 + q < nblk:
                 ops.stream(bulk_stream)
                 if bulk_stream != MAIN:
                     ops.wait(_ev2(E_COLREADY, 0))                        # this rank's own assembly of A (queued on MAIN)
@@ -920,6 +962,11 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None):
                 ops.record(_ev2(E_BULK, k))
                 bulk_recorded.add(k)
                 ops.stream(MAIN)
+        if k == nblk - 1:
+            while pending:
+                Ja, Jb, pks, pge = pending.pop(0)
+                update_cols(Ja, Jb, pks)
+                last_chunk_step[pge] = k
         ops.record(_ev2(E_UPD, k))
     ops.stream(MAIN)
 
@@ -1110,7 +1157,7 @@ class DistFitIvar2D:
         ops, geo = self.ops, self.geo
 
         q, last = self.agg, geo.nblk - 1
-        ivar_stream = EVAL if os.environ.get("GPX_DIST_IVAR_STREAM", "back") == "eval" else BACK
+        ivar_stream = EVAL if os.environ.get("GPX_DIST_IVAR_STREAM", "eval") == "eval" else BACK
 
         def hook(k):
             # one right-looking solve step per GROUP of stored panels (K = agg * nb updates), behind the copy of the group's
