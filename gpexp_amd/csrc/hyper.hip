@@ -108,6 +108,89 @@ __global__ __launch_bounds__(256) void lmlgrad_final_kernel(const double* __rest
   if (threadIdx.x == 0) out[q] = red[0];
 }
 
+// The same traces over a ROW SLAB of the inverse: Z[i][j] = P[r0 + i][r0 + j] for slab rows i < s and columns j < n2 = n - r0
+// (row stride ldz).  Only entries on / right of the diagonal count (global column >= global row): every unordered pair
+// {a, b}, a <= b, belongs to exactly one slab -- the one that holds row a -- so the slabs of a partition of the rows add up to
+// the full trace; off-diagonal entries count twice (symmetry), diagonal ones once.  partial[tile][q] as in lmlgrad_kernel.
+__global__ __launch_bounds__(256) void lmlgrad_slab_kernel(KParams kp, const double* __restrict__ X, int64_t n, int64_t r0,
+                                                           int64_t srows, const double* __restrict__ Z, int64_t ldz,
+                                                           const double* __restrict__ alpha,
+                                                           double* __restrict__ partial) {
+  extern __shared__ double sm[];
+  const int d = kp.d;
+  double* As = sm;               // [TS][d] raw coords of the row points
+  double* Bs = sm + TS * d;      // [TS][d] of the column points
+  double* red = Bs + TS * d;     // [4] per-wave partials
+  const int t = threadIdx.x;
+  const int64_t li0 = (int64_t)blockIdx.y * TS, lj0 = (int64_t)blockIdx.x * TS;  // slab-local row / column of the tile
+  const int64_t i0 = r0 + li0, j0 = r0 + lj0;
+  const bool below = lj0 + TS - 1 < li0;   // tile entirely left of the diagonal: nothing to add
+  for (int idx = t; idx < TS * d; idx += 256) {
+    int p = idx / d, k = idx - p * d;
+    int64_t gi = i0 + p, gj = j0 + p;
+    As[idx] = (gi < n && li0 + p < srows) ? X[gi * d + k] : 0.0;
+    Bs[idx] = gj < n ? X[gj * d + k] : 0.0;
+  }
+  __syncthreads();
+  const int tx = t & 31, ty = t >> 5;
+  double tk[16];
+  double diag = 0.0;
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    const int r = ty + 8 * a;
+    const int64_t gi = i0 + r;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int cc = 2 * tx + c;
+      const int64_t gj = j0 + cc;
+      double v = 0.0;
+      if (!below && gi < n && gj < n && li0 + r < srows && gj >= gi) {
+        double acc = 0.0;
+        for (int k = 0; k < d; ++k) {
+          const double e = (As[r * d + k] - Bs[cc * d + k]) * kp.scale[k];
+          acc = fma(e, e, acc);
+        }
+        const double tij = alpha[gi] * alpha[gj] - Z[(li0 + r) * ldz + (lj0 + cc)];
+        v = (gj == gi ? 1.0 : 2.0) * tij * kp.sig * exp(-0.5 * acc);
+        if (gi == gj) diag += tij;
+      }
+      tk[a * 2 + c] = v;
+    }
+  }
+  const int lane = t & 63, wave = t >> 6;
+  for (int q = 0; q <= d + 1; ++q) {
+    double s = 0.0;
+    if (q < d) {
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const int r = ty + 8 * a;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const double e = (As[r * d + q] - Bs[(2 * tx + c) * d + q]) * kp.scale[q];
+          s = fma(tk[a * 2 + c], e * e, s);
+        }
+      }
+    } else if (q == d) {
+#pragma unroll
+      for (int a = 0; a < 16; ++a) s += tk[a];
+    } else {
+      s = diag;
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    __syncthreads();
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (t == 0)
+      partial[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (d + 2) + q] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
+// Z (s x n2, row stride ldz) = [ I_s 0 ]
+__global__ __launch_bounds__(256) void unit_rows_kernel(double* __restrict__ Z, int64_t ldz, int64_t s) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < s) Z[i * ldz + i] = 1.0;
+}
+
 // ---- MI greedy -------------------------------------------------------------------------------------------
 __device__ __forceinline__ double kpair_se_like(const KParams& kp, const double* __restrict__ a,
                                                 const double* __restrict__ b) {
@@ -155,6 +238,27 @@ __global__ __launch_bounds__(256) void mi_downdate_kernel(double* __restrict__ P
   const int64_t i = blockIdx.y;
   if (j >= M || i == s || j == s) return;
   P[i * ld + j] -= P[i * ld + s] * P[s * ld + j] / P[s * ld + s];
+}
+
+// the same down-date for the rows [lo, hi) only, the pivot row coming from a separate buffer (the row's owner broadcast it):
+// P[i][j] -= P[i][s] prow[j] / prow[s]; identical arithmetic to mi_downdate_kernel, so a row-sharded run reproduces it bit for bit
+__global__ __launch_bounds__(256) void mi_downdate_rows_kernel(double* __restrict__ P, int64_t ld, int64_t M, int64_t lo,
+                                                               const int64_t* __restrict__ sel, int slot,
+                                                               const double* __restrict__ prow) {
+  const int64_t s = sel[slot];
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = lo + blockIdx.y;
+  if (j >= M || i == s || j == s) return;
+  P[i * ld + j] -= P[i * ld + s] * prow[j] / prow[s];
+}
+
+__global__ __launch_bounds__(256) void mi_ratio_range_kernel(const double* __restrict__ P, int64_t ld,
+                                                             const double* __restrict__ dnum,
+                                                             const int* __restrict__ alive, double noise, int64_t M,
+                                                             int64_t lo, int64_t hi, double* __restrict__ ratio) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= M) return;
+  ratio[c] = (c >= lo && c < hi && alive[c]) ? dnum[c] / (1.0 / P[c * ld + c] - noise) : -INFINITY;
 }
 
 __global__ __launch_bounds__(256) void mi_mark_kernel(int* __restrict__ alive, const int64_t* __restrict__ sel,
@@ -274,6 +378,65 @@ int gpx_lml_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, con
   return r;
 }
 
+// Raw trace sums of the hyper-parameter gradient over ONE ROW SLAB [r0, r1) of K^-1 (r0, r1 multiples of 128, r1 <= padded N):
+//   sums[q] = sum over slab rows a and columns b >= a of w_ab T_ab K0_ab e_q(a,b)^2   (q < d),  ... K0_ab (q = d),  T_aa (q = d+1)
+// with T = alpha alpha^T - K^-1, w = 1 on the diagonal and 2 off it.  The slab of the inverse comes from the TRAILING factor
+// alone -- K^-1[r0:, r0:] = L22^-T L22^-1 with L22 = L[r0:, r0:] (block-triangular inverse) -- as two triangular solves on the
+// s x (N - r0) slab [I 0]: no N x N inverse is ever formed, and slabs are independent: summed over a partition of the rows they
+// give the full traces (gp.py:444-466).  That is how the gradient shards over GPUs that each hold the factor (one
+// all-reduce of d+2 doubles, gpexp_amd/dist.py dist_lml_grad) and how a single GPU avoids the 3 N^2 doubles of gpx_potri.
+// Work: 2 (N - r0)^2 (r1 - r0) flops.  alpha: host, N doubles.  sums: host, d+2 doubles.
+int gpx_lml_grad_slab(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
+                      const double* alpha, int64_t r0, int64_t r1, double* sums) {
+  GPX_ARG(ctx && L && X && alpha && sums, "NULL argument");
+  GPX_ARG(L->factored && L->aux, "matrix has not been factored by gpx_potrf");
+  GPX_ARG(kind == GPX_K_SE, "lml_grad: only the squared-exponential kernel has hyper-parameter derivatives "
+                            "(the reference raises for the others, kernels.py:93-97)");
+  KParams kp;
+  GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
+  GPX_ARG(X->cols == d && X->pcols == d && X->rows == L->rows, "X does not match the factor");
+  const int64_t n = L->rows, np = L->prows;
+  GPX_ARG(r0 >= 0 && r0 < r1 && r1 <= np && r0 % GPX_TILE == 0 && r1 % GPX_TILE == 0, "slab bounds must be multiples of 128 inside the padded order");
+  const int nq = d + 2;
+  for (int q = 0; q < nq; ++q) sums[q] = 0.0;
+  if (r0 >= n) return 0;  // padding rows only
+  const int64_t s = r1 - r0, n2 = np - r0, ldz = gpx_skew_ld(n2);
+  int r = 0;
+  {
+    Scratch sc(ctx);
+    void *pz, *pal, *ppart, *pout;
+    const int64_t tr = s / TS, tc = n2 / TS;
+    do {
+      if ((r = sc.get(s * ldz * 8, &pz)) != 0) break;
+      if ((r = sc.get(n * 8, &pal)) != 0) break;
+      if ((r = sc.get(tr * tc * nq * 8, &ppart)) != 0) break;
+      if ((r = sc.get(nq * 8, &pout)) != 0) break;
+      double* Z = (double*)pz;
+      if (hipMemsetAsync(Z, 0, (size_t)(s * ldz * 8), ctx->stream) != hipSuccess) { r = -2; break; }
+      hipLaunchKernelGGL(unit_rows_kernel, dim3((unsigned)((s + 255) / 256)), dim3(256), 0, ctx->stream, Z, ldz, s);
+      if (hipMemcpyAsync(pal, alpha, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { r = -2; break; }
+      const double* L22 = L->p + r0 * L->ld + r0;
+      const double* inv22 = L->aux + (r0 / GPX_TILE) * GPX_TILE * GPX_TILE;
+      // Z <- Z L22^-T  (rows of L22^-1 ... transposed: Y^T with Y = L22^-1 [I 0]^T), then Z <- Z L22^-1: Z = (K^-1)[slab, r0:]
+      if ((r = chol_trsm_right(ctx, L22, L->ld, inv22, Z, ldz, s, n2)) != 0) break;
+      if ((r = chol_trsm_right_n(ctx, L22, L->ld, inv22, Z, ldz, s, n2)) != 0) break;
+      {
+        ProfScope ps(ctx, GPX_PROF_REDUCE, 0.0, 8.0 * (double)s * n2);
+        dim3 grid((unsigned)tc, (unsigned)tr);
+        size_t sh = (size_t)(2 * TS * d + 4) * sizeof(double);
+        hipLaunchKernelGGL(lmlgrad_slab_kernel, grid, dim3(256), sh, ctx->stream, kp, X->p, n, r0, s, (const double*)Z, ldz,
+                           (const double*)pal, (double*)ppart);
+        hipLaunchKernelGGL(lmlgrad_final_kernel, dim3(nq), dim3(256), 0, ctx->stream, (const double*)ppart, tr * tc, nq,
+                           (double*)pout);
+      }
+      if (hipMemcpyAsync(sums, pout, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->stream) != hipSuccess) { r = -2; break; }
+    } while (0);
+  }
+  if (r == -2) gpx_set_error("lml_grad_slab: HIP call failed: %s", hipGetErrorString(hipGetLastError()));
+  return r;
+}
+
 int gpx_mi_greedy(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* Cm, double noise,
                   int64_t nsel, int64_t start, int64_t* out_idx, double* out_ratio) {
   GPX_ARG(ctx && Cm && out_idx, "NULL argument");
@@ -334,6 +497,130 @@ int gpx_mi_greedy(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, co
   gpx_mat_free(ctx, P);
   if (r == -2) gpx_set_error("mi_greedy: HIP call failed: %s", hipGetErrorString(hipGetLastError()));
   return r;
+}
+
+
+// ---- greedy MI with the candidate scoring sharded by rows of the inverse (gpexp_amd/dist.py dist_mi_greedy) --------------------
+// State of one run on one rank: the full M x M inverse P (every rank builds it; only the rows [lo, hi) are kept current), the
+// replicated numerator chain, the picks.  Per pick: gpx_mi_row (numerator row; the owner of the picked row stages P[s, :] in a
+// buffer the caller broadcasts), gpx_mi_score (down-date of the rank's rows, ratios of its candidates, local first-max),
+// gpx_mi_select (the merged winner).  With lo = 0, hi = M this is gpx_mi_greedy step by step.
+struct gpx_mi {
+  KParams kp;
+  const gpx_mat* Cm;
+  gpx_mat* P;
+  double noise;
+  int64_t M, nsel, lo, hi;
+  double *W, *d0, *d1, *ratio, *val, *din, *dout;
+  int64_t* sel;
+  int* alive;
+};
+
+int gpx_mi_end(gpx_ctx* ctx, gpx_mi* st) {
+  if (!st) return 0;
+  GPX_ARG(ctx != nullptr, "ctx is NULL");
+  (void)hipDeviceSynchronize();
+  if (st->W) gpx_dev_release(ctx, st->W, st->nsel * st->M * 8);
+  if (st->d0) gpx_dev_release(ctx, st->d0, st->M * 8);
+  if (st->d1) gpx_dev_release(ctx, st->d1, st->M * 8);
+  if (st->ratio) gpx_dev_release(ctx, st->ratio, st->M * 8);
+  if (st->val) gpx_dev_release(ctx, st->val, st->nsel * 8);
+  if (st->sel) gpx_dev_release(ctx, st->sel, st->nsel * 8);
+  if (st->alive) gpx_dev_release(ctx, st->alive, st->M * 4);
+  if (st->P) gpx_mat_free(ctx, st->P);
+  delete st;
+  return 0;
+}
+
+int gpx_mi_begin(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* Cm, double noise, int64_t nsel,
+                 int64_t start, int64_t lo, int64_t hi, gpx_mi** out) {
+  GPX_ARG(ctx && Cm && out, "NULL argument");
+  KParams kp;
+  GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
+  GPX_ARG(Cm->cols == d && Cm->pcols == d, "candidates must be an unpadded (M x d) point set");
+  const int64_t M = Cm->rows;
+  GPX_ARG(nsel >= 1 && nsel <= M && start >= 0 && start < M, "bad nsel/start");
+  GPX_ARG(M <= 65535, "mi_greedy supports at most 65535 candidates");
+  GPX_ARG(lo >= 0 && lo <= hi && hi <= M, "bad row range");
+  gpx_mat* S = nullptr;
+  GPX_TRY(gpx_kfill(ctx, kind, d, hyp, nhyp, Cm, nullptr, &noise, 1, &S));
+  int r = gpx_potrf(ctx, S);
+  gpx_mat* P = nullptr;
+  if (r == 0) r = gpx_potri_impl(ctx, S, &P, 1);  // the down-dates touch both triangles
+  gpx_mat_free(ctx, S);
+  if (r != 0) return r;
+  gpx_mi* st = new gpx_mi();
+  st->kp = kp; st->Cm = Cm; st->P = P; st->noise = noise; st->M = M; st->nsel = nsel; st->lo = lo; st->hi = hi;
+  st->W = st->d0 = st->d1 = st->ratio = st->val = nullptr; st->sel = nullptr; st->alive = nullptr;
+  void* p;
+  do {
+    if ((r = gpx_dev_alloc(ctx, nsel * M * 8, &p)) != 0) break; st->W = (double*)p;
+    if ((r = gpx_dev_alloc(ctx, M * 8, &p)) != 0) break; st->d0 = (double*)p;
+    if ((r = gpx_dev_alloc(ctx, M * 8, &p)) != 0) break; st->d1 = (double*)p;
+    if ((r = gpx_dev_alloc(ctx, M * 8, &p)) != 0) break; st->ratio = (double*)p;
+    if ((r = gpx_dev_alloc(ctx, nsel * 8, &p)) != 0) break; st->val = (double*)p;
+    if ((r = gpx_dev_alloc(ctx, nsel * 8, &p)) != 0) break; st->sel = (int64_t*)p;
+    if ((r = gpx_dev_alloc(ctx, M * 4, &p)) != 0) break; st->alive = (int*)p;
+    const dim3 gM((unsigned)((M + 255) / 256));
+    if (hipMemcpyAsync(st->sel, &start, 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { r = -2; break; }
+    hipLaunchKernelGGL(fill_int_kernel, gM, dim3(256), 0, ctx->stream, st->alive, M, 1);
+    if ((r = launch_kdiag(ctx, kp, Cm->p, M, st->d0)) != 0) break;
+    st->din = st->d0;
+    st->dout = st->d1;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { r = -2; break; }
+  } while (0);
+  if (r != 0) {
+    gpx_mi_end(ctx, st);
+    if (r == -2) gpx_set_error("mi_begin: HIP call failed");
+    return r;
+  }
+  *out = st;
+  return 0;
+}
+
+// pick `cur` (sel[cur] = s): the numerator row for s (all candidates, replicated on every rank); if this rank owns row s of the
+// inverse, P[s, :] goes into rowbuf (M doubles) for the caller to broadcast.  Asynchronous.
+int gpx_mi_row(gpx_ctx* ctx, gpx_mi* st, int64_t cur, int64_t s, gpx_mat* rowbuf) {
+  GPX_ARG(ctx && st && rowbuf && cur >= 0 && cur + 1 < st->nsel && s >= 0 && s < st->M, "bad arguments");
+  GPX_ARG(rowbuf->bytes >= st->M * 8, "row buffer too small");
+  const dim3 gM((unsigned)((st->M + 255) / 256));
+  hipLaunchKernelGGL(mi_row_kernel, gM, dim3(256), 0, ctx->stream, st->kp, st->Cm->p, st->M, (const int64_t*)st->sel, (int)cur,
+                     st->noise, st->W, st->M, (const double*)st->din, st->dout);
+  { double* t = st->din; st->din = st->dout; st->dout = t; }
+  if (s >= st->lo && s < st->hi)
+    GPX_HIP(hipMemcpyAsync(rowbuf->p, st->P->p + s * st->P->ld, (size_t)st->M * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
+
+// rowbuf = P[s, :] (from its owner): down-date the rank's rows, score its candidates, local first-max (ties: lowest index);
+// an empty range answers (-inf, M).  Blocking (returns host scalars).
+int gpx_mi_score(gpx_ctx* ctx, gpx_mi* st, int64_t cur, const gpx_mat* rowbuf, double* best_val, int64_t* best_idx) {
+  GPX_ARG(ctx && st && rowbuf && best_val && best_idx && cur >= 0 && cur + 1 < st->nsel, "bad arguments");
+  const int64_t M = st->M;
+  const dim3 gM((unsigned)((M + 255) / 256));
+  if (st->hi > st->lo)
+    hipLaunchKernelGGL(mi_downdate_rows_kernel, dim3(gM.x, (unsigned)(st->hi - st->lo)), dim3(256), 0, ctx->stream, st->P->p,
+                       st->P->ld, M, st->lo, (const int64_t*)st->sel, (int)cur, (const double*)rowbuf->p);
+  hipLaunchKernelGGL(mi_mark_kernel, dim3(1), dim3(64), 0, ctx->stream, st->alive, (const int64_t*)st->sel, (int)cur);
+  hipLaunchKernelGGL(mi_ratio_range_kernel, gM, dim3(256), 0, ctx->stream, (const double*)st->P->p, st->P->ld,
+                     (const double*)st->din, (const int*)st->alive, st->noise, M, st->lo, st->hi, st->ratio);
+  hipLaunchKernelGGL(argmax_block_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const double*)st->ratio, M, st->sel,
+                     (int)(cur + 1), st->val);
+  GPX_HIP(hipGetLastError());
+  GPX_HIP(hipMemcpyAsync(best_val, st->val + cur + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
+  GPX_HIP(hipMemcpyAsync(best_idx, st->sel + cur + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
+  GPX_HIP(hipStreamSynchronize(ctx->stream));
+  if (!(*best_val > -INFINITY)) *best_idx = M;   // nothing alive in this rank's range
+  return 0;
+}
+
+// the merged winner of pick `slot`
+int gpx_mi_select(gpx_ctx* ctx, gpx_mi* st, int64_t slot, int64_t idx) {
+  GPX_ARG(ctx && st && slot >= 0 && slot < st->nsel && idx >= 0 && idx < st->M, "bad arguments");
+  GPX_HIP(hipMemcpyAsync(st->sel + slot, &idx, 8, hipMemcpyHostToDevice, ctx->stream));
+  GPX_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
 }
 
 }  // extern "C"

@@ -388,6 +388,73 @@ def lml_grad(ctx, spec, L, X, alpha):
     return out
 
 
+class MiState:
+    """One rank's state of a row-sharded greedy MI run (gpx_mi_*): rows [lo, hi) of the inverse are kept current."""
+
+    def __init__(self, ctx, spec, Cpts, noise, nsel, start, lo, hi):
+        self.ctx, self.Cpts = ctx, Cpts
+        self.picks = [int(start)]
+        h = c_vp()
+        check(ctx.lib.gpx_mi_begin(ctx.h, *spec.args(), Cpts.h, float(noise), int(nsel), int(start), int(lo), int(hi), C.byref(h)))
+        self.h = h
+
+    def row(self, cur, rowbuf):
+        check(self.ctx.lib.gpx_mi_row(self.ctx.h, self.h, int(cur), int(self.picks[cur]), rowbuf.h))
+
+    def score(self, cur, rowbuf):
+        v = C.c_double()
+        i = c_i64()
+        check(self.ctx.lib.gpx_mi_score(self.ctx.h, self.h, int(cur), rowbuf.h, C.byref(v), C.byref(i)))
+        return v.value, i.value
+
+    def select(self, slot, idx):
+        check(self.ctx.lib.gpx_mi_select(self.ctx.h, self.h, int(slot), int(idx)))
+        assert slot == len(self.picks)
+        self.picks.append(int(idx))
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self.ctx.lib.gpx_mi_end(self.ctx.h, self.h)
+            self.h = None
+        except Exception:
+            pass
+
+
+def alloc_vector(ctx, n):
+    """Zeroed device vector of n doubles (an unpadded n x 1 matrix)."""
+    return DeviceMatrix.zeros(ctx, max(int(n), 1), 1, pad=False)
+
+
+def lml_grad_slab_bounds(n, parts):
+    """Row boundaries (multiples of 128, inside the padded order) that cut the trace sums of the log-marginal gradient into
+    `parts` slabs of equal WORK: slab [r0, r1) costs ~ (N - r0)^2 (r1 - r0), so r_i = N (1 - (1 - i/parts)^(1/3))."""
+    npad = (max(n, 1) + 127) // 128 * 128
+    b = [int(round(npad * (1.0 - (1.0 - i / parts) ** (1.0 / 3.0)) / 128.0)) * 128 for i in range(parts + 1)]
+    b[0], b[-1] = 0, npad
+    for i in range(1, parts + 1):
+        b[i] = max(b[i], b[i - 1])
+    return b
+
+
+def lml_grad_slab(ctx, spec, L, X, alpha, r0, r1):
+    """Raw trace sums (d+2) of the log-marginal gradient over the row slab [r0, r1) of K^-1 (gpx_lml_grad_slab)."""
+    alpha = as_f64(alpha)
+    out = np.empty(spec.d + 2)
+    check(ctx.lib.gpx_lml_grad_slab(ctx.h, *spec.args(), L.h, X.h, dptr(alpha), int(r0), int(r1), dptr(out)))
+    return out
+
+
+def lml_grad_from_sums(spec, sums):
+    """[d/d cl_0 .. d/d cl_{d-1}, d/d signalSize, raw d/d noise] from the summed slab traces (as gpx_lml_grad returns them)."""
+    d = spec.d
+    g = np.empty(d + 2)
+    g[:d] = 0.5 * sums[:d] / spec.hyp[:d]
+    g[d] = 0.5 * sums[d] / spec.hyp[d]
+    g[d + 1] = 0.5 * sums[d + 1]
+    return g
+
+
 def ivar_grad(ctx, spec, L, X, Z, noise_deriv=None):
     """d IVAR / d design coordinates, flattened (N*d) in the reference's row order (point-major); noise_deriv (N, d) =
     d noise(x_j)/d x_j of a heteroscedastic noise model."""

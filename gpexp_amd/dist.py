@@ -1203,7 +1203,8 @@ class DistFitIvar2D:
         else:
             fn()
 
-    def step(self):
+    def fit(self):
+        """Distributed assembly + factorisation (+ the streamed evaluation solve when enabled); raises NotPositiveDefinite."""
         ops, comm, geo = self.ops, self.comm, self.geo
         ops.stream(MAIN)
         ops.kfill_local(self.spec, self.X, self.A, self.noise, geo)
@@ -1216,17 +1217,121 @@ class DistFitIvar2D:
         if info:
             from ._lib import NotPositiveDefinite
             raise NotPositiveDefinite(info)
+
+    def solve(self):
+        """alpha (host, on every rank) and the log marginal likelihood from the block-cyclic factor."""
+        ops, comm = self.ops, self.comm
+        self._run("solve", self._enqueue_solve)
+        logdet = float(comm.allreduce_host(np.array([ops.vec_to_host(self.scal, 1)[0]]))[0])
+        alpha = ops.vec_to_host(self.alpha, self.n)
+        ll = -0.5 * float(self.yh @ alpha) - 0.5 * logdet - self.n / 2.0 * np.log(2 * np.pi)
+        return ll, alpha
+
+    def step(self):
+        ops, comm = self.ops, self.comm
+        self.fit()
         if self.fit_only:
             part = float(np.sum(ops.variances(self.spec, self.Zloc, self.B, self.n))) if self.B is not None else 0.0
             return 0.0, part
-        self._run("solve", self._enqueue_solve)
-        logdet = float(comm.allreduce_host(np.array([ops.vec_to_host(self.scal, 1)[0]]))[0])
+        ll, _ = self.solve()
         part = 0.0
         if self.B is not None:     # the solve finished with the last panel (dist2_potrf synchronised every stream)
             part = float(np.sum(ops.variances(self.spec, self.Zloc, self.B, self.n)))
         elif self.Zloc is not None:
             part = float(np.sum(ops.posterior_var(self.spec, self.L, self.X, self.Zloc)))
-        alpha = ops.vec_to_host(self.alpha, self.n)
-        ll = -0.5 * float(self.yh @ alpha) - 0.5 * logdet - self.n / 2.0 * np.log(2 * np.pi)
-        iv = abs(ordered_sum(comm.allgather(np.array([part]))[:, 0]) / self.m)
+        iv = abs(ordered_sum(comm.allgather(np.array([part]))[:, 0]) / max(self.m, 1))
         return ll, iv
+
+
+# =====================================================================================================================
+# BASELINE config C5 on N GPUs: hyper-parameter gradient of the log marginal likelihood + mutual-information design
+# =====================================================================================================================
+def dist_lml_grad(ctx, comm, spec, L, X, alpha, be=None):
+    """Gradient of the log marginal likelihood w.r.t. (cl_0..cl_{d-1}, signalSize, noise [raw: the caller scales by 2 noise,
+    gp.py:463-464]) with the TRACES SHARDED over the ranks (gp.py:444-466 builds an (N, N, d+2) array and needs all of
+    K^-1).  Every rank holds the complete factor L (replicated by the distributed fit); rank r forms only the row slab
+    [b_r, b_{r+1}) of K^-1 -- two triangular solves against the TRAILING factor L[b_r:, b_r:], no N x N inverse anywhere --
+    and reduces its share of tr((alpha alpha^T - K^-1) dK/dtheta) (gpx_lml_grad_slab).  The slab boundaries equalise the work
+    (~(N - b)^2 per row).  One exchange: d+2 partial sums per rank, added in rank order (deterministic).
+    `be`: the device backend (gpexp_amd.device; the CPU tests pass a NumPy double with the same four functions)."""
+    be = be or _dev
+    n = X.shape[0]
+    b = be.lml_grad_slab_bounds(n, comm.world)
+    r0, r1 = b[comm.rank], b[comm.rank + 1]
+    sums = be.lml_grad_slab(ctx, spec, L, X, alpha, r0, r1) if r1 > r0 else np.zeros(spec.d + 2)
+    allsums = comm.allgather(sums)
+    tot = np.zeros(spec.d + 2)
+    for r in range(comm.world):
+        tot += allsums[r]
+    return be.lml_grad_from_sums(spec, tot)
+
+
+def mi_owner(m, s, world):
+    """Rank whose slice of the M candidates holds index s (eval_slice)."""
+    for r in range(world):
+        lo, hi = eval_slice(m, r, world)
+        if lo <= s < hi:
+            return r
+    raise ValueError("index outside the candidate set")
+
+
+def merge_argmax(values, indices):
+    """First-maximum rule across ranks: highest value, ties -> lowest global index (np.argmax semantics)."""
+    best = None
+    for v, i in zip(values, indices):
+        if best is None or v > best[0] or (v == best[0] and i < best[1]):
+            best = (float(v), int(i))
+    return best
+
+
+def dist_mi_greedy(ctx, comm, spec, cand_host, noise, nsel, start=0, be=None):
+    """Greedy mutual-information design (experimentalDesign.py:259-285, 753-785) with the candidate SCORING sharded: the
+    M x M inverse of the candidate covariance is down-dated by rows -- rank r owns the contiguous rows [lo, hi) of it and
+    scores exactly those candidates; per pick the owner of the chosen row broadcasts it (M doubles, ncclBroadcast), every
+    rank down-dates and scores its rows, and the ranks exchange one (ratio, index) pair each; the winner follows np.argmax
+    (highest ratio, ties to the lowest index), so the picks are identical to the single-GPU gpx_mi_greedy.  The numerator
+    chain (a Cholesky row per pick, O(M) each) is replicated.  Returns (indices, ratios)."""
+    be = be or _dev
+    m = cand_host.shape[0]
+    lo, hi = eval_slice(m, comm.rank, comm.world)
+    Cp = be.points(ctx, cand_host)
+    st = be.MiState(ctx, spec, Cp, noise, nsel, start, lo, hi)
+    row = be.alloc_vector(ctx, max(m, 1))
+    picks, ratios = [int(start)], []
+    for cur in range(int(nsel) - 1):
+        s = picks[-1]
+        st.row(cur, row)                                        # numerator chain everywhere; the owner stages its row P[s, :]
+        comm.bcast_grp(row, 0, m, mi_owner(m, s, comm.world), WORLD)
+        val, idx = st.score(cur, row)                           # down-date my rows, ratios of my candidates, local first-max
+        pairs = comm.allgather(np.array([val, float(idx)]))
+        best = merge_argmax(pairs[:, 0], pairs[:, 1].astype(np.int64))
+        st.select(cur + 1, best[1])
+        picks.append(best[1])
+        ratios.append(best[0])
+    return np.array(picks, dtype=np.int64), np.array(ratios)
+
+
+class DistFitGrad2D(DistFitIvar2D):
+    """BASELINE config C5 on the 2-D layout: distributed fit, alpha + log marginal likelihood, the hyper-parameter gradient
+    with its traces sharded over the ranks (dist_lml_grad) and -- optionally -- a greedy MI design over `cand` candidates with
+    the scoring sharded (dist_mi_greedy)."""
+
+    def __init__(self, ctx, comm, spec, Xh, yh, noise, nb=512, cand=None, nsel=8, be=None, **kw):
+        super().__init__(ctx, comm, spec, Xh, yh, np.zeros((0, Xh.shape[1])), noise, nb=nb, streamed=False, **kw)
+        self.cand, self.nsel, self.be = cand, int(nsel), be
+        self.times = {}
+
+    def step(self):
+        import time
+        t0 = time.perf_counter()
+        self.fit()
+        ll, alpha = self.solve()
+        t1 = time.perf_counter()
+        grad = dist_lml_grad(self.ctx, self.comm, self.spec, self.L, self.X, alpha, be=self.be)
+        t2 = time.perf_counter()
+        picks = None
+        if self.cand is not None:
+            picks, _ = dist_mi_greedy(self.ctx, self.comm, self.spec, self.cand, self.noise, self.nsel, be=self.be)
+        t3 = time.perf_counter()
+        self.times = {"fit_ms": 1e3 * (t1 - t0), "lml_grad_ms": 1e3 * (t2 - t1), "mi_ms": 1e3 * (t3 - t2)}
+        return ll, grad, picks

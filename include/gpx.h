@@ -187,6 +187,26 @@ int gpx_mi_greedy(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, co
 int gpx_lml_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
                  const double* alpha, double* grad);
 
+/* The same traces over ONE ROW SLAB [r0, r1) of K^-1 (multiples of 128), un-scaled: sums[q], q < d: sum T K0 e_q^2; q = d: sum T
+ * K0; q = d+1: tr T -- over slab rows a and columns b >= a, off-diagonal entries counted twice.  The slab of the inverse is two
+ * triangular solves against the TRAILING factor L[r0:, r0:]; no N x N inverse is formed.  Slabs of a partition of the rows add up
+ * to the full traces: grad[k] = sums[k] / (2 hyp[k]) (k < d), grad[d] = sums[d] / (2 hyp[d]), grad[d+1] = sums[d+1] / 2.  This is
+ * the unit the multi-GPU gradient shards by (gpexp_amd/dist.py dist_lml_grad; gp.py:444-466). */
+int gpx_lml_grad_slab(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
+                      const double* alpha, int64_t r0, int64_t r1, double* sums);
+
+/* Greedy MI with the candidate SCORING sharded by rows of the inverse (multi-GPU; gpexp_amd/dist.py dist_mi_greedy).  One
+ * state per rank: rows [lo, hi) of the M x M inverse are kept current and exactly those candidates are scored.  Per pick:
+ * gpx_mi_row (the owner of the picked row s stages P[s, :] in rowbuf -- the caller broadcasts it), gpx_mi_score (down-date,
+ * ratios, local first-max -> host), gpx_mi_select (the winner merged over the ranks).  lo = 0, hi = M reproduces gpx_mi_greedy. */
+typedef struct gpx_mi gpx_mi;
+int gpx_mi_begin(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* C, double noise, int64_t nsel,
+                 int64_t start, int64_t lo, int64_t hi, gpx_mi** out);
+int gpx_mi_row(gpx_ctx* ctx, gpx_mi* st, int64_t cur, int64_t s, gpx_mat* rowbuf);
+int gpx_mi_score(gpx_ctx* ctx, gpx_mi* st, int64_t cur, const gpx_mat* rowbuf, double* best_val, int64_t* best_idx);
+int gpx_mi_select(gpx_ctx* ctx, gpx_mi* st, int64_t slot, int64_t idx);
+int gpx_mi_end(gpx_ctx* ctx, gpx_mi* st);
+
 /* ---- point-location gradients of the posterior variance ----------------------------------------------
  * For the two kernels the reference differentiates: squared exponential (kernels.py:146-181, including its doubled
  * signalSize, :177) and 1-D Mehler (GPX_K_MEHLER with d == 1; kernels.py:295-324); any other kind is an argument error.

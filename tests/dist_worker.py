@@ -488,6 +488,163 @@ def run_cpu2d(args):
               flush=True)
 
 
+class NumpyC5:
+    """NumPy double of the device backend of dist_lml_grad / dist_mi_greedy (same four entry points + MiState): the slab sums
+    straight from their definition on a dense inverse, the MI state from the definition of the down-date."""
+
+    def __init__(self):
+        from gpexp_amd import device as dev
+        self.lml_grad_slab_bounds = dev.lml_grad_slab_bounds
+        self.lml_grad_from_sums = dev.lml_grad_from_sums
+
+    @staticmethod
+    def _k(spec, A, B):
+        d = spec.d
+        cl, sig = spec.hyp[:d], spec.hyp[d]
+        D = (A[:, None, :] - B[None, :, :]) / cl
+        return sig * np.exp(-0.5 * np.sum(D * D, axis=2)), D
+
+    def points(self, ctx, x):
+        return np.asarray(x, dtype=float)
+
+    def alloc_vector(self, ctx, n):
+        return NumpyMat(np.zeros(n))
+
+    def lml_grad_slab(self, ctx, spec, L, X, alpha, r0, r1):
+        n, d = X.shape[0], spec.d
+        K0, D = self._k(spec, X, X)
+        P = np.linalg.inv(np.tril(L.a[:n, :n]) @ np.tril(L.a[:n, :n]).T)
+        T = np.outer(alpha, alpha) - P
+        out = np.zeros(d + 2)
+        for a in range(r0, min(r1, n)):
+            w = np.full(n - a, 2.0)
+            w[0] = 1.0
+            tk = w * T[a, a:] * K0[a, a:]
+            for q in range(d):
+                out[q] += np.sum(tk * D[a, a:, q] ** 2)
+            out[d] += np.sum(tk)
+            out[d + 1] += T[a, a]
+        return out
+
+    def MiState(self, ctx, spec, Cp, noise, nsel, start, lo, hi):
+        be = self
+
+        class St:
+            def __init__(s_):
+                s_.K0, _ = be._k(spec, Cp, Cp)
+                s_.P = np.linalg.inv(s_.K0 + noise * np.eye(len(Cp)))
+                s_.alive = np.ones(len(Cp), bool)
+                s_.picks = [int(start)]
+                s_.A = []
+
+            def row(s_, cur, rowbuf):
+                sidx = s_.picks[cur]
+                if lo <= sidx < hi:
+                    rowbuf.a[:len(Cp)] = s_.P[sidx]
+
+            def score(s_, cur, rowbuf):
+                sidx = s_.picks[cur]
+                pr = rowbuf.a[:len(Cp)].copy()
+                for i in range(lo, hi):
+                    if i != sidx:
+                        keep = s_.P[i, sidx]
+                        s_.P[i] -= keep * pr / pr[sidx]
+                        s_.P[i, sidx] = keep
+                s_.alive[sidx] = False
+                s_.A.append(sidx)
+                A = s_.A
+                KA = s_.K0[np.ix_(A, A)] + noise * np.eye(len(A))
+                num = np.diag(s_.K0) - np.einsum("ia,ab,ib->i", s_.K0[:, A], np.linalg.inv(KA), s_.K0[:, A])
+                ratio = np.full(len(Cp), -np.inf)
+                for c in range(lo, hi):
+                    if s_.alive[c]:
+                        ratio[c] = num[c] / (1.0 / s_.P[c, c] - noise)
+                if not np.isfinite(ratio).any():
+                    return -np.inf, len(Cp)
+                i = int(np.argmax(ratio))
+                return float(ratio[i]), i
+
+            def select(s_, slot, idx):
+                s_.picks.append(int(idx))
+        return St()
+
+
+def run_cpu_c5(args):
+    """BASELINE config C5's multi-GPU form over gloo with the NumPy doubles: distributed fit (NumPy device double), sharded
+    log-marginal gradient (slab partition, rank-ordered sum) against the dense definition, sharded MI greedy (row owner,
+    broadcast, first-max merge) against a single-process run of the same double."""
+    from gpexp_amd import device as dev
+    rng = np.random.default_rng(args.n)
+    d, n, nb = 3, args.n, args.nb
+    X = rng.uniform(-1, 1, (n, d))
+    y = np.sin(2 * np.pi * X.sum(1) / d) + 0.2 * rng.standard_normal(n)
+    hyp = np.array([0.4, 0.55, 0.7, 1.3])
+    spec = dev.KernelSpec(dev.K_SE, d, hyp)
+    spec_o = dict(kind="se", cl=list(hyp[:d]), signalSize=float(hyp[d]), d=d)
+    comm = NumpyComm()
+    grid = tuple(int(v) for v in args.grid.split("x")) if args.grid else dist.choose_grid(comm.world)
+    ops = NumpyOps2D(spec_o)
+    be = NumpyC5()
+    Cand = rng.uniform(-1, 1, (47, d))
+    run = dist.DistFitGrad2D(None, comm, spec, X, y, 0.05, nb=nb, ops=ops, grid=grid, cand=Cand, nsel=6, be=be)
+    ll, grad, picks = run.step()
+    from oracle import gpexp_oracle as orc
+    K = orc.cov_matrix(spec_o, X, 0.05, row_loop=False)
+    alpha = np.linalg.solve(K, y)
+    P = np.linalg.inv(K)
+    T = np.outer(alpha, alpha) - P
+    K0, D = be._k(spec, X, X)
+    ref = np.array([0.5 * np.sum(T * K0 * D[:, :, q] ** 2) / hyp[q] for q in range(d)] +
+                   [0.5 * np.sum(T * K0) / hyp[d], 0.5 * np.trace(T)])
+    assert np.max(np.abs(grad - ref)) <= 1e-9 * np.max(np.abs(ref)), (grad, ref)
+    # slab boundaries: multiples of 128 covering the padded order, equal work to within one leaf row band
+    b = dev.lml_grad_slab_bounds(n, comm.world)
+    assert b[0] == 0 and b[-1] == dist.padded(n) and all(x % 128 == 0 for x in b) and b == sorted(b)
+    # MI: sharded == one process holding every row
+    class Solo:
+        rank, world = 0, 1
+        def bcast_grp(self, *a): pass
+        def allgather(self, v): return np.atleast_2d(v)
+    solo, _ = dist.dist_mi_greedy(None, Solo(), spec, Cand, 0.05, 6, be=be)
+    assert list(picks) == list(solo), (picks, solo)
+    assert len(set(picks)) == 6
+    if comm.rank == 0:
+        print("DIST_OK cpu-c5 world=%d grid=%dx%d n=%d grad0=%.6g picks=%s" % (comm.world, grid[0], grid[1], n, grad[0], list(picks)),
+              flush=True)
+
+
+def run_gpu_c5(args):
+    """C5's multi-GPU form on the real HIP primitives (ranks share GPU 0, host-staged exchange): gradient = single-GPU
+    gpx_lml_grad to 1e-10, MI picks identical to gpx_mi_greedy."""
+    from gpexp_amd import device as dev
+    ctx = dev.Context(int(os.environ.get("GPX_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+    dev._ctx = ctx
+    comm = dist.init_from_env(ctx)
+    rng = np.random.default_rng(args.n)
+    d, N = 5, args.n
+    Xh = rng.uniform(-1, 1, (N, d))
+    yh = np.sin(2 * np.pi * Xh.sum(1) / d) + 0.3 * rng.standard_normal(N)
+    hyp = np.array([0.5, 0.53, 0.56, 0.59, 0.62, 1.0])
+    spec = dev.KernelSpec(dev.K_SE, d, hyp)
+    grid = tuple(int(v) for v in args.grid.split("x")) if args.grid else None
+    Cand = rng.uniform(-1, 1, (args.m, d))
+    run = dist.DistFitGrad2D(ctx, comm, spec, Xh, yh, 0.1, nb=args.nb, grid=grid, cand=Cand, nsel=7)
+    ll, grad, picks = run.step()
+    X = dev.points(ctx, Xh)
+    K1 = dev.potrf(ctx, dev.kfill(ctx, spec, X, nugget=0.1))
+    a1 = dev.potrs(ctx, K1, yh)
+    g1 = dev.lml_grad(ctx, spec, K1, X, a1)
+    assert np.max(np.abs(grad - g1)) <= 1e-10 * np.max(np.abs(g1)), (grad, g1)
+    p1, r1 = dev.mi_greedy(ctx, spec, dev.points(ctx, Cand), 0.1, 7)
+    assert list(picks) == list(p1), (picks, p1)
+    comm.barrier()
+    if comm.rank == 0:
+        print("DIST_OK gpu-c5 world=%d n=%d comm=%s grad0=%.12g picks=%s" % (comm.world, N, type(comm).__name__, grad[0], list(picks)),
+              flush=True)
+    comm.close()
+    ctx.close()
+
+
 def _chaos_ops(ctx, seed, rank):
     """DeviceOps2D whose every primitive is preceded, with probability 1/3, by a kernel that holds the CURRENT stream back for
     1-40 ms (gpx_dbg_spin): results must not depend on how the streams of a rank -- or the ranks -- drift against each other.
@@ -668,7 +825,8 @@ if __name__ == "__main__":
     ap.add_argument("--chaos", type=int, default=0)
     a = ap.parse_args()
     print("WORKER_UP rank=%s mode=%s" % (os.environ.get("RANK", "0"), a.mode), flush=True)
-    {"cpu": run_cpu, "gpu": run_gpu, "cpu2d": run_cpu2d, "gpu2d": run_gpu2d, "gpu2d-chaos": run_gpu2d_chaos}[a.mode](a)
+    {"cpu": run_cpu, "gpu": run_gpu, "cpu2d": run_cpu2d, "gpu2d": run_gpu2d, "gpu2d-chaos": run_gpu2d_chaos,
+     "cpu-c5": run_cpu_c5, "gpu-c5": run_gpu_c5}[a.mode](a)
     if "torch" in sys.modules:  # orderly gloo teardown: a rank that exits while its peers still hold sub-group
         import torch.distributed as td   # connections aborts in a gloo thread (the RCCL path never imports torch)
         if td.is_initialized():

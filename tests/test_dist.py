@@ -98,6 +98,15 @@ def test_panel_loop_2d_schedules_gloo_cpu(world, n, nb, grid, agg, bulk):
     assert "world=%d" % world in out
 
 
+@pytest.mark.parametrize("world,n,nb", [(2, 700, 128), (4, 900, 128), (8, 1100, 128)])
+def test_c5_sharded_gradient_and_mi_gloo_cpu(world, n, nb):
+    """BASELINE config C5 in its multi-GPU form, host logic over gloo with NumPy doubles: distributed fit,
+    hyper-parameter gradient with the traces sharded by work-balanced row slabs of K^-1 (gp.py:444-466), greedy MI with the
+    scoring sharded by rows of the inverse and a first-max merge (experimentalDesign.py:259-285, 753-785)."""
+    out = launch(world, ["--mode", "cpu-c5", "--npts", str(n), "--blk", str(nb)], timeout=900)
+    assert "cpu-c5 world=%d" % world in out
+
+
 def test_grid_logic():
     from gpexp_amd import dist
     assert [dist.choose_grid(w) for w in (1, 2, 3, 4, 6, 8, 16)] == [(1, 1), (1, 2), (1, 3), (2, 2), (2, 3), (2, 4), (4, 4)]
@@ -184,6 +193,22 @@ def test_bench_c4_full_size_four_ranks_equals_single_gpu():
     assert got["n_gpus"] == 4 and "2x2" in got["config"]["parallelism"]
     for key in ("loglike", "ivar"):
         assert got["results"][key] == pytest.approx(ref["results"][key], rel=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n,m,nb", [(2, 1500, 300, 256), (4, 2100, 517, 256), (3, 1300, 200, 128)])
+def test_c5_distributed_gradient_and_mi_shared_gpu(world, n, m, nb):
+    """Config C5 on N ranks with the real kernels (ranks share the GPU, host-staged exchange): sharded gradient == single-GPU
+    gpx_lml_grad to 1e-10, sharded MI picks == gpx_mi_greedy."""
+    out = launch(world, ["--mode", "gpu-c5", "--npts", str(n), "--mpts", str(m), "--blk", str(nb)],
+                 {"GPX_COMM": "host", "GPX_FORCE_DEVICE": "0"}, timeout=900)
+    assert "gpu-c5 world=%d" % world in out
+
+
+@pytest.mark.gpu
+def test_rccl_c5_world1():
+    out = launch(1, ["--mode", "gpu-c5", "--npts", "1100", "--mpts", "300", "--blk", "256"], {"GPX_COMM": "rccl"})
+    assert "RcclComm" in out
 
 
 @pytest.mark.gpu

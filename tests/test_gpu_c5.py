@@ -1,0 +1,78 @@
+"""BASELINE config C5 building blocks on the GPU (-m gpu), through the C ABI: the slab form of the log-marginal gradient
+(gpx_lml_grad_slab: the unit the multi-GPU gradient shards by) and the row-sharded greedy MI state (gpx_mi_*).  The multi-rank
+runs of both are in tests/test_dist.py (gloo doubles on CPU, shared-GPU ranks on the GPU)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from gpexp_amd import device as dev
+    return dev.context()
+
+
+@pytest.mark.parametrize("n,d,parts", [(1500, 4, 1), (1500, 4, 3), (2100, 10, 5), (700, 2, 8), (130, 3, 2)])
+def test_lml_grad_slabs_sum_to_the_full_gradient(ctx, n, d, parts):
+    """Slabs of a partition of the rows add up to gpx_lml_grad (which forms the whole inverse): 1e-10, any partition; the
+    work-balanced boundaries are multiples of 128 that cover the padded order (gp.py:444-466)."""
+    from gpexp_amd import device as dev
+    rng = np.random.default_rng(n + d)
+    Xh = rng.uniform(-1, 1, (n, d))
+    y = np.sin(2 * np.pi * Xh.sum(1) / d) + 0.3 * rng.standard_normal(n)
+    spec = dev.KernelSpec(dev.K_SE, d, list(0.5 + 0.03 * np.arange(d)) + [1.2])
+    X = dev.points(ctx, Xh)
+    L = dev.potrf(ctx, dev.kfill(ctx, spec, X, nugget=0.1))
+    alpha = dev.potrs(ctx, L, y)
+    ref = dev.lml_grad(ctx, spec, L, X, alpha)
+    b = dev.lml_grad_slab_bounds(n, parts)
+    assert b[0] == 0 and b[-1] == (n + 127) // 128 * 128 and all(x % 128 == 0 for x in b) and b == sorted(b)
+    sums = np.zeros(d + 2)
+    for r0, r1 in zip(b[:-1], b[1:]):
+        if r1 > r0:
+            sums += dev.lml_grad_slab(ctx, spec, L, X, alpha, r0, r1)
+    got = dev.lml_grad_from_sums(spec, sums)
+    assert np.max(np.abs(got - ref)) <= 1e-10 * np.max(np.abs(ref)), (got, ref)
+    # an uneven hand-made partition gives the same
+    cuts = [0, 128, (n + 127) // 128 * 128]
+    sums2 = sum(dev.lml_grad_slab(ctx, spec, L, X, alpha, a, c) for a, c in zip(cuts[:-1], cuts[1:]) if c > a)
+    assert np.max(np.abs(dev.lml_grad_from_sums(spec, sums2) - ref)) <= 1e-10 * np.max(np.abs(ref))
+
+
+def test_slab_bounds_balance_the_work():
+    from gpexp_amd import device as dev
+    n, parts = 65536, 8
+    b = dev.lml_grad_slab_bounds(n, parts)
+    work = [((n - r0) ** 3 - (n - r1) ** 3) / 3.0 for r0, r1 in zip(b[:-1], b[1:])]
+    assert max(work) / (sum(work) / parts) < 1.05      # within 5 % of the mean at C5's size
+
+
+@pytest.mark.parametrize("m,nsel,slices", [(300, 8, 1), (300, 8, 3), (517, 6, 4), (64, 5, 7)])
+def test_row_sharded_mi_state_reproduces_mi_greedy(ctx, m, nsel, slices):
+    """gpx_mi_* with the rows of the inverse cut into `slices` ranges (one state per range, as one per rank; the picked row
+    travels through a buffer, the winners are merged first-max) == gpx_mi_greedy: identical picks AND identical ratios, bit
+    for bit -- the down-date of a row uses only that row and the pivot row (experimentalDesign.py:259-285, 753-785)."""
+    from gpexp_amd import device as dev, dist
+    rng = np.random.default_rng(m)
+    d = 3
+    Ch = rng.uniform(-1, 1, (m, d))
+    spec = dev.KernelSpec(dev.K_SE, d, [0.4, 0.6, 0.8, 2.0])
+    Cp = dev.points(ctx, Ch)
+    ref_idx, ref_ratio = dev.mi_greedy(ctx, spec, Cp, 1e-3, nsel)
+    ranges = [dist.eval_slice(m, r, slices) for r in range(slices)]
+    states = [dev.MiState(ctx, spec, Cp, 1e-3, nsel, 0, lo, hi) for lo, hi in ranges]
+    row = dev.alloc_vector(ctx, m)
+    picks, ratios = [0], []
+    for cur in range(nsel - 1):
+        for st in states:
+            st.row(cur, row)            # only the owner of picks[-1] writes the buffer
+        ctx.sync()
+        res = [st.score(cur, row) for st in states]
+        best = dist.merge_argmax([v for v, _ in res], [i for _, i in res])
+        for st in states:
+            st.select(cur + 1, best[1])
+        picks.append(best[1])
+        ratios.append(best[0])
+    assert picks == list(ref_idx)
+    assert ratios == list(ref_ratio)
