@@ -31,6 +31,13 @@ int gpx_dev_alloc(gpx_ctx* ctx, int64_t bytes, void** out) {
     base = it->second;
     ctx->pool.erase(it);
     ctx->pool_bytes -= key;
+    auto pf = ctx->pending.find(base);
+    if (pf != ctx->pending.end()) {  // freed by gpx_mat_free while work may still have been queued on it: wait for that work
+      for (hipEvent_t ev : pf->second->evs) (void)hipEventSynchronize(ev);
+      if (pf->second.use_count() == 1)
+        for (hipEvent_t ev : pf->second->evs) ctx->fence_free.push_back(ev);
+      ctx->pending.erase(pf);
+    }
   } else {
     hipError_t e = hipMalloc(&base, (size_t)key);
     if (e != hipSuccess) {
@@ -411,7 +418,11 @@ int gpx_dbg_guard_selftest(gpx_ctx* ctx) {
 
 int gpx_trim(gpx_ctx* ctx) {
   GPX_ARG(ctx != nullptr, "ctx is NULL");
-  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipDeviceSynchronize();  // fenced blocks (gpx_mat_free) may still be in use on any of the context's streams
+  for (auto& kv : ctx->pending)
+    if (kv.second.use_count() == 1)
+      for (hipEvent_t ev : kv.second->evs) ctx->fence_free.push_back(ev);
+  ctx->pending.clear();
   for (auto& kv : ctx->pool) (void)hipFree(kv.second);
   ctx->pool.clear();
   ctx->pool_bytes = 0;
@@ -425,6 +436,7 @@ int gpx_destroy(gpx_ctx* ctx) {
   gpx_prof_flush(ctx);
   gpx_trim(ctx);
   for (auto ev : ctx->ev_free) (void)hipEventDestroy(ev);
+  for (auto ev : ctx->fence_free) (void)hipEventDestroy(ev);
   (void)hipFree(ctx->d_info);
   (void)hipFree(ctx->d_scal);
   if (ctx->trsv_scratch) (void)hipFree(ctx->trsv_scratch);
@@ -515,9 +527,39 @@ int gpx_mat_from_host(gpx_ctx* ctx, const double* src, int64_t rows, int64_t col
 int gpx_mat_free(gpx_ctx* ctx, gpx_mat* m) {
   if (!m) return 0;
   GPX_ARG(ctx != nullptr, "ctx is NULL");
-  // work queued on ANY of the context's streams may still reference the buffers (side-stream solves, the background
-  // evaluation): the pool may hand them out again right away, so order the reuse behind all of it
-  (void)hipDeviceSynchronize();
+  // Work queued on ANY of the context's streams may still reference the buffers (side-stream solves, the background
+  // evaluation) and the pool may hand them out again right away.  Round 2 synchronised the whole device here -- several times
+  // per cost evaluation of an optimiser loop.  Now the buffers carry a FENCE (one event per stream, recorded here) and
+  // whoever reuses them waits for it (gpx_dev_alloc); the free itself never blocks.  (Guard mode checks the bands at release
+  // and needs the writes to have landed: it keeps the synchronisation.)
+  if (ctx->guard) {
+    (void)hipDeviceSynchronize();
+  } else {
+    auto f = std::make_shared<gpx_ctx::Fence>();
+    bool ok = true;
+    for (int i = 0; i < GPX_NSTREAMS && ok; ++i) {
+      hipEvent_t ev = nullptr;
+      if (!ctx->fence_free.empty()) {
+        ev = ctx->fence_free.back();
+        ctx->fence_free.pop_back();
+      } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+        ok = false;
+        break;
+      }
+      f->evs.push_back(ev);
+      if (hipEventRecord(ev, ctx->streams[i]) != hipSuccess) ok = false;
+    }
+    if (!ok) {
+      (void)hipGetLastError();
+      (void)hipDeviceSynchronize();
+      for (hipEvent_t ev : f->evs) ctx->fence_free.push_back(ev);
+    } else {
+      // a block that comes back while an older fence is still attached keeps the NEWER one (it covers everything queued since)
+      ctx->pending[m->p] = f;
+      if (m->aux) ctx->pending[m->aux] = f;
+      if (m->binv) ctx->pending[m->binv] = f;
+    }
+  }
   gpx_dev_release(ctx, m->p, m->bytes);
   if (m->aux) gpx_dev_release(ctx, m->aux, m->aux_bytes);
   if (m->binv) gpx_dev_release(ctx, m->binv, m->binv_bytes);

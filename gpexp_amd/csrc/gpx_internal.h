@@ -5,7 +5,9 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <memory>
 #include "../../include/gpx.h"
+#include "../../include/gpx_debug.h"
 
 #define GPX_TILE 128          // padding / GEMM tile / Cholesky leaf size
 #define GPX_MAXD GPX_MAX_DIM
@@ -132,6 +134,14 @@ struct gpx_ctx {
   // cached device allocations (exact-size reuse)
   std::multimap<int64_t, void*> pool;
   int64_t pool_bytes;
+  // deferred release (gpx_mat_free): a freed matrix's buffers go back to the pool AT ONCE, tagged with a fence -- one event per
+  // stream of the context, recorded at the time of the free; whoever takes such a block out of the pool waits for the fence
+  // first (normally long complete).  Replaces a device-wide synchronisation per free.
+  struct Fence {
+    std::vector<hipEvent_t> evs;
+  };
+  std::map<void*, std::shared_ptr<Fence>> pending;
+  std::vector<hipEvent_t> fence_free;
   // GPX_ALLOC_GUARD=1 (debug; there is no GPU address sanitizer on this pool): every pooled allocation gets a 4 KiB band of
   // 0xA5 on either side, checked when it goes back to the pool; violations are counted and reported on stderr
   int guard;

@@ -19,9 +19,9 @@
 //     scaling, and fills whose centred, scaled domain is still wide take the EXACT variant, which forms
 //     (a_k - b_k) * scale_k from the raw coordinates on the VALU -- the reference's own order of operations
 //     (kernels.py:121-122) -- instead of the expanded product.
-//   * exp: shifter-trick rounding + one-constant reduction to |r| <= ln2/128 + 64-entry 2^(j/64) table in LDS + degree-5
-//     polynomial + v_ldexp; sqrt: v_rsq_f64 (2^-23) + one coupled Newton step + residual correction.  Both stay within
-//     2 ulp (tests: 1e-13 against the oracle / the reference).
+//   * exp: argument clamped at -750, shifter-trick rounding + one-constant reduction to |r| <= ln2/512 + 256-entry
+//     2^(j/256) table in LDS + degree-4 polynomial (truncation 3.8e-17) + v_ldexp; sqrt: v_rsq_f64 (2^-23) + one coupled
+//     Newton step + residual correction.  Both stay within 2 ulp (tests: 1e-13 against the oracle / the reference).
 #include "gpx_internal.h"
 #include <math.h>
 #include <stdlib.h>

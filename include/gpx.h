@@ -361,39 +361,8 @@ int gpx_profile_reset(gpx_ctx* ctx);
 /* sums since reset: launches, elapsed ms (HIP events), algorithmic flops and bytes */
 int gpx_profile_get(gpx_ctx* ctx, int prof_class, int64_t* launches, double* ms, double* flops, double* bytes);
 
-/* ---- kernel-level test hooks (used by tests/ only; same kernels the entry points above launch) -- */
-/* C (m x n) = beta*C + alpha*A*op(B); bt != 0: B is (n x k) used transposed; alpha,beta in {(-1,1),(1,0)};
- * lower != 0: only tiles on/below the diagonal are touched */
-int gpx_dbg_gemm(gpx_ctx* ctx, const gpx_mat* A, const gpx_mat* B, gpx_mat* C, int bt, int accumulate, int lower);
-/* triangular-operand GEMM modes: tri = 1 (A lower triangular, k == m), 2 (B lower-triangular n x k used transposed, bt),
- * 3 (lower C = U U^T with A = B = U upper triangular, bt); the structurally zero part of every tile's k range is skipped */
-int gpx_dbg_gemm_tri(gpx_ctx* ctx, const gpx_mat* A, const gpx_mat* B, gpx_mat* C, int bt, int accumulate, int tri);
-/* GPX_CHAOS=<seed> in the environment at gpx_create (debug): every launch site holds its stream back by a random 0.1-3 ms with
- * probability 1/4; results must not change (a dependency between the context's streams that is only met by lucky timing would). */
-/* queues a kernel that spins for ~ms milliseconds (<= 500) on the selected stream: lets a test hold one stream back so that a
- * missing cross-stream dependency shows every time instead of once in a dozen runs */
-int gpx_dbg_spin(gpx_ctx* ctx, int ms);
-/* GPX_ALLOC_GUARD=1 in the environment at gpx_create (debug; this pool has no GPU address sanitizer): every pooled device
- * allocation carries a 4 KiB band of 0xA5 on either side, checked when the block returns to the pool; =2 also fills every
- * block with NaNs when it is handed out (a read of memory nobody wrote then shows in the results).  Returns the number of
- * blocks found overwritten so far (each also reported on stderr), or -1 when the mode is off. */
-int64_t gpx_dbg_guard_violations(gpx_ctx* ctx);
-/* guard mode only: overruns a scratch block by 16 bytes on purpose; 1 if the check caught it, 0 if not, < 0 on error */
-int gpx_dbg_guard_selftest(gpx_ctx* ctx);
-/* host logic of gpx_comm_panel_bcast: the ncclSend / ncclRecv schedule of rank `me` in a W-rank communicator, rows of 6 int64
- * (phase 1|2, is_send, piece, offset within the piece, length, peer) in issue order; *nops = rows needed (at most max_ops are
- * written).  `small` = the direct-send threshold in doubles.  No device, no RCCL: tests replay it for all ranks. */
-int gpx_dbg_panel_bcast_plan(int W, int me, int64_t small_elems, int npieces, const int64_t* counts, const int* roots,
-                             int64_t* ops, int64_t max_ops, int64_t* nops);
-/* host logic of the deterministic column reduction: number of row chunks (= partial sums per column) a rows x pcols launch
- * uses, and the scratch bound callers allocate; the bound is monotone in both arguments (one buffer serves every sub-block
- * a sweep reduces).  No device work. */
-int gpx_dbg_colreduce_plan(int64_t rows, int64_t pcols, int64_t* nchunk, int64_t* bound_elems);
-/* what an assembly between X and Z (NULL: X with itself) would do: *exact = 1 when distances are formed from raw
- * coordinate differences on the VALU (wide domain relative to the length scale) instead of the centred expanded MFMA
- * product; center[d] = the origin subtracted before scaling (bounding-box midpoint; 0 for Mehler) */
-int gpx_dbg_kfill_plan(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* X, const gpx_mat* Z,
-                       int* exact, double* center);
+/* Test hooks (gpx_dbg_*: kernel-level entry points, allocator guards, schedule replays) are declared in gpx_debug.h; they are
+ * exported by the same library but are not part of the drop-in ABI. */
 
 #ifdef __cplusplus
 }

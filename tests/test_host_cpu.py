@@ -24,10 +24,14 @@ def built_lib():
     return so
 
 
-def header_symbols():
-    txt = open(os.path.join(ROOT, "include", "gpx.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(gpx_[a-z0-9_]+)\s*\(", txt)))
+def header_symbols(which=("gpx.h", "gpx_debug.h")):
+    """Functions declared by include/gpx.h (the drop-in ABI) and include/gpx_debug.h (test hooks)."""
+    out = set()
+    for name in which:
+        txt = open(os.path.join(ROOT, "include", name)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        out |= set(re.findall(r"\b(gpx_[a-z0-9_]+)\s*\(", txt))
+    return sorted(out)
 
 
 def test_header_symbols_all_exported(built_lib):
@@ -44,6 +48,18 @@ def test_binding_matches_header(built_lib):
     assert sorted(_lib.exported_symbols()) == header_symbols()
     lib = _lib.load()
     assert lib.gpx_abi_version() == 2
+
+
+def test_public_header_has_no_debug_hooks():
+    assert not [f for f in header_symbols(("gpx.h",)) if f.startswith("gpx_dbg_")]
+    assert all(f.startswith("gpx_dbg_") for f in header_symbols(("gpx_debug.h",)))
+
+
+def test_packed_row_stride_constant_matches_library(built_lib):
+    from gpexp_amd import _lib, dist
+    lib = _lib.load()
+    for nb in (128, 256, 512, 1024):
+        assert lib.gpx_dist2_row_stride(nb) == nb + dist.G_SKEW
 
 
 def test_header_cites_reference_lines():
