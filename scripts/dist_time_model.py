@@ -1,47 +1,65 @@
-"""Paper time model of the 2-D block-cyclic factorisation (gpexp_amd/dist.py) from single-GPU measurements.
-NOT a measurement: RCCL with more than one rank has never run (one GPU per lease).
+"""Time model of the 2-D block-cyclic fit (gpexp_amd/dist.py), round 3: the per-rank GPU time and the host issue
+time are MEASURED (single-rank replay of rank (pr, pc)'s exact kernel sequence on one MI355X, scripts/dist_replay.py ->
+profiles/r03_dist_replay_fit_only.json / _fit_ivar.json); only the xGMI terms are still assumptions, because RCCL with more
+than one rank has never run on the build's hardware (one GPU per lease).
 
-Inputs measured on one MI355X (scripts/probe_small_potrf.py, profiles/r02_dist_model_inputs.txt):
-  potrf(nb) of a diagonal block; rate of a rank-nb lower update; panel-solve rate ~40 TF/s (short-K products);
-assumed: xGMI 153 GB/s per link and direction, 7 links per GPU; 25 us per collective hand-off / dependent launch group.
-Per step k (h = rows below the diagonal block), the three concurrent strands of dist2_potrf:
-  diag   = potrf(nb) + solve of the ONE block L[k+1,k] + its broadcast along a process row + update of diagonal block k+1
-           (the critical-path-first chain: what diag(k+1) really waits for)
-  panel  = diagonal-block broadcast down the process column + panel solve of h/Pr rows + all-link panel broadcast
-           (2 phases, each piece/(W-1) bytes per link; 1 phase for 2 ranks) + look-ahead column update
-  update = h^2 nb / W flops at the rank-nb rate (every rank's share of the trailing update)
-The factorisation takes about max( sum_k diag_k , sum_k max(panel_k, update_k) ); "serial" = what it would take with the
-diagonal waiting for the whole panel (sum_k max(diag_k + panel_k, update_k)), the schedule before the chain was split."""
+    python scripts/dist_time_model.py [profiles/r03_dist_replay_fit_only.json profiles/r03_dist_replay_fit_ivar.json]
+
+Per grid: the slowest replayed rank's GPU time per step (every receive already costs its device copy there, so staging is in),
+its host issue time, the bytes that rank receives per fit, and two bracketing projections of the step on a real node:
+  overlapped  max(GPU time, communication time): transfers hidden behind compute (what the stream plumbing is built for)
+  exposed     GPU time + communication time: nothing hidden
+with communication time = bytes received / (links used x 153 GB/s x 0.8) + 2 latency hops x 25 us x panel steps.  Links used:
+the all-link panel broadcast (gpx_comm_panel_bcast) delivers over all W-1 links of the receiver; at 2 ranks there is one link."""
+import json
+import os
 import sys
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
-T_POTRF = {256: 0.118e-3, 512: 0.236e-3, 1024: 0.465e-3}
-RATE = {256: 49.9e12, 512: 57.3e12, 1024: 64.0e12}
-TRSM_RATE, LINK, LAT = 40e12, 153e9, 25e-6
-T1 = 0.190   # single-GPU potrf at N = 32768 (profiles/r02_potrf_variants.txt); scaled by N^3 for other sizes
-print("N = %d; single GPU %.1f ms" % (N, 1e3 * T1 * (N / 32768.0) ** 3))
-print("%-6s %-5s %5s | %8s %8s %9s %8s | %9s %8s | %9s" % ("ranks", "grid", "nb", "diag ms", "panel ms", "update ms", "comm ms",
-                                                         "total ms", "speed-up", "serial ms"))
-for W, (Pr, Pc) in ((2, (1, 2)), (4, (2, 2)), (8, (2, 4))):
-    for nb in (256, 512, 1024):
-        nblk = N // nb
-        diag_sum = panel_sum = upd_sum = comm_sum = pu = serial = 0.0
-        for k in range(nblk):
-            h = N - (k + 1) * nb
-            piece = (h / Pr) * nb * 8.0
-            phases = 1.0 if W == 2 else 2.0
-            comm = phases * piece / ((W - 1) * LINK) + LAT if W > 1 else 0.0
-            dbc = (nb * nb + nb * 128) * 8.0 / LINK + LAT if Pr > 1 else 0.0
-            early = (nb * nb * 8.0 / LINK + LAT) if Pc > 1 else 0.0
-            diag = T_POTRF[nb] + LAT + nb ** 3 / TRSM_RATE + early + 2.0 * nb ** 3 / RATE[nb] + LAT
-            panel = dbc + (h / Pr) * nb * nb / TRSM_RATE + LAT + comm + 2.0 * (h / Pr) * nb * nb / RATE[nb] + LAT
-            upd = h * h * nb / W / RATE[nb]
-            diag_sum += diag
-            panel_sum += panel
-            upd_sum += upd
-            comm_sum += comm
-            pu += max(panel, upd)
-            serial += max(diag + panel, upd)
-        tot = max(diag_sum, pu)
-        t1 = T1 * (N / 32768.0) ** 3
-        print("%-6d %dx%-3d %5d | %8.1f %8.1f %9.1f %8.1f | %9.1f %7.1fx | %9.1f" % (W, Pr, Pc, nb, 1e3 * diag_sum, 1e3 * panel_sum,
-              1e3 * upd_sum, 1e3 * comm_sum, 1e3 * tot, t1 / tot, 1e3 * serial))
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+f_fit = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_dist_replay_fit_only.json")
+f_all = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r03_dist_replay_fit_ivar.json")
+LINK, EFF, LAT = 153e9, 0.8, 25e-6
+
+
+def worst(path):
+    out = {}
+    for r in json.load(open(path)):
+        g = r["grid"]
+        if g not in out or r["ms_per_step"] > out[g]["ms_per_step"]:
+            out[g] = r
+    return out
+
+
+fit, full = worst(f_fit), worst(f_all)
+single_potrf = next(iter(fit.values()))["single_gpu_potrf_ms"]
+print("inputs: %s, %s" % (os.path.basename(f_fit), os.path.basename(f_all)))
+print("single-GPU potrf in the same run: %.1f ms (this box; boxes of the pool differ by up to 10 %%)\n" % single_potrf)
+print("FACTORISATION alone (kfill + dist2_potrf; evaluation set of 1024 points)")
+print("%-5s %6s | %12s %10s %9s %8s | %11s %11s | %18s" % ("grid", "ranks", "GPU ms/step", "host ms", "GB recv", "comm ms", "overlapped",
+                                                            "exposed", "speed-up vs 1 GPU"))
+for g in ("1x1", "1x2", "2x2", "2x4"):
+    if g not in fit:
+        continue
+    r = fit[g]
+    W = int(g[0]) * int(g[2])
+    links = max(W - 1, 1)
+    comm = (r["bytes_received_per_fit"] / (links * LINK * EFF) + 2 * LAT * r["steps_k"]) if W > 1 else 0.0
+    t = r["ms_per_step"] * 1e-3
+    lo, hi = max(t, comm), t + comm
+    print("%-5s %6d | %12.1f %10.1f %9.2f %8.1f | %8.1f ms %8.1f ms | %6.1fx .. %5.1fx" %
+          (g, W, 1e3 * t, r["host_issue_ms_per_fit"], r["bytes_received_per_fit"] / 1e9, 1e3 * comm, 1e3 * lo, 1e3 * hi,
+           single_potrf / (1e3 * hi), single_potrf / (1e3 * lo)))
+print("\nFIT + IVAR over M = 32768 (the bench step without alpha / logdet; IVAR streamed from 4 ranks)")
+print("%-5s %6s | %12s %9s %8s | %11s %11s" % ("grid", "ranks", "GPU ms/step", "GB recv", "comm ms", "overlapped", "exposed"))
+for g in ("1x1", "1x2", "2x2", "2x4"):
+    if g not in full:
+        continue
+    r = full[g]
+    W = int(g[0]) * int(g[2])
+    links = max(W - 1, 1)
+    comm = (r["bytes_received_per_fit"] / (links * LINK * EFF) + 2 * LAT * r["steps_k"]) if W > 1 else 0.0
+    t = r["ms_per_step"] * 1e-3
+    extra = "" if r["streamed_ivar"] else "  (+ IVAR after the fit: ~487 ms / %d ranks, not in this replay)" % W
+    print("%-5s %6d | %12.1f %9.2f %8.1f | %8.1f ms %8.1f ms%s" % (g, W, 1e3 * t, r["bytes_received_per_fit"] / 1e9, 1e3 * comm,
+                                                                 1e3 * max(t, comm), 1e3 * (t + comm), extra))
+print("\nNOT measured: xGMI transfer time, RCCL launch latency, waiting for peers.  Measured: everything a rank's GPU and host do.")
