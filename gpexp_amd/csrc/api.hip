@@ -625,6 +625,7 @@ int gpx_vec_op(gpx_ctx* ctx, gpx_mat* dst, int64_t doff, const gpx_mat* src, int
   GPX_ARG(doff >= 0 && n >= 0 && (doff + n) * 8 <= dst->bytes, "destination range out of bounds");
   GPX_ARG(mode == 2 || (soff >= 0 && (soff + n) * 8 <= src->bytes), "source range out of bounds");
   if (n == 0) return 0;
+  dst->bbox_ok = 0;  // a cached bounding box (point sets) does not survive a device-side write
   hipLaunchKernelGGL(vec_op_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dst->p + doff,
                      mode == 2 ? nullptr : src->p + soff, n, mode);
   GPX_HIP(hipGetLastError());

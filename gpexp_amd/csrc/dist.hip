@@ -215,6 +215,7 @@ int gpx_comm_bcast_grp(gpx_ctx* ctx, gpx_mat* buf, int64_t offset, int64_t count
   GPX_ARG(root >= 0 && root < ctx->grp_size[grp], "root outside the group");
   if (count == 0 || ctx->grp_size[grp] == 1) return 0;
   ProfScope ps(ctx, GPX_PROF_COMM, 0.0, 8.0 * (double)count);
+  buf->bbox_ok = 0;  // a cached bounding box (point sets) does not survive a device-side write
   double* p = buf->p + offset;
   GPX_NCCL(g_rccl.Broadcast(p, p, (size_t)count, ncclFloat64, root, (ncclComm_t)ctx->grp[grp], ctx->stream));
   return 0;
@@ -228,6 +229,7 @@ int gpx_comm_reduce_grp(gpx_ctx* ctx, gpx_mat* buf, int64_t offset, int64_t coun
   GPX_ARG(root >= 0 && root < ctx->grp_size[grp], "root outside the group");
   if (count == 0 || ctx->grp_size[grp] == 1) return 0;
   ProfScope ps(ctx, GPX_PROF_COMM, 0.0, 8.0 * (double)count);
+  buf->bbox_ok = 0;  // a cached bounding box (point sets) does not survive a device-side write
   double* p = buf->p + offset;
   GPX_NCCL(g_rccl.Reduce(p, p, (size_t)count, ncclFloat64, ncclSum, root, (ncclComm_t)ctx->grp[grp], ctx->stream));
   return 0;
@@ -240,6 +242,7 @@ int gpx_comm_allreduce(gpx_ctx* ctx, gpx_mat* buf, int64_t offset, int64_t count
   GPX_ARG(offset >= 0 && count >= 0 && (offset + count) * 8 <= buf->bytes, "allreduce range exceeds the buffer");
   if (count == 0 || ctx->world == 1) return 0;
   ProfScope ps(ctx, GPX_PROF_COMM, 0.0, 8.0 * (double)count);
+  buf->bbox_ok = 0;  // a cached bounding box (point sets) does not survive a device-side write
   double* p = buf->p + offset;
   GPX_NCCL(g_rccl.AllReduce(p, p, (size_t)count, ncclFloat64, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
   return 0;
@@ -352,6 +355,7 @@ int gpx_comm_panel_bcast(gpx_ctx* ctx, gpx_mat* buf, const int64_t* offsets, con
     GPX_ARG(roots[i] >= 0 && roots[i] < W, "piece root outside the communicator");
     total += 8.0 * (double)counts[i];
   }
+  buf->bbox_ok = 0;
   if (W == 1 || npieces == 0) return 0;
   ProfScope ps(ctx, GPX_PROF_COMM, 0.0, total);
   ncclComm_t comm = (ncclComm_t)ctx->comm;
@@ -402,6 +406,7 @@ int gpx_dbg_panel_bcast_plan(int W, int me, int64_t small, int npieces, const in
 int gpx_comm_bcast(gpx_ctx* ctx, gpx_mat* buf, int64_t count, int root) {
   GPX_ARG(ctx && buf && ctx->comm, "communicator not initialised");
   GPX_ARG(count >= 0 && count * 8 <= buf->bytes, "broadcast count exceeds the buffer");
+  buf->bbox_ok = 0;
   ProfScope ps(ctx, GPX_PROF_COMM, 0.0, 8.0 * (double)count);
   GPX_NCCL(g_rccl.Broadcast(buf->p, buf->p, (size_t)count, ncclFloat64, root, (ncclComm_t)ctx->comm, ctx->stream));
   return 0;

@@ -217,8 +217,12 @@ def potrf(ctx, K):
 
 
 def potrf_policy(ctx, piv_min=0.0, skip=False):
-    """Pivot policy of the factorisations that follow (gpx_potrf_policy); (0, False) is the library default."""
+    """Pivot policy of the factorisations that follow (gpx_potrf_policy); (0, False) is the library default.  Returns the
+    policy that was in force before, so that a caller can put it back (the policy is state of the shared context)."""
+    prev = getattr(ctx, "_potrf_policy", (0.0, False))
     check(ctx.lib.gpx_potrf_policy(ctx.h, float(piv_min), 1 if skip else 0))
+    ctx._potrf_policy = (float(piv_min), bool(skip))
+    return prev
 
 
 def potrf_dropped(ctx):

@@ -122,6 +122,7 @@ class GP:
         diag = float(spec.hyp[-1]) if spec.kind != _dev.K_MEHLER else float(np.max(_dev.kdiag(ctx, spec, X)))
         tau = 1e-13 * (diag + float(np.max(np.asarray(nugget, dtype=float))))
         self.dropped = 0
+        prev_policy = getattr(ctx, "_potrf_policy", (0.0, False))   # a policy the user set on the shared context survives
         try:
             _dev.potrf_policy(ctx, tau, False)
             keep = self._reusable_rows(nodes, nugget, spec) if remember else 0
@@ -145,13 +146,22 @@ class GP:
                 _dev.potrf_policy(ctx, tau, True)
                 _dev.potrf(ctx, K)
                 self.dropped = _dev.potrf_dropped(ctx)
-                warnings.warn("covariance matrix not positive definite (pivot %d <= %.1e): %d point(s) whose "
-                              "conditional variance is at round-off level were dropped from the factor (the "
-                              "reference's pinv truncates the same directions)" % (first.pivot, tau, self.dropped),
-                              RuntimeWarning)
+                # once per (GP object, remember-mode): an optimiser loop over near-singular hyper-parameters would otherwise
+                # raise it on every likelihood evaluation
+                if not getattr(self, "_warned_dropped", {}).get(remember):
+                    warnings.warn("covariance matrix not positive definite (pivot %d <= %.1e): %d point(s) whose "
+                                  "conditional variance is at round-off level were dropped from the factor (the "
+                                  "reference's pinv truncates the same directions)%s" %
+                                  (first.pivot, tau, self.dropped,
+                                   "" if remember else "; the log-likelihood returned is that of the REDUCED model -- the "
+                                   "reference's value there is -0.5 y^T pinv(K) y - 0.5 slogdet(K) with slogdet -> -inf "
+                                   "(gp.py:431-435), which no optimiser can use"), RuntimeWarning)
+                    seen = dict(getattr(self, "_warned_dropped", {}))
+                    seen[remember] = True
+                    self._warned_dropped = seen
                 return X, K, 0.0
         finally:
-            _dev.potrf_policy(ctx, 0.0, False)
+            _dev.potrf_policy(ctx, *prev_policy)
 
     @staticmethod
     def _spec_key(spec):
