@@ -882,6 +882,40 @@ static int trsm_right_binv_rec(gpx_ctx* ctx, const double* Ld, int64_t ldl, cons
   return trsm_right_binv_rec(ctx, Ld, ldl, binv, ib, X, ldx, m, n, mid, b1, T);
 }
 
+// X (m x n) <- X L^-1 (NOT transposed) with the same block inverses: block columns from the last to the first, X_b <- X_b Binv_b
+// as a product with the stored TRANSPOSE of the inverse (binvT, upper triangular, used transposed; dense product: the zero half
+// is multiplied too -- 1/8 of the solve's flops at four blocks), between them X[:, earlier] -= X[:, done] L[done, earlier] with
+// K >= ib.  The leaf-level recursion of chol_trsm_right_n spends its time in K = 128..512 products.
+static int trsm_right_n_binv_rec(gpx_ctx* ctx, const double* Ld, int64_t ldl, const double* binvT, int64_t ib, double* X,
+                                 int64_t ldx, int64_t m, int64_t n, int64_t b0, int64_t b1, double* T) {
+  auto off = [&](int64_t b) { return b * ib < n ? b * ib : n; };
+  if (b1 - b0 == 1) {
+    const int64_t o = off(b0), sz = off(b0 + 1) - o;
+    GPX_TRY(launch_gemm(ctx, X + o, ldx, binvT + b0 * ib * ib, ib, T, ib, m, sz, sz, true, false, false));
+    return gpx_copy2d(ctx, T, ib, X + o, ldx, m, sz);
+  }
+  const int64_t mid = (b0 + b1) / 2, o0 = off(b0), om = off(mid), o1 = off(b1);
+  GPX_TRY(trsm_right_n_binv_rec(ctx, Ld, ldl, binvT, ib, X, ldx, m, n, mid, b1, T));
+  GPX_TRY(launch_gemm(ctx, X + om, ldx, Ld + om * ldl + o0, ldl, X + o0, ldx, m, om - o0, o1 - om, false, true, false));
+  return trsm_right_n_binv_rec(ctx, Ld, ldl, binvT, ib, X, ldx, m, n, b0, mid, T);
+}
+
+// Both right solves against the TRAILING factor L[r0:, r0:] of a complete factor with block inverses (r0 a multiple of the
+// inverse order): X <- X L22^-T (transposed != 0) or X <- X L22^-1.  T >= m * ib doubles of scratch.  Used by the slab form of the
+// log-marginal gradient (hyper.hip), whose two solves are 2 (N - r0)^2 m flops.
+int chol_trsm_right_trailing(gpx_ctx* ctx, gpx_mat* Lm, int64_t r0, double* X, int64_t ldx, int64_t m, int transposed, double* T) {
+  GPX_ARG(Lm && Lm->factored && X && T, "trsm trailing: NULL argument / not factored");
+  GPX_TRY(chol_binv_ensure(ctx, Lm));
+  const int64_t ib = Lm->binv_ib, n2 = Lm->prows - r0;
+  GPX_ARG(r0 >= 0 && r0 % ib == 0 && n2 > 0, "trsm trailing: the offset must be a multiple of the block-inverse order");
+  const int64_t nblk_all = (Lm->prows + ib - 1) / ib, nb2 = (n2 + ib - 1) / ib;
+  const double* Ld = Lm->p + r0 * (Lm->ld + 1);
+  const double* binv = Lm->binv + (r0 / ib) * ib * ib;
+  const double* binvT = Lm->binv + nblk_all * ib * ib + (r0 / ib) * ib * ib;
+  if (transposed) return trsm_right_binv_rec(ctx, Ld, Lm->ld, binv, ib, X, ldx, m, n2, 0, nb2, T);
+  return trsm_right_n_binv_rec(ctx, Ld, Lm->ld, binvT, ib, X, ldx, m, n2, 0, nb2, T);
+}
+
 // Blocked right-looking factorisation with panels of width B (4096) and ONE PANEL OF LOOK-AHEAD for large matrices.
 // Per panel k: solve the rows below the diagonal block, then the trailing update A22 -= P P^T with K = B.  The diagonal
 // block of panel k+1 -- a chain of ~100 latency-bound kernels (128-wide leaves, strip multiplies, rank-128 updates: 2.3 ms
@@ -993,7 +1027,12 @@ static int potrf_blocked(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double*
       double* P2 = P + w2 * ld;
       double* C2 = C + w2 * (ld + 1);
       t0 = mark(M);
-      GPX_TRY(launch_gemm(ctx, P2, ld, P2, ld, C2, ld, rest, rest, w, true, true, true));
+      // GPX_POTRF_KSPLIT > 1 (experiment): the update as that many launches over slices of the k range -- shorter
+      // retirement waves of the GEMM workgroups (the chain's kernels get their slots at those), more traffic on C
+      static const int64_t ksplit = env_i64("GPX_POTRF_KSPLIT", 1);
+      const int64_t kparts = (ksplit > 1 && w % (ksplit * 16) == 0) ? ksplit : 1, kw = w / kparts;
+      for (int64_t kp = 0; kp < kparts; ++kp)
+        GPX_TRY(launch_gemm(ctx, P2 + kp * kw, ld, P2 + kp * kw, ld, C2, ld, rest, rest, kw, true, true, true));
       spans.push_back({"bulk", j0 / B, t0, mark(M)});
       GPX_HIP(hipStreamWaitEvent(M, ev_diag, 0));
     } else if (rest > 0) {

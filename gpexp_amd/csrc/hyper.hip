@@ -418,8 +418,19 @@ int gpx_lml_grad_slab(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp
       const double* L22 = L->p + r0 * L->ld + r0;
       const double* inv22 = L->aux + (r0 / GPX_TILE) * GPX_TILE * GPX_TILE;
       // Z <- Z L22^-T  (rows of L22^-1 ... transposed: Y^T with Y = L22^-1 [I 0]^T), then Z <- Z L22^-1: Z = (K^-1)[slab, r0:]
-      if ((r = chol_trsm_right(ctx, L22, L->ld, inv22, Z, ldz, s, n2)) != 0) break;
-      if ((r = chol_trsm_right_n(ctx, L22, L->ld, inv22, Z, ldz, s, n2)) != 0) break;
+      // Large factors: through the explicit inverses of the 1024-order diagonal blocks (every product K >= 1024); the slab must
+      // then start on a block boundary (lml_grad_slab_bounds rounds to it).  Otherwise the leaf-level recursion.
+      const int64_t ibo = chol_binv_order(np);
+      if (np >= 8192 && r0 % ibo == 0) {
+        void* pt;
+        if ((r = sc.get(s * ibo * 8, &pt)) != 0) break;
+        gpx_mat* Lw = const_cast<gpx_mat*>(L);  // the block-inverse cache of the factor may be completed (not its contents)
+        if ((r = chol_trsm_right_trailing(ctx, Lw, r0, Z, ldz, s, 1, (double*)pt)) != 0) break;
+        if ((r = chol_trsm_right_trailing(ctx, Lw, r0, Z, ldz, s, 0, (double*)pt)) != 0) break;
+      } else {
+        if ((r = chol_trsm_right(ctx, L22, L->ld, inv22, Z, ldz, s, n2)) != 0) break;
+        if ((r = chol_trsm_right_n(ctx, L22, L->ld, inv22, Z, ldz, s, n2)) != 0) break;
+      }
       {
         ProfScope ps(ctx, GPX_PROF_REDUCE, 0.0, 8.0 * (double)s * n2);
         dim3 grid((unsigned)tc, (unsigned)tr);

@@ -434,7 +434,8 @@ def lml_grad_slab_bounds(n, parts):
     """Row boundaries (multiples of 128, inside the padded order) that cut the trace sums of the log-marginal gradient into
     `parts` slabs of equal WORK: slab [r0, r1) costs ~ (N - r0)^2 (r1 - r0), so r_i = N (1 - (1 - i/parts)^(1/3))."""
     npad = (max(n, 1) + 127) // 128 * 128
-    b = [int(round(npad * (1.0 - (1.0 - i / parts) ** (1.0 / 3.0)) / 128.0)) * 128 for i in range(parts + 1)]
+    q = 1024 if npad >= 8192 else 128     # large factors: on the boundaries of the 1024-order block inverses the solves use
+    b = [int(round(npad * (1.0 - (1.0 - i / parts) ** (1.0 / 3.0)) / q)) * q for i in range(parts + 1)]
     b[0], b[-1] = 0, npad
     for i in range(1, parts + 1):
         b[i] = max(b[i], b[i - 1])

@@ -13,7 +13,7 @@ def ctx():
     return dev.context()
 
 
-@pytest.mark.parametrize("n,d,parts", [(1500, 4, 1), (1500, 4, 3), (2100, 10, 5), (700, 2, 8), (130, 3, 2)])
+@pytest.mark.parametrize("n,d,parts", [(1500, 4, 1), (1500, 4, 3), (2100, 10, 5), (700, 2, 8), (130, 3, 2), (8300, 3, 3), (9216, 2, 4)])
 def test_lml_grad_slabs_sum_to_the_full_gradient(ctx, n, d, parts):
     """Slabs of a partition of the rows add up to gpx_lml_grad (which forms the whole inverse): 1e-10, any partition; the
     work-balanced boundaries are multiples of 128 that cover the padded order (gp.py:444-466)."""
@@ -45,7 +45,8 @@ def test_slab_bounds_balance_the_work():
     n, parts = 65536, 8
     b = dev.lml_grad_slab_bounds(n, parts)
     work = [((n - r0) ** 3 - (n - r1) ** 3) / 3.0 for r0, r1 in zip(b[:-1], b[1:])]
-    assert max(work) / (sum(work) / parts) < 1.05      # within 5 % of the mean at C5's size
+    assert max(work) / (sum(work) / parts) < 1.10      # within 10 % of the mean at C5's size (bounds sit on 1024-row
+    #                                                     block-inverse boundaries there)
 
 
 @pytest.mark.parametrize("m,nsel,slices", [(300, 8, 1), (300, 8, 3), (517, 6, 4), (64, 5, 7)])
