@@ -28,6 +28,7 @@ import time
 import numpy as np
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+os.environ.setdefault("NCCL_DEBUG", "WARN")                 # RCCL says why when a collective fails (stderr; stdout stays one JSON line)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -448,7 +449,12 @@ def main():
     dt_instr = reduce_max(time.perf_counter() - t0)
     prof = ctx.profile_get()
     ctx.profile(False)
-    assert out2 == out, "the instrumented repeat must reproduce the timed steps bit for bit"
+    if world == 1:
+        assert out2 == out, "the instrumented repeat must reproduce the timed steps bit for bit"
+    else:
+        # several ranks: the sums inside ncclReduce / ncclAllReduce are not promised to associate the same way twice; a
+        # mismatch beyond round-off is still an error, but it must not kill a timing run over the last bit
+        assert all(abs(a - b) <= 1e-12 * abs(b) for a, b in zip(out2, out)), (out2, out)
     phases = {k: v["ms"] / args.steps for k, v in prof.items() if v["launches"]}
     watchdog.cancel()
 
