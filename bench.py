@@ -439,6 +439,8 @@ def main():
     # ... they are recorded in an identical repeat right behind it (same steps, same inputs, same results): per-class spans,
     # launch counts and algorithmic flops for the roofline object and the rocprofv3 cross-check
     progress["at"] = "the instrumented repeat"
+    if world > 1 or os.environ.get("GPX_FORCE_DIST") == "1":
+        runner.force_interpret = True     # profiler events cannot live inside a captured graph: issue this repeat row by row
     ctx.profile(True)
     ctx.profile_reset()
     t0 = time.perf_counter()

@@ -103,6 +103,9 @@ _SIGS = {
     "gpx_dist2_pack_rows": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64]),
     "gpx_dist2_pack_diag": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64]),
     "gpx_program_run": (C.c_int, [c_vp, c_ip, c_i64, c_ip, c_i64, c_dp]),
+    "gpx_program_capture": (C.c_int, [c_vp, c_ip, c_i64, c_ip, c_i64, C.POINTER(c_vp)]),
+    "gpx_graph_launch": (C.c_int, [c_vp, c_vp, c_dp, c_ip]),
+    "gpx_graph_free": (C.c_int, [c_vp, c_vp]),
     "gpx_dist2_unpack_rows": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64]),
     "gpx_dist2_unpack_diag": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64]),
     "gpx_dist2_trsv_diag": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, C.c_int]),

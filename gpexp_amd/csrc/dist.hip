@@ -13,6 +13,8 @@
 //   updates the block columns it owns.
 #include "gpx_internal.h"
 #include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 // ---- minimal RCCL surface (ABI-compatible with rccl.h / nccl.h) -------------------------------------------
@@ -98,24 +100,33 @@ static int rccl_load() {
 
 namespace {
 
-// dst[r][c] = src[r][c] for an (rows x cols) block with independent leading dimensions
+// dst[r][c] = src[r][c] for an (rows x cols) block with independent leading dimensions.  A workgroup moves COPY_RPB rows of a
+// 512-column stripe (all loads first): with one 4 KB row per workgroup the panel copies of the distributed loop were
+// dispatch-bound at ~190 GB/s (profiles/r03_dist_replay_trace_2x4.txt, round-3 first trace: 20 ms of copies per step).
+constexpr int COPY_RPB = 8;
 __global__ __launch_bounds__(256) void copy2d_kernel(const double* __restrict__ src, int64_t lds_,
                                                      double* __restrict__ dst, int64_t ldd, int64_t rows,
                                                      int64_t cols) {
   const int64_t c2 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
-  const int64_t r = blockIdx.y;
-  if (c2 >= cols || r >= rows) return;
-  *reinterpret_cast<double2*>(dst + r * ldd + c2) = *reinterpret_cast<const double2*>(src + r * lds_ + c2);
+  const int64_t r0 = (int64_t)blockIdx.y * COPY_RPB;
+  if (c2 >= cols) return;
+  double2 v[COPY_RPB];
+#pragma unroll
+  for (int i = 0; i < COPY_RPB; ++i)
+    if (r0 + i < rows) v[i] = *reinterpret_cast<const double2*>(src + (r0 + i) * lds_ + c2);
+#pragma unroll
+  for (int i = 0; i < COPY_RPB; ++i)
+    if (r0 + i < rows) *reinterpret_cast<double2*>(dst + (r0 + i) * ldd + c2) = v[i];
 }
 
 }  // namespace
 
 int gpx_copy2d(gpx_ctx* ctx, const double* src, int64_t lds_, double* dst, int64_t ldd, int64_t rows, int64_t cols) {
   if (rows <= 0 || cols <= 0) return 0;
-  // grid.y is limited to 65535 rows per launch
-  for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
-    const int64_t rr = rows - r0 < 65535 ? rows - r0 : 65535;
-    dim3 grid((unsigned)((cols / 2 + 255) / 256), (unsigned)rr);
+  // grid.y is limited to 65535 row groups per launch
+  for (int64_t r0 = 0; r0 < rows; r0 += 65535 * (int64_t)COPY_RPB) {
+    const int64_t rr = rows - r0 < 65535 * (int64_t)COPY_RPB ? rows - r0 : 65535 * (int64_t)COPY_RPB;
+    dim3 grid((unsigned)((cols / 2 + 255) / 256), (unsigned)((rr + COPY_RPB - 1) / COPY_RPB));
     hipLaunchKernelGGL(copy2d_kernel, grid, dim3(256), 0, ctx->stream, src + r0 * lds_, lds_, dst + r0 * ldd, ldd, rr,
                        cols);
   }
@@ -605,10 +616,16 @@ __global__ __launch_bounds__(256) void copy_cyclic_rows_kernel(const double* __r
                                                                double* __restrict__ dst, int64_t ldd, int64_t rows,
                                                                int64_t cols, int64_t nb, int64_t first, int64_t stride) {
   const int64_t c2 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
-  const int64_t r = blockIdx.y;
-  if (c2 >= cols || r >= rows) return;
-  const int64_t gr = ((r / nb) * stride + first) * nb + r % nb;
-  *reinterpret_cast<double2*>(dst + gr * ldd + c2) = *reinterpret_cast<const double2*>(src + r * lds_ + c2);
+  const int64_t r0 = (int64_t)blockIdx.y * COPY_RPB;   // COPY_RPB divides nb: the rows of a group share their block
+  if (c2 >= cols || r0 >= rows) return;
+  const int64_t g0 = ((r0 / nb) * stride + first) * nb + r0 % nb;
+  double2 v[COPY_RPB];
+#pragma unroll
+  for (int i = 0; i < COPY_RPB; ++i)
+    if (r0 + i < rows) v[i] = *reinterpret_cast<const double2*>(src + (r0 + i) * lds_ + c2);
+#pragma unroll
+  for (int i = 0; i < COPY_RPB; ++i)
+    if (r0 + i < rows) *reinterpret_cast<double2*>(dst + (g0 + i) * ldd + c2) = v[i];
 }
 
 // src[((r / nb) * stride + first) * nb + r % nb][c] -> dst[r][c]: the inverse of copy_cyclic_rows_kernel (rows of a
@@ -617,10 +634,16 @@ __global__ __launch_bounds__(256) void gather_cyclic_rows_kernel(const double* _
                                                                  double* __restrict__ dst, int64_t ldd, int64_t rows,
                                                                  int64_t cols, int64_t nb, int64_t first, int64_t stride) {
   const int64_t c2 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
-  const int64_t r = blockIdx.y;
-  if (c2 >= cols || r >= rows) return;
-  const int64_t gr = ((r / nb) * stride + first) * nb + r % nb;
-  *reinterpret_cast<double2*>(dst + r * ldd + c2) = *reinterpret_cast<const double2*>(src + gr * lds_ + c2);
+  const int64_t r0 = (int64_t)blockIdx.y * COPY_RPB;
+  if (c2 >= cols || r0 >= rows) return;
+  const int64_t g0 = ((r0 / nb) * stride + first) * nb + r0 % nb;
+  double2 v[COPY_RPB];
+#pragma unroll
+  for (int i = 0; i < COPY_RPB; ++i)
+    if (r0 + i < rows) v[i] = *reinterpret_cast<const double2*>(src + (g0 + i) * lds_ + c2);
+#pragma unroll
+  for (int i = 0; i < COPY_RPB; ++i)
+    if (r0 + i < rows) *reinterpret_cast<double2*>(dst + (r0 + i) * ldd + c2) = v[i];
 }
 
 // acc[c] -= sum_r A[r][c] x[r] over an m x w block (row stride ld), m a multiple of 4: a workgroup owns 128 columns (64
@@ -860,7 +883,7 @@ int gpx_dist2_pack_rows(gpx_ctx* ctx, const gpx_mat* L, int64_t first_block, int
   for (int64_t r0 = 0; r0 < m; r0 += 65535 / nb * nb) {
     int64_t rr = m - r0;
     if (rr > 65535 / nb * nb) rr = 65535 / nb * nb;
-    dim3 grid((unsigned)((w / 2 + 255) / 256), (unsigned)rr);
+    dim3 grid((unsigned)((w / 2 + 255) / 256), (unsigned)((rr + COPY_RPB - 1) / COPY_RPB));
     hipLaunchKernelGGL(gather_cyclic_rows_kernel, grid, dim3(256), 0, ctx->stream, L->p + col0, L->ld, G->p + roff + r0 * gld, gld,
                        rr, w, nb, first_block + (r0 / nb) * stride, stride);
   }
@@ -890,7 +913,7 @@ int gpx_dist2_unpack_rows(gpx_ctx* ctx, const gpx_mat* G, int64_t roff, int64_t 
   for (int64_t r0 = 0; r0 < m; r0 += 65535 / nb * nb) {
     int64_t rr = m - r0;
     if (rr > 65535 / nb * nb) rr = 65535 / nb * nb;
-    dim3 grid((unsigned)((w / 2 + 255) / 256), (unsigned)rr);
+    dim3 grid((unsigned)((w / 2 + 255) / 256), (unsigned)((rr + COPY_RPB - 1) / COPY_RPB));
     hipLaunchKernelGGL(copy_cyclic_rows_kernel, grid, dim3(256), 0, ctx->stream, G->p + roff + r0 * gld, gld,
                        L->p + col0, L->ld, rr, w, nb, first_block + (r0 / nb) * stride, stride);
   }
@@ -987,13 +1010,27 @@ int gpx_dist_finish(gpx_ctx* ctx, gpx_mat* K) {
 // =====================================================================================================================
 #include <chrono>
 
+static bool g_in_capture = false;   // debug aid of gpx_program_capture (GPX_PROGRAM_SKIP applies to captures only)
+
 extern "C" {
 
 int gpx_program_run(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const int64_t* extra, int64_t nextra, double* host_ms) {
   GPX_ARG(ctx && (ops || nops == 0) && nops >= 0 && nextra >= 0, "bad program");
   const auto t0 = std::chrono::steady_clock::now();
+  static const bool trace = getenv("GPX_PROGRAM_TRACE") != nullptr;  // debug: name every row on stderr before it is issued
   for (int64_t i = 0; i < nops; ++i) {
     const int64_t* o = ops + 16 * i;
+    if (trace) {
+      fprintf(stderr, "gpx_program_run: row %lld op %lld\n", (long long)i, (long long)o[0]);
+      fflush(stderr);
+      static const char* skip = getenv("GPX_PROGRAM_SKIP");   // debug: comma-separated opcodes NOT to execute (bisecting a capture)
+      if (skip && g_in_capture) {
+        char key[16];
+        snprintf(key, sizeof key, ",%lld,", (long long)o[0]);
+        std::string sk = std::string(",") + skip + ",";
+        if (sk.find(key) != std::string::npos) continue;
+      }
+    }
     gpx_mat* h0 = reinterpret_cast<gpx_mat*>((uintptr_t)o[1]);
     gpx_mat* h1 = reinterpret_cast<gpx_mat*>((uintptr_t)o[2]);
     gpx_mat* h2 = reinterpret_cast<gpx_mat*>((uintptr_t)o[3]);
@@ -1064,6 +1101,82 @@ int gpx_program_run(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const int64_
     if (r != 0) return r;
   }
   if (host_ms) *host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return 0;
+}
+
+
+// ---- the recorded program as a hipGraph ------------------------------------------------------------------------------------------
+// gpx_program_run still pays one HIP launch per kernel (~3 us per row: 6-10 ms per C4 factorisation).  A program whose streams
+// all fork from and join back into the main stream (the panel loop emits the fork / join rows itself) can instead be CAPTURED
+// once -- the rows are issued under hipStreamBeginCapture, every kernel, copy and event edge becomes a graph node -- and the
+// whole step is then ONE hipGraphLaunch.  Nothing that allocates or synchronises may run during capture: capture a program only
+// after it has run once in the ordinary way (scratch buffers, leaf-inverse storage and kernel attributes exist by then).
+// RCCL collectives inside a capture are NOT validated on this project's hardware (RCCL never ran with two ranks here): the
+// Python side captures only when no rank of a real communicator would have to (world 1 / replay), unless told otherwise.
+struct gpx_graph {
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+  int64_t nodes;
+};
+
+int gpx_graph_free(gpx_ctx* ctx, gpx_graph* g) {
+  if (!g) return 0;
+  (void)ctx;
+  (void)hipDeviceSynchronize();
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
+  delete g;
+  return 0;
+}
+
+int gpx_program_capture(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const int64_t* extra, int64_t nextra, gpx_graph** out) {
+  GPX_ARG(ctx && out && (ops || nops == 0), "bad program");
+  GPX_ARG(ctx->prof_on == 0, "profiling events cannot be captured: disable the profile first");
+  GPX_HIP(hipDeviceSynchronize());
+  hipStream_t origin = ctx->streams[0];
+  ctx->stream = origin;
+  GPX_HIP(hipStreamBeginCapture(origin, hipStreamCaptureModeRelaxed));
+  g_in_capture = true;
+  int r = gpx_program_run(ctx, ops, nops, extra, nextra, nullptr);
+  g_in_capture = false;
+  hipGraph_t graph = nullptr;
+  static const bool trace = getenv("GPX_PROGRAM_TRACE") != nullptr;
+  if (trace) { fprintf(stderr, "capture: rows issued (rc %d), ending capture\n", r); fflush(stderr); }
+  hipError_t e = hipStreamEndCapture(origin, &graph);
+  if (trace) { fprintf(stderr, "capture: hipStreamEndCapture -> %s\n", hipGetErrorString(e)); fflush(stderr); }
+  ctx->stream = origin;
+  if (r != 0 || e != hipSuccess || !graph) {
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    if (r == 0) gpx_set_error("program capture: hipStreamEndCapture -> %s (do all streams join the main stream?)", hipGetErrorString(e));
+    return r != 0 ? r : -2;
+  }
+  gpx_graph* g = new gpx_graph();
+  g->graph = graph;
+  g->exec = nullptr;
+  size_t n = 0;
+  (void)hipGraphGetNodes(graph, nullptr, &n);
+  g->nodes = (int64_t)n;
+  if (trace) { fprintf(stderr, "capture: %zu nodes, instantiating\n", n); fflush(stderr); }
+  e = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
+  if (trace) { fprintf(stderr, "capture: hipGraphInstantiate -> %s\n", hipGetErrorString(e)); fflush(stderr); }
+  if (e != hipSuccess) {
+    gpx_set_error("program capture: hipGraphInstantiate -> %s", hipGetErrorString(e));
+    gpx_graph_free(ctx, g);
+    return -2;
+  }
+  *out = g;
+  return 0;
+}
+
+// one step = one launch; *host_ms (nullable) = host time of the launch call; *nodes (nullable) = nodes of the graph
+int gpx_graph_launch(gpx_ctx* ctx, gpx_graph* g, double* host_ms, int64_t* nodes) {
+  GPX_ARG(ctx && g && g->exec, "no graph");
+  const auto t0 = std::chrono::steady_clock::now();
+  GPX_HIP(hipGraphLaunch(g->exec, ctx->streams[0]));
+  if (host_ms) *host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (nodes) *nodes = g->nodes;
+  ctx->stream = ctx->streams[0];
   return 0;
 }
 

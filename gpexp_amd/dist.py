@@ -121,16 +121,45 @@ class Program:
     def __len__(self):
         return len(self.rows)
 
-    def run(self, ctx):
+    def _arrays(self):
         if self._frozen is None:
             self._frozen = (np.ascontiguousarray(np.array(self.rows, dtype=np.int64).reshape(-1, 16)),
                             np.ascontiguousarray(np.array(self.extra + [0], dtype=np.int64)))
-        ops, extra = self._frozen
+        return self._frozen
+
+    def run(self, ctx):
+        ops, extra = self._arrays()
         ms = C.c_double(0.0)
         check(ctx.lib.gpx_program_run(ctx.h, ops.ctypes.data_as(C.POINTER(c_i64)), ops.shape[0],
                                       extra.ctypes.data_as(C.POINTER(c_i64)), extra.size, C.byref(ms)))
         self.host_ms = ms.value
         return ms.value
+
+    # ---- the program as a hipGraph: one launch per step (gpx_program_capture; only after one ordinary run) ----
+    graph = None
+    graph_nodes = 0
+
+    def capture(self, ctx):
+        ops, extra = self._arrays()
+        h = C.c_void_p()
+        check(ctx.lib.gpx_program_capture(ctx.h, ops.ctypes.data_as(C.POINTER(c_i64)), ops.shape[0],
+                                          extra.ctypes.data_as(C.POINTER(c_i64)), extra.size, C.byref(h)))
+        self.graph, self._ctx = h, ctx
+
+    def launch(self, ctx):
+        ms = C.c_double(0.0)
+        n = c_i64(0)
+        check(ctx.lib.gpx_graph_launch(ctx.h, self.graph, C.byref(ms), C.byref(n)))
+        self.host_ms, self.graph_nodes = ms.value, n.value
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self.graph is not None and self._ctx.h:
+                self._ctx.lib.gpx_graph_free(self._ctx.h, self.graph)
+            self.graph = None
+        except Exception:
+            pass
 
 
 class Emitter:
@@ -628,14 +657,26 @@ class DeviceOps2D(Emitter, DeviceOps):
         check(self.ctx.lib.gpx_dist2_kfill(self.ctx.h, *spec.args(), X.h, dptr(nug), nlen, A.h, geo.nb, geo.Pr, geo.Pc,
                                            geo.pr, geo.pc))
 
-    # stream / event plumbing
+    # stream / event plumbing.  A wait on an event that was recorded on the SAME stream is dropped: the stream is in order, so
+    # it orders nothing -- and inside a stream capture it crashes hipStreamEndCapture on ROCm 7.2 when the stream is not the
+    # capture's origin (scripts/_graph_bisect.py: PANEL records E_DIAGREADY after the early update and waits for it one step
+    # later as the diagonal owner).
+    _cur_stream = MAIN
+    _ev_stream = None
+
     def stream(self, which):
+        self._cur_stream = int(which)
         self._emit(OP["STREAM"], (), (which,))
 
     def record(self, ev):
+        if self._ev_stream is None:
+            self._ev_stream = {}
+        self._ev_stream[int(ev)] = self._cur_stream
         self._emit(OP["RECORD"], (), (ev,))
 
     def wait(self, ev):
+        if self._ev_stream is not None and self._ev_stream.get(int(ev)) == self._cur_stream:
+            return
         self._emit(OP["WAIT"], (), (ev,))
 
     def begin(self):
@@ -702,6 +743,10 @@ class DeviceOps2D(Emitter, DeviceOps):
 
 def _ev2(kind, k):
     return 13 * (k + 1) + kind
+
+
+EV_FORK, EV_PRE, EV_JOIN0 = 1, 2, 3            # event ids below 13 are free (ids of step k start at 13 (k + 1))
+ALL_SIDE_STREAMS = (PANEL, COMM, BACK, EVAL, BULK)
 
 
 def default_agg():
@@ -818,6 +863,14 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None):
     bulk_recorded = set()
     pending = []                 # chunks of the last group's bulk update still to be issued (chunked mode)
     last_chunk_step = {}         # group end -> step at which its last chunk was issued
+    ops.stream(MAIN)
+    # FORK: every other stream starts behind this point of MAIN (behind the assembly queued there).  Costs nothing when the
+    # rows are issued one by one, and is what lets the whole step be captured as one hipGraph (every stream of a capture must
+    # branch off the capturing stream and rejoin it: the JOIN rows at the end).
+    ops.record(EV_FORK)
+    for s_ in ALL_SIDE_STREAMS:
+        ops.stream(s_)
+        ops.wait(EV_FORK)
     ops.stream(MAIN)
     ops.begin()
     ops.record(_ev2(E_DIAGREADY, 0))  # the assembly was queued on MAIN
@@ -968,7 +1021,12 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None):
                 update_cols(Ja, Jb, pks)
                 last_chunk_step[pge] = k
         ops.record(_ev2(E_UPD, k))
+    for i_, s_ in enumerate(ALL_SIDE_STREAMS):                           # JOIN
+        ops.stream(s_)
+        ops.record(EV_JOIN0 + i_)
     ops.stream(MAIN)
+    for i_ in range(len(ALL_SIDE_STREAMS)):
+        ops.wait(EV_JOIN0 + i_)
 
 
 def dist2_potrs(ops, comm, geo, A, yv, acc_r, acc_c, out):
@@ -1148,7 +1206,16 @@ class DistFitIvar2D:
         self.programs = None
         self.recordable = (type(self.ops) is DeviceOps2D and getattr(comm, "recordable", False)
                            and os.environ.get("GPX_DIST_RECORD", "1") == "1")
+        # hipGraph replay of the recorded programs: EXPERIMENTAL, off unless GPX_DIST_GRAPH=1.  The programs fork every stream
+        # off MAIN and join it again, so they are capturable in principle (gpx_program_capture), and small ones are (four
+        # panels: 68 nodes, one hipGraphLaunch per step) -- but on ROCm 7.2 hipStreamEndCapture SEGFAULTS on the full loop's
+        # cross-stream event pattern: first on a side stream waiting for an event recorded on that same stream (now dropped
+        # by DeviceOps2D.wait), then on the panel stream's buffer-reuse waits from the ninth panel on
+        # (scripts/graph_capture_bisect.py cuts the recorded program to the first failing row; scripts/graph_check.hip shows the
+        # elementary patterns work).  RCCL under capture is unvalidated on top of that.  Row-by-row replay stays the product path.
+        self.use_graph = self.recordable and os.environ.get("GPX_DIST_GRAPH", "0") == "1"
         self.host_ms = {}
+        self._runs = {}
 
     # the three asynchronous phases of a step, written once, either executed directly or recorded
     def _hook(self):
@@ -1196,12 +1263,21 @@ class DistFitIvar2D:
         self.programs = progs
 
     def _run(self, name, fn):
-        if self.recordable:
-            if self.programs is None:
-                self._record()
-            self.host_ms[name] = self.programs[name].run(self.ctx)
-        else:
+        if not self.recordable:
             fn()
+            return
+        if self.programs is None:
+            self._record()
+        prog = self.programs[name]
+        n = self._runs.get(name, 0)
+        self._runs[name] = n + 1
+        if self.use_graph and n >= 1 and not getattr(self, "force_interpret", False):   # (profiled steps need the launches)
+            if prog.graph is None:      # second use: scratch buffers and kernel attributes exist, nothing allocates any more
+                self.ctx.sync()
+                prog.capture(self.ctx)
+            self.host_ms[name] = prog.launch(self.ctx)
+        else:
+            self.host_ms[name] = prog.run(self.ctx)
 
     def fit(self):
         """Distributed assembly + factorisation (+ the streamed evaluation solve when enabled); raises NotPositiveDefinite."""
@@ -1211,7 +1287,9 @@ class DistFitIvar2D:
         if self.B is not None:
             ops.stream(BACK)
             ops.cross_fill(self.spec, self.X, self.Zloc, self.B)   # independent of the factorisation
+            ops.record(EV_PRE)          # the program forks every stream off MAIN: MAIN carries the cross fill's completion
             ops.stream(MAIN)
+            ops.wait(EV_PRE)
         self._run("factor", self._enqueue_factor)
         info = dist2_potrf_finish(ops, comm, self.L)
         if info:

@@ -329,6 +329,13 @@ enum {
   GPX_OP_VEC_OP, GPX_OP_SPIN, GPX_OP_COPY, GPX_OP_IVAR_GROUP
 };
 int gpx_program_run(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const int64_t* extra, int64_t nextra, double* host_ms);
+/* The same program as a hipGraph: captured once (after it has run once the ordinary way; every stream it uses must fork from
+ * and join back into stream 0 -- the panel loop emits those rows), then one hipGraphLaunch per step.  Collectives inside a
+ * capture are not validated on this project's hardware: see gpexp_amd/dist.py for when the host side captures. */
+typedef struct gpx_graph gpx_graph;
+int gpx_program_capture(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const int64_t* extra, int64_t nextra, gpx_graph** out);
+int gpx_graph_launch(gpx_ctx* ctx, gpx_graph* g, double* host_ms, int64_t* nodes);
+int gpx_graph_free(gpx_ctx* ctx, gpx_graph* g);
 
 /* out[j] = sum over the first `rows` rows of B[i][j]^2 (host out[B->cols]): variance reduction of a solved cross matrix */
 int gpx_col_sumsq(gpx_ctx* ctx, const gpx_mat* B, int64_t rows, double* out);

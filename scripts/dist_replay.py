@@ -88,18 +88,23 @@ def main():
                 ctx.sync()
                 ts.append(1e3 * (time.perf_counter() - t0))
                 host.append(run.host_ms.get("factor", 0.0))
-            # per-class kernel time of one more, instrumented, step
+            # per-class kernel time of one more, instrumented, step (row by row: profiler events cannot live inside a graph)
+            run.force_interpret = True
             ctx.profile(True)
             ctx.profile_reset()
             run.step()
             ctx.sync()
             prof = ctx.profile_get()
             ctx.profile(False)
+            host_rows = run.host_ms.get("factor", 0.0)
+            run.force_interpret = False
             geo = run.geo
             res = dict(grid=gs, rank=rank, pr=geo.pr, pc=geo.pc, N=args.n, M=args.m, nb=args.nb, agg=args.agg, steps_k=geo.nblk,
                        streamed_ivar=streamed, ms_per_step=float(np.median(ts)), ms_all=ts,
                        host_issue_ms_per_fit=float(np.median(host)), host_issue_us_per_panel_step=1e3 * float(np.median(host)) / geo.nblk,
                        program_rows=len(run.programs["factor"]), rows_per_panel_step=len(run.programs["factor"]) / geo.nblk,
+                       issue_mode="hipGraph (one launch per step)" if run.use_graph else "rows (one HIP call per row)",
+                       graph_nodes=run.programs["factor"].graph_nodes, host_issue_ms_row_by_row=host_rows,
                        bytes_received_per_fit=comm.bytes_in,
                        class_ms={k: round(v["ms"], 3) for k, v in prof.items() if v["launches"]},
                        class_launches={k: v["launches"] for k, v in prof.items() if v["launches"]},
