@@ -74,7 +74,23 @@ int run3() {
   printf("ok, result %.0f (expect 522)\n", h);
   return 0;
 }
+// the pattern that makes hipStreamEndCapture SEGFAULT on ROCm 7.2 (argument 98; run it alone): a forked, otherwise empty
+// side stream waits for an event it has just recorded ITSELF
+int run4() {
+  hipStream_t s0, s1; CK(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+  hipEvent_t f, e, j; CK(hipEventCreateWithFlags(&f, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  CK(hipEventCreateWithFlags(&j, hipEventDisableTiming));
+  printf("side stream waits for its own event inside a capture: "); fflush(stdout);
+  CK(hipStreamBeginCapture(s0, hipStreamCaptureModeRelaxed));
+  CK(hipEventRecord(f, s0)); CK(hipStreamWaitEvent(s1, f, 0));
+  CK(hipEventRecord(e, s1)); CK(hipStreamWaitEvent(s1, e, 0));
+  CK(hipEventRecord(j, s1)); CK(hipStreamWaitEvent(s0, j, 0));
+  hipGraph_t g; CK(hipStreamEndCapture(s0, &g));
+  printf("survived\n");
+  return 0;
+}
 int main(int argc, char** argv) {
+  if (argc > 1 && atoi(argv[1]) == 98) return run4();
   if (argc > 1 && atoi(argv[1]) == 99) return run3();
   if (argc > 1) { int v = atoi(argv[1]); return run2(v & 1, (v >> 1) & 1, (v >> 2) & 1); }
   for (int m = 0; m < 2; ++m) for (int c = 0; c < 2; ++c) { fflush(stdout); if (run(m, c)) return 1; }
