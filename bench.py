@@ -359,7 +359,22 @@ def main():
         # runner class, checked on every rank against the single-GPU path before anything is timed.  A mismatch names the
         # first block of the replicated factor that differs; the bench then stops instead of timing garbage.
         if world > 1 or os.environ.get("GPX_BENCH_PREFLIGHT") == "1":
+            # its own, SHORT watchdog: a collective that never completes at first contact should cost minutes, not the timed
+            # region's whole allowance, and say that it was the preflight
+            import threading
+            pf_limit = float(os.environ.get("GPX_BENCH_PREFLIGHT_WATCHDOG_S", "300"))
+
+            def _pf_expired():
+                print("bench.py: watchdog: rank %d of %d: the PREFLIGHT step (N = 2048, %s layout) did not finish within %.0f s -- "
+                      "a collective of the distributed path never completed; aborting (try GPX_DIST_LAYOUT=1d)"
+                      % (rank, world, "2-D" if want_2d else "1-D", pf_limit), file=sys.stderr, flush=True)
+                os._exit(124)
+
+            pf_timer = threading.Timer(pf_limit, _pf_expired)
+            pf_timer.daemon = True
+            pf_timer.start()
             preflight = dist_preflight(ctx, comm, dist, dev, spec, d, nb=min(nb, 256), two_d=want_2d)
+            pf_timer.cancel()
             print("bench.py: preflight rank %d: %s" % (rank, json.dumps(preflight)), file=sys.stderr, flush=True)
             bad = comm.allgather(np.array([0.0 if preflight["ok"] else 1.0]))[:, 0]
             if bad.max() > 0:
