@@ -179,11 +179,13 @@ def bench_c5(args, ctx, dev, world, rank, stdout_fd):
             return out
         barrier, reduce_max = comm.barrier, comm.max_float
     else:
-        layout = "1 GPU (gradient traces over 8 row slabs of K^-1)"
+        nslab = int(os.environ.get("GPX_C5_SLABS", "16"))   # measured 1 / 2 / 4 / 8 / 16 / 32 slabs: 7.8 / 5.7 / 4.4 / 3.7 / 3.5 / 3.5 s (fewer
+        #                                                      flops with more slabs -- 2 N^3 down to 2 N^3 / 3 -- thinner products)
+        layout = "1 GPU (gradient traces over %d row slabs of K^-1)" % nslab
         X = dev.points(ctx, Xh)
         Cp = dev.points(ctx, Ch)
         K = dev.DeviceMatrix.zeros(ctx, N, N)
-        bounds = dev.lml_grad_slab_bounds(N, int(os.environ.get("GPX_C5_SLABS", "8")))
+        bounds = dev.lml_grad_slab_bounds(N, nslab)
 
         def step():
             t0 = time.perf_counter()
