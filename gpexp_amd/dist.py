@@ -812,9 +812,14 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None):
     #           following steps -- one GEMM stream, the big launches never share the chip with each other.  Expected to win
     #           where the GPU is the bound (1-2 ranks); measured it does not (the thin near updates -- 2 to 4 rounds of tiles,
     #           42-57 TF/s -- then run alone instead of underneath a bulk launch).
-    #   bulk    the same on the CU-masked stream (round 2's reserved CUs; the chain no longer needs them); main: whole, on MAIN.
-    mode = os.environ.get("GPX_DIST_BULK", "eval")   # measured (replay, C4): eval 213 / 119 / 192 / 103 ms at 1 / 2 / 4 / 8 ranks,
-                                                     # chunks 225 / 124 / 191 / 103 (profiles/r03_dist_replay.txt)
+    #   bulk    whole, on the second CU-masked stream (its own queue; default where the evaluation is streamed underneath the
+    #           factorisation -- `on_stored` given, 4 ranks and more: there EVAL already carries the per-group IVAR solves and the
+    #           bulk update would queue behind them);
+    #   main    whole, on MAIN.
+    # Measured (replay, C4 fit + IVAR, ms at 1 / 2 / 4 / 8 ranks, MAIN at normal priority): eval 202 / 114 / 192 / 103,
+    # bulk 244 / 134 / 185 / 100, chunks 225 / 124 / 191 / 103; fit alone at 4 / 8 ranks: eval 74 / 46, bulk 87 / 51 (the masked
+    # stream has 224 of the 256 CUs) -- profiles/r03_dist_replay_*.json.
+    mode = os.environ.get("GPX_DIST_BULK", "bulk" if on_stored is not None else "eval")
     bulk_stream = {"bulk": BULK, "eval": EVAL, "main": MAIN, "chunks": MAIN}[mode]
     chunked = mode == "chunks"
     at_step = getattr(comm, "at_step", None)

@@ -10,7 +10,8 @@ measure -- the rank's GPU time per step, the per-class kernel time, and the HOST
 it cannot: xGMI transfer time and the waiting for peers.  The variance sum of the rank's evaluation slice is checked against
 the single-GPU path, so the replayed rank demonstrably computed its share of the factor.
 
-Prints one JSON object per (grid, rank) and a table; scripts/dist_time_model.py reads the JSON (profiles/r03_dist_replay.json).
+Prints one JSON object per (grid, rank) and a table; scripts/dist_time_model.py reads the JSON
+(profiles/r03_dist_replay_fit_only.json: `--no-stream --m 1024`; profiles/r03_dist_replay_fit_ivar.json: defaults).
 """
 import argparse
 import json
@@ -36,6 +37,7 @@ def main():
     ap.add_argument("--nb", type=int, default=512)
     ap.add_argument("--agg", type=int, default=dist.default_agg())
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--no-stream", action="store_true", help="factorisation alone (no evaluation streamed underneath, as the C5 fit)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
 
@@ -64,7 +66,7 @@ def main():
         ranks = sorted({(world - 1 if r == "last" else int(r)) for r in args.ranks.split(",") if r == "last" or int(r) < world})
         for rank in ranks:
             comm = dist.ReplayComm(ctx, world, rank, Lref)
-            streamed = world >= 4
+            streamed = world >= 4 and not args.no_stream
             run = dist.DistFitIvar2D(ctx, comm, spec, Xh, yh, Zh, noise, nb=args.nb, grid=(Pr, Pc), agg=args.agg,
                                      streamed=streamed, fit_only=True)
             _, part = run.step()          # records the program, first run
