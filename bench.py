@@ -248,8 +248,9 @@ def bench_c5(args, ctx, dev, world, rank, stdout_fd):
 
 def dist_preflight(ctx, comm, dist, dev, spec, d, nb=256, two_d=True, n=2048, m=512):
     """One small distributed step (N = 2048, M = 512, the bench's kernel) against the single-GPU path on the same inputs:
-    log-likelihood and IVAR to 1e-10, and -- 2-D layout -- the replicated factor block by block.  Returns a dict with
-    `ok`; on a mismatch `first_bad_block` = (I, J) of the first nb-block of L that differs by more than 1e-10."""
+    log-likelihood and IVAR to 1e-10, and the factor block by block (2-D layout: every rank checks the blocks of the
+    distributed factor it owns).  Returns a dict with `ok`; on a mismatch `first_bad_block` = (I, J) of the first nb-block of L
+    that differs by more than 1e-10."""
     Xh, yh, Zh, noise = workload(n, d, m, seed=12345)
     t0 = time.perf_counter()
     if two_d:
@@ -266,16 +267,40 @@ def dist_preflight(ctx, comm, dist, dev, spec, d, nb=256, two_d=True, n=2048, m=
            "rel_err_loglike": abs(ll - ll1) / abs(ll1) if (two_d or comm.rank == 0) else 0.0,
            "rel_err_ivar": abs(iv - iv1) / abs(iv1)}
     ok = out["rel_err_loglike"] <= 1e-10 and out["rel_err_ivar"] <= 1e-10
-    Ld = (run.L if two_d else run.K).to_host(tri=1)
     L1 = K1.to_host(tri=1)
     scale = float(np.max(np.abs(L1)))
-    diff = np.abs(Ld - L1)
-    out["max_err_L"] = float(diff.max() / scale)
-    if not (diff.max() <= 1e-10 * scale):
-        ok = False
-        bad = np.argwhere(~(diff <= 1e-10 * scale))
-        i, j = min(((int(a) // nb, int(b) // nb) for a, b in bad), key=lambda t: (t[1], t[0]))
-        out["first_bad_block"] = [i, j]
+    if two_d:
+        # this rank's blocks of the DISTRIBUTED factor (the streamed evaluation keeps no replica): block (I, J) of L at local
+        # block (I // Pr, J // Pc)
+        geo, Al = run.geo, run.A.to_host()
+        worst, first_bad = 0.0, None
+        for J in range(geo.pc, geo.nblk, geo.Pc):
+            for I in range(geo.pr, geo.nblk, geo.Pr):
+                if I < J:
+                    continue
+                h, wj = min(geo.height(I), n - I * nb), min(geo.height(J), n - J * nb)
+                if h <= 0 or wj <= 0:
+                    continue
+                loc = Al[(I // geo.Pr) * nb:(I // geo.Pr) * nb + h, (J // geo.Pc) * nb:(J // geo.Pc) * nb + wj]
+                ref = L1[I * nb:I * nb + h, J * nb:J * nb + wj]
+                if I == J:
+                    loc = np.tril(loc)
+                e = float(np.max(np.abs(loc - ref)))
+                worst = max(worst, e) if e == e else float("inf")
+                if not (e <= 1e-10 * scale) and first_bad is None:
+                    first_bad = [I, J]
+        out["max_err_L"] = worst / scale
+        if first_bad is not None:
+            ok = False
+            out["first_bad_block"] = first_bad
+    else:
+        diff = np.abs(run.K.to_host(tri=1) - L1)
+        out["max_err_L"] = float(diff.max() / scale)
+        if not (diff.max() <= 1e-10 * scale):
+            ok = False
+            bad = np.argwhere(~(diff <= 1e-10 * scale))
+            i, j = min(((int(a) // nb, int(b) // nb) for a, b in bad), key=lambda t: (t[1], t[0]))
+            out["first_bad_block"] = [i, j]
     out["ok"] = bool(ok)
     out["seconds"] = time.perf_counter() - t0
     del run

@@ -588,14 +588,23 @@ int gpx_dist_ivar_step(gpx_ctx* ctx, const gpx_mat* K, int64_t k, int64_t nb, gp
 // i.e. (k1 - k0 + 1) steps of gpx_dist_ivar_step at once: the update below the group runs with K = r1 - r0 (2048 at nb = 512,
 // four panels) instead of one K = nb product per panel -- the same aggregation as the factorisation's trailing updates.
 int gpx_dist_ivar_group(gpx_ctx* ctx, const gpx_mat* K, int64_t k0, int64_t k1, int64_t nb, gpx_mat* B) {
+  return gpx_dist_ivar_group_at(ctx, K, k0, k1, nb, B, k0 * nb);
+}
+
+// The same against a WINDOW of the factor: K holds only the block columns of the group, starting at its column c0 (rows: all
+// of them, leaf inverses per row block as usual).  With c0 = (k0 % window) * nb the streamed evaluation needs no N x N copy of
+// the factor on any rank -- each panel is consumed when it arrives and its column slot is reused `window` panels later (SURVEY
+// 8e (1): "keep L distributed" above the size where a replica is cheap).
+int gpx_dist_ivar_group_at(gpx_ctx* ctx, const gpx_mat* K, int64_t k0, int64_t k1, int64_t nb, gpx_mat* B, int64_t c0) {
   GPX_ARG(ctx && K && B && K->aux, "NULL argument / no stored panel yet");
   const int64_t np = K->prows, r0 = k0 * nb;
   GPX_ARG(nb % GPX_TILE == 0 && k0 >= 0 && k1 >= k0 && r0 < np && B->prows == np, "bad panel range / B does not match the factor");
   const int64_t r1 = (k1 + 1) * nb < np ? (k1 + 1) * nb : np, w = r1 - r0, below = np - r1, mcp = B->pcols;
+  GPX_ARG(c0 >= 0 && c0 % GPX_TILE == 0 && c0 + w <= K->pcols, "the group's columns fall outside the stored window");
   double* Bk = B->p + r0 * B->ld;
-  GPX_TRY(chol_trsm_left(ctx, K->p + r0 * K->ld + r0, K->ld, K->aux + (r0 / GPX_TILE) * GPX_TILE * GPX_TILE, Bk, B->ld, w, mcp));
+  GPX_TRY(chol_trsm_left(ctx, K->p + r0 * K->ld + c0, K->ld, K->aux + (r0 / GPX_TILE) * GPX_TILE * GPX_TILE, Bk, B->ld, w, mcp));
   if (below > 0)
-    GPX_TRY(launch_gemm(ctx, K->p + r1 * K->ld + r0, K->ld, Bk, B->ld, B->p + r1 * B->ld, B->ld, below, mcp, w, false, true, false));
+    GPX_TRY(launch_gemm(ctx, K->p + r1 * K->ld + c0, K->ld, Bk, B->ld, B->p + r1 * B->ld, B->ld, below, mcp, w, false, true, false));
   return 0;
 }
 
@@ -923,15 +932,22 @@ int gpx_dist2_unpack_rows(gpx_ctx* ctx, const gpx_mat* G, int64_t roff, int64_t 
 
 // replicated factor: diagonal block k (global offset r0 = k * nb) and its leaf inverses from the D region
 int gpx_dist2_unpack_diag(gpx_ctx* ctx, const gpx_mat* G, int64_t doff, int64_t w, int64_t nb, gpx_mat* L, int64_t r0) {
+  return gpx_dist2_unpack_diag_at(ctx, G, doff, w, nb, L, r0, r0);
+}
+
+// ... to rows r0.., columns c0.. of L (c0 != r0: L is a window of block columns, see gpx_dist_ivar_group_at)
+int gpx_dist2_unpack_diag_at(gpx_ctx* ctx, const gpx_mat* G, int64_t doff, int64_t w, int64_t nb, gpx_mat* L, int64_t r0,
+                             int64_t c0) {
   GPX_ARG(ctx && G && L, "NULL argument");
-  GPX_ARG(doff >= 0 && (doff + gpx_dist2_diag_elems(nb)) * 8 <= G->bytes && r0 + w <= L->prows && w <= nb, "bad D region");
+  GPX_ARG(doff >= 0 && (doff + gpx_dist2_diag_elems(nb)) * 8 <= G->bytes && r0 + w <= L->prows && w <= nb && c0 >= 0 &&
+              c0 + w <= L->pcols, "bad D region");
   if (!L->aux) {
     L->aux_bytes = L->prows * GPX_TILE * 8;
     void* p;
     GPX_TRY(gpx_dev_alloc(ctx, L->aux_bytes, &p));
     L->aux = (double*)p;
   }
-  GPX_TRY(gpx_copy2d(ctx, G->p + doff, nb, L->p + r0 * L->ld + r0, L->ld, w, w));
+  GPX_TRY(gpx_copy2d(ctx, G->p + doff, nb, L->p + r0 * L->ld + c0, L->ld, w, w));
   GPX_HIP(hipMemcpyAsync(L->aux + (r0 / GPX_TILE) * GPX_TILE * GPX_TILE, G->p + doff + nb * nb,
                          (size_t)((w / GPX_TILE) * GPX_TILE * GPX_TILE * 8), hipMemcpyDeviceToDevice, ctx->stream));
   return 0;
@@ -1058,7 +1074,7 @@ int gpx_program_run(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const int64_
         break;
       }
       case GPX_OP_UNPACK_ROWS: r = gpx_dist2_unpack_rows(ctx, h0, a[0], a[1], a[2], a[3], h1, a[4], a[5], a[6]); break;
-      case GPX_OP_UNPACK_DIAG: r = gpx_dist2_unpack_diag(ctx, h0, a[0], a[1], a[2], h1, a[3]); break;
+      case GPX_OP_UNPACK_DIAG: r = gpx_dist2_unpack_diag_at(ctx, h0, a[0], a[1], a[2], h1, a[3], a[4] ? a[4] - 1 : a[3]); break;
       case GPX_OP_PACK_ROWS: r = gpx_dist2_pack_rows(ctx, h0, a[0], a[1], a[2], h1, a[3], a[4], a[5], a[6]); break;
       case GPX_OP_PACK_DIAG: r = gpx_dist2_pack_diag(ctx, h0, a[0], a[1], a[2], h1, a[3]); break;
       case GPX_OP_BCAST_GRP: r = gpx_comm_bcast_grp(ctx, h0, a[0], a[1], (int)a[2], (int)a[3]); break;
@@ -1077,7 +1093,7 @@ int gpx_program_run(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const int64_
         break;
       }
       case GPX_OP_IVAR_STEP: r = gpx_dist_ivar_step(ctx, h0, a[0], a[1], h1); break;
-      case GPX_OP_IVAR_GROUP: r = gpx_dist_ivar_group(ctx, h0, a[0], a[1], a[2], h1); break;
+      case GPX_OP_IVAR_GROUP: r = gpx_dist_ivar_group_at(ctx, h0, a[0], a[1], a[2], h1, a[3] ? a[3] - 1 : a[0] * a[2]); break;
       case GPX_OP_TRSV_DIAG: r = gpx_dist2_trsv_diag(ctx, h0, a[0], a[1], a[2], h1, a[3], (int)a[4]); break;
       case GPX_OP_GEMV: r = gpx_dist2_gemv(ctx, h0, a[0], a[1], a[2], a[3], h1, a[4], h2, a[5], (int)a[6]); break;
       case GPX_OP_LOGDET_ACC: r = gpx_dist2_logdet_acc(ctx, h0, a[0], a[1], a[2], a[3], h1); break;

@@ -704,14 +704,19 @@ class DeviceOps2D(Emitter, DeviceOps):
     def unpack_rows(self, G, roff, m, w, nb, L, first_block, stride, col0):
         self._emit(OP["UNPACK_ROWS"], (G, L), (roff, m, w, nb, first_block, stride, col0))
 
-    def unpack_diag(self, G, doff, w, nb, L, r0):
-        self._emit(OP["UNPACK_DIAG"], (G, L), (doff, w, nb, r0))
+    def unpack_diag(self, G, doff, w, nb, L, r0, c0=None):
+        """c0: column of the block inside L when L is a WINDOW of block columns (default: the diagonal, c0 = r0)."""
+        self._emit(OP["UNPACK_DIAG"], (G, L), (doff, w, nb, r0, 0 if c0 is None else c0 + 1))
 
     def ivar_step(self, K, k, nb, B):
         self._emit(OP["IVAR_STEP"], (K, B), (k, nb))
 
-    def ivar_group(self, K, k0, k1, nb, B):
-        self._emit(OP["IVAR_GROUP"], (K, B), (k0, k1, nb))
+    def ivar_group(self, K, k0, k1, nb, B, c0=None):
+        """c0: column of panel k0 inside K when K is a window of block columns (default k0 * nb)."""
+        self._emit(OP["IVAR_GROUP"], (K, B), (k0, k1, nb, 0 if c0 is None else c0 + 1))
+
+    def alloc_window(self, n, cols):
+        return _dev.DeviceMatrix.zeros(self.ctx, n, cols)
 
     def trsv_diag(self, A, lr, lc, w, v, voff, transposed):
         self._emit(OP["TRSV_DIAG"], (A, v), (lr, lc, w, voff, int(transposed)))
@@ -738,14 +743,15 @@ class DeviceOps2D(Emitter, DeviceOps):
 
 # event kinds of the 2-D pipeline (per step k)
 (E_COLREADY, E_DFACT, E_DBC, E_PIECE, E_ARRIVED, E_STORED, E_UPD, E_DIAGREADY, E_EARLYSOLVED, E_EARLY, E_COL2,
- E_PANELDONE, E_BULK) = range(13)
+ E_PANELDONE, E_BULK, E_IVAR) = range(14)
+N_EVENT_KINDS = 14
 
 
 def _ev2(kind, k):
-    return 13 * (k + 1) + kind
+    return N_EVENT_KINDS * (k + 1) + kind
 
 
-EV_FORK, EV_PRE, EV_JOIN0 = 1, 2, 3            # event ids below 13 are free (ids of step k start at 13 (k + 1))
+EV_FORK, EV_PRE, EV_JOIN0 = 1, 2, 3            # event ids below 14 are free (ids of step k start at 14 (k + 1))
 ALL_SIDE_STREAMS = (PANEL, COMM, BACK, EVAL, BULK)
 
 
@@ -760,7 +766,7 @@ def ring_size(agg):
     return 2 * agg
 
 
-def dist2_potrf(ops, comm, geo, A, G, L=None, on_stored=None, agg=None):
+def dist2_potrf(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, window=0):
     """2-D block-cyclic right-looking Cholesky of the distributed matrix A (in place: A ends as the block-cyclic factor)
     with look-ahead, a CRITICAL-PATH-FIRST diagonal chain and AGGREGATED trailing updates.  G = ring of packed panel
     buffers (geo.buf_elems() doubles each, len(G) >= ring_size(agg), or 2 with agg = 1); L (optional) = full-size matrix
@@ -785,8 +791,8 @@ def dist2_potrf(ops, comm, geo, A, G, L=None, on_stored=None, agg=None):
     order on every rank of every communicator), MAIN (near updates), BULK (aggregated updates), BACK (copies into L, then the
     streamed-evaluation hook `on_stored(k)`).  A panel buffer is rewritten one ring later, after everything that reads it.
     Returns 0 or the 1-based index of the first non-positive pivot (agreed by all)."""
-    dist2_potrf_enqueue(ops, comm, geo, A, G, L=L, on_stored=on_stored, agg=agg)
-    return dist2_potrf_finish(ops, comm, L)
+    dist2_potrf_enqueue(ops, comm, geo, A, G, L=L, on_stored=on_stored, agg=agg, window=window)
+    return dist2_potrf_finish(ops, comm, None if window else L)
 
 
 def dist2_potrf_finish(ops, comm, L=None):
@@ -798,13 +804,21 @@ def dist2_potrf_finish(ops, comm, L=None):
     return min(bad) if bad else 0
 
 
-def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None):
-    """The asynchronous part of dist2_potrf: pure enqueue, no host read -- recordable (Program)."""
+def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, window=0):
+    """The asynchronous part of dist2_potrf: pure enqueue, no host read -- recordable (Program).
+
+    window > 0: L is not a full-size replica but a WINDOW of `window` block columns (padded N rows x window * nb columns);
+    panel k lands in column slot k % window, behind the streamed-evaluation step that consumed the slot's previous panel
+    (event E_IVAR of that panel's group, recorded by the hook: streamed_ivar_hook).  window must be a multiple of the group
+    size and at least two groups."""
     nb, Pr, Pc, pr, pc = geo.nb, geo.Pr, geo.Pc, geo.pr, geo.pc
     nblk = geo.nblk
     q = default_agg() if agg is None else int(agg)
     R = len(G)
     assert R >= (ring_size(q) if q > 1 else 2), "panel-buffer ring too short for the aggregation depth"
+    window = int(window)
+    assert window == 0 or (L is not None and on_stored is not None and window % q == 0 and window >= 2 * q), \
+        "a window of the factor needs the streamed evaluation that consumes it, and two whole groups of column slots"
     # Where the group-end bulk update runs (GPX_DIST_BULK: chunks | eval | bulk | main):
     #   eval    (default) whole, on the low-priority unmasked stream beside the next group's chain and near updates: MAIN stays
     #           free for the near updates that gate the panel chain.
@@ -971,11 +985,14 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None):
         ops.stream(BACK)
         ops.wait(_ev2(E_ARRIVED, k))
         if L is not None:
-            ops.unpack_diag(g, geo.piece_off(kr), w, nb, L, k * nb)
+            col = (k % window) * nb if window else k * nb
+            if window and k >= window:
+                ops.wait(_ev2(E_IVAR, group_end(k - window)))            # the evaluation step that read this column slot
+            ops.unpack_diag(g, geo.piece_off(kr), w, nb, L, k * nb, col if window else None)
             for p in range(Pr):
                 m = geo.piece_rows(p, k)
                 if m > 0:
-                    ops.unpack_rows(g, geo.piece_off(p) + geo.dsz, m, w, nb, L, p + geo.li0(p, k) * Pr, Pr, k * nb)
+                    ops.unpack_rows(g, geo.piece_off(p) + geo.dsz, m, w, nb, L, p + geo.li0(p, k) * Pr, Pr, col)
         ops.record(_ev2(E_STORED, k))
         if on_stored is not None:
             on_stored(k)
@@ -1090,6 +1107,30 @@ def dist2_logdet(ops, comm, geo, A, scal):
     return float(comm.allreduce_host(np.array([ops.vec_to_host(scal, 1)[0]]))[0])
 
 
+def streamed_ivar_hook(ops, geo, L, B, q, window=0, stream=None):
+    """`on_stored` hook of dist2_potrf_enqueue for the STREAMED evaluation: one right-looking solve step of B = K(X, Z_local)
+    per GROUP of stored panels (K = q nb updates), behind the copy of the group's last panel into L.  With window > 0, L is the
+    window of block columns described at dist2_potrf_enqueue: the step reads the group at its column slot and records E_IVAR,
+    which releases the slot -- no rank ever holds the whole factor (above the size where a replica is cheap,
+    "keep L distributed": every panel reaches every rank anyway for the trailing update, the evaluation consumes it then)."""
+    last = geo.nblk - 1
+    if stream is None:
+        stream = EVAL if os.environ.get("GPX_DIST_IVAR_STREAM", "eval") == "eval" else BACK
+
+    def hook(k):
+        if k % q == q - 1 or k == last:
+            if stream != BACK:
+                ops.stream(stream)
+                ops.wait(_ev2(E_STORED, k))
+            else:
+                ops.stream(BACK)                            # same stream as the copies: already ordered
+            k0 = (k // q) * q
+            ops.ivar_group(L, k0, k, geo.nb, B, (k0 % window) * geo.nb if window else None)
+            if window:
+                ops.record(_ev2(E_IVAR, k))
+    return hook
+
+
 class ReplayComm(Emitter):
     """ONE process plays rank `rank` of a `world`-rank grid on one GPU: every receive of the panel loop becomes a device copy
     of the same bytes out of the complete factor `Lref` resident on this GPU (gpx_dist2_pack_*), sends cost nothing (the
@@ -1169,14 +1210,18 @@ class ReplayComm(Emitter):
 class DistFitIvar2D:
     """bench.py's multi-GPU step on the 2-D block-cyclic layout: distributed fit (local assembly + dist2_potrf), alpha
     by distributed substitution, logdet / y^T alpha through all-reduce, IVAR with the evaluation points sharded over the
-    ranks against the replicated factor (streamed underneath the factorisation from 4 ranks).
+    ranks (streamed underneath the factorisation from 4 ranks).
 
-    Memory per rank: the local share of the working matrix (N^2 / W), the ring of packed panel buffers (2 agg x N x nb) --
-    and a REPLICATED copy of the finished factor (N^2: 8.6 GB at C4, 34 GB at C5 of the 288 GB), which is what makes the
-    evaluation phase communication-free.  The 2-D layout distributes the factorisation's work and traffic, not its result."""
+    Memory per rank: the local share of the working matrix (N^2 / W), the ring of packed panel buffers (2 agg x N x nb), the
+    rank's slab of the cross matrix (N x M / W) -- and the finished factor in one of two forms:
+      streamed evaluation (default from 4 ranks)  a WINDOW of 2 agg block columns (N x 2 agg nb: 1.07 GB at C4): every panel
+          reaches every rank for the trailing update anyway, the evaluation's solve step consumes it right then, nothing reads
+          it later.  The factor itself stays distributed (block-cyclic A); N per node is bounded by A / W + B, not by N^2.
+      evaluation after the fit (1-2 ranks), C5   a REPLICATED copy (N^2: 8.6 GB at C4, 34 GB at C5 of the 288 GB), against
+          which the evaluation / the gradient slabs run with no exchange."""
 
     def __init__(self, ctx, comm, spec, Xh, yh, Zh, noise, nb=512, ops=None, streamed=None, grid=None, agg=None,
-                 fit_only=False):
+                 fit_only=False, replicate=None):
         self.ctx, self.comm, self.spec = ctx, comm, spec
         self.ops = ops or DeviceOps2D(ctx)
         Pr, Pc = grid or choose_grid(comm.world)
@@ -1196,7 +1241,20 @@ class DistFitIvar2D:
         self.Zloc = self.ops.points(Zh[lo:hi]) if hi > lo else None
         self.A = self.ops.alloc_local(self.geo)
         self.G = [self.ops.alloc_buf(self.geo) for _ in range(ring_size(self.agg) if self.agg > 1 else 2)]
-        self.L = self.ops.alloc_matrix(self.n)
+        # The finished factor: with the STREAMED evaluation nothing reads a panel after its group's solve step, so the rank
+        # keeps a window of two groups of block columns (N x 2 agg nb) instead of an N x N replica (`replicate`, or
+        # GPX_DIST_REPLICATE=1, forces the replica; the C5 gradient needs it).
+        env_r = os.environ.get("GPX_DIST_REPLICATE")
+        self.replicate = (not self.streamed) if replicate is None else bool(replicate)
+        if env_r is not None:
+            self.replicate = env_r == "1"
+        if not self.streamed:
+            self.replicate = True
+        self.window = 0 if self.replicate else 2 * self.agg
+        if self.window:
+            self.L = self.ops.alloc_window(self.n, self.window * nb)
+        else:
+            self.L = self.ops.alloc_matrix(self.n)
         self.yv = self.ops.alloc_vec(self.geo.np)
         self.y0 = self.ops.alloc_vec(self.geo.np)
         ypad = np.zeros(self.geo.np)
@@ -1226,25 +1284,13 @@ class DistFitIvar2D:
     def _hook(self):
         if self.B is None:
             return None
-        ops, geo = self.ops, self.geo
-
-        q, last = self.agg, geo.nblk - 1
-        ivar_stream = EVAL if os.environ.get("GPX_DIST_IVAR_STREAM", "eval") == "eval" else BACK
-
-        def hook(k):
-            # one right-looking solve step per GROUP of stored panels (K = agg * nb updates), behind the copy of the group's
-            # last panel into L
-            if k % q == q - 1 or k == last:
-                if ivar_stream != BACK:
-                    ops.stream(ivar_stream)
-                    ops.wait(_ev2(E_STORED, k))
-                else:
-                    ops.stream(BACK)                            # same stream as the copies: already ordered
-                ops.ivar_group(self.L, (k // q) * q, k, geo.nb, self.B)
-        return hook
+        return streamed_ivar_hook(self.ops, self.geo, self.L, self.B, self.agg, self.window)
 
     def _enqueue_factor(self):
-        dist2_potrf_enqueue(self.ops, self.comm, self.geo, self.A, self.G, L=self.L, on_stored=self._hook(), agg=self.agg)
+        hook = self._hook()
+        L = None if (self.window and hook is None) else self.L       # a rank without evaluation points keeps no window
+        dist2_potrf_enqueue(self.ops, self.comm, self.geo, self.A, self.G, L=L, on_stored=hook, agg=self.agg,
+                            window=self.window if hook is not None else 0)
 
     def _enqueue_solve(self):
         ops, geo = self.ops, self.geo
@@ -1296,7 +1342,7 @@ class DistFitIvar2D:
             ops.stream(MAIN)
             ops.wait(EV_PRE)
         self._run("factor", self._enqueue_factor)
-        info = dist2_potrf_finish(ops, comm, self.L)
+        info = dist2_potrf_finish(ops, comm, None if self.window else self.L)
         if info:
             from ._lib import NotPositiveDefinite
             raise NotPositiveDefinite(info)

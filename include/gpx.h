@@ -260,6 +260,9 @@ int gpx_dist_panel_update(gpx_ctx* ctx, gpx_mat* K, int64_t k, int64_t nb, const
 int gpx_dist_ivar_step(gpx_ctx* ctx, const gpx_mat* K, int64_t k, int64_t nb, gpx_mat* B);
 /* the same for the panels k0 .. k1 at once (the update below the group runs with K = (k1 - k0 + 1) nb) */
 int gpx_dist_ivar_group(gpx_ctx* ctx, const gpx_mat* K, int64_t k0, int64_t k1, int64_t nb, gpx_mat* B);
+/* the same against a WINDOW of the factor: K (padded N rows x window columns) holds the group's block columns from column c0
+ * on -- no rank keeps an N x N copy of the factor, each panel is consumed as it arrives (L stays distributed) */
+int gpx_dist_ivar_group_at(gpx_ctx* ctx, const gpx_mat* K, int64_t k0, int64_t k1, int64_t nb, gpx_mat* B, int64_t c0);
 int gpx_dist_finish(gpx_ctx* ctx, gpx_mat* K);
 
 /* ---- multi-GPU, 2-D block-cyclic (north_star) ---------------------------------------------------------
@@ -311,6 +314,9 @@ int gpx_dist2_pack_diag(gpx_ctx* ctx, const gpx_mat* L, int64_t r0, int64_t w, i
 int gpx_dist2_unpack_rows(gpx_ctx* ctx, const gpx_mat* G, int64_t roff, int64_t m, int64_t w, int64_t nb, gpx_mat* L,
                           int64_t first_block, int64_t stride, int64_t col0);
 int gpx_dist2_unpack_diag(gpx_ctx* ctx, const gpx_mat* G, int64_t doff, int64_t w, int64_t nb, gpx_mat* L, int64_t r0);
+/* ... at rows r0, columns c0 of a window of block columns (gpx_dist_ivar_group_at) */
+int gpx_dist2_unpack_diag_at(gpx_ctx* ctx, const gpx_mat* G, int64_t doff, int64_t w, int64_t nb, gpx_mat* L, int64_t r0,
+                             int64_t c0);
 /* distributed forward / back substitution on the block-cyclic factor: diagonal-block solve, block GEMV, log-det partial */
 int gpx_dist2_trsv_diag(gpx_ctx* ctx, const gpx_mat* A, int64_t lr, int64_t lc, int64_t w, gpx_mat* v, int64_t voff,
                         int transposed);

@@ -71,17 +71,20 @@ def main():
                                      streamed=streamed, fit_only=True)
             _, part = run.step()          # records the program, first run
             ctx.sync()
-            # the replicated factor this rank assembled from its own solves and the staged pieces must BE the factor
-            Zc = dev.points(ctx, Zh[:512])
-            _, v1 = dev.posterior(ctx, spec, run.L, X, None, Zc, want_mean=False)
-            _, v0 = dev.posterior(ctx, spec, Lref, X, None, Zc, want_mean=False)
-            check = float(np.max(np.abs(v1 - v0)) / np.max(np.abs(v0)))
-            assert check < 1e-10, (gs, rank, check)
+            check = 0.0
+            if not run.window:
+                # the replicated factor this rank assembled from its own solves and the staged pieces must BE the factor
+                Zc = dev.points(ctx, Zh[:512])
+                _, v1 = dev.posterior(ctx, spec, run.L, X, None, Zc, want_mean=False)
+                _, v0 = dev.posterior(ctx, spec, Lref, X, None, Zc, want_mean=False)
+                check = float(np.max(np.abs(v1 - v0)) / np.max(np.abs(v0)))
+                assert check < 1e-10, (gs, rank, check)
             if run.B is not None:     # streamed evaluation of the rank's slice against the single-GPU path
                 lo, hi = dist.eval_slice(args.m, rank, world)
                 _, var = dev.posterior(ctx, spec, Lref, X, None, dev.points(ctx, Zh[lo:hi]), want_mean=False)
                 ref = float(np.sum(var))
                 assert abs(part - ref) <= 1e-10 * abs(ref), (gs, rank, part, ref)
+                check = max(check, abs(part - ref) / abs(ref))
             ts, host = [], []
             for _ in range(args.steps):
                 ctx.sync()
@@ -102,7 +105,7 @@ def main():
             run.force_interpret = False
             geo = run.geo
             res = dict(grid=gs, rank=rank, pr=geo.pr, pc=geo.pc, N=args.n, M=args.m, nb=args.nb, agg=args.agg, steps_k=geo.nblk,
-                       streamed_ivar=streamed, ms_per_step=float(np.median(ts)), ms_all=ts,
+                       streamed_ivar=streamed, factor_window_panels=run.window, ms_per_step=float(np.median(ts)), ms_all=ts,
                        host_issue_ms_per_fit=float(np.median(host)), host_issue_us_per_panel_step=1e3 * float(np.median(host)) / geo.nblk,
                        program_rows=len(run.programs["factor"]), rows_per_panel_step=len(run.programs["factor"]) / geo.nblk,
                        issue_mode="hipGraph (one launch per step)" if run.use_graph else "rows (one HIP call per row)",

@@ -120,18 +120,20 @@ class NumpyOps:
         B.a[:] = 0.0
         B.a[:X.shape[0], :] = self.orc.cross_matrix(self.spec, Z, X).T
 
-    def ivar_step(self, K, k, nb, B):
+    def ivar_step(self, K, k, nb, B, c0=None):
         np_ = K.a.shape[0]
         r0 = k * nb
+        c0 = r0 if c0 is None else c0
         w = min(nb, np_ - r0)
-        Lkk = np.tril(K.a[r0:r0 + w, r0:r0 + w])
+        Lkk = np.tril(K.a[r0:r0 + w, c0:c0 + w])
+        assert not np.isnan(Lkk).any() and not np.isnan(K.a[r0 + w:, c0:c0 + w]).any(), "evaluation reads a panel that is not stored"
         B.a[r0:r0 + w] = np.linalg.solve(Lkk, B.a[r0:r0 + w])
         if r0 + w < np_:
-            B.a[r0 + w:] -= K.a[r0 + w:, r0:r0 + w] @ B.a[r0:r0 + w]
+            B.a[r0 + w:] -= K.a[r0 + w:, c0:c0 + w] @ B.a[r0:r0 + w]
 
-    def ivar_group(self, K, k0, k1, nb, B):
+    def ivar_group(self, K, k0, k1, nb, B, c0=None):
         for k in range(k0, k1 + 1):
-            self.ivar_step(K, k, nb, B)
+            self.ivar_step(K, k, nb, B, None if c0 is None else c0 + (k - k0) * nb)
 
     def variances(self, spec, Z, B, n):
         return self.orc.kernel_diag(self.spec, Z) - np.sum(B.a[:n] ** 2, axis=0)
@@ -265,8 +267,15 @@ class NumpyOps2D(NumpyOps):
             g0 = (first_block + t * stride) * nb
             L.a[g0:g0 + h, col0:col0 + w] = rows[t * nb:t * nb + h]
 
-    def unpack_diag(self, G, doff, w, nb, L, r0):
-        L.a[r0:r0 + w, r0:r0 + w] = self._D(G, doff, nb)[:w, :w]
+    def unpack_diag(self, G, doff, w, nb, L, r0, c0=None):
+        if c0 is None:
+            c0 = r0
+        else:
+            L.a[:, c0:c0 + w] = np.nan       # window of block columns: the slot's previous panel is gone
+        L.a[r0:r0 + w, c0:c0 + w] = self._D(G, doff, nb)[:w, :w]
+
+    def alloc_window(self, n, cols):
+        return NumpyMat(np.full((dist.padded(n), cols), np.nan))
 
     def trsv_diag(self, A, lr, lc, w, v, voff, transposed):
         self._inside(A, lr, w, lc, w)
@@ -435,27 +444,33 @@ def run_cpu2d(args):
     Kref = orc.cov_matrix(spec, X, 0.05, row_loop=False)
     Lref = np.linalg.cholesky(Kref)
     aref = np.linalg.solve(Kref, y)
-    for streamed in (False, True):
-        run = dist.DistFitIvar2D(None, comm, None, X, y, Z, 0.05, nb=nb, ops=ops, streamed=streamed, grid=grid)
+    # evaluation after the fit against the replica / streamed against a WINDOW of the factor (no replica) / streamed + replica
+    for streamed, replicate in ((False, None), (True, None), (True, True)):
+        run = dist.DistFitIvar2D(None, comm, None, X, y, Z, 0.05, nb=nb, ops=ops, streamed=streamed, grid=grid,
+                                 replicate=replicate)
         geo = run.geo
         assert (geo.Pr, geo.Pc) == grid and geo.Pr * geo.Pc == comm.world
+        assert bool(run.window) == (streamed and not replicate)
+        if run.window:
+            assert run.L.a.shape == (geo.np, 2 * run.agg * nb), run.L.a.shape     # no N x N copy of the factor on this rank
         seen = []
         if streamed:
             orig = ops.ivar_group
 
-            def spy(K, k0, k1, nb_, B):
+            def spy(K, k0, k1, nb_, B, c0=None):
+                assert (c0 is None) == (not run.window) and (c0 is None or c0 == (k0 % run.window) * nb_)
                 seen.extend(range(k0, k1 + 1))
-                orig(K, k0, k1, nb_, B)
+                orig(K, k0, k1, nb_, B, c0)
             ops.ivar_group = spy
         ll, iv = run.step()
         if streamed:
             ops.ivar_group = orig
             if run.B is not None:
                 assert seen == list(range(geo.nblk)), seen
-        # replicated factor on every rank
-        L = np.tril(run.L.a[:n, :n])
-        err = np.max(np.abs(L - Lref)) / np.max(np.abs(Lref))
-        assert err < 1e-12, err
+        if not run.window:        # replicated factor on every rank
+            L = np.tril(run.L.a[:n, :n])
+            err = np.max(np.abs(L - Lref)) / np.max(np.abs(Lref))
+            assert err < 1e-12, err
         # the local matrix holds exactly this rank's blocks of the factor (2-D block-cyclic)
         for I in range(geo.pr, geo.nblk, geo.Pr):
             for J in range(geo.pc, geo.nblk, geo.Pc):
@@ -730,8 +745,10 @@ def run_gpu2d(args):
     assert ll == ll2 and iv == iv2, (ll, ll2, iv, iv2)
     other = dist.DistFitIvar2D(ctx, comm, spec, Xh, yh, Zh, 0.1, nb=args.nb, streamed=not runner.streamed, grid=grid)
     ll3, iv3 = other.step()
+    # the streamed schedule keeps a window of the factor, the other one the replica
+    assert bool(runner.window) == runner.streamed and bool(other.window) == other.streamed
+    Ld = (other if runner.window else runner).L.to_host(tri=1)
     del other
-    Ld = runner.L.to_host(tri=1)
     X = dev.points(ctx, Xh)
     K1 = dev.kfill(ctx, spec, X, nugget=0.1)
     dev.potrf(ctx, K1)

@@ -28,7 +28,7 @@ class FakeMat:
         self.h = ctypes.c_void_p(FakeMat._n[0])
 
 
-def record_rank(n, nb, Pr, Pc, rank, agg, bulk, streamed, monkeypatch):
+def record_rank(n, nb, Pr, Pc, rank, agg, bulk, streamed, monkeypatch, window=0):
     monkeypatch.setenv("GPX_DIST_BULK", bulk)
     geo = dist.Grid2D(n, nb, Pr, Pc, rank)
     ops = dist.DeviceOps2D(None)
@@ -38,14 +38,8 @@ def record_rank(n, nb, Pr, Pc, rank, agg, bulk, streamed, monkeypatch):
     ops.prog = comm.prog = prog
     A, L, B = FakeMat(), FakeMat(), FakeMat()
     G = [FakeMat() for _ in range(dist.ring_size(agg) if agg > 1 else 2)]
-    hook = None
-    if streamed:
-        def hook(k):
-            if k % agg == agg - 1 or k == geo.nblk - 1:
-                ops.stream(dist.EVAL)
-                ops.wait(dist._ev2(dist.E_STORED, k))
-                ops.ivar_group(L, (k // agg) * agg, k, nb, B)
-    dist.dist2_potrf_enqueue(ops, comm, geo, A, G, L=L, on_stored=hook, agg=agg)
+    hook = dist.streamed_ivar_hook(ops, geo, L, B, agg, window, stream=dist.EVAL) if streamed else None
+    dist.dist2_potrf_enqueue(ops, comm, geo, A, G, L=L, on_stored=hook, agg=agg, window=window)
     return geo, prog, G
 
 
@@ -95,7 +89,9 @@ def test_recorded_programs_event_discipline_and_collective_order(Pr, Pc, n, nb, 
     W = Pr * Pc
     progs = {}
     for rank in range(W):
-        geo, prog, G = record_rank(n, nb, Pr, Pc, rank, agg, bulk, streamed=W >= 4, monkeypatch=monkeypatch)
+        # from 4 ranks: the product default -- evaluation streamed against a WINDOW of the factor (two groups of block columns)
+        geo, prog, G = record_rank(n, nb, Pr, Pc, rank, agg, bulk, streamed=W >= 4, monkeypatch=monkeypatch,
+                                   window=2 * agg if W >= 4 else 0)
         analyse_events(prog)
         progs[rank] = collectives(prog)
     # world communicator: identical sequences on every rank
@@ -132,6 +128,36 @@ def test_buffer_ring_reuse_is_fenced(monkeypatch):
             seen = waits_before(i)
             ge = min((old // agg + 1) * agg - 1, geo.nblk - 1)
             assert dist._ev2(dist.E_STORED, old) in seen and dist._ev2(dist.E_UPD, ge) in seen, (rank, k)
+
+
+@pytest.mark.parametrize("Pr,Pc,n,nb,agg", [(2, 2, 4200, 128, 4), (2, 4, 4200, 128, 2), (1, 2, 2500, 128, 3), (2, 4, 32768, 512, 4)])
+def test_factor_window_slots_are_fenced(Pr, Pc, n, nb, agg, monkeypatch):
+    """Streamed evaluation against a WINDOW of the factor (no N x N replica): panel k is copied into column slot k % window only
+    behind a wait on the evaluation step that consumed the slot's previous panel (E_IVAR of that panel's group), every
+    evaluation step reads its group at the group's slot, behind the copy of the group's last panel, and the steps come in
+    panel order."""
+    window = 2 * agg
+    for rank in range(Pr * Pc):
+        geo, prog, G = record_rank(n, nb, Pr, Pc, rank, agg, "bulk", streamed=True, monkeypatch=monkeypatch, window=window)
+        analyse_events(prog)
+        waits, groups = set(), []
+        for r in prog.rows:
+            op, a = NAMES[r[0]], r[4:]
+            if op == "WAIT":
+                waits.add(a[0])
+            elif op == "UNPACK_DIAG":
+                k = a[3] // nb
+                assert a[4] - 1 == (k % window) * nb, "panel %d lands in the wrong column slot" % k
+                if k >= window:
+                    ge = min(((k - window) // agg + 1) * agg - 1, geo.nblk - 1)
+                    assert dist._ev2(dist.E_IVAR, ge) in waits, "slot of panel %d rewritten before its evaluation step" % (k - window)
+            elif op == "UNPACK_ROWS":
+                assert a[6] % nb == 0 and a[6] < window * nb
+            elif op == "IVAR_GROUP":
+                k0, k1 = a[0], a[1]
+                assert a[3] - 1 == (k0 % window) * nb and dist._ev2(dist.E_STORED, k1) in waits
+                groups.append((k0, k1))
+        assert groups == [(g, min(g + agg - 1, geo.nblk - 1)) for g in range(0, geo.nblk, agg)], groups
 
 
 @pytest.mark.parametrize("Pr,Pc,n,nb", [(1, 2, 1500, 128), (2, 2, 1500, 128), (2, 4, 2500, 128), (2, 3, 1500, 128), (4, 2, 1500, 128)])
