@@ -981,6 +981,55 @@ static int potrf_blocked(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double*
     }
     double* P = A + (j0 + w) * ld + j0;        // below x w panel
     double* C = A + (j0 + w) * (ld + 1);       // trailing block, below x below
+    static const int64_t la_mode = env_i64("GPX_POTRF_LA_MODE", 2);
+    if (la && bi && la_mode == 2) {
+      // Round 3, critical path first: only block row k+1 of the panel and the diagonal block (k+1, k+1) stand between this
+      // panel and the next diagonal chain.  So: solve THOSE rows, update THAT block, start the chain on the side stream --
+      // and only then solve the rest of the panel, update the rest of block column k+1 and the bulk, all underneath the
+      // chain (its kernels fit beside resident GEMM workgroups).  The chain used to start behind the whole solve and the
+      // whole column update and outlasted the bulk update from the fourth panel on (8.7 + 2.5 ms exposed at N = 32768).
+      const int64_t w2 = below < B ? below : B, rest = below - w2;
+      double* invn = invd + ((j0 + w) / NB) * NB * NB;
+      hipEvent_t ev_col = ctx->la_events[0], ev_diag = ctx->la_events[1];
+      hipEvent_t t0 = mark(M);
+      GPX_TRY(trsm_right_binv_rec(ctx, A + j0 * (ld + 1), ld, binv_at(j0), ib, P, ld, w2, w, 0, (w + ib - 1) / ib, ctx->pw_tmp_T));
+      GPX_TRY(launch_gemm(ctx, P, ld, P, ld, C, ld, w2, w2, w, true, true, true));
+      spans.push_back({"top", j0 / B, t0, mark(M)});
+      GPX_HIP(hipEventRecord(ev_col, M));
+      ctx->stream = S;
+      int r = 0;
+      if (hipStreamWaitEvent(S, ev_col, 0) != hipSuccess) r = -2;
+      t0 = mark(S);
+      if (r == 0) r = potrf_rec(ctx, C, ld, w2, invn, base + j0 + w, n_valid);
+      if (r == 0) r = binv_build_range(ctx, C, ld, invn, binv_at(j0 + w), ib, w2, ctx->pw_tmp_build, 0, CHAIN_MAX);
+      spans.push_back({"chain", j0 / B, t0, mark(S)});
+      if (r == 0 && hipEventRecord(ev_diag, S) != hipSuccess) r = -2;
+      ctx->stream = M;
+      if (r != 0) {
+        if (r == -2) gpx_set_error("potrf: look-ahead stream plumbing failed");
+        return r;
+      }
+      if (rest > 0) {
+        double* P2 = P + w2 * ld;
+        t0 = mark(M);
+        // (its own scratch: the top rows' solve may still be running through pw_tmp_T -- same stream, so in order)
+        GPX_TRY(trsm_right_binv_rec(ctx, A + j0 * (ld + 1), ld, binv_at(j0), ib, P2, ld, rest, w, 0, (w + ib - 1) / ib,
+                                    ctx->pw_tmp_T));
+        spans.push_back({"solve", j0 / B, t0, mark(M)});
+        GPX_TRY(panel_done(j0 / B));
+        t0 = mark(M);
+        GPX_TRY(launch_gemm(ctx, P2, ld, P, ld, C + w2 * ld, ld, rest, w2, w, true, true, false));
+        spans.push_back({"column", j0 / B, t0, mark(M)});
+        t0 = mark(M);
+        GPX_TRY(launch_gemm(ctx, P2, ld, P2, ld, C + w2 * (ld + 1), ld, rest, rest, w, true, true, true));
+        spans.push_back({"bulk", j0 / B, t0, mark(M)});
+      } else {
+        GPX_TRY(panel_done(j0 / B));
+      }
+      GPX_HIP(hipStreamWaitEvent(M, ev_diag, 0));
+      if (bi) GPX_TRY(binv_build_range(ctx, C, ld, invn, binv_at(j0 + w), ib, w2, ctx->pw_tmp_build, CHAIN_MAX, INT64_MAX));
+      continue;
+    }
     hipEvent_t t0 = mark(M);
     if (bi)
       GPX_TRY(trsm_right_binv_rec(ctx, A + j0 * (ld + 1), ld, binv_at(j0), ib, P, ld, below, w, 0, (w + ib - 1) / ib,
@@ -1018,8 +1067,7 @@ static int potrf_blocked(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double*
       if (r == -2) gpx_set_error("potrf: look-ahead stream plumbing failed");
       return r;
     }
-    static const int64_t la_mode = env_i64("GPX_POTRF_LA_MODE", 1);
-    if (rest > 0 && la_mode == 1) {
+    if (rest > 0 && la_mode >= 1) {
       // Round 3: the chain's kernels now fit beside resident GEMM workgroups (leaf 78 KB / 240 VGPRs, strip multiplies 33-66
       // KB; scripts/dispatch_check2.hip), so they get a slot whenever one GEMM workgroup retires -- no reserved CUs, no
       // masked chunk: the WHOLE remaining update runs on the main stream, all CUs, with the chain of the next diagonal block
