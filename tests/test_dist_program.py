@@ -104,6 +104,61 @@ def test_recorded_programs_event_discipline_and_collective_order(Pr, Pc, n, nb, 
         for ranks in members:
             seqs = [[c for c in progs[r] if c[0] == grp] for r in ranks]
             assert all(s == seqs[0] for s in seqs), "ranks %s disagree on the order of their group-%d collectives" % (ranks, grp)
+    assert_global_collective_order(progs, Pr, Pc)
+
+
+def assert_global_collective_order(progs, Pr, Pc):
+    """Deadlock freedom across DIFFERENT communicators: every rank issues all its collectives on one stream, so a collective
+    blocks the ones behind it.  Node = the i-th collective of a communicator (world / one process row / one process column),
+    edge = "issued before" on some rank; the union over all ranks must be acyclic (a total order all ranks agree with exists).
+    Per-communicator agreement alone does not give that: X: [row-op, col-op], Z: [col-op', ...] can still form a cycle."""
+    def members(grp, rank):
+        pr, pc = rank // Pc, rank % Pc
+        if grp == dist.WORLD:
+            return ("w",)
+        return ("r", pr) if grp == dist.ROW else ("c", pc)
+    size = {dist.WORLD: Pr * Pc, dist.ROW: Pc, dist.COL: Pr}
+    succ, indeg = {}, {}
+    for rank, seq in progs.items():
+        count, prev = {}, None
+        for c in seq:
+            if size[c[0]] == 1:
+                continue                                  # a one-member group issues nothing
+            key = members(c[0], rank)
+            i = count.get(key, 0)
+            count[key] = i + 1
+            node = (key, i)
+            indeg.setdefault(node, 0)
+            succ.setdefault(node, set())
+            if prev is not None and node not in succ[prev]:
+                succ[prev].add(node)
+                indeg[node] += 1
+            prev = node
+    ready = [n for n, d in indeg.items() if d == 0]
+    done = 0
+    while ready:
+        n = ready.pop()
+        done += 1
+        for m in succ[n]:
+            indeg[m] -= 1
+            if indeg[m] == 0:
+                ready.append(m)
+    assert done == len(indeg), "the ranks' collective orders form a cycle across communicators (%d of %d ordered)" % (done, len(indeg))
+
+
+def test_global_collective_order_detects_a_cycle():
+    """The checker itself: two ranks of a 2x2 grid that issue a row and a column collective in opposite order -- with a third
+    rank closing the loop -- must be flagged."""
+    ok = {0: [(dist.ROW, "bcast", 1, 0), (dist.COL, "bcast", 1, 0)], 1: [(dist.ROW, "bcast", 1, 0), (dist.COL, "bcast", 1, 0)],
+          2: [(dist.ROW, "bcast", 1, 0), (dist.COL, "bcast", 1, 0)], 3: [(dist.ROW, "bcast", 1, 0), (dist.COL, "bcast", 1, 0)]}
+    assert_global_collective_order(ok, 2, 2)
+    R, Cc = (dist.ROW, "bcast", 1, 0), (dist.COL, "bcast", 1, 0)
+    # rank 0 sits in its column collective waiting for rank 2, which sits in its row collective waiting for rank 3, which sits in
+    # its column collective waiting for rank 1, which sits in its row collective waiting for rank 0
+    bad = {0: [Cc, R], 1: [R, Cc], 3: [Cc, R], 2: [R, Cc]}
+    assert_global_collective_order({0: [Cc, R], 1: [R, Cc], 2: [R, Cc], 3: [R, Cc]}, 2, 2)   # one odd rank alone is no cycle
+    with pytest.raises(AssertionError):
+        assert_global_collective_order(bad, 2, 2)
 
 
 def test_buffer_ring_reuse_is_fenced(monkeypatch):
@@ -183,3 +238,4 @@ def test_recorded_substitution_collective_order(Pr, Pc, n, nb):
         for ranks in members:
             s = [[c for c in seqs[r] if c[0] == grp] for r in ranks]
             assert all(x == s[0] for x in s), (grp, ranks)
+    assert_global_collective_order(seqs, Pr, Pc)
