@@ -393,6 +393,26 @@ int gpx_create(int device, gpx_ctx** out) {
       }
     }
   }
+  {
+    // GPX_STREAM_ALIAS="3=4,5=4" (experiment): stream index a becomes the SAME HIP stream as index b -- fewer hardware queues.
+    // (Measured: the number and kind of streams a context creates changes how fast the others run -- a seventh, idle,
+    // high-priority stream cost the distributed replay 20 %, DESIGN.md 6.2 -- so the mapping is worth being able to vary.)
+    const char* al = getenv("GPX_STREAM_ALIAS");
+    std::string spec = al ? al : "";
+    for (size_t pos = 0; pos < spec.size();) {
+      int a = -1, b = -1;
+      if (sscanf(spec.c_str() + pos, "%d=%d", &a, &b) == 2 && a > 0 && a < GPX_NSTREAMS && b >= 0 && b < GPX_NSTREAMS && a != b &&
+          c->streams[a] != c->streams[b]) {
+        bool shared = false;
+        for (int i = 0; i < GPX_NSTREAMS; ++i) shared = shared || (i != a && c->streams[i] == c->streams[a]);
+        if (!shared) (void)hipStreamDestroy(c->streams[a]);
+        c->streams[a] = c->streams[b];
+      }
+      const size_t nx = spec.find(',', pos);
+      if (nx == std::string::npos) break;
+      pos = nx + 1;
+    }
+  }
   GPX_HIP(hipMalloc((void**)&c->d_info, 256));
   GPX_HIP(hipMalloc((void**)&c->d_scal, 64 * sizeof(double)));
   GPX_HIP(hipMemset(c->d_info, 0, 256));
@@ -456,7 +476,11 @@ int gpx_destroy(gpx_ctx* ctx) {
   if (ctx->d2_scratch) (void)hipFree(ctx->d2_scratch);
   for (auto ev : ctx->sync_events) (void)hipEventDestroy(ev);
   for (auto ev : ctx->la_events) (void)hipEventDestroy(ev);
-  for (int i = 0; i < GPX_NSTREAMS; ++i) (void)hipStreamDestroy(ctx->streams[i]);
+  for (int i = 0; i < GPX_NSTREAMS; ++i) {
+    bool seen = false;   // (GPX_STREAM_ALIAS: an index may share its stream with an earlier one)
+    for (int j = 0; j < i; ++j) seen = seen || ctx->streams[j] == ctx->streams[i];
+    if (!seen) (void)hipStreamDestroy(ctx->streams[i]);
+  }
   for (auto ev : ctx->panel_events) (void)hipEventDestroy(ev);
   delete ctx;
   return 0;
