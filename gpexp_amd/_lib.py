@@ -44,6 +44,7 @@ _SIGS = {
     "gpx_dist_ivar_step": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp]),
     "gpx_dist_ivar_group": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]),
     "gpx_dist_ivar_group_at": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64]),
+    "gpx_dist_fwd_group_at": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64]),
     "gpx_matvec": (C.c_int, [c_vp, c_vp, c_dp, c_dp]),
     "gpx_fitc_fit": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, C.c_double, C.POINTER(c_vp)]),
     "gpx_fitc_free": (C.c_int, [c_vp, c_vp]),

@@ -608,6 +608,23 @@ int gpx_dist_ivar_group_at(gpx_ctx* ctx, const gpx_mat* K, int64_t k0, int64_t k
   return 0;
 }
 
+// Forward substitution riding along the streamed evaluation: v (padded N doubles, y at the start) takes the group's step of
+// L w = y against the same window of the factor --  v[r0:r1] <- L[r0:r1, r0:r1]^-1 v[r0:r1];  v[r1:] -= L[r1:, r0:r1] v[r0:r1].
+// Every rank receives every panel, so every rank ends with the complete w = L^-1 y and the distributed substitution needs no
+// forward sweep (N / nb block steps with a reduce and a broadcast each); memory-bound: one more read of the window's group.
+int gpx_dist_fwd_group_at(gpx_ctx* ctx, const gpx_mat* K, int64_t k0, int64_t k1, int64_t nb, gpx_mat* v, int64_t c0) {
+  GPX_ARG(ctx && K && v && K->aux, "NULL argument / no stored panel yet");
+  const int64_t np = K->prows, r0 = k0 * nb;
+  GPX_ARG(nb % GPX_TILE == 0 && k0 >= 0 && k1 >= k0 && r0 < np && v->bytes >= np * 8, "bad panel range / vector shorter than the factor");
+  const int64_t r1 = (k1 + 1) * nb < np ? (k1 + 1) * nb : np, w = r1 - r0, below = np - r1;
+  GPX_ARG(c0 >= 0 && c0 % GPX_TILE == 0 && c0 + w <= K->pcols, "the group's columns fall outside the stored window");
+  v->bbox_ok = 0;
+  GPX_TRY(chol_trsv_with_scratch(ctx, K->p + r0 * K->ld + c0, K->ld, K->aux + (r0 / GPX_TILE) * GPX_TILE * GPX_TILE, v->p + r0, w,
+                                 false, nullptr));
+  if (below > 0) GPX_TRY(launch_gemv_sub(ctx, K->p + r1 * K->ld + c0, K->ld, below, w, v->p + r0, v->p + r1));
+  return 0;
+}
+
 // =====================================================================================================================
 // 2-D block-cyclic distributed Cholesky (north_star).  Process grid Pr x Pc, rank (pr, pc) = (rank / Pc,
 // rank % Pc); global block (I, J) of the padded matrix (block size nb, the last block may be shorter) lives on rank
@@ -1094,6 +1111,7 @@ int gpx_program_run(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const int64_
       }
       case GPX_OP_IVAR_STEP: r = gpx_dist_ivar_step(ctx, h0, a[0], a[1], h1); break;
       case GPX_OP_IVAR_GROUP: r = gpx_dist_ivar_group_at(ctx, h0, a[0], a[1], a[2], h1, a[3] ? a[3] - 1 : a[0] * a[2]); break;
+      case GPX_OP_FWD_GROUP: r = gpx_dist_fwd_group_at(ctx, h0, a[0], a[1], a[2], h1, a[3] ? a[3] - 1 : a[0] * a[2]); break;
       case GPX_OP_TRSV_DIAG: r = gpx_dist2_trsv_diag(ctx, h0, a[0], a[1], a[2], h1, a[3], (int)a[4]); break;
       case GPX_OP_GEMV: r = gpx_dist2_gemv(ctx, h0, a[0], a[1], a[2], a[3], h1, a[4], h2, a[5], (int)a[6]); break;
       case GPX_OP_LOGDET_ACC: r = gpx_dist2_logdet_acc(ctx, h0, a[0], a[1], a[2], a[3], h1); break;

@@ -92,7 +92,7 @@ def merge_argmin(values, indices):
 # ---- recorded programs (include/gpx.h: gpx_program_run) -----------------------------------------------------------
 OP = dict(STREAM=1, RECORD=2, WAIT=3, BEGIN=4, DIAG_FACTOR=5, PANEL_TRSM=6, UPDATE=7, UPDATE_MULTI=8, UNPACK_ROWS=9,
           UNPACK_DIAG=10, PACK_ROWS=11, PACK_DIAG=12, BCAST_GRP=13, REDUCE_GRP=14, ALLREDUCE=15, PANEL_BCAST=16, IVAR_STEP=17,
-          TRSV_DIAG=18, GEMV=19, LOGDET_ACC=20, VEC_OP=21, SPIN=22, COPY=23, IVAR_GROUP=24)
+          TRSV_DIAG=18, GEMV=19, LOGDET_ACC=20, VEC_OP=21, SPIN=22, COPY=23, IVAR_GROUP=24, FWD_GROUP=25)
 
 
 class Program:
@@ -715,8 +715,19 @@ class DeviceOps2D(Emitter, DeviceOps):
         """c0: column of panel k0 inside K when K is a window of block columns (default k0 * nb)."""
         self._emit(OP["IVAR_GROUP"], (K, B), (k0, k1, nb, 0 if c0 is None else c0 + 1))
 
+    def fwd_group(self, K, k0, k1, nb, v, c0=None):
+        """the group's step of the forward substitution on the vector v, against the same (window of the) factor"""
+        self._emit(OP["FWD_GROUP"], (K, v), (k0, k1, nb, 0 if c0 is None else c0 + 1))
+
     def alloc_window(self, n, cols):
         return _dev.DeviceMatrix.zeros(self.ctx, n, cols)
+
+    # alpha / log-det straight from a REPLICATED factor (every rank holds it: no exchange, the single-GPU sweeps)
+    def replica_solve(self, L, y0, alpha):
+        _dev.potrs_dev(self.ctx, L, y0, alpha)
+
+    def replica_logdet(self, L):
+        return _dev.logdet(self.ctx, L)
 
     def trsv_diag(self, A, lr, lc, w, v, voff, transposed):
         self._emit(OP["TRSV_DIAG"], (A, v), (lr, lc, w, voff, int(transposed)))
@@ -1051,18 +1062,20 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
         ops.wait(EV_JOIN0 + i_)
 
 
-def dist2_potrs(ops, comm, geo, A, yv, acc_r, acc_c, out):
+def dist2_potrs(ops, comm, geo, A, yv, acc_r, acc_c, out, skip_forward=False):
     """alpha = K^-1 y on the block-cyclic factor A: block forward substitution (partial sums reduced along the process
     row of the diagonal owner, the solved block broadcast down its process column), then the transposed sweep with the
     roles of rows and columns exchanged; the blocks of alpha (one per diagonal owner) are assembled on every rank by one
     ncclAllReduce.  yv: device vector (padded N) holding y on every rank -- overwritten; acc_r / acc_c: scratch vectors
-    of local_rows / local_cols doubles; out: device vector (padded N) that receives alpha everywhere.  Pure enqueue."""
+    of local_rows / local_cols doubles; out: device vector (padded N) that receives alpha everywhere.  Pure enqueue.
+    skip_forward: yv holds w = L^-1 y on every rank already (the streamed evaluation carried the forward substitution along,
+    streamed_ivar_hook) -- only the transposed sweep runs: half the block steps, half the collectives."""
     nb, Pr, Pc, pr, pc = geo.nb, geo.Pr, geo.Pc, geo.pr, geo.pc
     ops.stream(MAIN)
     ops.vec_op(acc_r, 0, None, 0, max(geo.local_rows(pr), 1), 2)
     ops.vec_op(acc_c, 0, None, 0, max(geo.local_cols(pc), 1), 2)
     ops.vec_op(out, 0, None, 0, geo.np, 2)
-    for k in range(geo.nblk):                                   # L w = y
+    for k in (() if skip_forward else range(geo.nblk)):         # L w = y  (skip_forward: yv already holds w on every rank)
         kr, kc = k % Pr, k % Pc
         w = geo.height(k)
         lr, lc = (k // Pr) * nb, (k // Pc) * nb
@@ -1107,11 +1120,12 @@ def dist2_logdet(ops, comm, geo, A, scal):
     return float(comm.allreduce_host(np.array([ops.vec_to_host(scal, 1)[0]]))[0])
 
 
-def streamed_ivar_hook(ops, geo, L, B, q, window=0, stream=None):
+def streamed_ivar_hook(ops, geo, L, B, q, window=0, stream=None, fwd=None):
     """`on_stored` hook of dist2_potrf_enqueue for the STREAMED evaluation: one right-looking solve step of B = K(X, Z_local)
     per GROUP of stored panels (K = q nb updates), behind the copy of the group's last panel into L.  With window > 0, L is the
     window of block columns described at dist2_potrf_enqueue: the step reads the group at its column slot and records E_IVAR,
-    which releases the slot -- no rank ever holds the whole factor (above the size where a replica is cheap,
+    which releases the slot; `fwd` (device vector holding y) takes the same step of the forward substitution -- no rank ever
+    holds the whole factor (above the size where a replica is cheap,
     "keep L distributed": every panel reaches every rank anyway for the trailing update, the evaluation consumes it then)."""
     last = geo.nblk - 1
     if stream is None:
@@ -1125,7 +1139,10 @@ def streamed_ivar_hook(ops, geo, L, B, q, window=0, stream=None):
             else:
                 ops.stream(BACK)                            # same stream as the copies: already ordered
             k0 = (k // q) * q
-            ops.ivar_group(L, k0, k, geo.nb, B, (k0 % window) * geo.nb if window else None)
+            c0 = (k0 % window) * geo.nb if window else None
+            ops.ivar_group(L, k0, k, geo.nb, B, c0)
+            if fwd is not None:           # the forward substitution L w = y rides along (every rank: the complete w)
+                ops.fwd_group(L, k0, k, geo.nb, fwd, c0)
             if window:
                 ops.record(_ev2(E_IVAR, k))
     return hook
@@ -1255,6 +1272,10 @@ class DistFitIvar2D:
             self.L = self.ops.alloc_window(self.n, self.window * nb)
         else:
             self.L = self.ops.alloc_matrix(self.n)
+        # The forward substitution L w = y rides along the streamed evaluation when EVERY rank streams (all have evaluation
+        # points): each rank then ends the factorisation with the complete w and the distributed substitution keeps only its
+        # backward sweep (half the block steps and collectives).  Decided from (M, world) alone: the same on every rank.
+        self.fused_fwd = bool(self.window) and Zh.shape[0] >= comm.world and os.environ.get("GPX_DIST_FUSED_FWD", "1") == "1"
         self.yv = self.ops.alloc_vec(self.geo.np)
         self.y0 = self.ops.alloc_vec(self.geo.np)
         ypad = np.zeros(self.geo.np)
@@ -1284,7 +1305,8 @@ class DistFitIvar2D:
     def _hook(self):
         if self.B is None:
             return None
-        return streamed_ivar_hook(self.ops, self.geo, self.L, self.B, self.agg, self.window)
+        return streamed_ivar_hook(self.ops, self.geo, self.L, self.B, self.agg, self.window,
+                                  fwd=self.yv if self.fused_fwd else None)
 
     def _enqueue_factor(self):
         hook = self._hook()
@@ -1295,8 +1317,9 @@ class DistFitIvar2D:
     def _enqueue_solve(self):
         ops, geo = self.ops, self.geo
         ops.stream(MAIN)
-        ops.vec_op(self.yv, 0, self.y0, 0, geo.np, 0)
-        dist2_potrs(ops, self.comm, geo, self.A, self.yv, self.acc_r, self.acc_c, self.alpha)
+        if not self.fused_fwd:
+            ops.vec_op(self.yv, 0, self.y0, 0, geo.np, 0)
+        dist2_potrs(ops, self.comm, geo, self.A, self.yv, self.acc_r, self.acc_c, self.alpha, skip_forward=self.fused_fwd)
         dist2_logdet_enqueue(ops, geo, self.A, self.scal)
 
     def _record(self):
@@ -1341,6 +1364,9 @@ class DistFitIvar2D:
             ops.record(EV_PRE)          # the program forks every stream off MAIN: MAIN carries the cross fill's completion
             ops.stream(MAIN)
             ops.wait(EV_PRE)
+        if self.fused_fwd:
+            ops.stream(MAIN)                                       # (the program forks every stream off MAIN behind this)
+            ops.vec_op(self.yv, 0, self.y0, 0, geo.np, 0)
         self._run("factor", self._enqueue_factor)
         info = dist2_potrf_finish(ops, comm, None if self.window else self.L)
         if info:
@@ -1348,8 +1374,19 @@ class DistFitIvar2D:
             raise NotPositiveDefinite(info)
 
     def solve(self):
-        """alpha (host, on every rank) and the log marginal likelihood from the block-cyclic factor."""
+        """alpha (host, on every rank) and the log marginal likelihood.  With a replicated factor on every rank (evaluation
+        after the fit, C5) they come from the replica -- the single-GPU sweeps, no exchange: the distributed substitution is a
+        chain of 2 N / nb block steps with two collectives each (11 ms at C4 before any communication; the local sweeps:
+        2.3 ms).  Without a replica (streamed evaluation against a window of the factor) they come from the block-cyclic
+        factor by distributed substitution; GPX_DIST_SOLVE=dist forces that form everywhere."""
         ops, comm = self.ops, self.comm
+        if self.replicate and os.environ.get("GPX_DIST_SOLVE", "local") != "dist":
+            ops.stream(MAIN)
+            ops.replica_solve(self.L, self.y0, self.alpha)
+            logdet = ops.replica_logdet(self.L)
+            alpha = ops.vec_to_host(self.alpha, self.n)
+            ll = -0.5 * float(self.yh @ alpha) - 0.5 * logdet - self.n / 2.0 * np.log(2 * np.pi)
+            return ll, alpha
         self._run("solve", self._enqueue_solve)
         logdet = float(comm.allreduce_host(np.array([ops.vec_to_host(self.scal, 1)[0]]))[0])
         alpha = ops.vec_to_host(self.alpha, self.n)

@@ -263,6 +263,9 @@ int gpx_dist_ivar_group(gpx_ctx* ctx, const gpx_mat* K, int64_t k0, int64_t k1, 
 /* the same against a WINDOW of the factor: K (padded N rows x window columns) holds the group's block columns from column c0
  * on -- no rank keeps an N x N copy of the factor, each panel is consumed as it arrives (L stays distributed) */
 int gpx_dist_ivar_group_at(gpx_ctx* ctx, const gpx_mat* K, int64_t k0, int64_t k1, int64_t nb, gpx_mat* B, int64_t c0);
+/* the group's step of the forward substitution L w = y on the vector v (padded N doubles), against the same window: every rank
+ * ends with the complete w, the distributed substitution keeps only its backward sweep */
+int gpx_dist_fwd_group_at(gpx_ctx* ctx, const gpx_mat* K, int64_t k0, int64_t k1, int64_t nb, gpx_mat* v, int64_t c0);
 int gpx_dist_finish(gpx_ctx* ctx, gpx_mat* K);
 
 /* ---- multi-GPU, 2-D block-cyclic (north_star) ---------------------------------------------------------
@@ -332,7 +335,7 @@ enum {
   GPX_OP_STREAM = 1, GPX_OP_RECORD, GPX_OP_WAIT, GPX_OP_BEGIN, GPX_OP_DIAG_FACTOR, GPX_OP_PANEL_TRSM, GPX_OP_UPDATE,
   GPX_OP_UPDATE_MULTI, GPX_OP_UNPACK_ROWS, GPX_OP_UNPACK_DIAG, GPX_OP_PACK_ROWS, GPX_OP_PACK_DIAG, GPX_OP_BCAST_GRP,
   GPX_OP_REDUCE_GRP, GPX_OP_ALLREDUCE, GPX_OP_PANEL_BCAST, GPX_OP_IVAR_STEP, GPX_OP_TRSV_DIAG, GPX_OP_GEMV, GPX_OP_LOGDET_ACC,
-  GPX_OP_VEC_OP, GPX_OP_SPIN, GPX_OP_COPY, GPX_OP_IVAR_GROUP
+  GPX_OP_VEC_OP, GPX_OP_SPIN, GPX_OP_COPY, GPX_OP_IVAR_GROUP, GPX_OP_FWD_GROUP
 };
 int gpx_program_run(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const int64_t* extra, int64_t nextra, double* host_ms);
 /* The same program as a hipGraph: captured once (after it has run once the ordinary way; every stream it uses must fork from

@@ -277,6 +277,26 @@ class NumpyOps2D(NumpyOps):
     def alloc_window(self, n, cols):
         return NumpyMat(np.full((dist.padded(n), cols), np.nan))
 
+    def fwd_group(self, K, k0, k1, nb, v, c0=None):
+        np_ = K.a.shape[0]
+        y = v.a.reshape(-1)
+        for k in range(k0, k1 + 1):
+            r0 = k * nb
+            c = r0 if c0 is None else c0 + (k - k0) * nb
+            w = min(nb, np_ - r0)
+            blk = K.a[r0:, c:c + w]
+            assert not np.isnan(np.tril(blk[:w])).any() and not np.isnan(blk[w:]).any(), "forward step reads a panel that is not stored"
+            y[r0:r0 + w] = np.linalg.solve(np.tril(blk[:w]), y[r0:r0 + w])
+            y[r0 + w:] -= blk[w:] @ y[r0:r0 + w]
+
+    def replica_solve(self, L, y0, alpha):
+        Lt = np.tril(L.a)
+        assert not np.isnan(Lt).any(), "the replicated factor is incomplete"
+        alpha.a.reshape(-1)[:] = np.linalg.solve(Lt.T, np.linalg.solve(Lt, y0.a.reshape(-1)))
+
+    def replica_logdet(self, L):
+        return 2.0 * float(np.sum(np.log(np.diag(L.a))))      # (the padding of the matrix is an identity block)
+
     def trsv_diag(self, A, lr, lc, w, v, voff, transposed):
         self._inside(A, lr, w, lc, w)
         Lkk = np.tril(A.a[lr:lr + w, lc:lc + w])

@@ -92,9 +92,11 @@ def test_panel_loop_2d_schedules_gloo_cpu(world, n, nb, grid, agg, bulk):
     """The aggregated schedule of dist2_potrf in every mode: group sizes 1..8 (panels per trailing update; ragged last
     groups), the bulk update cut into chunks behind the near updates on MAIN / whole on a second stream, buffer-ring reuse
     (2 x agg packed buffers against 12-17 panels, so buffers are rewritten; the NumPy double starts every buffer NaN-filled and
-    asserts on reads of anything unwritten, and a stale read of an older panel's bytes shows as a wrong factor)."""
+    asserts on reads of anything unwritten, and a stale read of an older panel's bytes shows as a wrong factor).  These runs
+    also take alpha / log-det from the block-cyclic factor by DISTRIBUTED substitution in every variant (GPX_DIST_SOLVE=dist;
+    by default a rank that holds a replica of the factor uses that)."""
     out = launch(world, ["--mode", "cpu2d", "--npts", str(n), "--blk", str(nb), "--grid", grid],
-                 {"GPX_DIST_AGG": str(agg), "GPX_DIST_BULK": bulk}, timeout=900)
+                 {"GPX_DIST_AGG": str(agg), "GPX_DIST_BULK": bulk, "GPX_DIST_SOLVE": "dist"}, timeout=900)
     assert "world=%d" % world in out
 
 

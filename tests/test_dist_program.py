@@ -38,7 +38,7 @@ def record_rank(n, nb, Pr, Pc, rank, agg, bulk, streamed, monkeypatch, window=0)
     ops.prog = comm.prog = prog
     A, L, B = FakeMat(), FakeMat(), FakeMat()
     G = [FakeMat() for _ in range(dist.ring_size(agg) if agg > 1 else 2)]
-    hook = dist.streamed_ivar_hook(ops, geo, L, B, agg, window, stream=dist.EVAL) if streamed else None
+    hook = dist.streamed_ivar_hook(ops, geo, L, B, agg, window, stream=dist.EVAL, fwd=FakeMat() if window else None) if streamed else None
     dist.dist2_potrf_enqueue(ops, comm, geo, A, G, L=L, on_stored=hook, agg=agg, window=window)
     return geo, prog, G
 
@@ -195,7 +195,7 @@ def test_factor_window_slots_are_fenced(Pr, Pc, n, nb, agg, monkeypatch):
     for rank in range(Pr * Pc):
         geo, prog, G = record_rank(n, nb, Pr, Pc, rank, agg, "bulk", streamed=True, monkeypatch=monkeypatch, window=window)
         analyse_events(prog)
-        waits, groups = set(), []
+        waits, groups, fwd_groups, pending_release = set(), [], [], None
         for r in prog.rows:
             op, a = NAMES[r[0]], r[4:]
             if op == "WAIT":
@@ -212,7 +212,14 @@ def test_factor_window_slots_are_fenced(Pr, Pc, n, nb, agg, monkeypatch):
                 k0, k1 = a[0], a[1]
                 assert a[3] - 1 == (k0 % window) * nb and dist._ev2(dist.E_STORED, k1) in waits
                 groups.append((k0, k1))
+                pending_release = dist._ev2(dist.E_IVAR, k1)
+            elif op == "FWD_GROUP":         # the forward substitution's step: same group, same slot, before the slot is released
+                assert (a[0], a[1]) == groups[-1] and a[3] - 1 == (a[0] % window) * nb and pending_release is not None
+                fwd_groups.append((a[0], a[1]))
+            elif op == "RECORD" and a[0] == pending_release:
+                pending_release = None
         assert groups == [(g, min(g + agg - 1, geo.nblk - 1)) for g in range(0, geo.nblk, agg)], groups
+        assert fwd_groups == groups
 
 
 @pytest.mark.parametrize("Pr,Pc,n,nb", [(1, 2, 1500, 128), (2, 2, 1500, 128), (2, 4, 2500, 128), (2, 3, 1500, 128), (4, 2, 1500, 128)])
