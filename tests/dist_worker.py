@@ -456,7 +456,10 @@ def run_cpu2d(args):
     n, nb = args.n, args.nb
     X = rng.uniform(-1, 1, (n, d))
     y = np.sin(2 * np.pi * X.sum(1) / d) + 0.2 * rng.standard_normal(n)
-    Z = rng.uniform(-1, 1, (53 + 2 * int(os.environ.get("WORLD_SIZE", "1")), d))
+    # --mpts below 10: FEWER evaluation points than ranks may have -- some ranks stream nothing, keep no window, and the
+    # forward substitution cannot ride along (every rank must take that decision alike)
+    mz = args.m if args.m < 10 else 53 + 2 * int(os.environ.get("WORLD_SIZE", "1"))
+    Z = rng.uniform(-1, 1, (mz, d))
     spec = dict(kind="se", cl=[0.3], signalSize=1.0, d=d)
     comm = NumpyComm()
     grid = tuple(int(v) for v in args.grid.split("x")) if args.grid else dist.choose_grid(comm.world)
@@ -471,6 +474,7 @@ def run_cpu2d(args):
         geo = run.geo
         assert (geo.Pr, geo.Pc) == grid and geo.Pr * geo.Pc == comm.world
         assert bool(run.window) == (streamed and not replicate)
+        assert run.fused_fwd == (bool(run.window) and mz >= comm.world)
         if run.window:
             assert run.L.a.shape == (geo.np, 2 * run.agg * nb), run.L.a.shape     # no N x N copy of the factor on this rank
         seen = []

@@ -84,6 +84,13 @@ def test_panel_loop_2d_gloo_cpu(world, n, nb, grid):
         assert "grid=%dx%d" % dist.choose_grid(world) in out
 
 
+def test_panel_loop_2d_fewer_points_than_ranks_gloo_cpu():
+    """Three evaluation points on four ranks: one rank streams nothing (no window, no hook), the others do; the forward
+    substitution then does NOT ride along (all ranks agree from (M, world)) and alpha comes from the full distributed sweeps."""
+    out = launch(4, ["--mode", "cpu2d", "--npts", "900", "--mpts", "3", "--blk", "128"], timeout=900)
+    assert "world=4" in out
+
+
 @pytest.mark.parametrize("world,n,nb,grid,agg,bulk", [(4, 2100, 128, "", 4, "chunks"), (4, 1500, 128, "", 2, "chunks"),
                                                      (2, 1700, 128, "", 3, "eval"), (8, 2100, 128, "", 8, "eval"),
                                                      (4, 1500, 128, "", 1, "main"), (6, 1500, 128, "", 4, "bulk"),

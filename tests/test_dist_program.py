@@ -11,7 +11,6 @@ recorder for EVERY rank of a grid -- no device, fake handles -- and the recorded
 """
 import ctypes
 
-import numpy as np
 import pytest
 
 from gpexp_amd import dist

@@ -1,6 +1,5 @@
 """GPU tests (-m gpu) of the GPEXP class API (gpexp_amd / gpExp): same calls a user of the reference makes,
 checked against the golden vectors the reference produced for those calls.  Tolerance 1e-10 relative (fp64)."""
-import copy
 import os
 
 import numpy as np
