@@ -595,11 +595,13 @@ int gpx_mat_free(gpx_ctx* ctx, gpx_mat* m) {
       ctx->pending[m->p] = f;
       if (m->aux) ctx->pending[m->aux] = f;
       if (m->binv) ctx->pending[m->binv] = f;
+      if (m->dinv) ctx->pending[m->dinv] = f;
     }
   }
   gpx_dev_release(ctx, m->p, m->bytes);
   if (m->aux) gpx_dev_release(ctx, m->aux, m->aux_bytes);
   if (m->binv) gpx_dev_release(ctx, m->binv, m->binv_bytes);
+  if (m->dinv) gpx_dev_release(ctx, m->dinv, m->dinv_bytes);
   delete m;
   return 0;
 }

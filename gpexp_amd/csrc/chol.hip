@@ -1281,6 +1281,22 @@ int chol_binv_finish(gpx_ctx* ctx, gpx_mat* Lm, int64_t ib) {
   return 0;
 }
 
+// out (n x n, row stride n) = in^T; n a multiple of 32
+int chol_block_transpose(gpx_ctx* ctx, const double* in, double* out, int64_t n) {
+  GPX_ARG(in && out && n > 0 && n % 32 == 0, "block transpose: order must be a multiple of 32");
+  hipLaunchKernelGGL(binv_transpose_kernel, dim3((unsigned)(n / 32), (unsigned)(n / 32), 1), dim3(256), 0, ctx->stream, in, out, n);
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
+
+// x = M y for a triangular sz x sz matrix (row stride ld): lower != 0: M lower triangular, else upper; x != y.  One wave per row.
+int chol_tri_gemv(gpx_ctx* ctx, const double* M, int64_t ld, int64_t sz, const double* y, double* x, int lower) {
+  GPX_ARG(M && y && x && x != y && sz > 0 && sz % NB == 0 && ld % 2 == 0, "triangular gemv: bad arguments");
+  hipLaunchKernelGGL(binv_gemv_kernel, dim3((unsigned)((sz + 3) / 4)), dim3(256), 0, ctx->stream, M, ld, sz, y, x, lower);
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
+
 int chol_binv_ensure(gpx_ctx* ctx, gpx_mat* Lm) {
   const int64_t n = Lm->prows, ib = potrs_block(n);
   if (Lm->binv && Lm->binv_ib == ib) return 0;

@@ -798,6 +798,7 @@ int gpx_dist2_diag_factor(gpx_ctx* ctx, gpx_mat* A, int64_t lr, int64_t lc, int6
   double* D = G->p + doff;
   double* Dinv = D + nb * nb;
   double* Ablk = A->p + lr * A->ld + lc;
+  if (A->dinv && A->dinv_nb == nb && (size_t)(lr / nb) < A->dinv_ok.size()) A->dinv_ok[(size_t)(lr / nb)] = 0;  // a new factor
   GPX_TRY(gpx_copy2d(ctx, Ablk, A->ld, D, nb, w, w));
   GPX_TRY(chol_potrf_nozero(ctx, D, nb, w, Dinv, base, n_valid));
   GPX_TRY(gpx_copy2d(ctx, D, nb, Ablk, A->ld, w, w));
@@ -816,6 +817,14 @@ int gpx_dist2_diag_factor(gpx_ctx* ctx, gpx_mat* A, int64_t lr, int64_t lc, int6
 // context-owned scratch: calls must be issued in order on ONE stream (the PANEL stream of the panel loop).
 int gpx_dist2_panel_trsm(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t lc, int64_t w, gpx_mat* G, int64_t doff,
                          int64_t roff, int64_t nb) {
+  return gpx_dist2_panel_trsm_keep(ctx, A, lr0, m, lc, w, G, doff, roff, nb, -1);
+}
+
+// ... and, on the OWNER of the diagonal block (dslot = its local block row, -1 elsewhere), the explicit inverse is kept in the
+// local matrix for the distributed substitution: its diagonal solves then are one small GEMV instead of a 512-row sweep
+// through one workgroup (45 us), 2 N / nb of them in a chain.
+int gpx_dist2_panel_trsm_keep(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t lc, int64_t w, gpx_mat* G, int64_t doff,
+                              int64_t roff, int64_t nb, int64_t dslot) {
   GPX_ARG(ctx && G, "NULL argument");
   GPX_TRY(check_local(A, lr0, m, lc, w));
   const int64_t gld = gpx_g_ld(nb);
@@ -841,6 +850,24 @@ int gpx_dist2_panel_trsm(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64
     }
     double* inv = ctx->d2_scratch;
     GPX_TRY(chol_block_inverse(ctx, D, nb, D + nb * nb, inv, w, inv + nb * nb));
+    if (dslot >= 0) {
+      const int64_t slots = (A->prows + nb - 1) / nb;
+      GPX_ARG(dslot < slots, "diagonal slot outside the local matrix");
+      if (!A->dinv || A->dinv_nb != nb) {
+        if (A->dinv) gpx_dev_release(ctx, A->dinv, A->dinv_bytes);
+        A->dinv = nullptr;
+        void* pd;
+        GPX_TRY(gpx_dev_alloc(ctx, slots * 2 * nb * nb * 8, &pd));
+        A->dinv = (double*)pd;
+        A->dinv_bytes = slots * 2 * nb * nb * 8;
+        A->dinv_nb = nb;
+        A->dinv_ok.assign((size_t)slots, 0);
+      }
+      double* slot = A->dinv + dslot * 2 * nb * nb;   // [inverse | its transpose: the transposed sweep reads rows too]
+      GPX_HIP(hipMemcpyAsync(slot, inv, (size_t)(nb * nb * 8), hipMemcpyDeviceToDevice, ctx->stream));
+      GPX_TRY(chol_block_transpose(ctx, slot, slot + nb * nb, nb));
+      A->dinv_ok[(size_t)dslot] = 1;
+    }
     GPX_TRY(launch_gemm_tri(ctx, X, A->ld, inv, w, G->p + roff, gld, m, w, w, true, false, false, 2));
     return gpx_copy2d(ctx, G->p + roff, gld, X, A->ld, m, w);
   }
@@ -987,6 +1014,16 @@ int gpx_dist2_trsv_diag(gpx_ctx* ctx, const gpx_mat* A, int64_t lr, int64_t lc, 
     GPX_HIP(hipMalloc((void**)&ctx->trsv_scratch, (size_t)need));
     ctx->trsv_scratch_bytes = need;
   }
+  static const bool use_dinv = !(getenv("GPX_DIST2_DINV") && atoi(getenv("GPX_DIST2_DINV")) == 0);
+  if (use_dinv && A->dinv && w == A->dinv_nb && lr % w == 0 && (size_t)(lr / w) < A->dinv_ok.size() && A->dinv_ok[(size_t)(lr / w)]) {
+    // the block's explicit inverse is at hand (kept by the panel solve): v <- Dinv v or Dinv^T v as a row-per-wave GEMV
+    // (the transposed form reads the stored transpose), through the scratch vector
+    v->bbox_ok = 0;
+    const double* slot = A->dinv + (lr / w) * 2 * w * w;
+    GPX_TRY(chol_tri_gemv(ctx, transposed ? slot + w * w : slot, w, w, v->p + voff, ctx->trsv_scratch, transposed ? 0 : 1));
+    GPX_HIP(hipMemcpyAsync(v->p + voff, ctx->trsv_scratch, (size_t)(w * 8), hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+  }
   return chol_trsv_with_scratch(ctx, A->p + lr * A->ld + lc, A->ld, A->aux + (lr / GPX_TILE) * GPX_TILE * GPX_TILE,
                                 v->p + voff, w, transposed != 0, ctx->trsv_scratch);
 }
@@ -1075,7 +1112,7 @@ int gpx_program_run(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const int64_
       case GPX_OP_WAIT: r = gpx_event_wait(ctx, (int)a[0]); break;
       case GPX_OP_BEGIN: r = gpx_dist_begin(ctx); break;
       case GPX_OP_DIAG_FACTOR: r = gpx_dist2_diag_factor(ctx, h0, a[0], a[1], a[2], h1, a[3], a[4], a[5], a[6]); break;
-      case GPX_OP_PANEL_TRSM: r = gpx_dist2_panel_trsm(ctx, h0, a[0], a[1], a[2], a[3], h1, a[4], a[5], a[6]); break;
+      case GPX_OP_PANEL_TRSM: r = gpx_dist2_panel_trsm_keep(ctx, h0, a[0], a[1], a[2], a[3], h1, a[4], a[5], a[6], a[7] - 1); break;
       case GPX_OP_UPDATE: r = gpx_dist2_update(ctx, h0, a[0], a[1], a[2], a[3], h1, a[4], a[5], a[6], a[7]); break;
       case GPX_OP_UPDATE_MULTI: {
         // a: lr0, m, lc0, n, nb, Pr, Pc, pr, pc, piece_stride, nseg | below_diag << 8, extra offset of [G handles..., ks...]

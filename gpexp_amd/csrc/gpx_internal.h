@@ -101,6 +101,14 @@ struct gpx_mat {
   double* binv;
   int64_t binv_bytes;
   int64_t binv_ib;
+  // block-cyclic LOCAL matrix of the 2-D distributed factorisation: explicit inverses of the diagonal blocks this rank owns
+  // (slot = local block row), kept from the panel solves for the distributed substitution (gpx_dist2_trsv_diag):
+  // per slot [inverse | its transpose], dinv_nb x dinv_nb doubles each; dinv_ok[slot] = the slot holds the inverse of the
+  // CURRENT factor's block
+  double* dinv;
+  int64_t dinv_bytes;
+  int64_t dinv_nb;
+  std::vector<unsigned char> dinv_ok;
 };
 
 struct ProfRec {
@@ -264,6 +272,8 @@ int64_t chol_potrs_scratch_bytes(int64_t n);
 int chol_potrs(gpx_ctx* ctx, gpx_mat* L, double* v, double* scratch);
 // y[r] -= sum_c A[r][c] x[c] over a rows x cols block (cols a multiple of 2, ld even)
 int launch_gemv_sub(gpx_ctx* ctx, const double* A, int64_t ld, int64_t rows, int64_t cols, const double* x, double* y);
+int chol_block_transpose(gpx_ctx* ctx, const double* in, double* out, int64_t n);
+int chol_tri_gemv(gpx_ctx* ctx, const double* M, int64_t ld, int64_t sz, const double* y, double* x, int lower);
 
 // reduce.hip
 // out[j] = sum_i B[i][j] * v[i]   (v == nullptr: sum_i B[i][j]^2), i < rows, j < pcols; deterministic

@@ -685,8 +685,10 @@ class DeviceOps2D(Emitter, DeviceOps):
     def diag_factor(self, A, lr, lc, w, G, doff, nb, base, n_valid):
         self._emit(OP["DIAG_FACTOR"], (A, G), (lr, lc, w, doff, nb, base, n_valid))
 
-    def panel_trsm(self, A, lr0, m, lc, w, G, doff, roff, nb):
-        self._emit(OP["PANEL_TRSM"], (A, G), (lr0, m, lc, w, doff, roff, nb))
+    def panel_trsm(self, A, lr0, m, lc, w, G, doff, roff, nb, dslot=None):
+        """dslot (owner of the diagonal block only): its local block row -- the explicit inverse the solve builds is kept in A
+        for the distributed substitution's diagonal solves."""
+        self._emit(OP["PANEL_TRSM"], (A, G), (lr0, m, lc, w, doff, roff, nb, 0 if dslot is None else dslot + 1))
 
     def update(self, A, lr0, m, lc0, n, G, aoff, boff, w, nb):
         self._emit(OP["UPDATE"], (A, G), (lr0, m, lc0, n, aoff, boff, w, nb))
@@ -951,12 +953,13 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
             ops.wait(_ev2(E_COLREADY, k))
             lr0, m = geo.row_off(pr, geo.li0(pr, k)), geo.piece_rows(pr, k)
             roff = geo.piece_off(pr) + geo.dsz
+            dslot = (k // Pr) if owner else None                         # the owner keeps the block's explicit inverse
             if nxt and pr == r1:                                         # block row k+1 first: the next diagonal needs it
                 ops.panel_trsm(A, lr0, h1, lc, w, g, geo.piece_off(kr), roff, nb)
                 ops.record(_ev2(E_EARLYSOLVED, k))
-                ops.panel_trsm(A, lr0 + h1, m - h1, lc, w, g, geo.piece_off(kr), roff + h1 * geo.gld, nb)
+                ops.panel_trsm(A, lr0 + h1, m - h1, lc, w, g, geo.piece_off(kr), roff + h1 * geo.gld, nb, dslot)
             else:
-                ops.panel_trsm(A, lr0, m, lc, w, g, geo.piece_off(kr), roff, nb)
+                ops.panel_trsm(A, lr0, m, lc, w, g, geo.piece_off(kr), roff, nb, dslot)
             ops.record(_ev2(E_PIECE, k))
         if nxt and pr == r1:
             ops.stream(COMM)

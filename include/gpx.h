@@ -299,6 +299,10 @@ int gpx_dist2_diag_factor(gpx_ctx* ctx, gpx_mat* A, int64_t lr, int64_t lc, int6
 /* holders of block column k: local rows [lr0, lr0+m) of the column <- X L_kk^-T, packed into G at roff */
 int gpx_dist2_panel_trsm(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t lc, int64_t w, gpx_mat* G, int64_t doff,
                          int64_t roff, int64_t nb);
+/* the same; on the owner of the diagonal block (dslot = its local block row, -1 elsewhere) the explicit inverse the solve
+ * builds is KEPT in the local matrix, and gpx_dist2_trsv_diag uses it (one small GEMV instead of a block sweep) */
+int gpx_dist2_panel_trsm_keep(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t lc, int64_t w, gpx_mat* G, int64_t doff,
+                              int64_t roff, int64_t nb, int64_t dslot);
 /* A[lr0:lr0+m, lc0:lc0+n] -= G[aoff] (m x w) * G[boff] (n x w)^T : trailing update of one local block column */
 int gpx_dist2_update(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t lc0, int64_t n, const gpx_mat* G,
                      int64_t aoff, int64_t boff, int64_t w, int64_t nb);

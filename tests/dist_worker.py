@@ -198,7 +198,7 @@ class NumpyOps2D(NumpyOps):
         """The C primitives reject blocks outside the local matrix (NumPy slicing would not)."""
         assert 0 <= lr0 and lr0 + m <= A.a.shape[0] and 0 <= lc and lc + w <= A.a.shape[1], (lr0, m, lc, w, A.a.shape)
 
-    def panel_trsm(self, A, lr0, m, lc, w, G, doff, roff, nb):
+    def panel_trsm(self, A, lr0, m, lc, w, G, doff, roff, nb, dslot=None):
         self._inside(A, lr0, m, lc, w)
         if m == 0:
             return
