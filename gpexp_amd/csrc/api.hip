@@ -420,6 +420,8 @@ int gpx_create(int device, gpx_ctx** out) {
   c->trsv_scratch_bytes = 0;
   c->d2_scratch = nullptr;
   c->d2_scratch_bytes = 0;
+  c->ev_scratch = nullptr;
+  c->ev_scratch_bytes = 0;
   *out = c;
   return 0;
 }
@@ -474,6 +476,7 @@ int gpx_destroy(gpx_ctx* ctx) {
   (void)hipFree(ctx->d_scal);
   if (ctx->trsv_scratch) (void)hipFree(ctx->trsv_scratch);
   if (ctx->d2_scratch) (void)hipFree(ctx->d2_scratch);
+  if (ctx->ev_scratch) (void)hipFree(ctx->ev_scratch);
   for (auto ev : ctx->sync_events) (void)hipEventDestroy(ev);
   for (auto ev : ctx->la_events) (void)hipEventDestroy(ev);
   for (int i = 0; i < GPX_NSTREAMS; ++i) {

@@ -1430,6 +1430,25 @@ int chol_trsm_left_oop(gpx_ctx* ctx, gpx_mat* Lm, double* B, int64_t ldb, double
   return trsm_left_oop_rec(ctx, P, 0, P.nblk, B, ldb, W, ldw, m);
 }
 
+int chol_trsm_left_group(gpx_ctx* ctx, const double* Lg, int64_t ld, const double* invd, int64_t w, int64_t below, int64_t ib,
+                         double* B, int64_t ldb, int64_t m, double* inv, double* tmp, double* W, int64_t ldw) {
+  GPX_ARG(Lg && invd && B && inv && tmp && W && W != B && w > 0 && w % NB == 0 && ib >= NB && ib % NB == 0, "trsm group: bad arguments");
+  if (m == 0) return 0;
+  GPX_TRY(binv_build_range(ctx, Lg, ld, invd, inv, ib, w, tmp));
+  PotrsPlan P;
+  P.L = Lg;
+  P.ld = ld;
+  P.n = w;
+  P.ib = P.sib = ib;
+  P.nblk = (w + ib - 1) / ib;
+  P.binv = inv;
+  P.binvT = nullptr;
+  P.part = nullptr;
+  GPX_TRY(trsm_left_oop_rec(ctx, P, 0, P.nblk, B, ldb, W, ldw, m));
+  if (below > 0) GPX_TRY(launch_gemm(ctx, Lg + w * ld, ld, W, ldw, B + w * ldb, ldb, below, m, w, false, true, false));
+  return gpx_copy2d(ctx, W, ldw, B, ldb, w, m);   // the solved rows belong into B (the variances sum over all of its rows)
+}
+
 int64_t chol_potrs_scratch_bytes(int64_t n) { return n * 8 + colreduce_partial_elems(n, n) * 8 + 64; }
 
 int chol_potrs(gpx_ctx* ctx, gpx_mat* Lm, double* v, double* scratch) {

@@ -166,6 +166,8 @@ struct gpx_ctx {
   int64_t trsv_scratch_bytes;
   double* d2_scratch;        // 2-D distributed panel solve: explicit inverse of the current diagonal block + build scratch
   int64_t d2_scratch_bytes;  // (2 nb^2 doubles; used on the PANEL stream only, in step order)
+  double* ev_scratch;        // streamed evaluation (gpx_dist_ivar_group_at): block inverses of the group + their build scratch +
+  int64_t ev_scratch_bytes;  // the solved block rows W (w x m); used on ONE stream only, in group order
   // multi-GPU (RCCL communicator, opaque here; see dist.hip)
   void* comm;
   int rank, world;
@@ -263,6 +265,12 @@ int64_t chol_binv_elems(int64_t n);
 int chol_binv_finish(gpx_ctx* ctx, gpx_mat* L, int64_t ib);  // explicit inverses of L's diagonal blocks (order <= 1024), cached in L
 // W (n x m, separate buffer) = L^-1 B through the block inverses: B is consumed (its lower block rows are updated in place)
 int chol_trsm_left_oop(gpx_ctx* ctx, gpx_mat* L, double* B, int64_t ldb, double* W, int64_t ldw, int64_t m);
+// one GROUP step of a right-looking left solve: Lg = the group's w x w diagonal triangle (row stride ld, `below` more rows
+// underneath it), invd = the leaf inverses of its first row block, B = the group's w rows of the right-hand sides (m columns):
+//   B[0:w] <- Lg^-1 B[0:w];  B[w : w+below] -= Lg[w:, 0:w] B[0:w]
+// through explicit ib-order inverses built here (inv: ceil(w/ib) ib^2 doubles, tmp: the same, W: w x ldw doubles of scratch)
+int chol_trsm_left_group(gpx_ctx* ctx, const double* Lg, int64_t ld, const double* invd, int64_t w, int64_t below, int64_t ib,
+                         double* B, int64_t ldb, int64_t m, double* inv, double* tmp, double* W, int64_t ldw);
 // one right-looking panel step of that solve with the rows [r0, r1) of the factor only (a finished look-ahead panel): W[r0:r1]
 // from B[r0:r1] through the block inverses at `binv` (order ib, row stride ib), then B[r1:] -= L[r1:, r0:r1] W[r0:r1]
 int chol_trsm_left_oop_panel(gpx_ctx* ctx, const double* L, int64_t ld, int64_t n, const double* binv, int64_t ib, double* B,

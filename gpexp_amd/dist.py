@@ -1415,7 +1415,7 @@ class DistFitIvar2D:
 # =====================================================================================================================
 # BASELINE config C5 on N GPUs: hyper-parameter gradient of the log marginal likelihood + mutual-information design
 # =====================================================================================================================
-def dist_lml_grad(ctx, comm, spec, L, X, alpha, be=None):
+def dist_lml_grad(ctx, comm, spec, L, X, alpha, be=None, slabs=None):
     """Gradient of the log marginal likelihood w.r.t. (cl_0..cl_{d-1}, signalSize, noise [raw: the caller scales by 2 noise,
     gp.py:463-464]) with the TRACES SHARDED over the ranks (gp.py:444-466 builds an (N, N, d+2) array and needs all of
     K^-1).  Every rank holds the complete factor L (replicated by the distributed fit); rank r forms only the row slab
@@ -1425,9 +1425,15 @@ def dist_lml_grad(ctx, comm, spec, L, X, alpha, be=None):
     `be`: the device backend (gpexp_amd.device; the CPU tests pass a NumPy double with the same four functions)."""
     be = be or _dev
     n = X.shape[0]
-    b = be.lml_grad_slab_bounds(n, comm.world)
-    r0, r1 = b[comm.rank], b[comm.rank + 1]
-    sums = be.lml_grad_slab(ctx, spec, L, X, alpha, r0, r1) if r1 > r0 else np.zeros(spec.d + 2)
+    # A rank's share is cut further into `sub` slabs of equal work (the solves of a slab run against the trailing factor below
+    # its FIRST row: one slab over all rows costs 2 N^3, many slabs approach 2 N^3 / 3 -- single GPU, N = 65536: 7.8 s with one
+    # slab, 3.5 s with 16); about 16 slabs in total, at least one per rank.
+    sub = max(1, int(os.environ.get("GPX_C5_SLABS", "16")) // comm.world) if slabs is None else max(1, int(slabs))
+    b = be.lml_grad_slab_bounds(n, comm.world * sub)
+    sums = np.zeros(spec.d + 2)
+    for i in range(comm.rank * sub, (comm.rank + 1) * sub):
+        if b[i + 1] > b[i]:
+            sums = sums + be.lml_grad_slab(ctx, spec, L, X, alpha, b[i], b[i + 1])
     allsums = comm.allgather(sums)
     tot = np.zeros(spec.d + 2)
     for r in range(comm.world):
