@@ -167,7 +167,7 @@ def test_c5_full_size_fit_on_one_gpu(dev, ctx):
     """BASELINE config C5 at its full size: N=65536, d=10 ARD-SE (K = 34.4 GB, resident in HBM): K alpha = y on exact rows
     of K, 0 < var < noise at training points, log-likelihood reproducible bit for bit, and the hyper-parameter gradient
     (gpx_lml_grad: potri + one fused trace pass over K^-1) against central differences of the GPU log-likelihood at the
-    same size.  Phase times go to gpurun_out/r02_c5_times.json (copied to profiles/)."""
+    same size.  Phase times go to gpurun_out/c5_times.json (copied to profiles/)."""
     import json
     import os
     import time
@@ -226,7 +226,7 @@ def test_c5_full_size_fit_on_one_gpu(dev, ctx):
     times["eight_full_fits_for_fd_s"] = time.perf_counter() - t0
     times.update(N=N, d=d, loglike=float(ll), grad=[float(v) for v in g])
     if os.path.isdir("gpurun_out"):
-        with open(os.path.join("gpurun_out", "r02_c5_times.json"), "w") as f:
+        with open(os.path.join("gpurun_out", "c5_times.json"), "w") as f:
             json.dump(times, f, indent=1)
     del K
     ctx.trim()
