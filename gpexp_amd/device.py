@@ -384,12 +384,36 @@ def mi_greedy(ctx, spec, Cpts, noise, nsel, start=0):
     return out, ratios
 
 
-def lml_grad(ctx, spec, L, X, alpha):
-    """[d/d hyp_0 .. d/d hyp_{n-1}, raw d/d noise] of the log marginal likelihood (SE kernel)."""
+# From this order on the gradient is formed slab by slab (no N x N inverse is ever allocated).  Measured warm, MI355X (scripts/
+# probe_lml_grad.py): N = 32768: potri form 0.446 s, 32 slabs 0.485 s; N = 65536: 3.415 s against 3.457 s -- but the potri form's
+# first call at that size costs 4.6 s (a fresh 34 GB allocation) and keeps those 34 GB in the pool.
+LML_GRAD_SLAB_MIN = 49152
+
+
+def lml_grad_full(ctx, spec, L, X, alpha):
+    """gpx_lml_grad: explicit inverse (potri) + one fused trace pass over it -- allocates an N x N matrix."""
     alpha = as_f64(alpha)
     out = np.empty(spec.hyp.size + 1)
     check(ctx.lib.gpx_lml_grad(ctx.h, *spec.args(), L.h, X.h, dptr(alpha), dptr(out)))
     return out
+
+
+def lml_grad(ctx, spec, L, X, alpha, slabs=None):
+    """[d/d hyp_0 .. d/d hyp_{n-1}, raw d/d noise] of the log marginal likelihood (SE kernel; gp.py:444-466).
+    Large factors: the traces are summed over `slabs` row slabs of K^-1 of equal work (gpx_lml_grad_slab: two triangular solves
+    against the trailing factor per slab) -- the same flops as potri in the limit, but no N x N inverse in memory (34 GB at
+    N = 65536, whose first allocation alone costs seconds) and the form the multi-GPU path shards; small ones: gpx_lml_grad."""
+    n = X.shape[0]
+    if slabs is None:
+        slabs = 32 if n >= LML_GRAD_SLAB_MIN else 0
+    if not slabs:
+        return lml_grad_full(ctx, spec, L, X, alpha)
+    b = lml_grad_slab_bounds(n, int(slabs))
+    sums = np.zeros(spec.d + 2)
+    for r0, r1 in zip(b[:-1], b[1:]):
+        if r1 > r0:
+            sums += lml_grad_slab(ctx, spec, L, X, alpha, r0, r1)
+    return lml_grad_from_sums(spec, sums)
 
 
 class MiState:
