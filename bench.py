@@ -267,6 +267,9 @@ def dist_preflight(ctx, comm, dist, dev, spec, d, nb=256, two_d=True, n=2048, m=
            "rel_err_loglike": abs(ll - ll1) / abs(ll1) if (two_d or comm.rank == 0) else 0.0,
            "rel_err_ivar": abs(iv - iv1) / abs(iv1)}
     ok = out["rel_err_loglike"] <= 1e-10 and out["rel_err_ivar"] <= 1e-10
+    if two_d and os.environ.get("GPX_TEST_FAIL_2D_PREFLIGHT") == "1":     # test hook: exercise the fall-back to the 1-D layout
+        ok = False
+        out["forced_failure"] = True
     L1 = K1.to_host(tri=1)
     scale = float(np.max(np.abs(L1)))
     if two_d:
@@ -401,9 +404,23 @@ def main():
             pf_timer.daemon = True
             pf_timer.start()
             preflight = dist_preflight(ctx, comm, dist, dev, spec, d, nb=min(nb, 256), two_d=want_2d)
-            pf_timer.cancel()
             print("bench.py: preflight rank %d: %s" % (rank, json.dumps(preflight)), file=sys.stderr, flush=True)
             bad = comm.allgather(np.array([0.0 if preflight["ok"] else 1.0]))[:, 0]
+            if bad.max() > 0 and want_2d:
+                # a WRONG (not hanging) 2-D step: all ranks agree (the all-gather above) to try the simpler 1-D block-column
+                # layout -- one ncclBroadcast per panel, every rank holds the matrix -- rather than to report nothing
+                print("bench.py: rank %d: 2-D preflight FAILED on rank(s) %s; ALL ranks fall back to the 1-D block-column layout"
+                      % (rank, [i for i, v in enumerate(bad) if v > 0]), file=sys.stderr, flush=True)
+                first = preflight
+                del runner
+                want_2d = False
+                runner = dist.DistFitIvar(ctx, comm, spec, Xh, yh, Zh, noise, nb=nb)
+                layout = "1-D block-cyclic columns (the 2-D preflight failed)"
+                preflight = dist_preflight(ctx, comm, dist, dev, spec, d, nb=min(nb, 256), two_d=False)
+                preflight["failed_2d_preflight"] = first
+                print("bench.py: preflight (1-D) rank %d: %s" % (rank, json.dumps(preflight)), file=sys.stderr, flush=True)
+                bad = comm.allgather(np.array([0.0 if preflight["ok"] else 1.0]))[:, 0]
+            pf_timer.cancel()
             if bad.max() > 0:
                 print("bench.py: preflight FAILED on rank(s) %s -- not timing a wrong result" % [i for i, v in enumerate(bad) if v > 0],
                       file=sys.stderr, flush=True)
