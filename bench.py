@@ -253,6 +253,8 @@ def dist_preflight(ctx, comm, dist, dev, spec, d, nb=256, two_d=True, n=2048, m=
     that differs by more than 1e-10."""
     Xh, yh, Zh, noise = workload(n, d, m, seed=12345)
     t0 = time.perf_counter()
+    if two_d and os.environ.get("GPX_TEST_HANG_2D_PREFLIGHT") == "1":     # test hook: a collective that never completes
+        time.sleep(1e6)
     if two_d:
         run = dist.DistFitIvar2D(ctx, comm, spec, Xh, yh, Zh, noise, nb=nb)
     else:
@@ -310,6 +312,35 @@ def dist_preflight(ctx, comm, dist, dev, spec, d, nb=256, two_d=True, n=2048, m=
     return out
 
 
+PREFLIGHT_HANG = 125     # exit code of a rank whose preflight step never finished (its own watchdog)
+
+
+def supervise(world, rank):
+    """N > 1: the work runs in a CHILD process of this one.  This process never touches the GPU, so it may start programs; it
+    exists for one case -- RCCL with more than one rank has never run on the build's hardware, and a collective that never
+    completes can only be left by ending the process.  When the child ends at the PREFLIGHT watchdog on the 2-D layout (every
+    rank's child does: they hang in the same collective, and a rank that got through waits for the others in the all-gather
+    behind it), every rank's supervisor starts a second child on the simpler 1-D block-column layout (one ncclBroadcast per
+    panel) with a fresh rendezvous, instead of reporting nothing.  Any other outcome is passed through."""
+    import subprocess
+    key = "%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid())
+    attempts = ["2d", "1d"] if os.environ.get("GPX_DIST_LAYOUT", "2d") != "1d" else ["1d"]
+    code = 1
+    for i, layout in enumerate(attempts):
+        env = dict(os.environ, GPX_BENCH_CHILD="1", GPX_RDV_KEY="%s_try%d" % (key, i), GPX_DIST_LAYOUT=layout)
+        if i > 0 and env.get("MASTER_PORT", "").isdigit():
+            # (only the host-staged TEST communicator rendezvouses through torch.distributed: a store of its own, on the next
+            # port, instead of the launcher's, which still holds the first attempt's keys)
+            env["MASTER_PORT"] = str(int(env["MASTER_PORT"]) + 1)
+            env["TORCHELASTIC_USE_AGENT_STORE"] = "False"
+        code = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env).returncode
+        if code != PREFLIGHT_HANG or i + 1 == len(attempts):
+            break
+        print("bench.py: supervisor of rank %d: the %s preflight never finished -- second attempt on the 1-D block-column layout"
+              % (rank, layout), file=sys.stderr, flush=True)
+    return code
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -328,6 +359,10 @@ def main():
     ap.add_argument("--cpu-baseline", choices=["bounded", "full"], default="bounded",
                     help="full: SURVEY.md 8d's whole protocol (adds N=8192 and the fair-CPU Cholesky at N=32768; minutes)")
     args = ap.parse_args()
+
+    if (int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("GPX_BENCH_CHILD") != "1"
+            and os.environ.get("GPX_BENCH_SUPERVISE", "1") == "1"):
+        sys.exit(supervise(int(os.environ["WORLD_SIZE"]), int(os.environ.get("RANK", "0"))))
 
     # The contract is ONE JSON line on stdout, and native libraries write there too (RCCL's version banner at init and at
     # ncclCommSplit, gloo's connection lines in the host-staged rehearsal): fd 1 points at stderr until the line is printed.
@@ -392,13 +427,13 @@ def main():
             # its own, SHORT watchdog: a collective that never completes at first contact should cost minutes, not the timed
             # region's whole allowance, and say that it was the preflight
             import threading
-            pf_limit = float(os.environ.get("GPX_BENCH_PREFLIGHT_WATCHDOG_S", "300"))
+            pf_limit = float(os.environ.get("GPX_BENCH_PREFLIGHT_WATCHDOG_S", "180"))
 
             def _pf_expired():
                 print("bench.py: watchdog: rank %d of %d: the PREFLIGHT step (N = 2048, %s layout) did not finish within %.0f s -- "
                       "a collective of the distributed path never completed; aborting (try GPX_DIST_LAYOUT=1d)"
                       % (rank, world, "2-D" if want_2d else "1-D", pf_limit), file=sys.stderr, flush=True)
-                os._exit(124)
+                os._exit(PREFLIGHT_HANG)
 
             pf_timer = threading.Timer(pf_limit, _pf_expired)
             pf_timer.daemon = True

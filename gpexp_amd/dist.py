@@ -186,8 +186,8 @@ class FileRendezvous:
     def __init__(self):
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        key = "%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
-                            os.getppid())
+        key = os.environ.get("GPX_RDV_KEY") or "%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"),
+                                                             os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid())
         self.path = os.path.join(os.environ.get("GPX_RDV_DIR", "/tmp"), "gpx_rdv_" + key)
 
     def exchange(self, payload):

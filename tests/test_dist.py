@@ -201,6 +201,26 @@ def test_bench_falls_back_to_1d_layout_when_the_2d_preflight_is_wrong():
 
 
 @pytest.mark.gpu
+def test_bench_restarts_on_1d_layout_when_the_2d_preflight_hangs():
+    """First contact, the other failure: a 2-D preflight that never finishes (forced: both ranks sleep in it).  The ranks' own
+    preflight watchdogs end the children (exit code 125), every rank's supervisor -- a process that never touched the GPU --
+    starts a second child on the 1-D layout with a fresh rendezvous, and ONE JSON line comes out, labelled 1-D."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPX_COMM="host", GPX_FORCE_DEVICE="0", MASTER_ADDR="127.0.0.1",
+               GPX_TEST_HANG_2D_PREFLIGHT="1", GPX_BENCH_PREFLIGHT_WATCHDOG_S="15")
+    flags = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--train-points", "4096", "--mc-points", "2048"]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2"] + flags, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-3000:]
+    assert "second attempt on the 1-D block-column layout" in two.stderr
+    lines = [ln for ln in two.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines[:3]
+    got = json.loads(lines[0])
+    assert got["n_gpus"] == 2 and "1-D" in got["config"]["parallelism"] and got["preflight"]["ok"]
+
+
+@pytest.mark.gpu
 def test_bench_c4_full_size_four_ranks_equals_single_gpu():
     """The headline step at its full size (N = 32768, d = 8, M = 32768) through bench.py exactly as the driver launches it
     with 4 ranks (2 x 2 grid, streamed evaluation; the ranks share this box's GPU through the host-staged communicator)
