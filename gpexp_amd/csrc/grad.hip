@@ -56,6 +56,26 @@ __device__ __forceinline__ bool same_point(const double* __restrict__ a, const d
 
 // ---- IVAR gradient: one workgroup per design point a ------------------------------------------------------------------
 // grad[a][l] = 1/M ( 2 sum_m Bm[a][m] dk(z_m, x_a)[l] + 2 sum_i c_al[i] S[a][i] - c_al[a] S[a][a] )
+// S (n x n, row stride ld, n a multiple of 32): the strictly upper triangle <- the transpose of the lower one.  One 32 x 32
+// tile pair per workgroup (blockIdx.x enumerates the tiles on / below the diagonal); a diagonal tile mirrors inside itself.
+__global__ __launch_bounds__(256) void mirror_lower_kernel(double* __restrict__ S, int64_t ld, int nt) {
+  __shared__ double tile[32][33];
+  // tile (ti, tj), tj <= ti, from the linear index: ti (ti + 1) / 2 + tj
+  int ti = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
+  while ((int64_t)(ti + 1) * (ti + 2) / 2 <= (int64_t)blockIdx.x) ++ti;
+  while ((int64_t)ti * (ti + 1) / 2 > (int64_t)blockIdx.x) --ti;
+  const int tj = (int)((int64_t)blockIdx.x - (int64_t)ti * (ti + 1) / 2);
+  if (ti >= nt) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int64_t i0 = (int64_t)ti * 32, j0 = (int64_t)tj * 32;
+  for (int r = ty; r < 32; r += 8) tile[r][tx] = S[(i0 + r) * ld + j0 + tx];
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    // element (j0 + r, i0 + tx) = S[i0 + tx][j0 + r]; on a diagonal tile only the part above the diagonal is written
+    if (ti != tj || tx > r) S[(j0 + r) * ld + i0 + tx] = tile[tx][r];
+  }
+}
+
 __global__ __launch_bounds__(256) void ivar_grad_row_kernel(KParams kp, const double* __restrict__ X, int64_t n,
                                                             const double* __restrict__ Z, int64_t m,
                                                             const double* __restrict__ Bm, int64_t ldb,
@@ -276,7 +296,14 @@ int gpx_ivar_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, co
   GPX_TRY(upload(ctx, sc, noise_deriv, n * d, &d_nd));
   double* W = (double*)pW;
   GPX_TRY(solve_beta(ctx, kp, L, X, Z->p, m, mp, nullptr, W, (double*)pWt));
-  GPX_TRY(launch_gemm(ctx, W, mp, W, mp, (double*)pS, np, np, np, mp, true, false, false));  // S = beta beta^T
+  // S = beta beta^T: symmetric -- only the tiles on / below the diagonal are computed (N^2 M flops instead of 2 N^2 M), the
+  // rest is mirrored (the row kernel reads whole rows)
+  GPX_TRY(launch_gemm(ctx, W, mp, W, mp, (double*)pS, np, np, np, mp, true, false, true));
+  {
+    const int nt = (int)(np / 32);
+    hipLaunchKernelGGL(mirror_lower_kernel, dim3((unsigned)((int64_t)nt * (nt + 1) / 2)), dim3(256), 0, ctx->stream, (double*)pS, np, nt);
+    GPX_HIP(hipGetLastError());
+  }
   {
     ProfScope ps(ctx, GPX_PROF_REDUCE, 0.0, 8.0 * ((double)n * m + (double)n * n));
     hipLaunchKernelGGL(ivar_grad_row_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, kp, X->p, n, Z->p, m,
