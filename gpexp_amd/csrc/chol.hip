@@ -1222,8 +1222,13 @@ static int binv_build_rec(gpx_ctx* ctx, const double* L, int64_t ld, int64_t sl,
   const double* Bi = binv + (r0 + s1) * ib + r0 + s1;
   double* R = binv + (r0 + s1) * ib + r0;  // zero so far
   // T = C A^-1 ; R = 0 - B^-1 T
-  if (batch == 1 && s1 >= 1024) {  // one large block: the tuned kernel, B^-1 as a triangular operand
-    GPX_TRY(launch_gemm(ctx, C, ld, Ai, ib, tmp, s1, s2, s1, s1, false, false, false));
+  if (batch == 1 && s1 >= 1024) {  // one large block: the tuned kernel, both inverses as triangular operands (A^-1: k range
+    // of a column tile starts at its diagonal, mode 4; B^-1: ends at it, mode 1) -- n^3 / 3 for the whole recursion
+    static const bool tri_a = !(getenv("GPX_TRTRI_DENSE_A") && atoi(getenv("GPX_TRTRI_DENSE_A")) != 0);
+    if (tri_a)
+      GPX_TRY(launch_gemm_tri(ctx, C, ld, Ai, ib, tmp, s1, s2, s1, s1, false, false, false, 4));
+    else
+      GPX_TRY(launch_gemm(ctx, C, ld, Ai, ib, tmp, s1, s2, s1, s1, false, false, false));
     return launch_gemm_tri(ctx, Bi, ib, tmp, s1, R, ib, s2, s1, s2, false, true, false, 1);
   }
   GPX_TRY(launch_gemm_batched(ctx, C, ld, sl, Ai, ib, ib * ib, tmp, s1, ib * ib, s2, s1, s1, false, false, batch));

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64
   const int xcd = w & 7, q = w >> 3;
   const int sbs2 = 2 * sb_shift;
   int by, bx;
-  if (!tile_of<LOWER>((q >> sbs2) * 8 + xcd, q & ((1 << sbs2) - 1), tiles_m, tiles_n, sb_cols, sb_shift, &by, &bx, tri == 2))
+  if (!tile_of<LOWER>((q >> sbs2) * 8 + xcd, q & ((1 << sbs2) - 1), tiles_m, tiles_n, sb_cols, sb_shift, &by, &bx, tri == 2 || tri == 4))
     return;
   // (Dealing single tiles of a triangular product to XCDs diagonally balances them too, but gives up the super-blocks'
   // operand reuse in L2: measured 11.9 ms against 13.1 dense for 28672 x 4096 x 4096 -- fabric-bound.)
@@ -378,6 +378,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64
     A += k0;
     B += k0;
     nkt = nk - by * (TE / KB);
+  }
+  if (tri == 4) {  // B (k x n, not transposed) lower triangular: column tile bx has nothing above row bx * TE
+    const int64_t k0 = (int64_t)bx * TE;
+    A += k0;
+    B += k0 * ldb;
+    nkt = nk - bx * (TE / KB);
   }
   gemm_tile<BT, ACC, TE>(sm, A, lda, B, ldb, C, ldc, nkt, by, bx);
 }
@@ -552,12 +558,14 @@ int launch_gemm(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int
 }
 
 // tri: 0 = dense operands; 1 = A is lower triangular (k == m); 2 = B is a lower-triangular n x k matrix used transposed
-// (bt, k == n); 3 = lower C = U U^T with A = B = U upper triangular (bt, lower): the structurally zero part of the k range
+// (bt, k == n); 4 = B is a lower-triangular k x n matrix used as it is (!bt, k == n: the k range of a column tile STARTS at
+// its diagonal); 3 = lower C = U U^T with A = B = U upper triangular (bt, lower): the structurally zero part of the k range
 // is skipped per tile
 int launch_gemm_tri(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
                     int64_t m, int64_t n, int64_t k, bool bt, bool accumulate, bool lower, int tri) {
   if (m == 0 || n == 0) return 0;
-  GPX_ARG(tri == 0 || (!lower && ((tri == 1 && k == m) || (tri == 2 && bt && k == n))) || (tri == 3 && lower && bt && k == m),
+  GPX_ARG(tri == 0 || (!lower && ((tri == 1 && k == m) || (tri == 2 && bt && k == n) || (tri == 4 && !bt && k == n))) ||
+              (tri == 3 && lower && bt && k == m),
           "gemm: bad triangular-operand mode");
   GPX_ARG(m % 128 == 0 && n % 128 == 0 && k % KB == 0 && k > 0, "gemm: m,n must be multiples of 128 and k of 16");
   GPX_ARG((lda % 2) == 0 && (ldb % 2) == 0, "gemm: leading dimensions must be even (16-byte loads)");
@@ -618,6 +626,7 @@ int launch_gemm_tri(gpx_ctx* ctx, const double* A, int64_t lda, const double* B,
     else if (tri == 1 && !bt && accumulate) GPX_GT(false, true, false, 1);
     else if (tri == 2 && !accumulate) GPX_GT(true, false, false, 2);
     else if (tri == 3 && !accumulate) GPX_GT(true, false, true, 3);
+    else if (tri == 4 && !accumulate) GPX_GT(false, false, false, 4);
     else {
       gpx_set_error("gemm: triangular-operand mode %d is not instantiated for bt=%d accumulate=%d", tri, (int)bt, (int)accumulate);
       return -1;

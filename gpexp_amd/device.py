@@ -385,8 +385,8 @@ def mi_greedy(ctx, spec, Cpts, noise, nsel, start=0):
 
 
 # From this order on the gradient is formed slab by slab (no N x N inverse is ever allocated).  Measured warm, MI355X (scripts/
-# probe_lml_grad.py): N = 32768: potri form 0.446 s, 32 slabs 0.485 s; N = 65536: 3.415 s against 3.457 s -- but the potri form's
-# first call at that size costs 4.6 s (a fresh 34 GB allocation) and keeps those 34 GB in the pool.
+# probe_lml_grad.py): N = 32768: potri form 0.365 s, 32 slabs 0.485 s; N = 65536: 2.82 s against 3.48 s -- but the potri form
+# then holds 210 GB of the 288 GB (inverse + the recursion's scratch), so the default stays on the side of memory.
 LML_GRAD_SLAB_MIN = 49152
 
 
