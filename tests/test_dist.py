@@ -180,6 +180,19 @@ def test_2d_loop_under_random_stream_delays(world, n, nb, grid, seed):
 
 
 @pytest.mark.gpu
+def test_replayed_ranks_over_block_sizes_group_sizes_and_grids():
+    """scripts/replay_matrix.sh: one process plays ranks of 1x2 ... 4x2 grids with the recorded programs and real kernels --
+    evaluation streamed against the WINDOW of the factor at every world size, block sizes 128 ... 1024, 1 ... 8 panels per
+    group (ragged last groups, the window wrapping many times); every run checks its rank's variance sum against the
+    single-GPU path to 1e-10."""
+    env = dict(os.environ, GPX_DIST_STREAM_IVAR="1")
+    r = subprocess.run(["bash", os.path.join(ROOT, "scripts", "replay_matrix.sh")], env=env, cwd=ROOT, capture_output=True, text=True,
+                       timeout=1200)
+    assert r.returncode == 0 and "FAIL" not in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("ok ") == 24, r.stdout
+
+
+@pytest.mark.gpu
 def test_bench_falls_back_to_1d_layout_when_the_2d_preflight_is_wrong():
     """First contact: a 2-D preflight that computes something WRONG (forced here on both ranks) must not end the run -- all
     ranks agree to rebuild the runner on the 1-D block-column layout, that layout passes its own preflight, and the line that
