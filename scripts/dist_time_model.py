@@ -19,6 +19,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 f_fit = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_dist_replay_fit_only.json")
 f_all = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r03_dist_replay_fit_ivar.json")
 LINK, EFF, LAT = 153e9, 0.8, 25e-6
+# The GLOBAL diagonal chain, which no single-rank replay contains (a rank executes only the diagonal blocks it owns; the others'
+# arrive as copies): per panel step the potrf of one nb = 512 block (4 leaves + strip multiplies + rank-128 updates: 0.30 ms
+# measured), the early solve of block row k+1 (0.08 ms) and two small broadcasts -- a lower bound of the factorisation at any grid.
+CHAIN_STEP = 0.30e-3 + 0.08e-3 + 2 * LAT
 
 
 def worst(path):
@@ -45,10 +49,11 @@ for g in ("1x1", "1x2", "2x2", "2x4"):
     links = max(W - 1, 1)
     comm = (r["bytes_received_per_fit"] / (links * LINK * EFF) + 2 * LAT * r["steps_k"]) if W > 1 else 0.0
     t = r["ms_per_step"] * 1e-3
-    lo, hi = max(t, comm), t + comm
-    print("%-5s %6d | %12.1f %10.1f %9.2f %8.1f | %8.1f ms %8.1f ms | %6.1fx .. %5.1fx" %
+    chain = CHAIN_STEP * r["steps_k"] if W > 1 else 0.0
+    lo, hi = max(t, comm, chain), max(t, chain) + comm
+    print("%-5s %6d | %12.1f %10.1f %9.2f %8.1f | %8.1f ms %8.1f ms | %6.1fx .. %5.1fx   (global chain floor %.1f ms)" %
           (g, W, 1e3 * t, r["host_issue_ms_per_fit"], r["bytes_received_per_fit"] / 1e9, 1e3 * comm, 1e3 * lo, 1e3 * hi,
-           single_potrf / (1e3 * hi), single_potrf / (1e3 * lo)))
+           single_potrf / (1e3 * hi), single_potrf / (1e3 * lo), 1e3 * chain))
 print("\nFIT + IVAR over M = 32768 (the bench step without alpha / logdet; IVAR streamed from 4 ranks)")
 print("%-5s %6s | %12s %9s %8s | %11s %11s" % ("grid", "ranks", "GPU ms/step", "GB recv", "comm ms", "overlapped", "exposed"))
 for g in ("1x1", "1x2", "2x2", "2x4"):
@@ -62,4 +67,6 @@ for g in ("1x1", "1x2", "2x2", "2x4"):
     extra = "" if r["streamed_ivar"] else "  (+ IVAR after the fit: ~487 ms / %d ranks, not in this replay)" % W
     print("%-5s %6d | %12.1f %9.2f %8.1f | %8.1f ms %8.1f ms%s" % (g, W, 1e3 * t, r["bytes_received_per_fit"] / 1e9, 1e3 * comm,
                                                                  1e3 * max(t, comm), 1e3 * (t + comm), extra))
-print("\nNOT measured: xGMI transfer time, RCCL launch latency, waiting for peers.  Measured: everything a rank's GPU and host do.")
+print("\nalpha / log det behind the step: 2.8 ms of launches (streamed grids: backward sweep only, 128 small collectives) or 3.6 ms "
+      "(grids with a replica: local sweeps, no exchange) -- scripts/probe_dist_solve.py")
+print("NOT measured: xGMI transfer time, RCCL launch latency, waiting for peers.  Measured: everything a rank's GPU and host do.")
