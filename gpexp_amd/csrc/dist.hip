@@ -5,8 +5,9 @@
 //   2-D block-cyclic (the default; second half of this file, "gpx_dist2_*"): process grid Pr x Pc, global block (I, J) on rank
 //   (I % Pr, J % Pc); ncclCommSplit row / column sub-communicators; diagonal block broadcast down the process column, every
 //   piece of a panel to every rank over all xGMI links (grouped ncclSend / ncclRecv scatter + all-gather), trailing updates by
-//   groups of panels in one segmented launch; every rank keeps the finished panels in a replicated copy of L for the
-//   evaluation phase.  The recorded-program executor (gpx_program_run) is at the end.
+//   groups of panels in one segmented launch; every rank keeps the finished panels for the evaluation phase -- a window of
+//   block columns that the streamed evaluation consumes as they arrive (gpx_dist_ivar_group_at), or a replicated copy of L.
+//   The recorded-program executor (gpx_program_run) is at the end.
 //
 //   1-D block columns (round 1, GPX_DIST_LAYOUT=1d; first half, "gpx_dist_*"): every rank holds a full-size matrix, block
 //   column j is owned by rank j % world; the owner packs + factors the panel and ncclBroadcast's it, every rank stores it and

@@ -11,7 +11,9 @@ two shardings:
         reaches every rank over all xGMI links (grouped ncclSend / ncclRecv scatter + all-gather), and every rank
         updates its local blocks -- the next two block columns at once (look-ahead: they gate the diagonal chain),
         everything else in GROUPS of `agg` panels (one launch over the whole local trailing matrix with K = agg * nb).
-        Every rank also keeps each finished panel in a replicated copy of L for the evaluation phase.
+        Every rank also keeps the finished panels for the evaluation phase: a WINDOW of two groups of them when the
+        evaluation is streamed underneath the factorisation (every panel is consumed when it arrives: no N x N replica, the
+        factor stays distributed), a replicated copy of L otherwise (evaluation after the fit at 1-2 ranks, the C5 gradient).
         (`DistFitIvar` / `dist_potrf`: round 1's 1-D block-column layout, GPX_DIST_LAYOUT=1d.)
   eval  posterior / IVAR evaluation points are split in contiguous slices [r*M/W, (r+1)*M/W), exactly the
         chunking the reference's helper intends (parallel_utilities.py:46-60); each rank solves against its own
