@@ -12,7 +12,9 @@ One step = the whole hot path on that batch, inputs already resident in HBM:
     K = kfill(X) + noise I  ->  L = potrf(K)  ->  alpha = potrs(L, y)  ->  logdet  ->  log marginal likelihood
     ->  IVAR = mean_z [k(z,z) - |L^-1 k(X,z)|^2] over the M points.
 value = (N + M) points / step time (whole job, all ranks); ms_per_step is the GP-fit + IVAR-eval wall time.
-With --gpus N > 1 the same total problem is split over the ranks (strong scaling): see gpexp_amd/dist.py.
+With --gpus N > 1 the same total problem is split over the ranks (strong scaling): see gpexp_amd/dist.py.  Each launched rank
+process then only SUPERVISES a child that does the work (it never touches the GPU): a first-contact preflight that hangs on the
+2-D layout is retried once on the 1-D layout instead of ending the run (supervise()).
 
 Extra objects on the JSON line: "roofline" for the dominant kernel (the fp64 MFMA GEMM behind SYRK/TRSM; HIP
 events recorded on the launch stream by the library around every launch inside the timed region) and
