@@ -29,6 +29,7 @@ _SIGS = {
     "gpx_mat_from_host": (C.c_int, [c_vp, c_dp, c_i64, c_i64, C.c_int, C.POINTER(c_vp)]),
     "gpx_mat_alloc": (C.c_int, [c_vp, c_i64, c_i64, C.c_int, C.POINTER(c_vp)]),
     "gpx_mat_free": (C.c_int, [c_vp, c_vp]),
+    "gpx_mat_clone": (C.c_int, [c_vp, c_vp, C.POINTER(c_vp)]),
     "gpx_mat_shape": (C.c_int, [c_vp, c_ip, c_ip, c_ip]),
     "gpx_mat_to_host": (C.c_int, [c_vp, c_vp, c_dp, C.c_int]),
     "gpx_kfill": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_dp, c_i64, C.POINTER(c_vp)]),

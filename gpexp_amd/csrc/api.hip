@@ -564,6 +564,41 @@ int gpx_mat_from_host(gpx_ctx* ctx, const double* src, int64_t rows, int64_t col
   return 0;
 }
 
+int gpx_mat_clone(gpx_ctx* ctx, const gpx_mat* src, gpx_mat** out) {
+  GPX_ARG(ctx && src && out, "NULL argument");
+  const int padded = src->prows != (src->rows > 0 ? src->rows : 1) || src->pcols != (src->cols > 0 ? src->cols : 1) ||
+                     src->ld != src->pcols;
+  GPX_TRY(gpx_mat_new(ctx, src->rows, src->cols, padded, out));
+  gpx_mat* m = *out;
+  if (m->bytes != src->bytes || m->ld != src->ld) {
+    gpx_mat_free(ctx, m);
+    *out = nullptr;
+    GPX_ARG(false, "clone: storage layout of the copy differs from the source");
+  }
+  GPX_HIP(hipMemcpyAsync(m->p, src->p, (size_t)src->bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  if (src->aux) {
+    void* p = nullptr;
+    int r = gpx_dev_alloc(ctx, src->aux_bytes, &p);
+    if (r != 0) {
+      gpx_mat_free(ctx, m);
+      *out = nullptr;
+      return r;
+    }
+    m->aux = (double*)p;
+    m->aux_bytes = src->aux_bytes;
+    GPX_HIP(hipMemcpyAsync(m->aux, src->aux, (size_t)src->aux_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  m->factored = src->factored;
+  m->bbox_ok = src->bbox_ok;
+  for (int k = 0; k < GPX_MAXD; ++k) {
+    m->lo[k] = src->lo[k];
+    m->hi[k] = src->hi[k];
+  }
+  // binv / dinv are caches rebuilt on demand (binv_ib = 0 from gpx_mat_new)
+  GPX_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
 int gpx_mat_free(gpx_ctx* ctx, gpx_mat* m) {
   if (!m) return 0;
   GPX_ARG(ctx != nullptr, "ctx is NULL");

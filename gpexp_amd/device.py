@@ -147,6 +147,13 @@ class DeviceMatrix:
             pass
 
 
+def clone(ctx, M):
+    """Device-to-device duplicate of a matrix including its factor state (gpx_mat_clone)."""
+    h = c_vp()
+    check(ctx.lib.gpx_mat_clone(ctx.h, M.h, C.byref(h)))
+    return DeviceMatrix(ctx, h)
+
+
 class KernelSpec:
     """Flat (kind, d, hyp[]) form of a covariance kernel, as the C ABI takes it."""
 

@@ -549,10 +549,14 @@ G_SKEW = 0                  # packed panel rows have stride nb + G_SKEW doubles 
                             # was measured and made no difference on MI355X)
 
 
+MAX_PR = 4                  # GPX_MAX_PR of csrc/gpx_internal.h: the segmented trailing update addresses at most 4 process rows
+
+
 def choose_grid(world):
-    """Pr x Pc with Pr <= Pc, Pr the largest divisor of `world` not above sqrt(world): 8 -> 2x4, 4 -> 2x2, 2 -> 1x2."""
+    """Pr x Pc with Pr <= Pc, Pr the largest divisor of `world` not above min(sqrt(world), MAX_PR): 8 -> 2x4, 4 -> 2x2, 2 -> 1x2,
+    25 -> 1x25 (a 5x5 grid would be rejected by the update kernel inside the first step)."""
     pr = 1
-    for c in range(1, int(world ** 0.5) + 1):
+    for c in range(1, min(int(world ** 0.5), MAX_PR) + 1):
         if world % c == 0:
             pr = c
     return pr, world // pr
@@ -563,6 +567,7 @@ class Grid2D:
 
     def __init__(self, n, nb, Pr, Pc, rank):
         assert nb % TILE == 0 and 0 <= rank < Pr * Pc
+        assert 1 <= Pr <= MAX_PR, "at most %d process rows (GPX_MAX_PR)" % MAX_PR
         self.n, self.nb, self.Pr, self.Pc, self.rank = int(n), int(nb), int(Pr), int(Pc), int(rank)
         self.pr, self.pc = rank // Pc, rank % Pc
         self.np = padded(n)
@@ -1512,3 +1517,236 @@ class DistFitGrad2D(DistFitIvar2D):
         t3 = time.perf_counter()
         self.times = {"fit_ms": 1e3 * (t1 - t0), "lml_grad_ms": 1e3 * (t2 - t1), "mi_ms": 1e3 * (t3 - t2)}
         return ll, grad, picks
+
+
+# =====================================================================================================================
+# The class API under a multi-process launch
+# =====================================================================================================================
+# Role replaced: the fork-and-gather INSIDE GP.evaluateVariance (gp.py:244-258 -> parallel_utilities.py:26-80) -- in the
+# reference the parallel backend sits behind the class API, so it does here.  Contract: SPMD.  Every rank runs the same
+# script on the same host data (one process per GPU, `python -m torch.distributed.run --nproc-per-node 8 demo.py`) and every
+# rank gets the same arrays back, bit for bit:
+#   fit        GP.train / addNodesAndComputeCovariance / computeLogLike / loglikeParams and every cost function that refits:
+#              2-D block-cyclic distributed assembly + factorisation (DistFitIvar2D.fit); every panel reaches every rank for
+#              the trailing update anyway, so every rank also assembles a REPLICA of the finished factor (N^2 doubles: 8.6 GB
+#              at C4, 34 GB at C5 of the 288 GB) -- the object the class API keeps as its "precision matrix" (gp.py:181).
+#              coeff / log det then come from the replica by the single-GPU sweeps (no exchange, identical on every rank).
+#   evaluate   GP.evaluate(compvar=0/1) / evaluateVariance / costFunctionGP_IVAR.evaluate / greedyIVARStep: the evaluation
+#              (candidate) points are split in contiguous slices (eval_slice: the chunking parallelizeMcForLoop intends,
+#              parallel_utilities.py:46-60), each rank solves its slice against its replica, and the slices are
+#              all-gathered (posterior MEAN and the per-point variance VECTOR on every rank, not only the IVAR sum).
+#   gradient   loglikeParams(returnDeriv=1): dist_lml_grad (row slabs of K^-1);  MI design: dist_mi_greedy.
+# Small problems stay replicated (every rank computes everything, no exchange): below GPX_DIST_MIN_N training points
+# (default 2048) a distributed factorisation is latency, not throughput, and below GPX_DIST_MIN_M evaluation points
+# (default 4096) so is the gather.  All ranks take these decisions from the same numbers.
+_session = None
+_auto_tried = False
+
+
+class Session:
+    """Link between the GPEXP class API and the distributed runners of this module.  `be` = the device backend module
+    (gpexp_amd.device; the CPU tests pass a NumPy double), `ops_factory()` -> DeviceOps2D (or its double)."""
+
+    def __init__(self, ctx, comm, be=None, ops_factory=None, min_n=None, min_m=None, check=None):
+        self.ctx, self.comm = ctx, comm
+        self.be = be or _dev
+        self.ops_factory = ops_factory or (lambda: DeviceOps2D(ctx))
+        self.min_n = int(os.environ.get("GPX_DIST_MIN_N", "2048")) if min_n is None else int(min_n)
+        self.min_m = int(os.environ.get("GPX_DIST_MIN_M", "4096")) if min_m is None else int(min_m)
+        self.check = (os.environ.get("GPX_DIST_CHECK", "1") == "1") if check is None else bool(check)
+        self._runner = None          # (key, DistFitIvar2D): buffers + recorded programs of the last problem size
+        self.stats = dict(fits=0, evals=0, grads=0)
+
+    @property
+    def rank(self):
+        return self.comm.rank
+
+    @property
+    def world(self):
+        return self.comm.world
+
+    # ---- decisions (functions of sizes only: identical on every rank) ----
+    def use_fit(self, n):
+        return self.world > 1 and n >= max(self.min_n, 1)
+
+    def use_eval(self, m):
+        return self.world > 1 and m >= max(self.min_m, self.world)
+
+    @staticmethod
+    def nb_for(n):
+        return 512 if n >= 8192 else (256 if n >= 2048 else 128)
+
+    # ---- the SPMD contract, checked ----
+    def agree(self, what, *arrays):
+        """Every rank must have passed the same data: one all-gather of a 96-bit digest; raises on EVERY rank otherwise
+        (a rank that went on alone would hang the others in the next collective).  GPX_DIST_CHECK=0 switches it off."""
+        if not self.check:
+            return
+        import hashlib
+        h = hashlib.blake2b(digest_size=12)
+        for a in arrays:
+            a = np.ascontiguousarray(a)
+            h.update(str((a.dtype.str, a.shape)).encode())
+            h.update(a.tobytes())
+        raw = h.digest()
+        mine = np.array([float(int.from_bytes(raw[0:6], "little")), float(int.from_bytes(raw[6:12], "little"))])
+        allv = self.comm.allgather(mine)
+        if not (np.all(allv[:, 0] == allv[0, 0]) and np.all(allv[:, 1] == allv[0, 1])):
+            raise RuntimeError("gpexp_amd.dist: the ranks disagree on %s -- under a multi-process launch every rank must run "
+                               "the same calls on the same data (seed the generators alike); rank %d of %d"
+                               % (what, self.rank, self.world))
+
+    # ---- fit ----
+    def _get_runner(self, n, d, nb):
+        key = (int(n), int(d), int(nb))
+        if self._runner is not None and self._runner[0] == key:
+            return self._runner[1]
+        self._runner = None           # release the previous size's buffers before allocating the next
+        run = DistFitIvar2D(self.ctx, self.comm, None, np.zeros((n, d)), np.zeros(n), np.zeros((0, d)), 0.0, nb=nb,
+                            ops=self.ops_factory(), streamed=False, replicate=True)
+        self._runner = (key, run)
+        return run
+
+    def factor(self, spec, nodes, nugget):
+        """Distributed assembly + factorisation of K(nodes) + diag(nugget) -> (X, L): the device point set and this rank's own
+        copy of the replicated factor (an ordinary factored matrix: every single-GPU entry point works on it).  Raises
+        NotPositiveDefinite on every rank alike (the pivot index is agreed by an all-gather)."""
+        nodes = as_f64(nodes)
+        n, d = nodes.shape
+        self.agree("the training set / hyper-parameters", nodes, np.asarray(nugget, dtype=float), spec.hyp,
+                   np.array([spec.kind, spec.d]))
+        run = self._get_runner(n, d, self.nb_for(n))
+        run.spec = spec
+        run.X = run.ops.points(nodes)
+        run.noise = nugget if isinstance(nugget, np.ndarray) else float(nugget)
+        run.fit()
+        self.stats["fits"] += 1
+        return run.X, self.be.clone(self.ctx, run.L)
+
+    # ---- evaluation ----
+    def gather(self, local, m, width=1):
+        """Concatenate the ranks' slices (eval_slice order) of an (m, width) quantity; `local` = this rank's rows."""
+        world = self.world
+        per = (m + world - 1) // world
+        buf = np.zeros(per * width)
+        loc = as_f64(local).reshape(-1)
+        buf[:loc.size] = loc
+        allv = self.comm.allgather(buf)
+        out = np.empty((m, width))
+        for r in range(world):
+            lo, hi = eval_slice(m, r, world)
+            out[lo:hi] = allv[r, :(hi - lo) * width].reshape(hi - lo, width)
+        return out
+
+    def posterior(self, spec, L, X, alpha, newpt, want_mean=True, want_var=True):
+        """(mean, signed variance) at `newpt` (host array) on every rank; evaluation points sharded over the ranks."""
+        be, ctx = self.be, self.ctx
+        newpt = as_f64(newpt)
+        m = newpt.shape[0]
+        if not self.use_eval(m):
+            return be.posterior(ctx, spec, L, X, alpha, be.points(ctx, newpt), want_mean=want_mean, want_var=want_var)
+        self.agree("the evaluation points", newpt)
+        lo, hi = eval_slice(m, self.rank, self.world)
+        cols = []
+        if hi > lo:
+            mean, var = be.posterior(ctx, spec, L, X, alpha, be.points(ctx, newpt[lo:hi]), want_mean=want_mean,
+                                     want_var=want_var)
+            cols = [c for c in (mean if want_mean else None, var if want_var else None) if c is not None]
+        width = int(want_mean) + int(want_var)
+        local = np.stack(cols, axis=1) if cols else np.zeros((0, width))
+        full = self.gather(local, m, width)
+        self.stats["evals"] += 1
+        return (full[:, 0].copy() if want_mean else None), (full[:, width - 1].copy() if want_var else None)
+
+    def ivar(self, spec, L, X, mc, cache=None):
+        """Signed mean posterior variance over the MC points (costFunctionGP_IVAR.evaluate, experimentalDesign.py:100-117):
+        each rank sums the variances of its slice, partial sums are added in rank order."""
+        be, ctx = self.be, self.ctx
+        m = mc.shape[0]
+        lo, hi = eval_slice(m, self.rank, self.world)
+        part = 0.0
+        if hi > lo:
+            Z = getattr(cache, "_mc_slice_dev", None) if cache is not None else None
+            if Z is None:
+                self.agree("the Monte-Carlo points", mc)
+                Z = be.points(ctx, as_f64(mc[lo:hi]))
+                if cache is not None:
+                    cache._mc_slice_dev = Z
+            part = be.ivar(ctx, spec, L, X, Z) * (hi - lo)
+        elif cache is None or getattr(cache, "_mc_slice_dev", None) is None:
+            self.agree("the Monte-Carlo points", mc)
+            if cache is not None:
+                cache._mc_slice_dev = False
+        self.stats["evals"] += 1
+        return ordered_sum(self.comm.allgather(np.array([part]))[:, 0]) / max(m, 1)
+
+    def lml_grad(self, spec, L, X, alpha):
+        self.stats["grads"] += 1
+        return dist_lml_grad(self.ctx, self.comm, spec, L, X, alpha, be=self.be)
+
+    def greedy_ivar_step(self, spec, L, X, cand, mc, noise):
+        """(best index, costs[M]) of one discrete greedy-IVAR step with the CANDIDATES sharded (dist_greedy_ivar_step) and the
+        cost vector gathered; the winner follows np.argmin (lowest cost, ties -> lowest global index)."""
+        be, ctx = self.be, self.ctx
+        cand = as_f64(cand)
+        m = cand.shape[0]
+        self.agree("the candidate / Monte-Carlo points", cand, as_f64(mc))
+        lo, hi = eval_slice(m, self.rank, self.world)
+        Z = be.points(ctx, as_f64(mc))
+        if hi > lo:
+            best, costs = be.greedy_ivar_step(ctx, spec, L, X, be.points(ctx, cand[lo:hi]), Z, noise)
+            mine = np.array([costs[best], float(lo + best)])
+        else:
+            costs, mine = np.zeros(0), np.array([np.inf, float(m)])
+        pairs = self.comm.allgather(mine)
+        _, idx = merge_argmin(pairs[:, 0], pairs[:, 1].astype(np.int64))
+        return idx, self.gather(costs, m)[:, 0].copy()
+
+    def mi_greedy(self, spec, cand, noise, nsel, start=0):
+        self.agree("the candidate points", as_f64(cand))
+        return dist_mi_greedy(self.ctx, self.comm, spec, as_f64(cand), noise, nsel, start=start, be=self.be)
+
+    def close(self):
+        self._runner = None
+        try:
+            self.comm.close()
+        except Exception:
+            pass
+
+
+def attach(comm=None, ctx=None, **opts):
+    """Route the class API of this process through the distributed runners.  Without arguments: the communicator of the
+    launcher's process group (RANK / WORLD_SIZE / MASTER_* -> RCCL).  Called implicitly on the first use of a GP under
+    WORLD_SIZE > 1 (GPX_DIST_ATTACH=0 keeps the process single-GPU); explicit calls are for tests and embedders."""
+    global _session, _auto_tried
+    _auto_tried = True
+    if _session is not None:
+        return _session
+    if ctx is None and comm is None:
+        ctx = _dev.context()
+    if comm is None:
+        comm = init_from_env(ctx)
+    _session = Session(ctx, comm, **opts)
+    if comm.world > 1 and int(os.environ.get("RANK", "0")) == 0 and os.environ.get("GPX_DIST_QUIET", "0") != "1":
+        print("gpexp_amd: class API attached to %d ranks (fit distributed from N >= %d, evaluation sharded from M >= %d)"
+              % (comm.world, _session.min_n, _session.min_m), flush=True)
+    import atexit
+    atexit.register(detach)
+    return _session
+
+
+def detach():
+    global _session
+    if _session is not None:
+        s, _session = _session, None
+        s.close()
+
+
+def session():
+    """The active Session or None (single-process use: nothing changes)."""
+    global _auto_tried
+    if _session is None and not _auto_tried:
+        _auto_tried = True
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("GPX_DIST_ATTACH", "1") != "0":
+            attach()
+    return _session

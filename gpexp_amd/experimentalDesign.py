@@ -28,6 +28,7 @@ except ImportError:  # pragma: no cover
 import scipy.optimize as optimize
 
 from . import device as _dev
+from . import dist as _dist
 from . import gp_kernel_utilities  # noqa: F401  (the reference module exposes it)
 
 NLOPT = False
@@ -78,6 +79,9 @@ class costFunctionGP_IVAR(costFunctionBase):
             gp.addNodesAndComputeCovariance(inputPoints, self.space.noiseFunc(inputPoints))
         if gp._L is None:   # FITC model: the same mean through the Woodbury precision (gp.py:246-255), as the reference
             return np.abs(np.mean(gp.evaluateVariance(self.mcPoints)))
+        sess = _dist.session()
+        if sess is not None and sess.use_eval(self.nMC):          # MC points sharded over the ranks, partial sums in rank order
+            return np.abs(sess.ivar(gp.kernel._spec(), gp._L, gp._X, self.mcPoints, cache=self))
         cost = _dev.ivar(_dev.context(), gp.kernel._spec(), gp._L, gp._X, self._mc())
         return np.abs(cost)
 
@@ -280,6 +284,10 @@ def performGreedyMIExperimentalDesign(costFuncMI, nPoints, start=0):
     numerator as an incremental Cholesky row and the denominator as diag((K_SS+noise I)^-1) with rank-one
     down-dates of the inverse, so a step costs O(M^2)."""
     gp = costFuncMI.gaussianProcess
+    sess = _dist.session()
+    if sess is not None and sess.use_fit(len(costFuncMI.mcPoints)):   # scoring sharded by rows of the inverse (dist_mi_greedy)
+        idx, _ = sess.mi_greedy(gp.kernel._spec(), costFuncMI.mcPoints, float(gp.noise), int(nPoints), int(start))
+        return costFuncMI.mcPoints[list(idx), :]
     ctx = _dev.context()
     C = _dev.points(ctx, costFuncMI.mcPoints)
     idx, _ = _dev.mi_greedy(ctx, gp.kernel._spec(), C, float(gp.noise), int(nPoints), int(start))
@@ -315,6 +323,9 @@ def greedyIVARStep(gaussianProcess, candidates, mcPoints):
     gp = gaussianProcess
     if gp._L is None:
         raise NotImplementedError("greedyIVARStep needs the dense Cholesky factor (GP built with FITC=... has none)")
+    sess = _dist.session()
+    if sess is not None and sess.use_eval(len(candidates)):      # candidates sharded, first-minimum merge, costs gathered
+        return sess.greedy_ivar_step(gp.kernel._spec(), gp._L, gp._X, candidates, mcPoints, float(gp.noise))
     ctx = _dev.context()
     return _dev.greedy_ivar_step(ctx, gp.kernel._spec(), gp._L, gp._X, _dev.points(ctx, candidates),
                                  _dev.points(ctx, mcPoints), float(gp.noise))

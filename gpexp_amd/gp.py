@@ -33,6 +33,7 @@ import warnings
 import numpy as np
 
 from . import device as _dev
+from . import dist as _dist
 from ._lib import NotPositiveDefinite
 from .gp_kernel_utilities import calculateCovarianceMatrix, _check_nugget  # noqa: F401  (re-export like the reference)
 
@@ -133,6 +134,18 @@ class GP:
                     return X, L, 0.0
                 except NotPositiveDefinite:
                     pass  # fall through to the full path and its rank-deficient policy
+            sess = _dist.session()
+            if sess is not None and sess.use_fit(nodes.shape[0]):
+                # multi-process launch: 2-D block-cyclic distributed fit, every rank keeps a replica of the factor
+                # (dist.Session.factor).  A non-PD result is agreed by all ranks; they then all take the replicated
+                # single-GPU path below with its rank-deficient policy.
+                try:
+                    Xd, L = sess.factor(spec, nodes, nugget)
+                    if remember:
+                        self._remember(nodes, nugget, spec, L)
+                    return Xd, L, 0.0
+                except NotPositiveDefinite:
+                    pass
             K = _dev.kfill(ctx, spec, X, nugget=nugget)
             try:
                 L = _dev.potrf(ctx, K)
@@ -259,8 +272,14 @@ class GP:
                 kv = _dev.kfill(ctx, spec, Z, Z=self._X).to_host()
                 return out, _dev.kfill(ctx, spec, Z, Z=Z).to_host() - kv @ (self.precisionMatrix @ kv.T)
             return out
-        mean, var = _dev.posterior(ctx, spec, self._L, self._X, self.coeff, Z, want_mean=True,
-                                   want_var=(compvar == 1))
+        sess = _dist.session()
+        if sess is not None and sess.use_eval(newpt.shape[0]):
+            # evaluation points sharded over the ranks, mean and variance gathered on every rank (the role of
+            # parallelizeMcForLoop, parallel_utilities.py:26-80)
+            mean, var = sess.posterior(spec, self._L, self._X, self.coeff, newpt, want_mean=True, want_var=(compvar == 1))
+        else:
+            mean, var = _dev.posterior(ctx, spec, self._L, self._X, self.coeff, Z, want_mean=True,
+                                       want_var=(compvar == 1))
         out = mean + self.gpPriorMean(newpt)
         if compvar == 1:
             return out, np.abs(var)
@@ -270,12 +289,16 @@ class GP:
 
     def evaluateVariance(self, newpt, parallel=1):
         """Signed posterior variance at `newpt` (gp.py:213-259).  `parallel` is accepted and ignored: the
-        reference forks CPU processes above 500001 points (gp.py:244-258); the GPU path never forks."""
+        reference forks CPU processes above 500001 points (gp.py:244-258); here the parallel branch is the multi-process
+        launch itself -- one process per GPU, evaluation points sharded, the variance vector gathered on every rank."""
         assert self.pts is not None
         assert newpt.shape[1] == self.kernel.dimension, "evaluation points for GP is incorrect shape"
         ctx = _dev.context()
         if self._fitc is not None:
             return self._fitc.posterior(None, _dev.points(ctx, newpt), want_mean=False, want_var=True)[1]
+        sess = _dist.session()
+        if sess is not None and sess.use_eval(newpt.shape[0]):    # gp.py:244-258: the reference's own parallel branch
+            return sess.posterior(self.kernel._spec(), self._L, self._X, None, newpt, want_mean=False, want_var=True)[1]
         _, var = _dev.posterior(ctx, self.kernel._spec(), self._L, self._X, None, _dev.points(ctx, newpt),
                                 want_mean=False, want_var=True)
         return var
@@ -344,7 +367,11 @@ class GP:
         out = -0.5 * np.dot(evals, alpha) - 0.5 * _dev.logdet(ctx, L) - len(evals) / 2.0 * np.log(2.0 * np.pi)
         if returnDeriv == 1:
             keys = list(self.kernel.hyperParam.keys()) + ['noise']
-            grad = _dev.lml_grad(ctx, self.kernel._spec(), L, X, alpha)
+            sess = _dist.session()
+            if sess is not None and sess.use_fit(len(evals)):     # traces sharded by row slabs of K^-1 (dist_lml_grad)
+                grad = sess.lml_grad(self.kernel._spec(), L, X, alpha)
+            else:
+                grad = _dev.lml_grad(ctx, self.kernel._spec(), L, X, alpha)
             outD = dict(zip(keys, grad))
             outD['noise'] *= self.noise * 2.0  # gp.py:463-464
             return out, outD

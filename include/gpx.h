@@ -81,6 +81,10 @@ int gpx_device_info(gpx_ctx* ctx, char* name, int name_len, int* cus, int64_t* h
 int gpx_mat_from_host(gpx_ctx* ctx, const double* src, int64_t rows, int64_t cols, int pad, gpx_mat** out);
 int gpx_mat_alloc(gpx_ctx* ctx, int64_t rows, int64_t cols, int pad, gpx_mat** out);
 int gpx_mat_free(gpx_ctx* ctx, gpx_mat* m);
+/* device-to-device duplicate of a matrix INCLUDING its factor state (leaf inverses): the class API under a multi-process
+ * launch hands every GP object its own copy of the replicated factor the distributed runner assembled (gp.py:181's
+ * precisionMatrix role); blocking on the selected stream */
+int gpx_mat_clone(gpx_ctx* ctx, const gpx_mat* src, gpx_mat** out);
 int gpx_mat_shape(const gpx_mat* m, int64_t* rows, int64_t* cols, int64_t* ld);
 /* tri: 0 = as stored, 1 = lower triangle (strict upper written as 0), 2 = lower mirrored to upper.
  * Backs the lazy GP.covarianceMatrix / GP.precisionMatrix attributes (gp.py:178-181). */
