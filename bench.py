@@ -31,6 +31,8 @@ import numpy as np
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
 os.environ.setdefault("NCCL_DEBUG", "WARN")                 # RCCL says why when a collective fails (stderr; stdout stays one JSON line)
+os.environ.setdefault("GPX_DIST_ATTACH", "0")               # bench.py drives the distributed runners itself: the class API of this
+#                                                             process must not attach to the process group on its own (dist.session)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -159,9 +161,9 @@ def bench_c5(args, ctx, dev, world, rank, stdout_fd):
     and noise (gp.py:444-466) + greedy MI design, 8 picks over M = 8192 candidates (BASELINE fixes no M for MI).  One GPU: the
     single-GPU path with the gradient traces accumulated slab by slab (no N x N inverse); N GPUs: DistFitGrad2D (2-D
     block-cyclic fit, traces and MI scoring sharded).  Not the headline metric: one JSON line for the record."""
-    N = args.n if args.n != 32768 else 65536
-    d = args.d if args.d != 8 else 10
-    M = 8192
+    N = 65536 if args.n is None else args.n
+    d = 10 if args.d is None else args.d
+    M = 8192 if args.m is None else args.m
     rng = np.random.default_rng(N)
     noise = 0.1
     Xh = rng.uniform(-1, 1, (N, d))
@@ -171,8 +173,14 @@ def bench_c5(args, ctx, dev, world, rank, stdout_fd):
     times = {}
     if world > 1 or os.environ.get("GPX_FORCE_DIST") == "1":
         from gpexp_amd import dist
+        fc_timer, fc = first_contact_watchdog(rank, world) if world > 1 else (None, {})
         comm = dist.init_from_env(ctx)
+        fc["phase"] = "the runner's constructor (ncclCommSplit)"
         runner = dist.DistFitGrad2D(ctx, comm, spec, Xh, yh, noise, nb=int(os.environ.get("GPX_DIST_NB", "512")), cand=Ch, nsel=8)
+        fc["phase"] = "the first all-gather behind the constructor"
+        comm.barrier()
+        if fc_timer is not None:
+            fc_timer.cancel()
         layout = "%d ranks, 2-D block-cyclic %dx%d grid; gradient traces and MI scoring sharded" % (world, runner.geo.Pr, runner.geo.Pc)
 
         def step():
@@ -212,16 +220,30 @@ def bench_c5(args, ctx, dev, world, rank, stdout_fd):
 
         def reduce_max(v):
             return v
+    import threading
+    limit_s = float(os.environ.get("GPX_BENCH_WATCHDOG_S", "1500"))
+    progress = {"at": "warm-up"}
+
+    def _expired():
+        print("bench.py: watchdog: rank %d of %d still in %s of --config c5 after %.0f s (%s) -- aborting"
+              % (rank, world, progress["at"], limit_s, layout), file=sys.stderr, flush=True)
+        os._exit(124)
+
+    watchdog = threading.Timer(limit_s, _expired)
+    watchdog.daemon = True
+    watchdog.start()
     for _ in range(args.warmup):
         step()
     barrier()
     ctx.sync()
+    progress["at"] = "the timed steps"
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ll, grad, picks = step()
     ctx.sync()
     barrier()
     dt = reduce_max(time.perf_counter() - t0)
+    watchdog.cancel()
     if rank == 0:
         fit_flops = float(N) ** 3 / 3.0
         grad_flops = 2.0 * float(N) ** 3 / 3.0
@@ -255,7 +277,7 @@ def dist_preflight(ctx, comm, dist, dev, spec, d, nb=256, two_d=True, n=2048, m=
     that differs by more than 1e-10."""
     Xh, yh, Zh, noise = workload(n, d, m, seed=12345)
     t0 = time.perf_counter()
-    if two_d and os.environ.get("GPX_TEST_HANG_2D_PREFLIGHT") == "1":     # test hook: a collective that never completes
+    if two_d and debug_inject() == "hang2d":      # (debug switch) a collective that never completes
         time.sleep(1e6)
     if two_d:
         run = dist.DistFitIvar2D(ctx, comm, spec, Xh, yh, Zh, noise, nb=nb)
@@ -271,7 +293,7 @@ def dist_preflight(ctx, comm, dist, dev, spec, d, nb=256, two_d=True, n=2048, m=
            "rel_err_loglike": abs(ll - ll1) / abs(ll1) if (two_d or comm.rank == 0) else 0.0,
            "rel_err_ivar": abs(iv - iv1) / abs(iv1)}
     ok = out["rel_err_loglike"] <= 1e-10 and out["rel_err_ivar"] <= 1e-10
-    if two_d and os.environ.get("GPX_TEST_FAIL_2D_PREFLIGHT") == "1":     # test hook: exercise the fall-back to the 1-D layout
+    if two_d and debug_inject() == "fail2d":      # (debug switch) exercise the fall-back to the 1-D layout
         ok = False
         out["forced_failure"] = True
     L1 = K1.to_host(tri=1)
@@ -317,6 +339,34 @@ def dist_preflight(ctx, comm, dist, dev, spec, d, nb=256, two_d=True, n=2048, m=
 PREFLIGHT_HANG = 125     # exit code of a rank whose preflight step never finished (its own watchdog)
 
 
+def first_contact_watchdog(rank, world):
+    """Armed in the child BEFORE its first RCCL call: ncclCommInitRank + the barrier all-gather, the two blocking
+    ncclCommSplit of the 2-D runner's constructor and the layout agreement are the likeliest places for a first-contact hang,
+    and they all come before the preflight step.  On expiry the process leaves with PREFLIGHT_HANG, so supervise() starts the
+    second attempt on the 1-D layout instead of the run sitting until the launcher's limit with nothing on stderr.  The caller
+    updates `state["phase"]` as it goes and cancels the timer behind the post-preflight all-gather."""
+    import threading
+    limit = float(os.environ.get("GPX_BENCH_PREFLIGHT_WATCHDOG_S", "240"))
+    state = {"phase": "ncclCommInitRank / first barrier", "layout": os.environ.get("GPX_DIST_LAYOUT", "2d")}
+
+    def expired():
+        print("bench.py: watchdog: rank %d of %d: FIRST CONTACT did not finish within %.0f s (stuck in: %s; layout %s) -- a "
+              "collective of the distributed path never completed; aborting (try GPX_DIST_LAYOUT=1d)"
+              % (rank, world, limit, state["phase"], state["layout"]), file=sys.stderr, flush=True)
+        os._exit(PREFLIGHT_HANG)
+
+    t = threading.Timer(limit, expired)
+    t.daemon = True
+    t.start()
+    return t, state
+
+
+def debug_inject():
+    """ONE debug switch for the failure injections the first-contact tests need (GPX_BENCH_INJECT=hang2d | fail2d); nothing
+    else in this file changes behaviour for tests."""
+    return os.environ.get("GPX_BENCH_INJECT", "")
+
+
 def supervise(world, rank):
     """N > 1: the work runs in a CHILD process of this one.  This process never touches the GPU, so it may start programs; it
     exists for one case -- RCCL with more than one rank has never run on the build's hardware, and a collective that never
@@ -348,9 +398,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--train-points", dest="n", type=int, default=32768)
-    ap.add_argument("--dim", dest="d", type=int, default=8)
-    ap.add_argument("--mc-points", dest="m", type=int, default=32768)
+    ap.add_argument("--train-points", dest="n", type=int, default=None, help="default: 32768 (c4) / 65536 (c5)")
+    ap.add_argument("--dim", dest="d", type=int, default=None, help="default: 8 (c4) / 10 (c5)")
+    ap.add_argument("--mc-points", dest="m", type=int, default=None, help="default: 32768 (c4); c5: MI candidates, 8192")
     ap.add_argument("--kernel", choices=["matern52", "matern32"], default="matern52",
                     help="matern52 = BASELINE config C4; matern32 = the only Matern the reference itself can evaluate "
                          "(kernels.py:85-89), same workload")
@@ -390,14 +440,17 @@ def main():
     if args.config == "c5":
         bench_c5(args, ctx, dev, world, rank, stdout_fd)
         return
-    N, d, M = args.n, args.d, args.m
+    N, d, M = (32768 if args.n is None else args.n), (8 if args.d is None else args.d), (32768 if args.m is None else args.m)
     Xh, yh, Zh, noise = workload(N, d, M, seed=N)
     spec = dev.KernelSpec(dev.K_MATERN52 if args.kernel == "matern52" else dev.K_MATERN32, d, [0.5, 1.0])
     preflight = None
 
     if world > 1 or os.environ.get("GPX_FORCE_DIST") == "1":  # GPX_FORCE_DIST: rehearse the RCCL runner on one GPU
         from gpexp_amd import dist
+        fc_timer, fc = (first_contact_watchdog(rank, world) if (world > 1 or os.environ.get("GPX_BENCH_PREFLIGHT") == "1")
+                        else (None, {}))
         comm = dist.init_from_env(ctx)
+        fc["phase"] = "the runner's constructor (ncclCommSplit)"
         # default: north_star's 2-D block-cyclic layout (Pr x Pc grid, gpexp_amd/dist.py); GPX_DIST_LAYOUT=1d selects the
         # round-1 block-column layout (every rank holds the full matrix, one ncclBroadcast per panel)
         nb = int(os.environ.get("GPX_DIST_NB", "512"))
@@ -410,6 +463,7 @@ def main():
                 err = "%s: %s" % (type(exc).__name__, exc)
         # The layout is agreed on COLLECTIVELY: a rank that could not build the 2-D runner (while others could) would
         # otherwise issue the 1-D path's collectives against its peers' 2-D ones and hang until the watchdog.
+        fc["phase"] = "the layout agreement all-gather"
         ok_all = comm.allgather(np.array([1.0 if (runner is not None or not want_2d) else 0.0]))[:, 0]
         if want_2d and ok_all.min() < 1.0:
             print("bench.py: rank %d: 2-D layout unavailable on rank(s) %s%s; ALL ranks fall back to the 1-D block-column layout"
@@ -426,20 +480,10 @@ def main():
         # runner class, checked on every rank against the single-GPU path before anything is timed.  A mismatch names the
         # first block of the replicated factor that differs; the bench then stops instead of timing garbage.
         if world > 1 or os.environ.get("GPX_BENCH_PREFLIGHT") == "1":
-            # its own, SHORT watchdog: a collective that never completes at first contact should cost minutes, not the timed
-            # region's whole allowance, and say that it was the preflight
-            import threading
-            pf_limit = float(os.environ.get("GPX_BENCH_PREFLIGHT_WATCHDOG_S", "180"))
-
-            def _pf_expired():
-                print("bench.py: watchdog: rank %d of %d: the PREFLIGHT step (N = 2048, %s layout) did not finish within %.0f s -- "
-                      "a collective of the distributed path never completed; aborting (try GPX_DIST_LAYOUT=1d)"
-                      % (rank, world, "2-D" if want_2d else "1-D", pf_limit), file=sys.stderr, flush=True)
-                os._exit(PREFLIGHT_HANG)
-
-            pf_timer = threading.Timer(pf_limit, _pf_expired)
-            pf_timer.daemon = True
-            pf_timer.start()
+            # (the first-contact watchdog armed before ncclCommInitRank is still running: a collective that never completes
+            # here costs minutes, not the timed region's whole allowance, and the message says it was the preflight)
+            fc["phase"] = "the PREFLIGHT step (N = 2048)"
+            fc["layout"] = "2d" if want_2d else "1d"
             preflight = dist_preflight(ctx, comm, dist, dev, spec, d, nb=min(nb, 256), two_d=want_2d)
             print("bench.py: preflight rank %d: %s" % (rank, json.dumps(preflight)), file=sys.stderr, flush=True)
             bad = comm.allgather(np.array([0.0 if preflight["ok"] else 1.0]))[:, 0]
@@ -457,7 +501,7 @@ def main():
                 preflight["failed_2d_preflight"] = first
                 print("bench.py: preflight (1-D) rank %d: %s" % (rank, json.dumps(preflight)), file=sys.stderr, flush=True)
                 bad = comm.allgather(np.array([0.0 if preflight["ok"] else 1.0]))[:, 0]
-            pf_timer.cancel()
+            fc_timer.cancel()
             if bad.max() > 0:
                 print("bench.py: preflight FAILED on rank(s) %s -- not timing a wrong result" % [i for i, v in enumerate(bad) if v > 0],
                       file=sys.stderr, flush=True)

@@ -17,7 +17,7 @@ def pytest_configure(config):
 class Golden:
     """tests/golden/gpexp_golden.npz: vectors produced by the reference itself (make_golden.py)."""
 
-    FILES = ["gpexp_golden", "gpexp_golden_r2"]   # round 1 (make_golden.py), round 2 (make_golden_r2.py)
+    FILES = ["gpexp_golden", "gpexp_golden_r2", "gpexp_golden_r4"]   # make_golden.py, make_golden_r2.py, make_golden_r4.py
 
     def __init__(self):
         d = os.path.join(ROOT, "tests", "golden")

@@ -15,6 +15,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# the workers below drive the runners directly and use the single-GPU class API as their yardstick: the class API must not
+# attach itself to the process group behind their back (the cpu-api / gpu-api modes attach explicitly)
+os.environ.setdefault("GPX_DIST_ATTACH", "0")
 
 from gpexp_amd import dist  # noqa: E402
 import dist_testcomm  # noqa: E402  (tests/: the gloo communicators)
@@ -856,6 +859,21 @@ def run_gpu(args):
     ctx.close()
 
 
+def run_cpu_api(args):
+    import api_worker
+    api_worker.run_api(args, gpu=False)
+
+
+def run_gpu_api(args):
+    import api_worker
+    api_worker.run_api(args, gpu=True)
+
+
+def run_gpu_api_c4lite(args):
+    import api_worker
+    api_worker.run_api_c4lite(args)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", default="cpu")
@@ -867,7 +885,8 @@ if __name__ == "__main__":
     a = ap.parse_args()
     print("WORKER_UP rank=%s mode=%s" % (os.environ.get("RANK", "0"), a.mode), flush=True)
     {"cpu": run_cpu, "gpu": run_gpu, "cpu2d": run_cpu2d, "gpu2d": run_gpu2d, "gpu2d-chaos": run_gpu2d_chaos,
-     "cpu-c5": run_cpu_c5, "gpu-c5": run_gpu_c5}[a.mode](a)
+     "cpu-c5": run_cpu_c5, "gpu-c5": run_gpu_c5, "cpu-api": run_cpu_api, "gpu-api": run_gpu_api,
+     "gpu-api-c4lite": run_gpu_api_c4lite}[a.mode](a)
     if "torch" in sys.modules:  # orderly gloo teardown: a rank that exits while its peers still hold sub-group
         import torch.distributed as td   # connections aborts in a gloo thread (the RCCL path never imports torch)
         if td.is_initialized():

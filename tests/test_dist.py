@@ -116,6 +116,18 @@ def test_c5_sharded_gradient_and_mi_gloo_cpu(world, n, nb):
     assert "cpu-c5 world=%d" % world in out
 
 
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_class_api_golden_fixtures_gloo_cpu(world):
+    """the reference's golden fixtures THROUGH THE CLASS API (GP.train / evaluate / evaluateVariance /
+    computeLogLike / loglikeParams(returnDeriv=1), costFunctionGP_IVAR.evaluate, greedy variance / greedy IVAR / MI designs)
+    under a multi-process launch -- gloo + NumPy device doubles (tests/numpy_device.py), routed by gpexp_amd.dist.Session:
+    distributed fit into a replicated factor, evaluation points sharded and gathered.  coeff / mean / variance / log-marginal
+    1e-10 against the reference, indices exact, every rank returns bit-identical arrays, and ranks that pass different data
+    are detected (tests/api_worker.py)."""
+    out = launch(world, ["--mode", "cpu-api"], timeout=900)
+    assert "cpu-api world=%d cases=9" % world in out
+
+
 def test_grid_logic():
     from gpexp_amd import dist
     assert [dist.choose_grid(w) for w in (1, 2, 3, 4, 6, 8, 16)] == [(1, 1), (1, 2), (1, 3), (2, 2), (2, 3), (2, 4), (4, 4)]
@@ -152,6 +164,30 @@ def test_distributed_fit_ivar_2d_shared_gpu(world, n, nb, grid):
     out = launch(world, ["--mode", "gpu2d", "--npts", str(n), "--mpts", "777", "--blk", str(nb), "--grid", grid],
                  {"GPX_COMM": "host", "GPX_FORCE_DEVICE": "0"}, timeout=900)
     assert "HostStagedComm" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_class_api_golden_fixtures_shared_gpu(world):
+    """The same fixtures through the class API on the real HIP library, 2 / 4 ranks sharing the GPU (host-staged exchange):
+    1e-10 against the reference's outputs, greedy / MI indices exact, identical arrays on every rank."""
+    out = launch(world, ["--mode", "gpu-api"], {"GPX_COMM": "host", "GPX_FORCE_DEVICE": "0"}, timeout=900)
+    assert "gpu-api world=%d cases=9" % world in out
+
+
+@pytest.mark.gpu
+def test_class_api_golden_fixtures_rccl_world1():
+    """... and with the RCCL communicator at world 1 (ncclCommInitRank, the host all-gathers of the session)."""
+    out = launch(1, ["--mode", "gpu-api"], {"GPX_COMM": "rccl"}, timeout=900)
+    assert "gpu-api world=1 cases=9" in out
+
+
+@pytest.mark.gpu
+def test_class_api_c4_lite_reference_fixture_on_four_ranks():
+    """The N = 8192 reference fixture through the class API with the session's default thresholds on a 2 x 2 grid: distributed
+    fit (16 panels), replica-based coeff / log-marginal, sharded evaluation; 1e-10 / 5e-10 element-wise."""
+    out = launch(4, ["--mode", "gpu-api-c4lite"], {"GPX_COMM": "host", "GPX_FORCE_DEVICE": "0"}, timeout=900)
+    assert "gpu-api-c4lite world=4" in out
 
 
 @pytest.mark.gpu
@@ -199,7 +235,7 @@ def test_bench_falls_back_to_1d_layout_when_the_2d_preflight_is_wrong():
     comes out says so and carries the failed 2-D record."""
     import json
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPX_COMM="host", GPX_FORCE_DEVICE="0", MASTER_ADDR="127.0.0.1",
-               GPX_TEST_FAIL_2D_PREFLIGHT="1")
+               GPX_BENCH_INJECT="fail2d")
     flags = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--train-points", "4096", "--mc-points", "2048"]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"),
@@ -220,7 +256,7 @@ def test_bench_restarts_on_1d_layout_when_the_2d_preflight_hangs():
     starts a second child on the 1-D layout with a fresh rendezvous, and ONE JSON line comes out, labelled 1-D."""
     import json
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPX_COMM="host", GPX_FORCE_DEVICE="0", MASTER_ADDR="127.0.0.1",
-               GPX_TEST_HANG_2D_PREFLIGHT="1", GPX_BENCH_PREFLIGHT_WATCHDOG_S="15")
+               GPX_BENCH_INJECT="hang2d", GPX_BENCH_PREFLIGHT_WATCHDOG_S="45")
     flags = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--train-points", "4096", "--mc-points", "2048"]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"),

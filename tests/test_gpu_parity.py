@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 
 from oracle import gpexp_oracle as orc
+from helpers import elementwise, c4_lite_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -193,6 +194,9 @@ def test_fit_posterior_loglike_vs_reference(dev, ctx, golden, case):
     mean, var = dev.posterior(ctx, sp, L, X, alpha, Z)
     assert rel(mean, golden(case, "mean")) <= 1e-10
     assert rel(var, golden(case, "var")) <= 1e-10
+    # element-wise: every variance to a relative bound of ITS OWN size, down to entries 1e-3 of the
+    # largest (helpers.elementwise) -- 1e-9: the reference's pinv carries ~cond(K) eps of absolute error itself
+    assert elementwise(var, golden(case, "var")) <= 1e-9
     n = len(y)
     ll = -0.5 * y @ alpha - 0.5 * dev.logdet(ctx, L) - n / 2.0 * np.log(2 * np.pi)
     assert ll == pytest.approx(float(golden(case, "loglike")), rel=1e-10)
@@ -288,5 +292,31 @@ def test_c2_full_size_against_reference(dev, ctx, golden):
     mean, var = g.evaluate(Z[:256], compvar=1)
     assert rel(mean, golden(c, "mean256")) <= 1e-10
     assert rel(var, golden(c, "var256")) <= 1e-10
+    assert g.computeLogLike(X, y) == pytest.approx(float(golden(c, "loglike")), rel=1e-10)
+    assert float(y @ g.coeff) == pytest.approx(float(golden(c, "ytalpha")), rel=1e-10)
+
+
+def test_c4_lite_blocked_factorisation_against_reference(dev, ctx, golden):
+    """`c4_lite` (tests/golden/make_golden_r4.py: the REFERENCE at N=8192, d=8, Matern-3/2, rho=0.5, noise=0.1, 256 evaluation
+    points, cond(K) = 5e2): the smallest size that takes the blocked look-ahead factorisation (potrf_blocked, N >= 8192), its
+    1024-order block inverses and the out-of-place posterior solve (VERDICT r3 missing 3).  Through the class API, against
+    gp.py:76-145 (train / evaluate), gp.py:213-259 (evaluateVariance) and gp.py:373-440 (computeLogLike): 1e-10 max-norm on
+    coeff / mean / variance / log-marginal, and 5e-10 ELEMENT-WISE on the variances."""
+    from gpExp.kernels import KernelIsoMatern
+    from gpExp.gp import GP
+    c = "c4_lite"
+    ix = golden.index[c]
+    X, y, Z = c4_lite_inputs(ix)
+    k = ix["kernel"]
+    g = GP(KernelIsoMatern(k["rho"], k["signalSize"], k["d"]), ix["noise"])
+    g.train(X, y)
+    assert rel(g.coeff, golden(c, "coeff")) <= 1e-10
+    mean, var = g.evaluate(Z, compvar=1)
+    assert rel(mean, golden(c, "mean256")) <= 1e-10
+    assert rel(var, golden(c, "var256")) <= 1e-10
+    assert elementwise(var, golden(c, "var256")) <= 5e-10
+    signed = g.evaluateVariance(Z)
+    assert elementwise(signed, golden(c, "varsigned256")) <= 5e-10
+    assert elementwise(mean, golden(c, "mean256"), floor=1e-2) <= 1e-9
     assert g.computeLogLike(X, y) == pytest.approx(float(golden(c, "loglike")), rel=1e-10)
     assert float(y @ g.coeff) == pytest.approx(float(golden(c, "ytalpha")), rel=1e-10)

@@ -293,6 +293,38 @@ def test_c2_full_size_against_reference(golden):
     assert orc.loglike(s, X, y, ix["noise"]) == pytest.approx(float(golden(c, "loglike")), rel=1e-10)
 
 
+def test_c4_lite_fixture_against_lapack(golden):
+    """`c4_lite` (N=8192, d=8, Matern-3/2; make_golden_r4.py): the reference's pinv / slogdet outputs against an independent
+    LAPACK Cholesky of the same covariance, assembled with the oracle's kernel function (the oracle's own pinv at this size
+    takes minutes: it is pinned at N <= 4096 by the other fixtures).  Pins the FIXTURE on CPU -- inputs regenerate from the
+    seed, the reference's numbers are what a Cholesky-based implementation must reproduce to 1e-10 (cond(K) = 5e2)."""
+    import scipy.linalg as sla
+    from helpers import c4_lite_inputs, elementwise
+    c = "c4_lite"
+    ix = golden.index[c]
+    X, y, Z = c4_lite_inputs(ix)
+    s = ix["kernel"]
+    n = len(X)
+    K = np.empty((n, n))
+    for r0 in range(0, n, 512):        # same per-element arithmetic as cov_matrix(row_loop=False), in row bands (memory)
+        a = np.repeat(X[r0:r0 + 512], n, axis=0)
+        K[r0:r0 + 512] = orc.kernel_eval(s, np.tile(X, (len(X[r0:r0 + 512]), 1)), a).reshape(-1, n)
+    K[np.diag_indices(n)] += ix["noise"]
+    cf = sla.cho_factor(K, lower=True, overwrite_a=True, check_finite=False)
+    alpha = sla.cho_solve(cf, y, check_finite=False)
+    assert rel(alpha, golden(c, "coeff")) <= 1e-10
+    assert float(y @ alpha) == pytest.approx(float(golden(c, "ytalpha")), rel=1e-11)
+    ll = -0.5 * y @ alpha - np.sum(np.log(np.diag(cf[0]))) - n / 2.0 * np.log(2 * np.pi)
+    assert ll == pytest.approx(float(golden(c, "loglike")), rel=1e-11)
+    kz = orc.cross_matrix(s, Z, X)                                   # (M, N)
+    W = sla.solve_triangular(cf[0], kz.T, lower=True, check_finite=False)
+    var = orc.kernel_diag(s, Z) - np.sum(W * W, axis=0)
+    assert rel(kz @ alpha, golden(c, "mean256")) <= 1e-10
+    assert elementwise(var, golden(c, "varsigned256")) <= 5e-10
+    assert np.array_equal(np.abs(golden(c, "varsigned256")), golden(c, "var256"))
+    assert 4e2 < float(golden(c, "cond_proxy")) < 7e2
+
+
 def test_ivar_with_heteroscedastic_noise_function(golden):
     """experimentalDesign.py:111-115: space.noiseFunc(design) is the per-point nugget of the design's covariance."""
     c = "ivar_noisefunc"
