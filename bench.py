@@ -336,6 +336,40 @@ def dist_preflight(ctx, comm, dist, dev, spec, d, nb=256, two_d=True, n=2048, m=
     return out
 
 
+def multi_gpu_replay(ctx, dev, spec, Xh, yh, Zh, noise, K, X, fit_ms, grid=(2, 4), rank=0):
+    """After the timed region, --gpus 1 only: ONE process plays rank 0 of a 2 x 4 grid on this GPU -- that
+    rank's exact recorded program of the 2-D block-cyclic factorisation (gpexp_amd.dist.dist2_potrf_enqueue) with every receive
+    replaced by a device copy of the same bytes out of the factor the timed steps left in K (scripts/replay_comm.py).  It puts
+    the per-rank GPU time and host issue time of the 8-GPU form on the driver's clock, on a fresh box.  xGMI IS NOT IN IT:
+    transfers cost a device copy, nothing waits for a peer, and the diagonal blocks of the other ranks -- which sit on the same
+    global chain -- arrive as copies."""
+    scripts = os.path.join(ROOT, "scripts")
+    if scripts not in sys.path:
+        sys.path.insert(0, scripts)
+    import dist_replay
+    t0 = time.perf_counter()
+    nb = int(os.environ.get("GPX_DIST_NB", "512"))
+    dev.kfill_into(ctx, spec, X, K, nugget=noise)      # (the isolated fill launches above left an unfactored matrix in K)
+    dev.potrf(ctx, K)
+    ctx.sync()
+    fit = dist_replay.replay_rank(ctx, spec, Xh, yh, Zh[:1024], noise, K, X, grid, rank, nb=nb, streamed=False, steps=3,
+                                  profile=False)
+    both = dist_replay.replay_rank(ctx, spec, Xh, yh, Zh, noise, K, X, grid, rank, nb=nb, streamed=True, steps=3, profile=False)
+    out = {"grid": "%dx%d" % grid, "rank": rank, "nb": nb, "panels_per_trailing_update": fit["agg"],
+           "fit_only_ms": fit["ms_per_step"], "fit_ivar_ms": both["ms_per_step"],
+           "host_issue_ms_per_fit": fit["host_issue_ms_per_fit"], "host_issue_us_per_panel_step": fit["host_issue_us_per_panel_step"],
+           "bytes_received_per_fit": fit["bytes_received_per_fit"], "bytes_received_per_fit_ivar": both["bytes_received_per_fit"],
+           "program_rows": fit["program_rows"], "variance_check_rel": max(fit["variance_check_rel"], both["variance_check_rel"]),
+           "single_gpu_fit_ms": fit_ms,
+           "rank_time_ratio_fit": (fit_ms / fit["ms_per_step"]) if fit_ms else None,
+           "seconds": None,
+           "xgmi": "NOT INCLUDED -- receives are device copies of the same bytes, sends cost nothing, no peer is waited for; the "
+                   "ratio is single-GPU fit time / this rank's GPU time, an upper bound on what 8 GPUs can reach, not a measured "
+                   "scaling figure"}
+    out["seconds"] = time.perf_counter() - t0
+    return out
+
+
 PREFLIGHT_HANG = 125     # exit code of a rank whose preflight step never finished (its own watchdog)
 
 
@@ -408,6 +442,7 @@ def main():
                     help="c4 = the headline workload (default); c5 = BASELINE config 5: N=65536, d=10 ARD-SE, fit + log-marginal "
                          "gradient + greedy MI design (8 picks over 8192 candidates), 1..N GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-replay", action="store_true", help="skip the multi_gpu_replay object (rank 0 of a 2x4 grid replayed on this GPU)")
     ap.add_argument("--cpu-baseline", choices=["bounded", "full"], default="bounded",
                     help="full: SURVEY.md 8d's whole protocol (adds N=8192 and the fair-CPU Cholesky at N=32768; minutes)")
     args = ap.parse_args()
@@ -666,7 +701,7 @@ def main():
         traffic, traffic_src = None, None
         try:  # PMC counters cannot be read from inside the process: take the committed rocprofv3 --pmc passes of this
             # same command (profiles/), per launch like `achieved`; null when the profile is for another config
-            pmc = [f for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+            pmc = [f for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
                    if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
             with open(os.path.join(ROOT, "profiles", pmc)) as f:
                 pj = json.load(f)
@@ -696,6 +731,7 @@ def main():
                          "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS,
                          "traffic": traffic, "traffic_unit": "bytes per launch (mean over the step's launches)",
                          "traffic_source": traffic_src,
+                         "traffic_source_run": "builder" if traffic is not None else None,
                          "algorithmic_flop_per_step": algo_flops,
                          "algorithmic_flop_per_launch": (algo_flops * args.steps / g["launches"]) if g["launches"] else 0.0,
                          "launched_flop_per_step": g["flops"] / args.steps,
@@ -730,6 +766,8 @@ def main():
             line["host_issue_ms_per_step"] = dict(getattr(runner, "host_ms", {}) or {})
             line["comm_note"] = ("phases_ms_per_step.comm = HIP-event spans around the collectives on the communication stream "
                                  "(includes waiting for the peers); gemm / leaf = the compute strands")
+        if world == 1 and not args.no_replay and os.environ.get("GPX_FORCE_DIST") != "1" and N >= 8192:
+            line["multi_gpu_replay"] = multi_gpu_replay(ctx, dev, spec, Xh, yh, Zh, noise, K, X, fit_ms)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(d, full=(args.cpu_baseline == "full"), kind=args.kernel)
             ref = os.path.join(ROOT, "profiles", "r02_bench_n1_cpu_full.json")

@@ -53,11 +53,22 @@ __device__ __forceinline__ bool tile_of(int sblk, int within, int tiles_m, int t
                                         int* by, int* bx, int rot = 0) {
   const int sbm = (1 << sb_shift) - 1;
   int sr, sc;
-  if (LOWER) {  // sblk-th super-block of the lower triangle, row-major: sr(sr+1)/2 <= sblk
-    sr = (int)((sqrtf(8.0f * (float)sblk + 1.0f) - 1.0f) * 0.5f);
-    while ((sr + 1) * (sr + 2) / 2 <= sblk) ++sr;
-    while (sr * (sr + 1) / 2 > sblk) --sr;
-    sc = sblk - sr * (sr + 1) / 2;
+  if (LOWER) {
+    // Super-blocks of the lower triangle: the STRICTLY lower ones first (row-major), the diagonal ones last.  A diagonal
+    // super-block has 28 of its 64 slots exit at once; the XCD refills them with tiles of its next super-block, and from then
+    // on its 64 resident workgroups belong to two super-blocks at different k phases -- the lock-step that makes them share
+    // operand panels in L2 is gone for the rest of the launch (TCC hit rate 0.81 rectangular vs 0.58 lower, same shapes,
+    // profiles/r04_l2_hitrate.txt).  With the diagonal ones at the end only the launch's tail pays.
+    const int nsr = (tiles_m + sbm) >> sb_shift;   // super-block rows of the (main part of the) lower triangle
+    const int noff = nsr * (nsr - 1) / 2;
+    if (sblk < noff) {                             // sblk-th strictly-lower super-block: (sr-1) sr / 2 <= sblk, sr >= 1
+      sr = (int)((sqrtf(8.0f * (float)sblk + 1.0f) + 1.0f) * 0.5f);
+      while (sr * (sr + 1) / 2 <= sblk) ++sr;
+      while ((sr - 1) * sr / 2 > sblk) --sr;
+      sc = sblk - (sr - 1) * sr / 2;
+    } else {
+      sr = sc = sblk - noff;                       // (indices beyond the last diagonal block fall out below: by >= tiles_m)
+    }
   } else {
     sr = sblk / sb_cols;
     sc = sblk - sr * sb_cols;

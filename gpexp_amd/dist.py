@@ -26,9 +26,9 @@ against a recorder (`Program`), and the recorded rows are replayed natively by g
 sequence, no interpreter and no ctypes marshalling in the issue path.  Communicators (`bcast_grp`, `reduce_grp`,
 `allreduce`, `panel_bcast`, `allgather`, `barrier`, `max_float`):
   RcclComm    device-to-device over RCCL (the product path; no torch in the process, see FileRendezvous);
-  ReplayComm  ONE process plays rank (pr, pc) of a larger grid: every receive becomes a device copy of the same bytes
-              out of a complete factor resident on the GPU -- measures a rank's GPU time and host issue time without
-              the other GPUs (scripts/dist_replay.py);
+  (scripts/replay_comm.py: ReplayComm, a MEASUREMENT double -- one process plays rank (pr, pc) of a larger grid, every
+              receive becomes a device copy of the same bytes out of a complete factor resident on the GPU; it measures a
+              rank's GPU time and host issue time without the other GPUs and is not part of the product package);
   tests/dist_testcomm.py holds the host-staged gloo communicator of the shared-GPU tests (RCCL refuses two ranks on
               one device); GPX_COMM=host selects it, nothing in this package imports torch.
 The index arithmetic (ownership, slices, piece offsets, update ranges) is plain Python and unit-tested on CPU with gloo.
@@ -1156,82 +1156,6 @@ def streamed_ivar_hook(ops, geo, L, B, q, window=0, stream=None, fwd=None):
             if window:
                 ops.record(_ev2(E_IVAR, k))
     return hook
-
-
-class ReplayComm(Emitter):
-    """ONE process plays rank `rank` of a `world`-rank grid on one GPU: every receive of the panel loop becomes a device copy
-    of the same bytes out of the complete factor `Lref` resident on this GPU (gpx_dist2_pack_*), sends cost nothing (the
-    sender's data is its own), and nothing waits for a peer.  What it measures: the rank's kernel sequence, its GPU time per
-    strand and the host issue time -- not xGMI.  Only the factorisation + streamed evaluation are replayable (the substitution
-    sweeps need the peers' partial sums)."""
-    recordable = True
-
-    def __init__(self, ctx, world, rank, Lref):
-        self.ctx, self.world, self.rank, self.Lref = ctx, int(world), int(rank), Lref
-        self.k = None
-        self.bytes_in = 0     # bytes the collectives would have delivered to this rank (per recording)
-
-    def set_grid(self, Pr, Pc):
-        assert Pr * Pc == self.world
-        self.grid = (Pr, Pc)
-
-    def at_step(self, geo, k):
-        self.geo, self.k = geo, k
-
-    def _rows(self, buf, off, m, first_block, stride, k):
-        geo = self.geo
-        self._emit(OP["PACK_ROWS"], (self.Lref, buf), (first_block, stride, k * geo.nb, off, m, geo.height(k), geo.nb))
-        self.bytes_in += 8 * m * geo.gld
-
-    def _diag(self, buf, off, k):
-        geo = self.geo
-        self._emit(OP["PACK_DIAG"], (self.Lref, buf), (k * geo.nb, geo.height(k), geo.nb, off))
-        self.bytes_in += 8 * geo.dsz
-
-    def bcast_grp(self, buf, offset, count, root, grp):
-        geo, k = self.geo, self.k
-        mine = geo.pc if grp == ROW else geo.pr
-        if count == 0 or mine == root:
-            return
-        if grp == COL:
-            assert offset == geo.piece_off(k % geo.Pr) and count == geo.dsz
-            self._diag(buf, offset, k)
-        else:
-            assert grp == ROW and count == geo.height(k + 1) * geo.gld
-            self._rows(buf, offset, geo.height(k + 1), k + 1, 1, k)
-
-    def panel_bcast(self, buf, pieces):
-        geo, k = self.geo, self.k
-        for off, cnt, root in pieces:
-            if root == self.rank or cnt == 0:
-                continue
-            p = root // geo.Pc
-            m = geo.piece_rows(p, k)
-            if p == k % geo.Pr:
-                assert off == geo.piece_off(p) and cnt == geo.dsz + m * geo.gld
-                self._diag(buf, off, k)
-                off += geo.dsz
-            else:
-                assert off == geo.piece_off(p) + geo.dsz and cnt == m * geo.gld
-            if m > 0:
-                self._rows(buf, off, m, p + geo.li0(p, k) * geo.Pr, geo.Pr, k)
-
-    def reduce_grp(self, *a):
-        raise NotImplementedError("the substitution sweeps are not replayable on one rank")
-
-    allreduce = reduce_grp
-
-    def allgather(self, vec):
-        return np.tile(as_f64(np.atleast_1d(vec)), (self.world, 1))
-
-    def barrier(self):
-        self.ctx.sync()
-
-    def max_float(self, v):
-        return float(v)
-
-    def close(self):
-        pass
 
 
 class DistFitIvar2D:

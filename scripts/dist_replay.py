@@ -5,7 +5,7 @@
 
 One process plays rank (pr, pc) of a Pr x Pc grid: it runs that rank's exact kernel sequence of `dist2_potrf` + the streamed
 IVAR solve (the recorded program bench.py replays on a real node), and every receive of the panel loop is a device copy of
-the same bytes out of a complete factor resident on the GPU (gpexp_amd.dist.ReplayComm).  It measures what one GPU can
+the same bytes out of a complete factor resident on the GPU (scripts/replay_comm.py).  It measures what one GPU can
 measure -- the rank's GPU time per step, the per-class kernel time, and the HOST time spent issuing the step -- and not what
 it cannot: xGMI transfer time and the waiting for peers.  The variance sum of the rank's evaluation slice is checked against
 the single-GPU path, so the replayed rank demonstrably computed its share of the factor.
@@ -24,7 +24,72 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
 from gpexp_amd import device as dev, dist  # noqa: E402
+from replay_comm import ReplayComm  # noqa: E402
+
+
+def replay_rank(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=512, agg=None, streamed=True, steps=3, profile=True,
+                single_potrf_ms=None):
+    """One process plays `rank` of the Pr x Pc `grid` against the complete factor `Lref` resident on this GPU: records the
+    rank's program, checks what it computed against the single-GPU path, times `steps` steps.  Returns the result dict."""
+    Pr, Pc = grid
+    world = Pr * Pc
+    gs = "%dx%d" % (Pr, Pc)
+    n, m = Xh.shape[0], Zh.shape[0]
+    agg = dist.default_agg() if agg is None else agg
+    comm = ReplayComm(ctx, world, rank, Lref)
+    run = dist.DistFitIvar2D(ctx, comm, spec, Xh, yh, Zh, noise, nb=nb, grid=(Pr, Pc), agg=agg, streamed=streamed, fit_only=True)
+    _, part = run.step()          # records the program, first run
+    ctx.sync()
+    check = 0.0
+    if not run.window:
+        # the replicated factor this rank assembled from its own solves and the staged pieces must BE the factor
+        Zc = dev.points(ctx, Zh[:512])
+        _, v1 = dev.posterior(ctx, spec, run.L, X, None, Zc, want_mean=False)
+        _, v0 = dev.posterior(ctx, spec, Lref, X, None, Zc, want_mean=False)
+        check = float(np.max(np.abs(v1 - v0)) / np.max(np.abs(v0)))
+        assert check < 1e-10, (gs, rank, check)
+    if run.B is not None:     # streamed evaluation of the rank's slice against the single-GPU path
+        lo, hi = dist.eval_slice(m, rank, world)
+        _, var = dev.posterior(ctx, spec, Lref, X, None, dev.points(ctx, Zh[lo:hi]), want_mean=False)
+        ref = float(np.sum(var))
+        assert abs(part - ref) <= 1e-10 * abs(ref), (gs, rank, part, ref)
+        check = max(check, abs(part - ref) / abs(ref))
+    ts, host = [], []
+    for _ in range(steps):
+        ctx.sync()
+        t0 = time.perf_counter()
+        run.step()
+        ctx.sync()
+        ts.append(1e3 * (time.perf_counter() - t0))
+        host.append(run.host_ms.get("factor", 0.0))
+    geo = run.geo
+    res = dict(grid=gs, rank=rank, pr=geo.pr, pc=geo.pc, N=n, M=m, nb=nb, agg=agg, steps_k=geo.nblk,
+               streamed_ivar=bool(streamed), factor_window_panels=run.window, ms_per_step=float(np.median(ts)), ms_all=ts,
+               host_issue_ms_per_fit=float(np.median(host)), host_issue_us_per_panel_step=1e3 * float(np.median(host)) / geo.nblk,
+               program_rows=len(run.programs["factor"]), rows_per_panel_step=len(run.programs["factor"]) / geo.nblk,
+               issue_mode="hipGraph (one launch per step)" if run.use_graph else "rows (one HIP call per row)",
+               graph_nodes=run.programs["factor"].graph_nodes, bytes_received_per_fit=comm.bytes_in,
+               variance_check_rel=check, single_gpu_potrf_ms=single_potrf_ms)
+    if profile:
+        # per-class kernel time of one more, instrumented, step (row by row: profiler events cannot live inside a graph)
+        run.force_interpret = True
+        ctx.profile(True)
+        ctx.profile_reset()
+        run.step()
+        ctx.sync()
+        prof = ctx.profile_get()
+        ctx.profile(False)
+        res["host_issue_ms_row_by_row"] = run.host_ms.get("factor", 0.0)
+        run.force_interpret = False
+        res["class_ms"] = {k: round(v["ms"], 3) for k, v in prof.items() if v["launches"]}
+        res["class_launches"] = {k: v["launches"] for k, v in prof.items() if v["launches"]}
+        res["gemm_flops"] = prof["gemm"]["flops"]
+    del run, comm
+    ctx.trim()
+    return res
 
 
 def main():
@@ -65,59 +130,10 @@ def main():
         world = Pr * Pc
         ranks = sorted({(world - 1 if r == "last" else int(r)) for r in args.ranks.split(",") if r == "last" or int(r) < world})
         for rank in ranks:
-            comm = dist.ReplayComm(ctx, world, rank, Lref)
-            streamed = world >= 4 and not args.no_stream
-            run = dist.DistFitIvar2D(ctx, comm, spec, Xh, yh, Zh, noise, nb=args.nb, grid=(Pr, Pc), agg=args.agg,
-                                     streamed=streamed, fit_only=True)
-            _, part = run.step()          # records the program, first run
-            ctx.sync()
-            check = 0.0
-            if not run.window:
-                # the replicated factor this rank assembled from its own solves and the staged pieces must BE the factor
-                Zc = dev.points(ctx, Zh[:512])
-                _, v1 = dev.posterior(ctx, spec, run.L, X, None, Zc, want_mean=False)
-                _, v0 = dev.posterior(ctx, spec, Lref, X, None, Zc, want_mean=False)
-                check = float(np.max(np.abs(v1 - v0)) / np.max(np.abs(v0)))
-                assert check < 1e-10, (gs, rank, check)
-            if run.B is not None:     # streamed evaluation of the rank's slice against the single-GPU path
-                lo, hi = dist.eval_slice(args.m, rank, world)
-                _, var = dev.posterior(ctx, spec, Lref, X, None, dev.points(ctx, Zh[lo:hi]), want_mean=False)
-                ref = float(np.sum(var))
-                assert abs(part - ref) <= 1e-10 * abs(ref), (gs, rank, part, ref)
-                check = max(check, abs(part - ref) / abs(ref))
-            ts, host = [], []
-            for _ in range(args.steps):
-                ctx.sync()
-                t0 = time.perf_counter()
-                run.step()
-                ctx.sync()
-                ts.append(1e3 * (time.perf_counter() - t0))
-                host.append(run.host_ms.get("factor", 0.0))
-            # per-class kernel time of one more, instrumented, step (row by row: profiler events cannot live inside a graph)
-            run.force_interpret = True
-            ctx.profile(True)
-            ctx.profile_reset()
-            run.step()
-            ctx.sync()
-            prof = ctx.profile_get()
-            ctx.profile(False)
-            host_rows = run.host_ms.get("factor", 0.0)
-            run.force_interpret = False
-            geo = run.geo
-            res = dict(grid=gs, rank=rank, pr=geo.pr, pc=geo.pc, N=args.n, M=args.m, nb=args.nb, agg=args.agg, steps_k=geo.nblk,
-                       streamed_ivar=streamed, factor_window_panels=run.window, ms_per_step=float(np.median(ts)), ms_all=ts,
-                       host_issue_ms_per_fit=float(np.median(host)), host_issue_us_per_panel_step=1e3 * float(np.median(host)) / geo.nblk,
-                       program_rows=len(run.programs["factor"]), rows_per_panel_step=len(run.programs["factor"]) / geo.nblk,
-                       issue_mode="hipGraph (one launch per step)" if run.use_graph else "rows (one HIP call per row)",
-                       graph_nodes=run.programs["factor"].graph_nodes, host_issue_ms_row_by_row=host_rows,
-                       bytes_received_per_fit=comm.bytes_in,
-                       class_ms={k: round(v["ms"], 3) for k, v in prof.items() if v["launches"]},
-                       class_launches={k: v["launches"] for k, v in prof.items() if v["launches"]},
-                       gemm_flops=prof["gemm"]["flops"], variance_check_rel=check, single_gpu_potrf_ms=single_potrf_ms)
+            res = replay_rank(ctx, spec, Xh, yh, Zh, noise, Lref, X, (Pr, Pc), rank, nb=args.nb, agg=args.agg,
+                              streamed=(world >= 4 and not args.no_stream), steps=args.steps, single_potrf_ms=single_potrf_ms)
             results.append(res)
             print(json.dumps(res), flush=True)
-            del run, comm
-            ctx.trim()
     print("\n%-6s %-5s %10s %14s %16s %10s %12s" % ("grid", "rank", "ms/step", "host ms/fit", "host us/k-step", "rows/k", "GB received"))
     for r in results:
         print("%-6s %-5d %10.2f %14.2f %16.1f %10.1f %12.2f" % (r["grid"], r["rank"], r["ms_per_step"], r["host_issue_ms_per_fit"],

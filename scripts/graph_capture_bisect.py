@@ -7,6 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gpexp_amd import device as dev, dist
 from gpexp_amd.dist import OP, Program, MAIN, PANEL, COMM, BACK, EVAL, BULK
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from replay_comm import ReplayComm
 ncut = int(sys.argv[1])
 ctx = dev.Context(0); dev._ctx = ctx
 rng = np.random.default_rng(1)
@@ -15,7 +17,7 @@ Xh = rng.uniform(-1, 1, (n, d)); yh = rng.standard_normal(n); Zh = rng.uniform(-
 spec = dev.KernelSpec(dev.K_MATERN52, d, [0.5, 1.0])
 X = dev.points(ctx, Xh)
 Lref = dev.potrf(ctx, dev.kfill(ctx, spec, X, nugget=0.1))
-comm = dist.ReplayComm(ctx, 1, 0, Lref)
+comm = ReplayComm(ctx, 1, 0, Lref)
 os.environ["GPX_DIST_GRAPH"] = "0"
 run = dist.DistFitIvar2D(ctx, comm, spec, Xh, yh, Zh, 0.1, nb=256, grid=(1, 1), agg=4, streamed=False, fit_only=True)
 run.step(); ctx.sync()
