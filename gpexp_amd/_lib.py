@@ -64,6 +64,15 @@ _SIGS = {
     "gpx_greedy_var": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_dp, c_ip, c_i64, c_i64, c_ip]),
     "gpx_greedy_ivar_step": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_vp,
                                        C.c_double, c_dp, c_ip]),
+    "gpx_greedy_ivar": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_vp, C.c_double, c_i64, c_ip, c_dp,
+                                  c_dp]),
+    "gpx_givar_begin": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_vp, C.c_double, c_i64,
+                                  C.POINTER(c_vp)]),
+    "gpx_givar_pivot_elems": (c_i64, [c_vp]),
+    "gpx_givar_score": (C.c_int, [c_vp, c_vp, c_dp, c_ip, c_dp]),
+    "gpx_givar_pack": (C.c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "gpx_givar_apply": (C.c_int, [c_vp, c_vp, c_vp]),
+    "gpx_givar_end": (C.c_int, [c_vp, c_vp]),
     "gpx_mi_greedy": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, C.c_double, c_i64, c_i64, c_ip, c_dp]),
     "gpx_lml_grad": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_dp, c_dp]),
     "gpx_lml_grad_slab": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_dp, c_i64, c_i64, c_dp]),

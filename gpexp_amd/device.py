@@ -383,6 +383,50 @@ def greedy_ivar_step(ctx, spec, L, X, Cpts, Z, noise, want_costs=True):
     return best.value, costs
 
 
+def greedy_ivar(ctx, spec, L, X, Cpts, Z, noise, nsel, want_all=False):
+    """nsel picks of discrete greedy IVAR with resident state (gpx_greedy_ivar): (indices, winner costs[, all costs nsel x M])."""
+    nsel = int(nsel)
+    idx = np.empty(nsel, dtype=np.int64)
+    cost = np.empty(nsel)
+    allc = np.empty((nsel, Cpts.shape[0])) if want_all else None
+    check(ctx.lib.gpx_greedy_ivar(ctx.h, *spec.args(), L.h, X.h, Cpts.h, Z.h, float(noise), nsel,
+                                  idx.ctypes.data_as(_lib.c_ip), dptr(cost), dptr(allc)))
+    return (idx, cost, allc) if want_all else (idx, cost)
+
+
+class GivarState:
+    """One rank's state of a candidate-sharded greedy-IVAR run (gpx_givar_*): W_C = L^-1 K(X, C_local), cov(Z, C_local | design)
+    and the score vectors stay on the device; a pick is one pivot pack (from the winner's owner) applied by every rank."""
+
+    def __init__(self, ctx, spec, L, X, Cpts, Z, noise, nsel):
+        self.ctx, self.Cpts, self.Z, self.L, self.X = ctx, Cpts, Z, L, X      # (kept alive: the library reads C's points per pick)
+        self.m = Cpts.shape[0]
+        h = c_vp()
+        check(ctx.lib.gpx_givar_begin(ctx.h, *spec.args(), L.h, X.h, Cpts.h, Z.h, float(noise), int(nsel), C.byref(h)))
+        self.h = h
+        self.pivot_elems = int(ctx.lib.gpx_givar_pivot_elems(h))
+
+    def score(self, want_all=False):
+        v, i = C.c_double(), c_i64()
+        allc = np.empty(self.m) if want_all else None
+        check(self.ctx.lib.gpx_givar_score(self.ctx.h, self.h, C.byref(v), C.byref(i), dptr(allc)))
+        return v.value, i.value, allc
+
+    def pack(self, s, buf):
+        check(self.ctx.lib.gpx_givar_pack(self.ctx.h, self.h, int(s), buf.h))
+
+    def apply(self, buf):
+        check(self.ctx.lib.gpx_givar_apply(self.ctx.h, self.h, buf.h))
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self.ctx.lib.gpx_givar_end(self.ctx.h, self.h)
+            self.h = None
+        except Exception:
+            pass
+
+
 def mi_greedy(ctx, spec, Cpts, noise, nsel, start=0):
     out = np.empty(int(nsel), dtype=np.int64)
     ratios = np.empty(max(int(nsel) - 1, 0))

@@ -522,6 +522,53 @@ def dist_greedy_ivar_step(ctx, comm, spec, L, X, cand_host, Z, noise):
     return idx, cost
 
 
+def dist_greedy_ivar(ctx, comm, spec, L, X, cand_host, mc_host, noise, nsel, want_all=False, be=None):
+    """nsel picks of discrete greedy IVAR (composition of experimentalDesign.py:79-117) with the CANDIDATES sharded
+    and the state RESIDENT (gpx_givar_*): every rank holds the replicated factor, W_C and cov(Z, C | design) for its contiguous
+    slice of the candidates and the whole of Z.  Per pick: local first minimum -> one (cost, global index) pair per rank, merged
+    by np.argmin's rule; the winner's owner packs its pivot (delta, the point, cov(Z, c_s) / sqrt(delta), its column of W_C, its
+    coordinates along the earlier picks: 2 + d + nMC + N + nsel doubles) and broadcasts it; every rank conditions its slice on
+    it (one pass over its W_C, one over its G).  No refit, no N^2 solve after the set-up.  Returns (indices, costs[, all costs])."""
+    be = be or _dev
+    m = cand_host.shape[0]
+    nsel = int(nsel)
+    lo, hi = eval_slice(m, comm.rank, comm.world)
+    Z = be.points(ctx, mc_host)
+    st = be.GivarState(ctx, spec, L, X, be.points(ctx, cand_host[lo:hi]), Z, noise, nsel) if hi > lo else None
+    npad = padded(X.shape[0])
+    pack = 2 + spec.d + padded(mc_host.shape[0]) + npad + nsel
+    assert st is None or st.pivot_elems == pack
+    buf = be.alloc_vector(ctx, pack)
+    idx, costs = np.empty(nsel, dtype=np.int64), np.empty(nsel)
+    allc = np.empty((nsel, m)) if want_all else None
+    per = (m + comm.world - 1) // comm.world
+    for t in range(nsel):
+        if st is not None:
+            c, i, loc = st.score(want_all)
+            mine = np.array([c, float(lo + i)])
+        else:
+            loc, mine = np.zeros(0), np.array([np.inf, float(m)])
+        pairs = comm.allgather(mine)
+        cost, s = merge_argmin(pairs[:, 0], pairs[:, 1].astype(np.int64))
+        idx[t], costs[t] = s, cost
+        if want_all:
+            pad = np.zeros(per)
+            pad[:hi - lo] = loc
+            g = comm.allgather(pad)
+            for r in range(comm.world):
+                a, b = eval_slice(m, r, comm.world)
+                allc[t, a:b] = g[r, :b - a]
+        if t + 1 == nsel:
+            break
+        owner_rank = mi_owner(m, s, comm.world)
+        if comm.rank == owner_rank:
+            st.pack(s - lo, buf)
+        comm.bcast_grp(buf, 0, pack, owner_rank, WORLD)
+        if st is not None:
+            st.apply(buf)
+    return (idx, costs, allc) if want_all else (idx, costs)
+
+
 def dist_greedy_var(ctx, comm, spec, cand_host, nsel, keep=()):
     """Greedy maximum-variance design is O(M*n) per step and sequential in the steps: every rank runs the identical
     deterministic selection on the full candidate set (no exchange) -- "replicas" for this sub-path, by design."""
@@ -1625,6 +1672,12 @@ class Session:
         pairs = self.comm.allgather(mine)
         _, idx = merge_argmin(pairs[:, 0], pairs[:, 1].astype(np.int64))
         return idx, self.gather(costs, m)[:, 0].copy()
+
+    def greedy_ivar(self, spec, L, X, cand, mc, noise, nsel, want_all=False):
+        """nsel picks of discrete greedy IVAR with the CANDIDATES sharded and the state resident (dist_greedy_ivar)."""
+        self.agree("the candidate / Monte-Carlo points", as_f64(cand), as_f64(mc))
+        return dist_greedy_ivar(self.ctx, self.comm, spec, L, X, as_f64(cand), as_f64(mc), noise, nsel, want_all=want_all,
+                                be=self.be)
 
     def mi_greedy(self, spec, cand, noise, nsel, start=0):
         self.agree("the candidate points", as_f64(cand))

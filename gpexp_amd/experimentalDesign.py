@@ -35,7 +35,7 @@ NLOPT = False
 
 __all__ = ["costFunctionBase", "costFunctionGP_IVAR", "costFunctionGP_MI", "ExperimentalDesign",
            "ExperimentalDesignDerivative", "performGreedyVarExperimentalDesign",
-           "performGreedyMIExperimentalDesign", "greedyIVARStep", "np"]
+           "performGreedyMIExperimentalDesign", "greedyIVARStep", "performGreedyIVARExperimentalDesign", "np"]
 
 
 class costFunctionBase(object):
@@ -329,3 +329,26 @@ def greedyIVARStep(gaussianProcess, candidates, mcPoints):
     ctx = _dev.context()
     return _dev.greedy_ivar_step(ctx, gp.kernel._spec(), gp._L, gp._X, _dev.points(ctx, candidates),
                                  _dev.points(ctx, mcPoints), float(gp.noise))
+
+
+def performGreedyIVARExperimentalDesign(gaussianProcess, candidates, mcPoints, nPoints, returnCosts=False):
+    """`nPoints` picks of discrete greedy IVAR for a GP whose training set is already factored: at every pick the candidate whose
+    addition minimises costFunctionGP_IVAR.evaluate (experimentalDesign.py:79-117) is appended to the design -- the loop
+    `for k: best, _ = greedyIVARStep(gp, candidates, mcPoints); gp.addNodesAndComputeCovariance(vstack(gp.pts, candidates[best]))`
+    (the reference has no such function) -- WITHOUT refitting: gpx_greedy_ivar keeps L^-1 K(X, C) and
+    cov(Z, C | design) resident and conditions them on each pick by a rank-one update.  The GP itself is not modified.
+    Returns candidates[indices] (as the reference's greedy designs do) or (indices, costs) with returnCosts=True."""
+    gp = gaussianProcess
+    if gp._L is None:
+        raise NotImplementedError("performGreedyIVARExperimentalDesign needs the dense Cholesky factor (GP built with FITC=... has none)")
+    candidates = np.asarray(candidates, dtype=float)
+    sess = _dist.session()
+    if sess is not None and sess.use_eval(len(candidates)):
+        idx, costs = sess.greedy_ivar(gp.kernel._spec(), gp._L, gp._X, candidates, mcPoints, float(gp.noise), int(nPoints))
+    else:
+        ctx = _dev.context()
+        idx, costs = _dev.greedy_ivar(ctx, gp.kernel._spec(), gp._L, gp._X, _dev.points(ctx, candidates),
+                                      _dev.points(ctx, np.asarray(mcPoints, dtype=float)), float(gp.noise), int(nPoints))
+    if returnCosts:
+        return idx, costs
+    return candidates[list(idx), :]

@@ -177,6 +177,25 @@ int gpx_greedy_var(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp,
 int gpx_greedy_ivar_step(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp,
                          const gpx_mat* L, const gpx_mat* X, const gpx_mat* C, const gpx_mat* Z,
                          double noise, double* out_cost, int64_t* out_best);
+/* Multi-pick greedy IVAR with RESIDENT state (composition of experimentalDesign.py:79-117 per SURVEY 8c): nsel picks cost one
+ * set-up (the work of ONE gpx_greedy_ivar_step) + per pick one pass over W_C = L^-1 K(X, C) and one over cov(Z, C | design) --
+ * no refit, no N^2 solve.  Picks equal nsel rounds of gpx_greedy_ivar_step + refit on the winner (a candidate may be picked
+ * again, as there).  out_idx[nsel]; out_cost[nsel] (the winner's cost at each pick, optional); all_costs (nsel x M, optional). */
+int gpx_greedy_ivar(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
+                    const gpx_mat* C, const gpx_mat* Z, double noise, int64_t nsel, int64_t* out_idx, double* out_cost,
+                    double* all_costs);
+/* the same as a state machine, sharded by CANDIDATES for the multi-GPU form (every rank: its slice of C and the whole of Z):
+ * score -> local first minimum; the owner of the merged winner packs its pivot (gpx_givar_pivot_elems doubles: delta, the
+ * point, cov(Z, c_s | design) / sqrt(delta), its column of W_C, its coordinates along the earlier picks), the caller broadcasts
+ * it, every rank applies it.  The per-candidate arithmetic does not depend on the sharding. */
+typedef struct gpx_givar gpx_givar;
+int gpx_givar_begin(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
+                    const gpx_mat* C, const gpx_mat* Z, double noise, int64_t nsel, gpx_givar** out);
+int64_t gpx_givar_pivot_elems(const gpx_givar* st);
+int gpx_givar_score(gpx_ctx* ctx, gpx_givar* st, double* best_cost, int64_t* best_idx, double* all_costs);
+int gpx_givar_pack(gpx_ctx* ctx, gpx_givar* st, int64_t s, gpx_mat* buf);
+int gpx_givar_apply(gpx_ctx* ctx, gpx_givar* st, const gpx_mat* buf);
+int gpx_givar_end(gpx_ctx* ctx, gpx_givar* st);
 
 /* greedy mutual-information design among M candidates with noise variance `noise`, seeded with `start`
  * (experimentalDesign.py:223-285, 753-785): out_idx[nsel] = start followed by the picks (first-max tie rule);

@@ -136,6 +136,12 @@ def run_api(args, gpu):
         assert rel(costs, golden(c, "givar_allcosts")[step]) <= 1e-10
         same("greedy ivar", costs, [best])
         Xh = np.vstack((Xh, Ch[best:best + 1]))
+    # multi-pick greedy IVAR with resident state, candidates sharded (dist_greedy_ivar): the same four winners and costs
+    g.addNodesAndComputeCovariance(golden(c, "X0"))
+    gi, gc = edm.performGreedyIVARExperimentalDesign(g, Ch, Zh, 4, returnCosts=True)
+    assert list(gi) == list(golden(c, "givar_idx")[:4]), (gi, golden(c, "givar_idx"))
+    assert rel(gc, golden(c, "givar_cost")[:4]) <= 1e-10
+    same("greedy ivar multi-pick", gi, gc)
     # ---- MI design (experimentalDesign.py:223-285, 753-785): scoring sharded by rows of the inverse ----
     c = "kat6_mi"
     if c in golden.index:

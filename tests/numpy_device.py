@@ -166,9 +166,75 @@ class NumpyDevice(NumpyC5):
         costs = np.array([orc.ivar(s, np.vstack((X, Cpts[j:j + 1])), Z, float(noise)) for j in range(len(Cpts))])
         return int(np.argmin(costs)), costs
 
+    def GivarState(self, ctx, spec, L, X, Cpts, Z, noise, nsel):
+        return _GivarState(self, spec, L, X, Cpts, Z, noise, nsel)
+
+    def greedy_ivar(self, ctx, spec, L, X, Cpts, Z, noise, nsel, want_all=False):
+        st = _GivarState(self, spec, L, X, Cpts, Z, noise, nsel)
+        buf = NumpyMat(np.zeros(st.pivot_elems))
+        idx, costs = [], []
+        for t in range(int(nsel)):
+            c, i, _ = st.score()
+            idx.append(i)
+            costs.append(c)
+            if t + 1 < nsel:
+                st.pack(i, buf)
+                st.apply(buf)
+        return np.array(idx, dtype=np.int64), np.array(costs)
+
     def mi_greedy(self, ctx, spec, Cpts, noise, nsel, start=0):
         idx, ratios = orc.greedy_mi(oracle_spec(spec), Cpts, float(noise), int(nsel), start=int(start))
         return np.array(idx, dtype=np.int64), ratios
+
+
+class _GivarState:
+    """NumPy double of device.GivarState: same interface and pivot-pack layout, dense arithmetic from the definitions."""
+
+    def __init__(self, be, spec, L, X, Cpts, Z, noise, nsel):
+        s = oracle_spec(spec)
+        self.s, self.C, self.noise, self.nsel, self.cur = s, Cpts, float(noise), int(nsel), 0
+        n = X.shape[0]
+        Lt = be._L(L, n)
+        self.np_, self.zp, self.d = dist.padded(n), dist.padded(len(Z)), spec.d
+        self.Wc = np.zeros((self.np_, len(Cpts)))
+        self.Wc[:n] = np.linalg.solve(Lt, orc.cross_matrix(s, Cpts, X).T)
+        Wz = np.linalg.solve(Lt, orc.cross_matrix(s, Z, X).T)
+        self.G = np.zeros((self.zp, len(Cpts)))
+        self.G[:len(Z)] = orc.cross_matrix(s, Cpts, Z).T - Wz.T @ self.Wc[:n]
+        self.v = orc.kernel_diag(s, Cpts) - np.sum(self.Wc ** 2, axis=0)
+        self.s0 = float(np.sum(orc.kernel_diag(s, Z) - np.sum(Wz ** 2, axis=0)))
+        self.nmc = len(Z)
+        self.U = np.zeros((self.nsel, len(Cpts)))
+        self.pivot_elems = 2 + self.d + self.zp + self.np_ + self.nsel
+
+    def score(self, want_all=False):
+        cost = np.abs((self.s0 - np.sum(self.G ** 2, axis=0) / (self.v + self.noise)) / self.nmc)
+        i = int(np.argmin(cost))
+        return float(cost[i]), i, (cost if want_all else None)
+
+    def pack(self, sidx, buf):
+        d, zp, np_ = self.d, self.zp, self.np_
+        delta = self.v[sidx] + self.noise
+        b = buf.a
+        b[0] = delta
+        b[2:2 + d] = self.C[sidx]
+        r = self.G[:, sidx] / np.sqrt(delta)
+        b[1] = float(r @ r)
+        b[2 + d:2 + d + zp] = r
+        b[2 + d + zp:2 + d + zp + np_] = self.Wc[:, sidx]
+        b[2 + d + zp + np_:2 + d + zp + np_ + self.nsel] = self.U[:, sidx]
+
+    def apply(self, buf):
+        d, zp, np_ = self.d, self.zp, self.np_
+        b = buf.a
+        delta, cs = b[0], b[2:2 + d].reshape(1, d)
+        r, w, uc = b[2 + d:2 + d + zp], b[2 + d + zp:2 + d + zp + np_], b[2 + d + zp + np_:2 + d + zp + np_ + self.nsel]
+        u = (orc.kernel_eval(self.s, self.C, cs) - w @ self.Wc - uc[:self.cur] @ self.U[:self.cur]) / np.sqrt(delta)
+        self.U[self.cur] = u
+        self.v = self.v - u * u
+        self.G = self.G - np.outer(r, u)
+        self.s0 -= b[1]
+        self.cur += 1
 
 
 class ApiOps2D(NumpyOps2D):

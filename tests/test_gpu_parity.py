@@ -242,6 +242,64 @@ def test_greedy_ivar_indices_bit_exact(dev, ctx, golden):
         Xh = np.vstack((Xh, Ch[best:best + 1]))
 
 
+def test_greedy_ivar_multi_pick_resident_state_bit_exact(dev, ctx, golden):
+    """gpx_greedy_ivar: the reference-pinned KAT5 four-pick sequence from ONE call that keeps L^-1 K(X, C)
+    and cov(Z, C | design) resident and conditions them on each pick by a rank-one update -- winners exact, the winner's cost and
+    EVERY candidate's cost at every pick 1e-10 against the reference's refits (experimentalDesign.py:79-117 per SURVEY 8c)."""
+    c = "kat5_greedy"
+    sp = spec_of(dev, golden.index[c]["kernel"])
+    X = dev.points(ctx, golden(c, "X0"))
+    L = dev.potrf(ctx, dev.kfill(ctx, sp, X, nugget=1e-3))
+    C, Z = dev.points(ctx, golden(c, "C")), dev.points(ctx, golden(c, "Z"))
+    idx, cost, allc = dev.greedy_ivar(ctx, sp, L, X, C, Z, 1e-3, 4, want_all=True)
+    np.testing.assert_array_equal(idx, golden(c, "givar_idx")[:4])
+    assert rel(cost, golden(c, "givar_cost")[:4]) <= 1e-10
+    for t in range(4):
+        assert rel(allc[t], golden(c, "givar_allcosts")[t]) <= 1e-10
+    i2, c2 = dev.greedy_ivar(ctx, sp, L, X, C, Z, 1e-3, 4)
+    assert np.array_equal(i2, idx) and np.array_equal(c2, cost)          # deterministic
+    # the class-API form, and one pick = gpx_greedy_ivar_step
+    from gpExp.experimentalDesign import performGreedyIVARExperimentalDesign, greedyIVARStep
+    from gpExp.gp import GP
+    from gpExp.kernels import KernelSquaredExponential
+    s = golden.index[c]["kernel"]
+    g = GP(KernelSquaredExponential(list(s["cl"]), s["signalSize"], s["d"]), 1e-3)
+    g.addNodesAndComputeCovariance(golden(c, "X0"))
+    pts = performGreedyIVARExperimentalDesign(g, golden(c, "C"), golden(c, "Z"), 4)
+    np.testing.assert_array_equal(pts, golden(c, "C")[list(golden(c, "givar_idx")[:4])])
+    b1, c1 = greedyIVARStep(g, golden(c, "C"), golden(c, "Z"))
+    assert b1 == idx[0] and np.array_equal(c1, allc[0])                  # the set-up IS the step function's arithmetic
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_greedy_ivar_multi_pick_equals_refit_loop(dev, ctx, seed):
+    """Random configurations (kernel kind, d, ragged N / M / nMC, per-point training noise): k picks from the resident state ==
+    k rounds of gpx_greedy_ivar_step + an actual refit on the winner -- winners equal wherever the step's winner is clear
+    (gap > 1e-9 relative), costs 1e-9."""
+    rng = np.random.default_rng(100 + seed)
+    d = int(rng.integers(1, 7))
+    n, m, nmc, k = int(rng.integers(5, 400)), int(rng.integers(3, 700)), int(rng.integers(2, 300)), int(rng.integers(2, 9))
+    kind = ["se", "matern32", "matern52"][seed % 3]
+    s = dict(kind="se", cl=list(rng.uniform(0.3, 0.9, d)), signalSize=1.2, d=d) if kind == "se" else \
+        dict(kind=kind, rho=float(rng.uniform(0.4, 0.9)), signalSize=1.1, d=d)
+    sp = spec_of(dev, s)
+    noise = float(rng.uniform(0.01, 0.2))
+    Xh, Ch, Zh = rng.uniform(-1, 1, (n, d)), rng.uniform(-1, 1, (m, d)), rng.uniform(-1, 1, (nmc, d))
+    X, C, Z = dev.points(ctx, Xh), dev.points(ctx, Ch), dev.points(ctx, Zh)
+    L = dev.potrf(ctx, dev.kfill(ctx, sp, X, nugget=noise))
+    idx, cost, allc = dev.greedy_ivar(ctx, sp, L, X, C, Z, noise, k, want_all=True)
+    Xc = Xh.copy()
+    for t in range(k):
+        Xd = dev.points(ctx, Xc)
+        Lt = dev.potrf(ctx, dev.kfill(ctx, sp, Xd, nugget=noise))
+        best, costs = dev.greedy_ivar_step(ctx, sp, Lt, Xd, C, Z, noise)
+        assert rel(allc[t], costs) <= 1e-9, (seed, t)
+        srt = np.sort(costs)
+        if len(srt) < 2 or srt[1] - srt[0] > 1e-9 * abs(srt[0]):
+            assert idx[t] == best, (seed, t, idx[t], best)
+        Xc = np.vstack((Xc, Ch[idx[t]:idx[t] + 1]))
+
+
 def test_posterior_chunked_equals_unchunked(dev, ctx, monkeypatch):
     """ragged sizes + forced chunking of the evaluation set (size-independent property)."""
     rng = np.random.default_rng(9)
