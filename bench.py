@@ -191,7 +191,9 @@ def bench_c5(args, ctx, dev, world, rank, stdout_fd):
     else:
         nslab = int(os.environ.get("GPX_C5_SLABS", "16"))   # measured 1 / 2 / 4 / 8 / 16 / 32 slabs: 7.8 / 5.7 / 4.4 / 3.7 / 3.5 / 3.5 s (fewer
         #                                                      flops with more slabs -- 2 N^3 down to 2 N^3 / 3 -- thinner products)
-        layout = "1 GPU (gradient traces over %d row slabs of K^-1)" % nslab
+        linv_form = os.environ.get("GPX_LML_GRAD_FORM", "linv") == "linv" and dev.lml_grad_linv_fits(ctx, N)
+        layout = "1 GPU (gradient traces: %s)" % ("L^-1 once, lower K^-1 = L^-T L^-1 as one triangular-operand product over it"
+                                                  if linv_form else "%d row slabs of K^-1, two triangular solves each" % nslab)
         X = dev.points(ctx, Xh)
         Cp = dev.points(ctx, Ch)
         K = dev.DeviceMatrix.zeros(ctx, N, N)
@@ -204,10 +206,13 @@ def bench_c5(args, ctx, dev, world, rank, stdout_fd):
             alpha = dev.potrs(ctx, K, yh)
             ll = -0.5 * float(yh @ alpha) - 0.5 * dev.logdet(ctx, K) - N / 2.0 * np.log(2 * np.pi)
             t1 = time.perf_counter()
-            sums = np.zeros(d + 2)
-            for r0, r1 in zip(bounds[:-1], bounds[1:]):
-                if r1 > r0:
-                    sums += dev.lml_grad_slab(ctx, spec, K, X, alpha, r0, r1)
+            if linv_form:        # one explicit L^-1, lower K^-1 over it (gpx_lml_grad_linv: 2 N^2 + N^2/4 doubles of scratch)
+                sums = dev.lml_grad_linv(ctx, spec, K, X, alpha)
+            else:
+                sums = np.zeros(d + 2)
+                for r0, r1 in zip(bounds[:-1], bounds[1:]):
+                    if r1 > r0:
+                        sums += dev.lml_grad_slab(ctx, spec, K, X, alpha, r0, r1)
             grad = dev.lml_grad_from_sums(spec, sums)
             t2 = time.perf_counter()
             picks, _ = dev.mi_greedy(ctx, spec, Cp, noise, 8)

@@ -448,6 +448,59 @@ int gpx_lml_grad_slab(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp
   return r;
 }
 
+// The raw trace sums over ALL rows (what gpx_lml_grad_slab adds up to over a partition), for ONE GPU that can afford two more
+// N x N buffers: L^-1 by the halving recursion (chol_trtri: N^3/3 flops as large products), U = L^-T, then the LOWER triangle
+// of K^-1 = U U^T as ONE product that skips the structurally zero part of every tile's k range (N^3/3), written over L^-1 --
+// 2 N^3 / 3 flops at the rate of large GEMMs (66 TF/s at N = 65536) against 54 TF/s for the two-solve slabs, whose products have
+// K = 1024; memory 2 N^2 + N^2/4 of scratch against the 3 N^2 + N^2/4 of gpx_potri + gpx_lml_grad (which keeps L^-1, U and a
+// separate K^-1).  The multi-GPU form keeps the two-solve slabs: they shard ALL of the work, this form would replicate the
+// N^3/3 of L^-1 on every rank.  sums: host, d+2 doubles (as gpx_lml_grad_slab returns them).
+int gpx_lml_grad_linv(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
+                      const double* alpha, double* sums) {
+  GPX_ARG(ctx && L && X && alpha && sums, "NULL argument");
+  GPX_ARG(L->factored && L->aux, "matrix has not been factored by gpx_potrf");
+  GPX_ARG(kind == GPX_K_SE, "lml_grad: only the squared-exponential kernel has hyper-parameter derivatives "
+                            "(the reference raises for the others, kernels.py:93-97)");
+  KParams kp;
+  GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
+  GPX_ARG(X->cols == d && X->pcols == d && X->rows == L->rows, "X does not match the factor");
+  const int64_t n = L->rows, np = L->prows;
+  const int nq = d + 2;
+  for (int q = 0; q < nq; ++q) sums[q] = 0.0;
+  int r = 0;
+  {
+    Scratch sc(ctx);
+    void *pI, *pT, *ptmp, *pal, *ppart, *pout;
+    const int64_t tiles = gpx_round_up(n, TS) / TS;
+    do {
+      if ((r = sc.get(np * np * 8, &pI)) != 0) break;
+      if ((r = sc.get(np * np * 8, &pT)) != 0) break;
+      if ((r = sc.get((np / 2 + 64) * (np / 2 + 64) * 8, &ptmp)) != 0) break;
+      if ((r = sc.get(n * 8, &pal)) != 0) break;
+      if ((r = sc.get(tiles * tiles * nq * 8, &ppart)) != 0) break;
+      if ((r = sc.get(nq * 8, &pout)) != 0) break;
+      if (hipMemcpyAsync(pal, alpha, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { r = -2; break; }
+      if ((r = chol_trtri(ctx, L, (double*)pI, (double*)ptmp)) != 0) break;                             // L^-1
+      if ((r = launch_transpose(ctx, (double*)pI, np, np, np, (double*)pT, np)) != 0) break;            // U = L^-T
+      if ((r = launch_gemm_tri(ctx, (double*)pT, np, (double*)pT, np, (double*)pI, np, np, np, np, true, false, true, 3)) != 0)
+        break;                                                                                           // lower K^-1 over L^-1
+      {
+        ProfScope ps(ctx, GPX_PROF_REDUCE, 0.0, 8.0 * (double)n * n);
+        dim3 grid((unsigned)tiles, (unsigned)tiles);
+        size_t sh = (size_t)(2 * TS * d + 4) * sizeof(double);
+        hipLaunchKernelGGL(lmlgrad_kernel, grid, dim3(256), sh, ctx->stream, kp, X->p, n, (const double*)pI, np,
+                           (const double*)pal, (double*)ppart);
+        hipLaunchKernelGGL(lmlgrad_final_kernel, dim3(nq), dim3(256), 0, ctx->stream, (const double*)ppart, tiles * tiles, nq,
+                           (double*)pout);
+      }
+      if (hipMemcpyAsync(sums, pout, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->stream) != hipSuccess) { r = -2; break; }
+    } while (0);
+  }
+  if (r == -2) gpx_set_error("lml_grad_linv: HIP call failed: %s", hipGetErrorString(hipGetLastError()));
+  return r;
+}
+
 int gpx_mi_greedy(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* Cm, double noise,
                   int64_t nsel, int64_t start, int64_t* out_idx, double* out_ratio) {
   GPX_ARG(ctx && Cm && out_idx, "NULL argument");

@@ -449,6 +449,23 @@ def lml_grad_full(ctx, spec, L, X, alpha):
     return out
 
 
+def lml_grad_linv(ctx, spec, L, X, alpha):
+    """Raw trace sums (d+2) over all rows through ONE explicit L^-1 and the lower triangle of K^-1 written over it
+    (gpx_lml_grad_linv): the single-GPU form for large N when two more N x N buffers fit."""
+    alpha = as_f64(alpha)
+    out = np.empty(spec.d + 2)
+    check(ctx.lib.gpx_lml_grad_linv(ctx.h, *spec.args(), L.h, X.h, dptr(alpha), dptr(out)))
+    return out
+
+
+def lml_grad_linv_fits(ctx, n):
+    """Room for gpx_lml_grad_linv's buffers (L^-1 / K^-1: N^2, U: N^2, recursion scratch N^2/4) beside the factor itself and
+    whatever else is resident: at most 60 % of the HBM for 3.4 N^2 doubles (N = 65536: 117 of 288 GB)."""
+    if not hasattr(ctx, "_hbm_bytes"):
+        ctx._hbm_bytes = ctx.info()["hbm_bytes"]
+    return 3.4 * 8.0 * float(n) ** 2 <= 0.6 * ctx._hbm_bytes
+
+
 def lml_grad(ctx, spec, L, X, alpha, slabs=None):
     """[d/d hyp_0 .. d/d hyp_{n-1}, raw d/d noise] of the log marginal likelihood (SE kernel; gp.py:444-466).
     Large factors: the traces are summed over `slabs` row slabs of K^-1 of equal work (gpx_lml_grad_slab: two triangular solves
@@ -459,6 +476,8 @@ def lml_grad(ctx, spec, L, X, alpha, slabs=None):
         slabs = 32 if n >= LML_GRAD_SLAB_MIN else 0
     if not slabs:
         return lml_grad_full(ctx, spec, L, X, alpha)
+    if os.environ.get("GPX_LML_GRAD_FORM", "linv") == "linv" and lml_grad_linv_fits(ctx, n):
+        return lml_grad_from_sums(spec, lml_grad_linv(ctx, spec, L, X, alpha))
     b = lml_grad_slab_bounds(n, int(slabs))
     sums = np.zeros(spec.d + 2)
     for r0, r1 in zip(b[:-1], b[1:]):

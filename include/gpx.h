@@ -217,6 +217,11 @@ int gpx_lml_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, con
  * the unit the multi-GPU gradient shards by (gpexp_amd/dist.py dist_lml_grad; gp.py:444-466). */
 int gpx_lml_grad_slab(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
                       const double* alpha, int64_t r0, int64_t r1, double* sums);
+/* the same raw sums over ALL rows at once, for ONE GPU that can hold two more N x N buffers: L^-1 (N^3/3, large products),
+ * U = L^-T, lower K^-1 = U U^T with the zero part of every tile's k range skipped (N^3/3), written over L^-1 -- the 2 N^3 / 3
+ * flops of the slabs at the rate of large GEMMs, and N^2 less memory than gpx_potri + gpx_lml_grad (gp.py:444-466) */
+int gpx_lml_grad_linv(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
+                      const double* alpha, double* sums);
 
 /* Greedy MI with the candidate SCORING sharded by rows of the inverse (multi-GPU; gpexp_amd/dist.py dist_mi_greedy).  One
  * state per rank: rows [lo, hi) of the M x M inverse are kept current and exactly those candidates are scored.  Per pick:

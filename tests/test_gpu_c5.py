@@ -34,6 +34,9 @@ def test_lml_grad_slabs_sum_to_the_full_gradient(ctx, n, d, parts):
             sums += dev.lml_grad_slab(ctx, spec, L, X, alpha, r0, r1)
     got = dev.lml_grad_from_sums(spec, sums)
     assert np.max(np.abs(got - ref)) <= 1e-10 * np.max(np.abs(ref)), (got, ref)
+    # the single-GPU large-N form: one explicit L^-1, the lower triangle of K^-1 written over it (gpx_lml_grad_linv)
+    lin = dev.lml_grad_from_sums(spec, dev.lml_grad_linv(ctx, spec, L, X, alpha))
+    assert np.max(np.abs(lin - ref)) <= 1e-10 * np.max(np.abs(ref)), (lin, ref)
     # an uneven hand-made partition gives the same
     cuts = [0, 128, (n + 127) // 128 * 128]
     sums2 = sum(dev.lml_grad_slab(ctx, spec, L, X, alpha, a, c) for a, c in zip(cuts[:-1], cuts[1:]) if c > a)
