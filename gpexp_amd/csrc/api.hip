@@ -266,6 +266,23 @@ int gpx_kparams_sets(gpx_ctx* ctx, KParams* kp, const gpx_mat* A, const gpx_mat*
   return 0;
 }
 
+// C[i][j] -= sum_b P_b[i][j] for j <= i (P_b: n x n, row stride n, consecutive), partials added in batch order
+__global__ __launch_bounds__(256) static void sub_partials_kernel(const double* __restrict__ P, int64_t nbat, int64_t n,
+                                                                  double* __restrict__ C, int64_t ldc) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+  if (j >= n || j > i) return;
+  double s = 0.0;
+  for (int64_t b = 0; b < nbat; ++b) s += P[(b * n + i) * n + j];
+  C[i * ldc + j] -= s;
+}
+
+int launch_sub_partials(gpx_ctx* ctx, const double* P, int64_t nbat, int64_t n, double* C, int64_t ldc) {
+  hipLaunchKernelGGL(sub_partials_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, ctx->stream, P, nbat, n, C,
+                     ldc);
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
+
 // ---- matrices ----------------------------------------------------------------------------------------
 int gpx_mat_new(gpx_ctx* ctx, int64_t rows, int64_t cols, int pad, gpx_mat** out) {
   GPX_ARG(rows >= 0 && cols >= 0, "negative shape");
@@ -945,8 +962,33 @@ int gpx_refit_rows(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, c
       double* A21 = K->p + keep * K->ld;
       if ((r = launch_kfill_rows(ctx, kp, X->p, n, keep, d_nug, nugget_len, nscal, A21, n2, np, K->ld)) != 0) break;
       if (keep > 0) {
-        if ((r = chol_trsm_right(ctx, K->p, K->ld, K->aux, A21, K->ld, n2, keep)) != 0) break;
-        if ((r = launch_gemm(ctx, A21, K->ld, A21, K->ld, A21 + keep, K->ld, n2, n2, keep, true, true, true)) != 0) break;
+        // The strip solve A21 <- A21 L11^-T has few rows (one batch of design points): through the leaf recursion its products
+        // have K = 128..512 on a handful of tiles (20 TF/s at N = 16384, 512 changed rows).  Large factors: through the old
+        // factor's explicit 1024-order block inverses (every product K >= 1024, 64-tiles), and the small trailing SYRK -- K = keep
+        // on n2^2 / 64^2 tiles, a serial k loop in a few dozen workgroups -- split over K into 1024-wide batches whose partial
+        // products are then subtracted in a fixed order.
+        const int64_t kc = 1024;
+        const bool wide = keep >= 4096 && n2 <= 2048 && Lold->prows >= 2048;
+        if (wide) {
+          const int64_t ib = chol_binv_order(Lold->prows), nbat = keep / kc, rem = keep - nbat * kc;
+          void *pT = nullptr, *pP = nullptr;
+          const int64_t tb = n2 * ib * 8, pb = nbat * n2 * n2 * 8;
+          if ((r = gpx_dev_alloc(ctx, tb, &pT)) != 0) break;
+          if ((r = gpx_dev_alloc(ctx, pb, &pP)) != 0) { gpx_dev_release(ctx, pT, tb); break; }
+          r = chol_trsm_right_leading(ctx, const_cast<gpx_mat*>(Lold), keep, A21, K->ld, n2, (double*)pT);
+          if (r == 0)
+            r = launch_gemm_batched(ctx, A21, K->ld, kc, A21, K->ld, kc, (double*)pP, n2, n2 * n2, n2, n2, kc, true, false, nbat);
+          if (r == 0) r = launch_sub_partials(ctx, (const double*)pP, nbat, n2, A21 + keep, K->ld);
+          if (r == 0 && rem > 0)
+            r = launch_gemm(ctx, A21 + nbat * kc, K->ld, A21 + nbat * kc, K->ld, A21 + keep, K->ld, n2, n2, rem, true, true, true);
+          (void)hipStreamSynchronize(ctx->stream);
+          gpx_dev_release(ctx, pT, tb);
+          gpx_dev_release(ctx, pP, pb);
+          if (r != 0) break;
+        } else {
+          if ((r = chol_trsm_right(ctx, K->p, K->ld, K->aux, A21, K->ld, n2, keep)) != 0) break;
+          if ((r = launch_gemm(ctx, A21, K->ld, A21, K->ld, A21 + keep, K->ld, n2, n2, keep, true, true, true)) != 0) break;
+        }
       }
       if ((r = chol_potrf_nozero(ctx, A21 + keep, K->ld, n2, K->aux + (keep / GPX_TILE) * GPX_TILE * GPX_TILE, keep, n)) != 0)
         break;

@@ -916,6 +916,16 @@ int chol_trsm_right_trailing(gpx_ctx* ctx, gpx_mat* Lm, int64_t r0, double* X, i
   return trsm_right_n_binv_rec(ctx, Ld, Lm->ld, binvT, ib, X, ldx, m, n2, 0, nb2, T);
 }
 
+// X (m x ncols) <- X L11^-T against the LEADING ncols x ncols block of a complete factor, through its block inverses (every
+// product K >= the inverse order instead of the leaf recursion's K = 128..512): the strip solve of gpx_refit_rows, whose few
+// rows (one batch of design points) make short-K products latency-bound.  ncols a multiple of 128; T >= m * ib doubles.
+int chol_trsm_right_leading(gpx_ctx* ctx, gpx_mat* Lm, int64_t ncols, double* X, int64_t ldx, int64_t m, double* T) {
+  GPX_ARG(Lm && Lm->factored && X && T && ncols > 0 && ncols <= Lm->prows && ncols % NB == 0, "trsm leading: bad arguments");
+  GPX_TRY(chol_binv_ensure(ctx, Lm));
+  const int64_t ib = Lm->binv_ib;
+  return trsm_right_binv_rec(ctx, Lm->p, Lm->ld, Lm->binv, ib, X, ldx, m, ncols, 0, (ncols + ib - 1) / ib, T);
+}
+
 // Blocked right-looking factorisation with panels of width B (4096) and ONE PANEL OF LOOK-AHEAD for large matrices.
 // Per panel k: solve the rows below the diagonal block, then the trailing update A22 -= P P^T with K = B.  The diagonal
 // block of panel k+1 -- a chain of ~100 latency-bound kernels (128-wide leaves, strip multiplies, rank-128 updates: 2.3 ms

@@ -26,6 +26,20 @@ __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict
   for (int r = ty; r < 32; r += 8) out[(j0 + r) * ldo + i0 + tx] = tile[tx][r];
 }
 
+// upper triangle <- transpose of the lower one (32 x 32 tiles, grid = tiles x tiles; tiles above the diagonal exit)
+__global__ __launch_bounds__(256) void mirror_lower_kernel(double* __restrict__ P, int64_t ld) {
+  if (blockIdx.x > blockIdx.y) return;
+  __shared__ double tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int64_t i0 = (int64_t)blockIdx.y * 32, j0 = (int64_t)blockIdx.x * 32;   // tile (i0, j0) on / below the diagonal
+  for (int r = ty; r < 32; r += 8) tile[r][tx] = P[(i0 + r) * ld + j0 + tx];
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t gi = j0 + r, gj = i0 + tx;      // element (gi, gj) of the upper part = tile[tx][r]
+    if (gj > gi) P[gi * ld + gj] = tile[tx][r];
+  }
+}
+
 __global__ __launch_bounds__(256) void set_identity_kernel(double* __restrict__ A, int64_t n, int64_t ld) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx < n) A[idx * ld + idx] = 1.0;
@@ -443,10 +457,14 @@ int gpx_potri_impl(gpx_ctx* ctx, const gpx_mat* L, gpx_mat** outP, int full) {
     if ((r = sc.get((np / 2 + 64) * (np / 2 + 64) * 8, &ptmp)) != 0) break;
     if ((r = chol_trtri(ctx, L, (double*)pI, (double*)ptmp)) != 0) break;                           // L^-1
     if ((r = launch_transpose(ctx, (double*)pI, np, np, np, (double*)pT, np)) != 0) break;          // U = L^-T
-    if (full)
-      r = launch_gemm(ctx, (double*)pT, np, (double*)pT, np, P->p, P->ld, np, np, np, true, false, false);
-    else
-      r = launch_gemm_tri(ctx, (double*)pT, np, (double*)pT, np, P->p, P->ld, np, np, np, true, false, true, 3);
+    // lower triangle of U U^T with the structurally zero part of every tile's k range skipped (N^3/3); `full`: the upper one is
+    // its mirror image (two passes over N^2 doubles) -- round 3 formed both triangles by a dense product (2 N^3)
+    if ((r = launch_gemm_tri(ctx, (double*)pT, np, (double*)pT, np, P->p, P->ld, np, np, np, true, false, true, 3)) != 0) break;
+    if (full) {
+      hipLaunchKernelGGL(mirror_lower_kernel, dim3((unsigned)(np / 32), (unsigned)(np / 32)), dim3(256), 0, ctx->stream, P->p,
+                         P->ld);
+      if (hipGetLastError() != hipSuccess) r = -2;
+    }
   } while (0);
   if (r != 0) {
     gpx_mat_free(ctx, P);
