@@ -1,12 +1,13 @@
 // Cholesky factorisation, triangular solves and log-determinant for gfx950.
 //
 // Replaces numpy.linalg.pinv (SVD, gp.py:181,400; experimentalDesign.py:268,280,826) and
-// numpy.linalg.slogdet (LU, gp.py:434) by K = L L^T.  The factorisation is recursive
-// (A11 -> L11; A21 <- A21 L11^-T; A22 <- A22 - L21 L21^T; recurse on A22) so that every flop
-// outside the 128x128 leaves lands in the MFMA GEMM kernel with the largest possible inner
-// dimension (the top-level SYRK has K = N/2), which keeps the read-modify-write traffic on C
-// far below the HBM roof.  Leaves: one workgroup factors a 128x128 diagonal block in LDS and
-// also inverts it, so that all triangular solves against a leaf are GEMMs with the inverse.
+// numpy.linalg.slogdet (LU, gp.py:434) by K = L L^T.  From N = 8192 the factorisation is BLOCKED RIGHT-LOOKING with 4096-wide
+// panels and one panel of look-ahead (potrf_blocked: panel solve through explicit 1024-order block inverses, trailing SYRK with
+// K = 4096, the next diagonal block's chain on the high-priority side stream underneath the bulk of the update); below that,
+// and inside every diagonal block, it is recursive (A11 -> L11; A21 <- A21 L11^-T; A22 <- A22 - L21 L21^T; recurse on A22) so
+// that every flop outside the 128x128 leaves lands in the MFMA GEMM kernel with the largest possible inner dimension, which
+// keeps the read-modify-write traffic on C far below the HBM roof.  Leaves: one workgroup factors a 128x128 diagonal block in
+// LDS and also inverts it, so that all triangular solves against a leaf are GEMMs with the inverse.
 #include "gpx_internal.h"
 #include <math.h>
 #include <stdlib.h>

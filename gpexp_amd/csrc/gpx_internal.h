@@ -7,6 +7,7 @@
 #include <map>
 #include <memory>
 #include "../../include/gpx.h"
+#include "../../include/gpx_dist.h"
 #include "../../include/gpx_debug.h"
 
 #define GPX_TILE 128          // padding / GEMM tile / Cholesky leaf size

@@ -16,7 +16,7 @@ def built_lib():
     so = os.path.join(ROOT, "gpexp_amd", "libgpx_hip.so")
     csrc = os.path.join(ROOT, "gpexp_amd", "csrc")
     srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h"))] + \
-           [os.path.join(ROOT, "include", "gpx.h")]
+           [os.path.join(ROOT, "include", h) for h in ("gpx.h", "gpx_dist.h", "gpx_debug.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         if not os.path.exists("/opt/rocm/bin/hipcc"):
             pytest.skip("hipcc not available and library not built")
@@ -24,8 +24,9 @@ def built_lib():
     return so
 
 
-def header_symbols(which=("gpx.h", "gpx_debug.h")):
-    """Functions declared by include/gpx.h (the drop-in ABI) and include/gpx_debug.h (test hooks)."""
+def header_symbols(which=("gpx.h", "gpx_dist.h", "gpx_debug.h")):
+    """Functions declared by include/gpx.h (the drop-in ABI), include/gpx_dist.h (multi-GPU / scheduler primitives that only
+    gpexp_amd/dist.py drives) and include/gpx_debug.h (test hooks)."""
     out = set()
     for name in which:
         txt = open(os.path.join(ROOT, "include", name)).read()
@@ -53,6 +54,24 @@ def test_binding_matches_header(built_lib):
 def test_public_header_has_no_debug_hooks():
     assert not [f for f in header_symbols(("gpx.h",)) if f.startswith("gpx_dbg_")]
     assert all(f.startswith("gpx_dbg_") for f in header_symbols(("gpx_debug.h",)))
+
+
+def test_drop_in_header_is_free_of_scheduler_internals():
+    """include/gpx.h is the drop-in ABI -- one entry point per reference call site -- and nothing in it is a
+    primitive that only gpexp_amd/dist.py can drive; those (streams / events, communicators, panel primitives, recorded
+    programs, sharded state machines) are declared in include/gpx_dist.h, which includes gpx.h."""
+    pub = header_symbols(("gpx.h",))
+    internals = ("gpx_dist", "gpx_comm_", "gpx_program_", "gpx_graph_", "gpx_event_", "gpx_stream_", "gpx_mi_begin", "gpx_mi_row",
+                 "gpx_mi_score", "gpx_mi_select", "gpx_mi_end", "gpx_givar_", "gpx_lml_grad_slab", "gpx_vec_op", "gpx_mat_read",
+                 "gpx_mat_write")
+    assert not [f for f in pub if f.startswith(internals)], [f for f in pub if f.startswith(internals)]
+    dist = header_symbols(("gpx_dist.h",))
+    assert len(dist) >= 50 and not set(dist) & set(pub)
+    assert '#include "gpx.h"' in open(os.path.join(ROOT, "include", "gpx_dist.h")).read()
+    # everything the class API of ONE process calls is in gpx.h (gpexp_amd/device.py minus the sharded state machines)
+    for f in ("gpx_kfill", "gpx_potrf", "gpx_potrs", "gpx_logdet", "gpx_posterior", "gpx_ivar", "gpx_greedy_var",
+              "gpx_greedy_ivar_step", "gpx_greedy_ivar", "gpx_mi_greedy", "gpx_lml_grad", "gpx_lml_grad_linv", "gpx_mat_clone"):
+        assert f in pub, f
 
 
 def test_packed_row_stride_constant_matches_library(built_lib):
