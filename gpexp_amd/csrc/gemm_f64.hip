@@ -451,9 +451,16 @@ struct Dist2Upd {
   // (2 x 4 grid, rank 0: 992 tiles on XCD 0, 96 on XCD 7; measured 60 against 66 TF/s even on the 1 x 1 triangle).  So only the
   // super-blocks (8 x 8 tiles) that contain an active tile are enumerated, column by column: super-block column sc holds
   // rows sr_min[sc] .. nsr-1 and starts at index prefix[sc]; index s goes to XCD class s % 8.
-  int nsc, nsr;
+  // Round 4: the FULLY active super-blocks first (all columns), the partial ones of the staircase last.  A partial super-block
+  // has some of its 64 slots exit at once; the XCD refills them with tiles of its next super-block, and from then on its 64
+  // resident workgroups belong to two super-blocks at different k phases -- the lock-step that lets them share operand panels
+  // in L2 is gone for the rest of the launch (same effect, same cure as the SYRK map in tile_of<LOWER>).
+  // Column sc: rows sr_min[sc] .. sr_full[sc]-1 are partial, sr_full[sc] .. nsr-1 full; prefix_f / prefix_p = running counts.
+  int nsc, nsr, nfull;
   int sr_min[GPX_SC_MAX];
-  int prefix[GPX_SC_MAX + 1];
+  int sr_full[GPX_SC_MAX];
+  int prefix_f[GPX_SC_MAX + 1];
+  int prefix_p[GPX_SC_MAX + 1];
 };
 
 template <int TE>
@@ -479,13 +486,16 @@ __global__ __launch_bounds__(256, 2) void dist2_update_kernel(const Dist2Upd u, 
   const int w = blockIdx.x;
   const int xcd = w & 7, q = w >> 3;
   const int s = (q >> 6) * 8 + xcd, within = q & 63;  // s-th active super-block, tile `within` of its 8 x 8
-  if (s >= u.prefix[u.nsc]) return;
-  int lo = 0, hi = u.nsc - 1;  // last column with prefix[sc] <= s  (uniform: scalar loads)
+  if (s >= u.nfull + u.prefix_p[u.nsc]) return;
+  const bool full = s < u.nfull;
+  const int* pre = full ? u.prefix_f : u.prefix_p;
+  const int sq = full ? s : s - u.nfull;
+  int lo = 0, hi = u.nsc - 1;  // last column with pre[sc] <= sq  (uniform: scalar loads)
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if (u.prefix[mid] <= s) lo = mid; else hi = mid - 1;
+    if (pre[mid] <= sq) lo = mid; else hi = mid - 1;
   }
-  const int sc = lo, sr = u.sr_min[sc] + (s - u.prefix[sc]);
+  const int sc = lo, sr = (full ? u.sr_full[sc] : u.sr_min[sc]) + (sq - pre[sc]);
   const int by = sr * 8 + (within >> 3), bx = sc * 8 + (within & 7);
   if (by >= tiles_m || bx >= tiles_n) return;
   const int tpb = u.nb / TE;  // tiles per block edge
@@ -721,7 +731,7 @@ int launch_dist2_update(gpx_ctx* ctx, double* C, int64_t ldc, int64_t lr0, int64
   u.nsc = (tn + 7) / 8;
   u.nsr = (tm + 7) / 8;
   GPX_ARG(u.nsc <= GPX_SC_MAX, "dist2 update: too many column super-blocks in one launch");
-  int64_t nsb = 0;
+  int64_t nfull = 0, npart = 0;
   for (int sc = 0; sc < u.nsc; ++sc) {
     // first active local block row of this super-block column: the column's LEFTMOST block has the lowest global index
     const int64_t lj = lc0 / nb + (8 * sc) / tpb, J = lj * Pc + pc;
@@ -732,10 +742,27 @@ int launch_dist2_update(gpx_ctx* ctx, double* C, int64_t ldc, int64_t lr0, int64
     int srm = (int)(by_min / 8);
     if (srm > u.nsr) srm = u.nsr;
     u.sr_min[sc] = srm;
-    u.prefix[sc] = (int)nsb;
-    nsb += u.nsr - srm;
+    // first super-block row whose 8 x 8 tiles are ALL active: its top tile row against the column's RIGHTMOST block
+    int64_t bx_right = 8 * (int64_t)sc + 7;
+    if (bx_right > tn - 1) bx_right = tn - 1;
+    const int64_t ljr = lc0 / nb + bx_right / tpb, Jr = ljr * Pc + pc;
+    int64_t li_full = (Jr + (below_diag ? 1 : 0) - pr + Pr - 1) / Pr;   // smallest li with li Pr + pr >= Jr (+1)
+    if (Jr + (below_diag ? 1 : 0) - pr < 0) li_full = 0;
+    int64_t by_full = (li_full - lr0 / nb) * tpb;                        // first tile row with every column of the super-block active
+    if (by_full < 0) by_full = 0;
+    int srf = (int)((by_full + 7) / 8);
+    if (srf < srm) srf = srm;
+    if (srf > u.nsr) srf = u.nsr;
+    u.sr_full[sc] = srf;
+    u.prefix_p[sc] = (int)npart;
+    u.prefix_f[sc] = (int)nfull;
+    npart += srf - srm;
+    nfull += u.nsr - srf;
   }
-  u.prefix[u.nsc] = (int)nsb;
+  u.prefix_p[u.nsc] = (int)npart;
+  u.prefix_f[u.nsc] = (int)nfull;
+  u.nfull = (int)nfull;
+  const int64_t nsb = nfull + npart;
   if (nsb == 0) return 0;
   const int64_t wgs = (nsb + 7) / 8 * 8 * 64;
   GPX_ARG(wgs < ((int64_t)1 << 31), "dist2 update: grid too large");
