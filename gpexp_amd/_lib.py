@@ -109,8 +109,10 @@ _SIGS = {
     "gpx_dist2_kfill": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_dp, c_i64, c_vp, c_i64, C.c_int, C.c_int,
                                   C.c_int, C.c_int]),
     "gpx_dist2_diag_factor": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64]),
+    "gpx_dist2_panel_inv": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64]),
     "gpx_dist2_panel_trsm": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64]),
     "gpx_dist2_panel_trsm_keep": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64]),
+    "gpx_dist2_panel_trsm_inv": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64]),
     "gpx_dist2_update": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64]),
     "gpx_dist2_update_multi": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_i64,
                                          C.c_int, C.POINTER(c_vp), c_ip, C.c_int]),
@@ -145,6 +147,8 @@ _SIGS = {
     "gpx_dbg_guard_violations": (c_i64, [c_vp]),
     "gpx_dbg_guard_selftest": (C.c_int, [c_vp]),
     "gpx_dbg_spin": (C.c_int, [c_vp, C.c_int]),
+    "gpx_dbg_spin_us": (C.c_int, [c_vp, c_i64]),
+    "gpx_dbg_event_elapsed": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp]),
 }
 
 _lib = None

@@ -97,18 +97,35 @@ void gpx_dev_release(gpx_ctx* ctx, void* p, int64_t bytes) {
 // recursive factorisation issues ~2600 launches per step and two event records per launch cost ~15 ms of the timed
 // region.  The 1-2 us launch gaps inside such a run are then counted as kernel time -- a slightly pessimistic
 // `achieved`, within 0.5 % of the rocprofv3 kernel-only total.
-// one workgroup that spins for `ticks` of s_memtime (100 MHz): GPX_CHAOS and gpx_dbg_spin
+// one workgroup that spins for `ticks` of the constant-rate wall clock (wall_clock64: hipDeviceAttributeWallClockRate kHz, 100 MHz
+// on MI355X): GPX_CHAOS, gpx_dbg_spin and the paced replay.  (Rounds 2-3 counted s_memtime, which on gfx950 runs at the SHADER
+// clock -- measured round 4: a "5 ms" spin took 0.22 ms -- so the chaos mode's delays were 0.005 .. 0.13 ms, not 0.1 .. 3 ms.)
 __global__ void dbg_spin_kernel(long long ticks) {
-  const long long t0 = __builtin_amdgcn_s_memtime();
-  while (__builtin_amdgcn_s_memtime() - t0 < ticks) {}
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) {}
+}
+
+// ticks of the wall clock per microsecond on this device (queried once)
+static double spin_ticks_per_us(gpx_ctx* ctx) {
+  static double tpu = 0.0;
+  if (tpu == 0.0) {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || khz <= 0) {
+      (void)hipGetLastError();
+      khz = 100000;
+    }
+    tpu = (double)khz / 1000.0;
+  }
+  return tpu;
 }
 
 ProfScope::ProfScope(gpx_ctx* c, int cls, double flops, double bytes) : ctx(c), idx(-1) {
   if (c->chaos) {
     c->chaos = c->chaos * 6364136223846793005ULL + 1442695040888963407ULL;
     const unsigned r = (unsigned)(c->chaos >> 33);
-    if ((r & 3u) == 0u)  // ticks of s_memtime: 100 MHz -> 1e4 .. 3e5 = 0.1 .. 3 ms
-      hipLaunchKernelGGL(dbg_spin_kernel, dim3(1), dim3(64), 0, c->stream, (long long)(10000 + (r >> 2) % 290000));
+    if ((r & 3u) == 0u)  // 0.1 .. 3 ms of the wall clock
+      hipLaunchKernelGGL(dbg_spin_kernel, dim3(1), dim3(64), 0, c->stream,
+                         (long long)((100.0 + (double)((r >> 2) % 2900)) * spin_ticks_per_us(c)));
   }
   if (!c->prof_on) return;
   c->prof_launches[cls] += 1;
@@ -437,6 +454,8 @@ int gpx_create(int device, gpx_ctx** out) {
   c->trsv_scratch_bytes = 0;
   c->d2_scratch = nullptr;
   c->d2_scratch_bytes = 0;
+  c->d2_inv_src = nullptr;
+  c->d2_inv_nb = 0;
   c->ev_scratch = nullptr;
   c->ev_scratch_bytes = 0;
   *out = c;
@@ -448,7 +467,16 @@ int gpx_create(int device, gpx_ctx** out) {
 int gpx_dbg_spin(gpx_ctx* ctx, int ms) {
   GPX_ARG(ctx && ms >= 0 && ms <= 500, "spin: 0..500 ms");
   if (ms == 0) return 0;
-  hipLaunchKernelGGL(dbg_spin_kernel, dim3(1), dim3(64), 0, ctx->stream, (long long)ms * 100000LL);
+  hipLaunchKernelGGL(dbg_spin_kernel, dim3(1), dim3(64), 0, ctx->stream, (long long)((double)ms * 1000.0 * spin_ticks_per_us(ctx)));
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
+
+// the same in microseconds (<= 500 000): paces the receives of a single-rank replay (scripts/replay_comm.py)
+int gpx_dbg_spin_us(gpx_ctx* ctx, int64_t us) {
+  GPX_ARG(ctx && us >= 0 && us <= 500000, "spin: 0..500000 us");
+  if (us == 0) return 0;
+  hipLaunchKernelGGL(dbg_spin_kernel, dim3(1), dim3(64), 0, ctx->stream, (long long)((double)us * spin_ticks_per_us(ctx)));
   GPX_HIP(hipGetLastError());
   return 0;
 }
@@ -525,10 +553,26 @@ static int sync_event(gpx_ctx* ctx, int id, hipEvent_t* out) {
   GPX_ARG(ctx && id >= 0 && id < 65536, "event id out of range");
   while ((int)ctx->sync_events.size() <= id) {
     hipEvent_t ev;
-    GPX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    static int timing = -1;   // GPX_EVENT_TIMING=1 (debug): the pipeline's events carry time stamps (gpx_dbg_event_elapsed)
+    if (timing < 0) timing = getenv("GPX_EVENT_TIMING") ? atoi(getenv("GPX_EVENT_TIMING")) : 0;
+    GPX_HIP(hipEventCreateWithFlags(&ev, timing ? hipEventDefault : hipEventDisableTiming));
     ctx->sync_events.push_back(ev);
   }
   *out = ctx->sync_events[(size_t)id];
+  return 0;
+}
+
+// debug (gpx_debug.h): ms between the last records of two pipeline events (GPX_EVENT_TIMING=1; both must have completed);
+// returns 1 when an event of the pair was never recorded
+int gpx_dbg_event_elapsed(gpx_ctx* ctx, int id0, int id1, double* ms) {
+  GPX_ARG(ctx && ms && id0 >= 0 && id1 >= 0, "bad arguments");
+  if (id0 >= (int)ctx->sync_events.size() || id1 >= (int)ctx->sync_events.size()) return 1;
+  float f = 0.0f;
+  if (hipEventElapsedTime(&f, ctx->sync_events[(size_t)id0], ctx->sync_events[(size_t)id1]) != hipSuccess) {
+    (void)hipGetLastError();
+    return 1;
+  }
+  *ms = (double)f;
   return 0;
 }
 

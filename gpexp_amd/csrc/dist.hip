@@ -844,11 +844,60 @@ int gpx_dist2_panel_trsm(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64
   return gpx_dist2_panel_trsm_keep(ctx, A, lr0, m, lc, w, G, doff, roff, nb, -1);
 }
 
+static int d2_scratch_ensure(gpx_ctx* ctx, int64_t nb) {
+  const int64_t need = 2 * nb * nb * 8;
+  if (ctx->d2_scratch_bytes < need) {
+    GPX_HIP(hipDeviceSynchronize());
+    if (ctx->d2_scratch) (void)hipFree(ctx->d2_scratch);
+    ctx->d2_scratch = nullptr;
+    ctx->d2_scratch_bytes = 0;
+    ctx->d2_inv_src = nullptr;
+    GPX_HIP(hipMalloc((void**)&ctx->d2_scratch, (size_t)need));
+    ctx->d2_scratch_bytes = need;
+  }
+  return 0;
+}
+
+// Round 4: the explicit inverse of the diagonal block of panel k, built AHEAD of the panel solve.  It depends on the factored
+// block alone (in G at doff: available when the column broadcast lands, typically a millisecond before the column has its last
+// update), but gpx_dist2_panel_trsm used to build it inside the solve: eight small dependent kernels on the panel chain --
+// whose per-step latency, summed over the steps, IS the factorisation time of a multi-rank run (scripts/dist_replay.py
+// --paced-grid) -- and the block row the next diagonal needs went through the leaf recursion, eight more.  The panel loop now
+// calls this right behind the broadcast of the diagonal block, before it waits for the column; both solves of the step are then
+// one triangular-operand product each.  PANEL stream, step order: the scratch holds one inverse at a time.
+int gpx_dist2_panel_inv(gpx_ctx* ctx, const gpx_mat* G, int64_t doff, int64_t nb, int64_t w) {
+  GPX_ARG(ctx && G && nb > 0 && nb % GPX_TILE == 0 && doff >= 0 && (doff + gpx_dist2_diag_elems(nb)) * 8 <= G->bytes, "bad arguments");
+  if (w != nb || w <= GPX_TILE) return 0;   // ragged last block / single leaf: the solve walks the leaf recursion
+  GPX_TRY(d2_scratch_ensure(ctx, nb));
+  const double* D = G->p + doff;
+  double* inv = ctx->d2_scratch;
+  ctx->d2_inv_src = nullptr;
+  GPX_TRY(chol_block_inverse(ctx, D, nb, D + nb * nb, inv, w, inv + nb * nb));
+  ctx->d2_inv_src = D;
+  ctx->d2_inv_nb = nb;
+  return 0;
+}
+
 // ... and, on the OWNER of the diagonal block (dslot = its local block row, -1 elsewhere), the explicit inverse is kept in the
 // local matrix for the distributed substitution: its diagonal solves then are one small GEMV instead of a 512-row sweep
 // through one workgroup (45 us), 2 N / nb of them in a chain.
+static int panel_trsm_impl(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t lc, int64_t w, gpx_mat* G, int64_t doff,
+                           int64_t roff, int64_t nb, int64_t dslot, int use_prepared);
+
 int gpx_dist2_panel_trsm_keep(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t lc, int64_t w, gpx_mat* G, int64_t doff,
                               int64_t roff, int64_t nb, int64_t dslot) {
+  return panel_trsm_impl(ctx, A, lr0, m, lc, w, G, doff, roff, nb, dslot, 0);
+}
+
+// the same with the inverse gpx_dist2_panel_inv built for THIS step's diagonal block (the caller vouches for that: the panel
+// loop calls the two back to back on the PANEL stream); falls back to the leaf recursion for a ragged / single-leaf block
+int gpx_dist2_panel_trsm_inv(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t lc, int64_t w, gpx_mat* G, int64_t doff,
+                             int64_t roff, int64_t nb, int64_t dslot) {
+  return panel_trsm_impl(ctx, A, lr0, m, lc, w, G, doff, roff, nb, dslot, 1);
+}
+
+static int panel_trsm_impl(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t lc, int64_t w, gpx_mat* G, int64_t doff,
+                           int64_t roff, int64_t nb, int64_t dslot, int use_prepared) {
   GPX_ARG(ctx && G, "NULL argument");
   GPX_TRY(check_local(A, lr0, m, lc, w));
   const int64_t gld = gpx_g_ld(nb);
@@ -862,18 +911,17 @@ int gpx_dist2_panel_trsm_keep(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, 
     const char* e = getenv("GPX_DIST2_INV_MIN");  // rows from which the explicit inverse is used, in units of nb; 0 = never
     inv_min = e ? atoll(e) : 2;
   }
-  if (inv_min > 0 && m >= inv_min * nb && w == nb && w > GPX_TILE) {
-    const int64_t need = 2 * nb * nb * 8;
-    if (ctx->d2_scratch_bytes < need) {
-      GPX_HIP(hipDeviceSynchronize());
-      if (ctx->d2_scratch) (void)hipFree(ctx->d2_scratch);
-      ctx->d2_scratch = nullptr;
-      ctx->d2_scratch_bytes = 0;
-      GPX_HIP(hipMalloc((void**)&ctx->d2_scratch, (size_t)need));
-      ctx->d2_scratch_bytes = need;
-    }
+  const bool prepared = use_prepared && w == nb && w > GPX_TILE;
+  GPX_ARG(!prepared || (ctx->d2_inv_src == D && ctx->d2_inv_nb == nb), "panel solve: no inverse was prepared for this diagonal block");
+  if (prepared || (inv_min > 0 && m >= inv_min * nb && w == nb && w > GPX_TILE)) {
+    GPX_TRY(d2_scratch_ensure(ctx, nb));
     double* inv = ctx->d2_scratch;
-    GPX_TRY(chol_block_inverse(ctx, D, nb, D + nb * nb, inv, w, inv + nb * nb));
+    if (!prepared) {
+      ctx->d2_inv_src = nullptr;
+      GPX_TRY(chol_block_inverse(ctx, D, nb, D + nb * nb, inv, w, inv + nb * nb));
+      ctx->d2_inv_src = D;
+      ctx->d2_inv_nb = nb;
+    }
     if (dslot >= 0) {
       const int64_t slots = (A->prows + nb - 1) / nb;
       GPX_ARG(dslot < slots, "diagonal slot outside the local matrix");
@@ -1136,7 +1184,10 @@ int gpx_program_run(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const int64_
       case GPX_OP_WAIT: r = gpx_event_wait(ctx, (int)a[0]); break;
       case GPX_OP_BEGIN: r = gpx_dist_begin(ctx); break;
       case GPX_OP_DIAG_FACTOR: r = gpx_dist2_diag_factor(ctx, h0, a[0], a[1], a[2], h1, a[3], a[4], a[5], a[6]); break;
-      case GPX_OP_PANEL_TRSM: r = gpx_dist2_panel_trsm_keep(ctx, h0, a[0], a[1], a[2], a[3], h1, a[4], a[5], a[6], a[7] - 1); break;
+      case GPX_OP_PANEL_TRSM:
+        r = a[8] ? gpx_dist2_panel_trsm_inv(ctx, h0, a[0], a[1], a[2], a[3], h1, a[4], a[5], a[6], a[7] - 1)
+                 : gpx_dist2_panel_trsm_keep(ctx, h0, a[0], a[1], a[2], a[3], h1, a[4], a[5], a[6], a[7] - 1);
+        break;
       case GPX_OP_UPDATE: r = gpx_dist2_update(ctx, h0, a[0], a[1], a[2], a[3], h1, a[4], a[5], a[6], a[7]); break;
       case GPX_OP_UPDATE_MULTI: {
         // a: lr0, m, lc0, n, nb, Pr, Pc, pr, pc, piece_stride, nseg | below_diag << 8, extra offset of [G handles..., ks...]
@@ -1172,12 +1223,13 @@ int gpx_program_run(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const int64_
       }
       case GPX_OP_IVAR_STEP: r = gpx_dist_ivar_step(ctx, h0, a[0], a[1], h1); break;
       case GPX_OP_IVAR_GROUP: r = gpx_dist_ivar_group_at(ctx, h0, a[0], a[1], a[2], h1, a[3] ? a[3] - 1 : a[0] * a[2]); break;
+      case GPX_OP_PANEL_INV: r = gpx_dist2_panel_inv(ctx, h0, a[0], a[1], a[2]); break;
       case GPX_OP_FWD_GROUP: r = gpx_dist_fwd_group_at(ctx, h0, a[0], a[1], a[2], h1, a[3] ? a[3] - 1 : a[0] * a[2]); break;
       case GPX_OP_TRSV_DIAG: r = gpx_dist2_trsv_diag(ctx, h0, a[0], a[1], a[2], h1, a[3], (int)a[4]); break;
       case GPX_OP_GEMV: r = gpx_dist2_gemv(ctx, h0, a[0], a[1], a[2], a[3], h1, a[4], h2, a[5], (int)a[6]); break;
       case GPX_OP_LOGDET_ACC: r = gpx_dist2_logdet_acc(ctx, h0, a[0], a[1], a[2], a[3], h1); break;
       case GPX_OP_VEC_OP: r = gpx_vec_op(ctx, h0, a[0], h1, a[1], a[2], (int)a[3]); break;
-      case GPX_OP_SPIN: r = gpx_dbg_spin(ctx, (int)a[0]); break;
+      case GPX_OP_SPIN: r = a[1] ? gpx_dbg_spin_us(ctx, a[0]) : gpx_dbg_spin(ctx, (int)a[0]); break;   // a1 != 0: a0 in microseconds
       case GPX_OP_COPY: {  // h0[a0 : a0+a2] <- h1[a1 : a1+a2], device to device (replay stand-in for a point-to-point transfer)
         if (!h0 || !h1 || a[0] < 0 || a[1] < 0 || a[2] < 0 || (a[0] + a[2]) * 8 > h0->bytes || (a[1] + a[2]) * 8 > h1->bytes) {
           gpx_set_error("program op %lld: copy outside its buffers", (long long)i);

@@ -751,6 +751,12 @@ int launch_dist2_update(gpx_ctx* ctx, double* C, int64_t ldc, int64_t lr0, int64
     int64_t by_full = (li_full - lr0 / nb) * tpb;                        // first tile row with every column of the super-block active
     if (by_full < 0) by_full = 0;
     int srf = (int)((by_full + 7) / 8);
+    static int full_first = -1;
+    if (full_first < 0) {
+      const char* e5 = getenv("GPX_DIST2_FULL_FIRST");   // 0: round 3's order (every column's staircase blocks in place)
+      full_first = e5 ? atoi(e5) : 1;
+    }
+    if (!full_first) srf = srm;
     if (srf < srm) srf = srm;
     if (srf > u.nsr) srf = u.nsr;
     u.sr_full[sc] = srf;

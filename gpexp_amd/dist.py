@@ -94,7 +94,7 @@ def merge_argmin(values, indices):
 # ---- recorded programs (include/gpx.h: gpx_program_run) -----------------------------------------------------------
 OP = dict(STREAM=1, RECORD=2, WAIT=3, BEGIN=4, DIAG_FACTOR=5, PANEL_TRSM=6, UPDATE=7, UPDATE_MULTI=8, UNPACK_ROWS=9,
           UNPACK_DIAG=10, PACK_ROWS=11, PACK_DIAG=12, BCAST_GRP=13, REDUCE_GRP=14, ALLREDUCE=15, PANEL_BCAST=16, IVAR_STEP=17,
-          TRSV_DIAG=18, GEMV=19, LOGDET_ACC=20, VEC_OP=21, SPIN=22, COPY=23, IVAR_GROUP=24, FWD_GROUP=25)
+          TRSV_DIAG=18, GEMV=19, LOGDET_ACC=20, VEC_OP=21, SPIN=22, COPY=23, IVAR_GROUP=24, FWD_GROUP=25, PANEL_INV=26)
 
 
 class Program:
@@ -739,10 +739,15 @@ class DeviceOps2D(Emitter, DeviceOps):
     def diag_factor(self, A, lr, lc, w, G, doff, nb, base, n_valid):
         self._emit(OP["DIAG_FACTOR"], (A, G), (lr, lc, w, doff, nb, base, n_valid))
 
-    def panel_trsm(self, A, lr0, m, lc, w, G, doff, roff, nb, dslot=None):
+    def panel_inv(self, G, doff, nb, w):
+        """explicit inverse of the factored diagonal block in G at doff, kept for this step's panel solves (built as soon as the
+        block has arrived: off the panel chain)"""
+        self._emit(OP["PANEL_INV"], (G,), (doff, nb, w))
+
+    def panel_trsm(self, A, lr0, m, lc, w, G, doff, roff, nb, dslot=None, prepared=False):
         """dslot (owner of the diagonal block only): its local block row -- the explicit inverse the solve builds is kept in A
-        for the distributed substitution's diagonal solves."""
-        self._emit(OP["PANEL_TRSM"], (A, G), (lr0, m, lc, w, doff, roff, nb, 0 if dslot is None else dslot + 1))
+        for the distributed substitution's diagonal solves.  prepared: panel_inv ran for this step's diagonal block."""
+        self._emit(OP["PANEL_TRSM"], (A, G), (lr0, m, lc, w, doff, roff, nb, 0 if dslot is None else dslot + 1, int(bool(prepared))))
 
     def update(self, A, lr0, m, lc0, n, G, aoff, boff, w, nb):
         self._emit(OP["UPDATE"], (A, G), (lr0, m, lc0, n, aoff, boff, w, nb))
@@ -799,6 +804,9 @@ class DeviceOps2D(Emitter, DeviceOps):
 
     def spin(self, ms):
         self._emit(OP["SPIN"], (), (ms,))
+
+    def spin_us(self, us):
+        self._emit(OP["SPIN"], (), (int(us), 1))
 
     def vec_to_host(self, v, n):
         return v.to_host()[:n, 0]
@@ -904,6 +912,7 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
     bulk_stream = {"bulk": BULK, "eval": EVAL, "main": MAIN, "chunks": MAIN}[mode]
     chunked = mode == "chunks"
     at_step = getattr(comm, "at_step", None)
+    hoist_inv = os.environ.get("GPX_DIST2_HOIST_INV", "1") == "1" and hasattr(ops, "panel_inv")
 
     def group_end(k):
         return min((k // q + 1) * q - 1, nblk - 1)
@@ -1004,16 +1013,19 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
             ops.record(_ev2(E_DBC, k))
             ops.stream(PANEL)
             ops.wait(_ev2(E_DBC, k))
+            if hoist_inv:
+                ops.panel_inv(g, geo.piece_off(kr), nb, w)                # needs the diagonal block only: ahead of the column
             ops.wait(_ev2(E_COLREADY, k))
             lr0, m = geo.row_off(pr, geo.li0(pr, k)), geo.piece_rows(pr, k)
             roff = geo.piece_off(pr) + geo.dsz
             dslot = (k // Pr) if owner else None                         # the owner keeps the block's explicit inverse
+            pk = dict(prepared=True) if hoist_inv else {}
             if nxt and pr == r1:                                         # block row k+1 first: the next diagonal needs it
-                ops.panel_trsm(A, lr0, h1, lc, w, g, geo.piece_off(kr), roff, nb)
+                ops.panel_trsm(A, lr0, h1, lc, w, g, geo.piece_off(kr), roff, nb, **pk)
                 ops.record(_ev2(E_EARLYSOLVED, k))
-                ops.panel_trsm(A, lr0 + h1, m - h1, lc, w, g, geo.piece_off(kr), roff + h1 * geo.gld, nb, dslot)
+                ops.panel_trsm(A, lr0 + h1, m - h1, lc, w, g, geo.piece_off(kr), roff + h1 * geo.gld, nb, dslot, **pk)
             else:
-                ops.panel_trsm(A, lr0, m, lc, w, g, geo.piece_off(kr), roff, nb, dslot)
+                ops.panel_trsm(A, lr0, m, lc, w, g, geo.piece_off(kr), roff, nb, dslot, **pk)
             ops.record(_ev2(E_PIECE, k))
         if nxt and pr == r1:
             ops.stream(COMM)

@@ -43,6 +43,12 @@ int gpx_dbg_colreduce_plan(int64_t rows, int64_t pcols, int64_t* nchunk, int64_t
 int gpx_dbg_kfill_plan(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* X, const gpx_mat* Z,
                        int* exact, double* center);
 
+int gpx_dbg_spin_us(gpx_ctx* ctx, int64_t us);   /* gpx_dbg_spin in microseconds (<= 500 000) */
+/* ms between the last records of two pipeline events (gpx_event_record ids; GPX_EVENT_TIMING=1 in the environment makes them
+ * carry time stamps): the per-step timeline of the distributed loop's strands without a profiler in the way
+ * (scripts/dist_timeline.py).  Returns 1 when an event of the pair was never recorded / has not completed. */
+int gpx_dbg_event_elapsed(gpx_ctx* ctx, int id0, int id1, double* ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -140,6 +140,10 @@ int gpx_dist2_kfill(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, 
 /* diagonal owner: factor the w x w block at local (lr, lc) into the D region of the panel buffer G (offset doff) */
 int gpx_dist2_diag_factor(gpx_ctx* ctx, gpx_mat* A, int64_t lr, int64_t lc, int64_t w, gpx_mat* G, int64_t doff,
                           int64_t nb, int64_t base, int64_t n_valid);
+/* holders of block column k, as soon as the diagonal block has arrived in G (doff): its explicit inverse, kept for the panel
+ * solves of this step (gpx_dist2_panel_trsm then multiplies with it instead of building it on the panel chain; the block row the
+ * next diagonal needs takes the same one-product path instead of the leaf recursion) */
+int gpx_dist2_panel_inv(gpx_ctx* ctx, const gpx_mat* G, int64_t doff, int64_t nb, int64_t w);
 /* holders of block column k: local rows [lr0, lr0+m) of the column <- X L_kk^-T, packed into G at roff */
 int gpx_dist2_panel_trsm(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t lc, int64_t w, gpx_mat* G, int64_t doff,
                          int64_t roff, int64_t nb);
@@ -147,6 +151,10 @@ int gpx_dist2_panel_trsm(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64
  * builds is KEPT in the local matrix, and gpx_dist2_trsv_diag uses it (one small GEMV instead of a block sweep) */
 int gpx_dist2_panel_trsm_keep(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t lc, int64_t w, gpx_mat* G, int64_t doff,
                               int64_t roff, int64_t nb, int64_t dslot);
+/* the same with the inverse gpx_dist2_panel_inv prepared for this step's diagonal block (one triangular-operand product, also
+ * for a single block row) */
+int gpx_dist2_panel_trsm_inv(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t lc, int64_t w, gpx_mat* G, int64_t doff,
+                             int64_t roff, int64_t nb, int64_t dslot);
 /* A[lr0:lr0+m, lc0:lc0+n] -= G[aoff] (m x w) * G[boff] (n x w)^T : trailing update of one local block column */
 int gpx_dist2_update(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t lc0, int64_t n, const gpx_mat* G,
                      int64_t aoff, int64_t boff, int64_t w, int64_t nb);
@@ -183,7 +191,7 @@ enum {
   GPX_OP_STREAM = 1, GPX_OP_RECORD, GPX_OP_WAIT, GPX_OP_BEGIN, GPX_OP_DIAG_FACTOR, GPX_OP_PANEL_TRSM, GPX_OP_UPDATE,
   GPX_OP_UPDATE_MULTI, GPX_OP_UNPACK_ROWS, GPX_OP_UNPACK_DIAG, GPX_OP_PACK_ROWS, GPX_OP_PACK_DIAG, GPX_OP_BCAST_GRP,
   GPX_OP_REDUCE_GRP, GPX_OP_ALLREDUCE, GPX_OP_PANEL_BCAST, GPX_OP_IVAR_STEP, GPX_OP_TRSV_DIAG, GPX_OP_GEMV, GPX_OP_LOGDET_ACC,
-  GPX_OP_VEC_OP, GPX_OP_SPIN, GPX_OP_COPY, GPX_OP_IVAR_GROUP, GPX_OP_FWD_GROUP
+  GPX_OP_VEC_OP, GPX_OP_SPIN, GPX_OP_COPY, GPX_OP_IVAR_GROUP, GPX_OP_FWD_GROUP, GPX_OP_PANEL_INV
 };
 int gpx_program_run(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const int64_t* extra, int64_t nextra, double* host_ms);
 /* The same program as a hipGraph: captured once (after it has run once the ordinary way; every stream it uses must fork from

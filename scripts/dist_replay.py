@@ -30,8 +30,112 @@ from gpexp_amd import device as dev, dist  # noqa: E402
 from replay_comm import ReplayComm  # noqa: E402
 
 
+def own_step_latencies(ctx, geo):
+    """ms between the arrival of panel k-1 and of panel k for the steps k whose panel THIS rank's process column solves, from the
+    time stamps of the pipeline's own events (GPX_EVENT_TIMING=1): what the rank adds to the chain across ranks when it is the
+    holder -- its near update of column k, the panel solve, the hand-over to the communication stream."""
+    import ctypes as C
+
+    def at(kind, k):
+        ms = C.c_double()
+        rc = ctx.lib.gpx_dbg_event_elapsed(ctx.h, dist.EV_FORK, dist._ev2(kind, k), C.byref(ms))
+        return ms.value if rc == 0 else None
+    arr = [at(dist.E_ARRIVED, k) for k in range(geo.nblk)]
+    if any(a is None for a in arr):
+        return None, None
+    own = [k for k in range(geo.nblk) if k % geo.Pc == geo.pc]
+    lat = {k: arr[k] - (arr[k - 1] if k > 0 else 0.0) for k in own}
+    if os.environ.get("GPX_REPLAY_DETAIL") == "1":   # where an own holder step spends its latency
+        print("# own holder steps: k, [ARRIVED(k-1)] -> near update of column k done (COLREADY) -> diagonal factored (DFACT) -> "
+              "panel solved (PIECE) -> delivered (ARRIVED); ms relative to ARRIVED(k-1)", file=sys.stderr)
+        for k in own[1:]:
+            base = arr[k - 1]
+            v = [at(kind, k) for kind in (dist.E_COL2, dist.E_COLREADY, dist.E_DIAGREADY, dist.E_DFACT, dist.E_EARLYSOLVED, dist.E_PIECE)]
+            print("#  k=%2d  COL2 %7.3f  COLREADY %7.3f  DIAGREADY %7.3f  DFACT %7.3f  EARLYSOLVED %7.3f  PIECE %7.3f  ARRIVED %7.3f" %
+                  tuple([k] + [(x - base) if x is not None else float("nan") for x in v] + [arr[k] - base]), file=sys.stderr)
+    return lat, arr
+
+
+def pace_from(lat, nblk):
+    """Per-step pacing (us) for the foreign steps: the own-step latencies interpolated over k (they fall as the trailing matrix
+    shrinks)."""
+    ks = sorted(lat)
+    xs = np.arange(nblk)
+    return np.maximum(np.interp(xs, ks, [lat[k] for k in ks]) * 1e3, 0.0).astype(np.int64)
+
+
+def paced_replay(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=512, agg=None, streamed=False, iters=3, steps=2):
+    """The factorisation time of the WHOLE grid estimated on one GPU: replay `rank` with every foreign panel held back by the
+    latency this rank shows in its own holder steps, and iterate (the latencies depend on how busy the rank is, which depends
+    on the pacing).  Needs GPX_EVENT_TIMING=1 in the environment before the context's first event.  Returns a dict."""
+    hist = []
+    pace = None
+    res = None
+    for it in range(iters + 1):
+        res = replay_rank(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=nb, agg=agg, streamed=streamed, steps=steps,
+                          profile=False, pace_us=pace, want_latencies=True)
+        lat = res.pop("own_latency_ms")
+        if lat is None:
+            return dict(error="the pipeline's events carry no time stamps (set GPX_EVENT_TIMING=1 before the first use)")
+        hist.append(dict(paced=pace is not None, ms_per_step=res["ms_per_step"], own_latency_sum_ms=float(sum(lat.values())),
+                         chain_estimate_ms=float(sum(lat.values())) * grid[1]))
+        pace = pace_from(lat, res["steps_k"])
+    return dict(grid=res["grid"], rank=rank, nb=nb, streamed_ivar=bool(streamed), iterations=hist,
+                unpaced_rank_busy_ms=hist[0]["ms_per_step"], paced_step_ms=hist[-1]["ms_per_step"],
+                own_latency_ms_first_last=[round(lat[min(lat)], 3), round(lat[max(lat)], 3)],
+                bytes_received_per_fit=res["bytes_received_per_fit"], variance_check_rel=res["variance_check_rel"])
+
+
+def paced_grid(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, nb=512, agg=None, streamed=False, iters=3, steps=2, rows=None):
+    """The factorisation time of the WHOLE Pr x Pc grid estimated on ONE GPU.  Step k+1's panel solve needs step k's panel, so
+    the factorisation time of a real run is the SUM over the steps of what the step's holder column needs from the arrival of
+    panel k-1 to the delivery of panel k -- not any rank's busy time (a replay in which every foreign panel arrives at once keeps
+    the rank busy all the time and hides exactly that chain).  Here every process column is replayed in turn (its ranks in the
+    process rows `rows`, default all), each replay PACED: a foreign panel k arrives at the latency measured for ITS holder
+    column (the slowest of that column's replayed ranks); the latencies depend on how busy a rank is, which depends on the
+    pacing, so the sweep over the columns is iterated.  Result: the per-step holder latencies, their sum (the chain) and the
+    paced step time of every replayed rank (they share one global timeline, so they agree up to the ranks' last updates).
+    xGMI transfer time is NOT in it (receives are device copies).  Needs GPX_EVENT_TIMING=1 before the context's first event."""
+    Pr, Pc = grid
+    rows = list(range(Pr)) if rows is None else list(rows)
+    nblk = None
+    lat = {}           # step k -> holder latency (ms), max over the replayed ranks of the holder column
+    hist = []
+    last = {}
+    for it in range(iters):
+        newlat = {}
+        for pc in range(Pc):
+            for pr in rows:
+                rank = pr * Pc + pc
+                pace = None
+                if nblk is not None and len(lat) == nblk:
+                    pace = np.array([max(lat[k], 0.0) * 1e3 for k in range(nblk)]).astype(np.int64)
+                res = replay_rank(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=nb, agg=agg, streamed=streamed, steps=steps,
+                                  profile=False, pace_us=pace, want_latencies=True)
+                own = res.pop("own_latency_ms")
+                if own is None:
+                    return dict(error="the pipeline's events carry no time stamps (set GPX_EVENT_TIMING=1 before the first use)")
+                nblk = res["steps_k"]
+                for k, v in own.items():
+                    newlat[k] = max(newlat.get(k, 0.0), v)
+                last[rank] = dict(paced=pace is not None, ms_per_step=res["ms_per_step"], own_latency_sum_ms=float(sum(own.values())),
+                                  bytes_received_per_fit=res["bytes_received_per_fit"], check=res["variance_check_rel"])
+        lat = newlat
+        hist.append(dict(iteration=it, chain_ms=float(sum(lat.values())),
+                         rank_step_ms={str(r): round(v["ms_per_step"], 3) for r, v in last.items()},
+                         paced=all(v["paced"] for v in last.values())))
+    per_col = [float(sum(v for k, v in lat.items() if k % Pc == pc)) for pc in range(Pc)]
+    return dict(grid="%dx%d" % grid, nb=nb, agg=agg if agg is not None else dist.default_agg(), streamed_ivar=bool(streamed),
+                replayed_ranks=sorted(last), iterations=hist, chain_ms=float(sum(lat.values())), chain_ms_by_process_column=per_col,
+                paced_step_ms_max=max(v["ms_per_step"] for v in last.values()),
+                paced_step_ms={str(r): round(v["ms_per_step"], 3) for r, v in last.items()},
+                holder_latency_ms_first_mid_last=[round(lat[1], 3), round(lat[nblk // 2], 3), round(lat[nblk - 1], 3)],
+                variance_check_rel=max(v["check"] for v in last.values()),
+                bytes_received_per_fit=max(v["bytes_received_per_fit"] for v in last.values()))
+
+
 def replay_rank(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=512, agg=None, streamed=True, steps=3, profile=True,
-                single_potrf_ms=None):
+                single_potrf_ms=None, pace_us=None, want_latencies=False):
     """One process plays `rank` of the Pr x Pc `grid` against the complete factor `Lref` resident on this GPU: records the
     rank's program, checks what it computed against the single-GPU path, times `steps` steps.  Returns the result dict."""
     Pr, Pc = grid
@@ -39,7 +143,7 @@ def replay_rank(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=512, agg=N
     gs = "%dx%d" % (Pr, Pc)
     n, m = Xh.shape[0], Zh.shape[0]
     agg = dist.default_agg() if agg is None else agg
-    comm = ReplayComm(ctx, world, rank, Lref)
+    comm = ReplayComm(ctx, world, rank, Lref, pace_us=pace_us)
     run = dist.DistFitIvar2D(ctx, comm, spec, Xh, yh, Zh, noise, nb=nb, grid=(Pr, Pc), agg=agg, streamed=streamed, fit_only=True)
     _, part = run.step()          # records the program, first run
     ctx.sync()
@@ -66,6 +170,7 @@ def replay_rank(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=512, agg=N
         ts.append(1e3 * (time.perf_counter() - t0))
         host.append(run.host_ms.get("factor", 0.0))
     geo = run.geo
+    lat = own_step_latencies(ctx, geo)[0] if want_latencies else None
     res = dict(grid=gs, rank=rank, pr=geo.pr, pc=geo.pc, N=n, M=m, nb=nb, agg=agg, steps_k=geo.nblk,
                streamed_ivar=bool(streamed), factor_window_panels=run.window, ms_per_step=float(np.median(ts)), ms_all=ts,
                host_issue_ms_per_fit=float(np.median(host)), host_issue_us_per_panel_step=1e3 * float(np.median(host)) / geo.nblk,
@@ -73,6 +178,8 @@ def replay_rank(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=512, agg=N
                issue_mode="hipGraph (one launch per step)" if run.use_graph else "rows (one HIP call per row)",
                graph_nodes=run.programs["factor"].graph_nodes, bytes_received_per_fit=comm.bytes_in,
                variance_check_rel=check, single_gpu_potrf_ms=single_potrf_ms)
+    if want_latencies:
+        res["own_latency_ms"] = lat
     if profile:
         # per-class kernel time of one more, instrumented, step (row by row: profiler events cannot live inside a graph)
         run.force_interpret = True
@@ -104,7 +211,14 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--no-stream", action="store_true", help="factorisation alone (no evaluation streamed underneath, as the C5 fit)")
     ap.add_argument("--out", default="")
+    ap.add_argument("--paced-grid", action="store_true", help="whole-grid estimate: every process column replayed, paced by the "
+                                                             "holder latencies of the step's own column, iterated (paced_grid)")
+    ap.add_argument("--rows", default="", help="process rows replayed by --paced-grid (default: all)")
+    ap.add_argument("--paced", action="store_true", help="paced replay: foreign panels arrive at the latency this rank shows in its "
+                                                        "own holder steps (estimate of the whole grid's factorisation time)")
     args = ap.parse_args()
+    if args.paced or args.paced_grid:
+        os.environ.setdefault("GPX_EVENT_TIMING", "1")
 
     ctx = dev.Context(0)
     dev._ctx = ctx
@@ -128,12 +242,28 @@ def main():
     for gs in args.grids.split(","):
         Pr, Pc = (int(v) for v in gs.split("x"))
         world = Pr * Pc
+        if args.paced_grid:
+            res = paced_grid(ctx, spec, Xh, yh, Zh, noise, Lref, X, (Pr, Pc), nb=args.nb, agg=args.agg,
+                             streamed=(world >= 4 and not args.no_stream),
+                             rows=[int(v) for v in args.rows.split(",")] if args.rows else None)
+            res["single_gpu_potrf_ms"] = single_potrf_ms
+            print(json.dumps(res), flush=True)
+            continue
         ranks = sorted({(world - 1 if r == "last" else int(r)) for r in args.ranks.split(",") if r == "last" or int(r) < world})
         for rank in ranks:
+            if args.paced:
+                res = paced_replay(ctx, spec, Xh, yh, Zh, noise, Lref, X, (Pr, Pc), rank, nb=args.nb, agg=args.agg,
+                                   streamed=(world >= 4 and not args.no_stream))
+                res["single_gpu_potrf_ms"] = single_potrf_ms
+                print(json.dumps(res), flush=True)
+                continue
             res = replay_rank(ctx, spec, Xh, yh, Zh, noise, Lref, X, (Pr, Pc), rank, nb=args.nb, agg=args.agg,
                               streamed=(world >= 4 and not args.no_stream), steps=args.steps, single_potrf_ms=single_potrf_ms)
             results.append(res)
             print(json.dumps(res), flush=True)
+    if args.paced or args.paced_grid:
+        ctx.close()
+        return
     print("\n%-6s %-5s %10s %14s %16s %10s %12s" % ("grid", "rank", "ms/step", "host ms/fit", "host us/k-step", "rows/k", "GB received"))
     for r in results:
         print("%-6s %-5d %10.2f %14.2f %16.1f %10.1f %12.2f" % (r["grid"], r["rank"], r["ms_per_step"], r["host_issue_ms_per_fit"],

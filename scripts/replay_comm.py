@@ -21,10 +21,17 @@ class ReplayComm(Emitter):
     sweeps need the peers' partial sums)."""
     recordable = True
 
-    def __init__(self, ctx, world, rank, Lref):
+    def __init__(self, ctx, world, rank, Lref, pace_us=None):
         self.ctx, self.world, self.rank, self.Lref = ctx, int(world), int(rank), Lref
         self.k = None
         self.bytes_in = 0     # bytes the collectives would have delivered to this rank (per recording)
+        # PACED replay: pace_us[k] = microseconds the panel of step k takes to arrive after the panel of step k-1 when ANOTHER
+        # process column solves it (this rank's own holder steps take what they take).  Without pacing every foreign panel
+        # arrives at once, the rank is never idle, and its busy time says nothing about the chain ACROSS ranks -- step k+1's
+        # panel solve needs step k's panel, so a real run's factorisation time is the SUM of the holders' per-step latencies.
+        # With pacing set to the latencies this rank shows in its own holder steps (scripts/dist_replay.py iterates to a fixed
+        # point), the replayed step reproduces that chain on one GPU.  xGMI transfer time is still not in it.
+        self.pace_us = pace_us
 
     def set_grid(self, Pr, Pc):
         assert Pr * Pc == self.world
@@ -57,6 +64,8 @@ class ReplayComm(Emitter):
 
     def panel_bcast(self, buf, pieces):
         geo, k = self.geo, self.k
+        if self.pace_us is not None and geo.pc != k % geo.Pc and int(self.pace_us[k]) > 0:
+            self._emit(OP["SPIN"], (), (int(self.pace_us[k]), 1))      # the foreign holder's latency (COMM stream, in order)
         for off, cnt, root in pieces:
             if root == self.rank or cnt == 0:
                 continue

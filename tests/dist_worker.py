@@ -201,7 +201,11 @@ class NumpyOps2D(NumpyOps):
         """The C primitives reject blocks outside the local matrix (NumPy slicing would not)."""
         assert 0 <= lr0 and lr0 + m <= A.a.shape[0] and 0 <= lc and lc + w <= A.a.shape[1], (lr0, m, lc, w, A.a.shape)
 
-    def panel_trsm(self, A, lr0, m, lc, w, G, doff, roff, nb, dslot=None):
+    def panel_inv(self, G, doff, nb, w):
+        assert not self.poison or not np.isnan(self._D(G, doff, nb)[:w, :w][np.tril_indices(w)]).any(), \
+            "the inverse is built from a diagonal block that has not arrived"
+
+    def panel_trsm(self, A, lr0, m, lc, w, G, doff, roff, nb, dslot=None, prepared=False):
         self._inside(A, lr0, m, lc, w)
         if m == 0:
             return
