@@ -31,6 +31,10 @@ import numpy as np
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
 os.environ.setdefault("NCCL_DEBUG", "WARN")                 # RCCL says why when a collective fails (stderr; stdout stays one JSON line)
+if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    # the multi_gpu_replay object (N = 1 only, after the timed region) reads time stamps off the distributed loop's events; the
+    # single-GPU timed region records none of them
+    os.environ.setdefault("GPX_EVENT_TIMING", "1")
 os.environ.setdefault("GPX_DIST_ATTACH", "0")               # bench.py drives the distributed runners itself: the class API of this
 #                                                             process must not attach to the process group on its own (dist.session)
 
@@ -341,13 +345,16 @@ def dist_preflight(ctx, comm, dist, dev, spec, d, nb=256, two_d=True, n=2048, m=
     return out
 
 
-def multi_gpu_replay(ctx, dev, spec, Xh, yh, Zh, noise, K, X, fit_ms, grid=(2, 4), rank=0):
-    """After the timed region, --gpus 1 only: ONE process plays rank 0 of a 2 x 4 grid on this GPU -- that
-    rank's exact recorded program of the 2-D block-cyclic factorisation (gpexp_amd.dist.dist2_potrf_enqueue) with every receive
-    replaced by a device copy of the same bytes out of the factor the timed steps left in K (scripts/replay_comm.py).  It puts
-    the per-rank GPU time and host issue time of the 8-GPU form on the driver's clock, on a fresh box.  xGMI IS NOT IN IT:
-    transfers cost a device copy, nothing waits for a peer, and the diagonal blocks of the other ranks -- which sit on the same
-    global chain -- arrive as copies."""
+def multi_gpu_replay(ctx, dev, spec, Xh, yh, Zh, noise, K, X, fit_ms, step_ms, grid=(2, 4)):
+    """After the timed region, --gpus 1 only: the 8-GPU form of the step, measured on THIS GPU by PACED
+    single-rank replays (scripts/dist_replay.py paced_grid).  One process plays a rank of the 2 x 4 grid -- that rank's exact
+    recorded program of the 2-D block-cyclic factorisation (gpexp_amd.dist.dist2_potrf_enqueue), every receive a device copy of
+    the same bytes out of the factor the timed steps left in K (scripts/replay_comm.py).  A replay in which every foreign panel
+    arrives at once keeps the rank busy all the time and hides what bounds a real run: step k+1's panel solve needs step k's
+    panel, so the factorisation time is the SUM over the steps of the holder column's latency (near update of its column, panel
+    solve, hand-over).  So every process column is replayed in turn with each foreign panel held back by the latency measured
+    for ITS holder column, and the sweep is iterated to a fixed point.  `paced_step_ms_max` is then the step time of the grid.
+    xGMI IS NOT IN IT: transfers cost a device copy, so the figure is a lower bound on a real node's time."""
     scripts = os.path.join(ROOT, "scripts")
     if scripts not in sys.path:
         sys.path.insert(0, scripts)
@@ -357,20 +364,28 @@ def multi_gpu_replay(ctx, dev, spec, Xh, yh, Zh, noise, K, X, fit_ms, grid=(2, 4
     dev.kfill_into(ctx, spec, X, K, nugget=noise)      # (the isolated fill launches above left an unfactored matrix in K)
     dev.potrf(ctx, K)
     ctx.sync()
-    fit = dist_replay.replay_rank(ctx, spec, Xh, yh, Zh[:1024], noise, K, X, grid, rank, nb=nb, streamed=False, steps=3,
-                                  profile=False)
-    both = dist_replay.replay_rank(ctx, spec, Xh, yh, Zh, noise, K, X, grid, rank, nb=nb, streamed=True, steps=3, profile=False)
-    out = {"grid": "%dx%d" % grid, "rank": rank, "nb": nb, "panels_per_trailing_update": fit["agg"],
-           "fit_only_ms": fit["ms_per_step"], "fit_ivar_ms": both["ms_per_step"],
-           "host_issue_ms_per_fit": fit["host_issue_ms_per_fit"], "host_issue_us_per_panel_step": fit["host_issue_us_per_panel_step"],
-           "bytes_received_per_fit": fit["bytes_received_per_fit"], "bytes_received_per_fit_ivar": both["bytes_received_per_fit"],
-           "program_rows": fit["program_rows"], "variance_check_rel": max(fit["variance_check_rel"], both["variance_check_rel"]),
-           "single_gpu_fit_ms": fit_ms,
-           "rank_time_ratio_fit": (fit_ms / fit["ms_per_step"]) if fit_ms else None,
-           "seconds": None,
-           "xgmi": "NOT INCLUDED -- receives are device copies of the same bytes, sends cost nothing, no peer is waited for; the "
-                   "ratio is single-GPU fit time / this rank's GPU time, an upper bound on what 8 GPUs can reach, not a measured "
-                   "scaling figure"}
+    fit = dist_replay.paced_grid(ctx, spec, Xh, yh, Zh[:1024], noise, K, X, grid, nb=nb, streamed=False, iters=4, steps=2, rows=[0])
+    both = dist_replay.paced_grid(ctx, spec, Xh, yh, Zh, noise, K, X, grid, nb=nb, streamed=True, iters=5, steps=2, rows=[0])
+    if "error" in fit or "error" in both:
+        return {"error": fit.get("error") or both.get("error")}
+
+    def brief(r):
+        return {"panels_per_trailing_update": r["agg"], "replayed_ranks": r["replayed_ranks"],
+                "unpaced_rank_busy_ms": {k: v for k, v in r["iterations"][0]["rank_step_ms"].items()},
+                "chain_ms": r["chain_ms"], "chain_ms_by_process_column": r["chain_ms_by_process_column"],
+                "chain_ms_per_iteration": [h["chain_ms"] for h in r["iterations"]],
+                "paced_step_ms": r["paced_step_ms"], "paced_step_ms_max": r["paced_step_ms_max"],
+                "holder_latency_ms_first_mid_last": r["holder_latency_ms_first_mid_last"],
+                "bytes_received_per_step": r["bytes_received_per_fit"], "variance_check_rel": r["variance_check_rel"]}
+    out = {"grid": "%dx%d" % grid, "nb": nb,
+           "method": "paced single-rank replays on one GPU, one per process column (process row 0), foreign panels held back by the "
+                     "measured latency of their holder column, iterated; see scripts/dist_replay.py paced_grid",
+           "fit_only": brief(fit), "fit_ivar": brief(both),
+           "single_gpu_fit_ms": fit_ms, "single_gpu_step_ms": step_ms,
+           "ratio_fit": (fit_ms / fit["paced_step_ms_max"]) if fit_ms else None,
+           "ratio_fit_ivar": (step_ms / both["paced_step_ms_max"]) if step_ms else None,
+           "xgmi": "NOT INCLUDED -- receives are device copies of the same bytes, sends cost nothing; the ratios are single-GPU time / "
+                   "paced step time of the grid: upper bounds on what 8 GPUs can reach, not a measured scaling figure"}
     out["seconds"] = time.perf_counter() - t0
     return out
 
@@ -772,7 +787,7 @@ def main():
             line["comm_note"] = ("phases_ms_per_step.comm = HIP-event spans around the collectives on the communication stream "
                                  "(includes waiting for the peers); gemm / leaf = the compute strands")
         if world == 1 and not args.no_replay and os.environ.get("GPX_FORCE_DIST") != "1" and N >= 8192:
-            line["multi_gpu_replay"] = multi_gpu_replay(ctx, dev, spec, Xh, yh, Zh, noise, K, X, fit_ms)
+            line["multi_gpu_replay"] = multi_gpu_replay(ctx, dev, spec, Xh, yh, Zh, noise, K, X, fit_ms, ms)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(d, full=(args.cpu_baseline == "full"), kind=args.kernel)
             ref = os.path.join(ROOT, "profiles", "r02_bench_n1_cpu_full.json")

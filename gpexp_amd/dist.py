@@ -830,9 +830,12 @@ EV_FORK, EV_PRE, EV_JOIN0 = 1, 2, 3            # event ids below 14 are free (id
 ALL_SIDE_STREAMS = (PANEL, COMM, BACK, EVAL, BULK)
 
 
-def default_agg():
-    """Panels per aggregated trailing update (GPX_DIST_AGG; K = agg * nb per launch).  4 -> K = 2048 at nb = 512."""
-    return max(1, min(8, int(os.environ.get("GPX_DIST_AGG", "4"))))
+def default_agg(streamed=True):
+    """Panels per aggregated trailing update (GPX_DIST_AGG; K = agg * nb per launch).  4 -> K = 2048 at nb = 512 where the
+    evaluation is streamed underneath the factorisation (the rank is throughput-bound: longer K, fewer launches); 2 for the
+    factorisation alone, whose time on a real grid is the chain ACROSS ranks: shorter-lived bulk tiles give the chain's kernels
+    their slots sooner (paced replay of the 2 x 4 grid at C4: 51 ms with 2, 54 with 4 or 1; fit + IVAR: 113 with either)."""
+    return max(1, min(8, int(os.environ.get("GPX_DIST_AGG", "4" if streamed else "2"))))
 
 
 def ring_size(agg):
@@ -913,6 +916,7 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
     chunked = mode == "chunks"
     at_step = getattr(comm, "at_step", None)
     hoist_inv = os.environ.get("GPX_DIST2_HOIST_INV", "1") == "1" and hasattr(ops, "panel_inv")
+    gate_bulk = os.environ.get("GPX_DIST_GATE_BULK", "1") == "1"
 
     def group_end(k):
         return min((k // q + 1) * q - 1, nblk - 1)
@@ -1113,6 +1117,11 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
                 if bulk_stream != MAIN:
                     ops.wait(_ev2(E_COLREADY, 0))                        # this rank's own assembly of A (queued on MAIN)
                     ops.wait(_ev2(E_ARRIVED, k))                         # COMM is in order: implies the group's earlier panels
+                    if gate_bulk and nxt and pc == c1:
+                        # this rank's update of column k+1 gates the NEXT panel's solve -- the chain across ranks; a chip-filling
+                        # bulk launch issued at the same moment halves its rate (paced replay: the steps that follow a group end
+                        # took twice as long as the others).  The bulk update starts behind it.
+                        ops.wait(_ev2(E_COLREADY, k + 1))
                 update_cols(k + 3 + q, nblk - 1, ks)
                 ops.record(_ev2(E_BULK, k))
                 bulk_recorded.add(k)
@@ -1238,11 +1247,11 @@ class DistFitIvar2D:
         comm.set_grid(Pr, Pc)
         self.n, self.noise = Xh.shape[0], float(noise)
         self.geo = Grid2D(self.n, nb, Pr, Pc, comm.rank)
-        self.agg = default_agg() if agg is None else int(agg)
         env = os.environ.get("GPX_DIST_STREAM_IVAR")
         self.streamed = (comm.world >= 4) if streamed is None else bool(streamed)
         if env is not None:
             self.streamed = env == "1"
+        self.agg = default_agg(self.streamed and Zh.shape[0] > 0) if agg is None else int(agg)
         self.fit_only = bool(fit_only)       # replay: factorisation (+ streamed evaluation) only
         self.yh = np.ascontiguousarray(yh, dtype=np.float64)
         self.m = Zh.shape[0]

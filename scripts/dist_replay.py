@@ -116,16 +116,20 @@ def paced_grid(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, nb=512, agg=None, st
                 if own is None:
                     return dict(error="the pipeline's events carry no time stamps (set GPX_EVENT_TIMING=1 before the first use)")
                 nblk = res["steps_k"]
+                agg_used = res["agg"]
                 for k, v in own.items():
                     newlat[k] = max(newlat.get(k, 0.0), v)
                 last[rank] = dict(paced=pace is not None, ms_per_step=res["ms_per_step"], own_latency_sum_ms=float(sum(own.values())),
                                   bytes_received_per_fit=res["bytes_received_per_fit"], check=res["variance_check_rel"])
-        lat = newlat
+        # damped fixed point: a rank's holder latency falls when its foreign panels arrive later (it is less busy), which makes
+        # the next sweep's pacing shorter and the latencies rise again -- the plain iteration oscillates (fit + IVAR at 2 x 4:
+        # 215, 72, 110, 93, 102 ms of chain); from the second paced sweep on the pacing moves half-way
+        lat = newlat if it < 2 else {k: 0.5 * (lat[k] + newlat[k]) for k in newlat}
         hist.append(dict(iteration=it, chain_ms=float(sum(lat.values())),
                          rank_step_ms={str(r): round(v["ms_per_step"], 3) for r, v in last.items()},
                          paced=all(v["paced"] for v in last.values())))
     per_col = [float(sum(v for k, v in lat.items() if k % Pc == pc)) for pc in range(Pc)]
-    return dict(grid="%dx%d" % grid, nb=nb, agg=agg if agg is not None else dist.default_agg(), streamed_ivar=bool(streamed),
+    return dict(grid="%dx%d" % grid, nb=nb, agg=agg_used, streamed_ivar=bool(streamed),
                 replayed_ranks=sorted(last), iterations=hist, chain_ms=float(sum(lat.values())), chain_ms_by_process_column=per_col,
                 paced_step_ms_max=max(v["ms_per_step"] for v in last.values()),
                 paced_step_ms={str(r): round(v["ms_per_step"], 3) for r, v in last.items()},
@@ -142,7 +146,6 @@ def replay_rank(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=512, agg=N
     world = Pr * Pc
     gs = "%dx%d" % (Pr, Pc)
     n, m = Xh.shape[0], Zh.shape[0]
-    agg = dist.default_agg() if agg is None else agg
     comm = ReplayComm(ctx, world, rank, Lref, pace_us=pace_us)
     run = dist.DistFitIvar2D(ctx, comm, spec, Xh, yh, Zh, noise, nb=nb, grid=(Pr, Pc), agg=agg, streamed=streamed, fit_only=True)
     _, part = run.step()          # records the program, first run
@@ -171,7 +174,7 @@ def replay_rank(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=512, agg=N
         host.append(run.host_ms.get("factor", 0.0))
     geo = run.geo
     lat = own_step_latencies(ctx, geo)[0] if want_latencies else None
-    res = dict(grid=gs, rank=rank, pr=geo.pr, pc=geo.pc, N=n, M=m, nb=nb, agg=agg, steps_k=geo.nblk,
+    res = dict(grid=gs, rank=rank, pr=geo.pr, pc=geo.pc, N=n, M=m, nb=nb, agg=run.agg, steps_k=geo.nblk,
                streamed_ivar=bool(streamed), factor_window_panels=run.window, ms_per_step=float(np.median(ts)), ms_all=ts,
                host_issue_ms_per_fit=float(np.median(host)), host_issue_us_per_panel_step=1e3 * float(np.median(host)) / geo.nblk,
                program_rows=len(run.programs["factor"]), rows_per_panel_step=len(run.programs["factor"]) / geo.nblk,
@@ -207,7 +210,7 @@ def main():
     ap.add_argument("--m", type=int, default=32768)
     ap.add_argument("--d", type=int, default=8)
     ap.add_argument("--nb", type=int, default=512)
-    ap.add_argument("--agg", type=int, default=dist.default_agg())
+    ap.add_argument("--agg", type=int, default=None, help="panels per trailing update (default: 4 with the streamed evaluation, 2 without)")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--no-stream", action="store_true", help="factorisation alone (no evaluation streamed underneath, as the C5 fit)")
     ap.add_argument("--out", default="")
