@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 #include <map>
@@ -46,7 +47,15 @@ static inline int64_t gpx_round_up(int64_t v, int64_t m) { return (v + m - 1) / 
 // Leading dimension for a padded row of `cols` doubles: one extra 128-byte line per row when the row stride would
 // be a large power of two (N = 32768 -> 256 KiB).  Measured NEUTRAL on MI355X (GEMM 66.98 vs 66.97 TF/s: the L2 /
 // channel address hashing already spreads such strides); kept because it decouples ld from the padded width.
-static inline int64_t gpx_skew_ld(int64_t cols) { return (cols >= 1024 && cols % 256 == 0) ? cols + 16 : cols; }
+static inline int64_t gpx_skew_ld(int64_t cols) {
+  static int64_t skew = -1;   // GPX_LD_SKEW (experiment): doubles added to a power-of-two-ish row stride; default 16 = one 128-byte line
+  if (skew < 0) {
+    const char* e = getenv("GPX_LD_SKEW");
+    skew = e ? atoll(e) : 16;
+    if (skew < 0 || (skew & 1)) skew = 16;
+  }
+  return (cols >= 1024 && cols % 256 == 0) ? cols + skew : cols;
+}
 
 // Row stride of the rows region of a packed panel piece (dist.hip): nb + GPX_G_SKEW doubles.  At nb = 512 a stride of nb is
 // exactly 4 KiB, the textbook channel-conflict stride; measured on MI355X it makes NO difference (66.0 TF/s with skew 0, 65.9

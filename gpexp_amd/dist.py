@@ -830,12 +830,14 @@ EV_FORK, EV_PRE, EV_JOIN0 = 1, 2, 3            # event ids below 14 are free (id
 ALL_SIDE_STREAMS = (PANEL, COMM, BACK, EVAL, BULK)
 
 
-def default_agg(streamed=True):
+def default_agg(streamed=True, world=8):
     """Panels per aggregated trailing update (GPX_DIST_AGG; K = agg * nb per launch).  4 -> K = 2048 at nb = 512 where the
     evaluation is streamed underneath the factorisation (the rank is throughput-bound: longer K, fewer launches); 2 for the
     factorisation alone, whose time on a real grid is the chain ACROSS ranks: shorter-lived bulk tiles give the chain's kernels
     their slots sooner (paced replay of the 2 x 4 grid at C4: 51 ms with 2, 54 with 4 or 1; fit + IVAR: 113 with either)."""
-    return max(1, min(8, int(os.environ.get("GPX_DIST_AGG", "4" if streamed else "2"))))
+    # (1-2 ranks: each rank carries half or all of the trailing updates -- throughput-bound like the streamed case; world-1 RCCL
+    # bench 695 ms with 4 panels per update, 710 with 2)
+    return max(1, min(8, int(os.environ.get("GPX_DIST_AGG", "4" if (streamed or world < 4) else "2"))))
 
 
 def ring_size(agg):
@@ -1251,7 +1253,7 @@ class DistFitIvar2D:
         self.streamed = (comm.world >= 4) if streamed is None else bool(streamed)
         if env is not None:
             self.streamed = env == "1"
-        self.agg = default_agg(self.streamed and Zh.shape[0] > 0) if agg is None else int(agg)
+        self.agg = default_agg(self.streamed and Zh.shape[0] > 0, comm.world) if agg is None else int(agg)
         self.fit_only = bool(fit_only)       # replay: factorisation (+ streamed evaluation) only
         self.yh = np.ascontiguousarray(yh, dtype=np.float64)
         self.m = Zh.shape[0]
