@@ -324,6 +324,7 @@ int gpx_mat_new(gpx_ctx* ctx, int64_t rows, int64_t cols, int pad, gpx_mat** out
     return r;
   }
   m->p = (double*)p;
+  ctx->live_mats.insert(m);
   *out = m;
   return 0;
 }
@@ -697,6 +698,7 @@ int gpx_mat_free(gpx_ctx* ctx, gpx_mat* m) {
       if (m->dinv) ctx->pending[m->dinv] = f;
     }
   }
+  ctx->live_mats.erase(m);
   gpx_dev_release(ctx, m->p, m->bytes);
   if (m->aux) gpx_dev_release(ctx, m->aux, m->aux_bytes);
   if (m->binv) gpx_dev_release(ctx, m->binv, m->binv_bytes);

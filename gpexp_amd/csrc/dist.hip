@@ -858,6 +858,27 @@ static int d2_scratch_ensure(gpx_ctx* ctx, int64_t nb) {
   return 0;
 }
 
+// Size the context's two distributed-loop scratches UP FRONT: the panel solve's inverse (2 nb^2 doubles) and the
+// streamed evaluation's group scratch (2 ceil(w / nb) nb^2 + w mcols doubles, w = agg nb).  Both used to grow on first use from
+// inside the enqueue path -- hipDeviceSynchronize + hipFree + hipMalloc in the middle of a step that may have collectives in
+// flight (bench.py's preflight runs nb = 256 and the real runner 512), or inside a stream capture.  The runner's constructor
+// calls this; the hot path then finds them large enough.  Blocking.
+int gpx_dist2_reserve(gpx_ctx* ctx, int64_t nb, int64_t agg, int64_t mcols) {
+  GPX_ARG(ctx && nb > 0 && nb % GPX_TILE == 0 && agg >= 1 && mcols >= 0, "bad arguments");
+  GPX_TRY(d2_scratch_ensure(ctx, nb));
+  const int64_t w = agg * nb, mcp = gpx_round_up(mcols > 0 ? mcols : 1, GPX_TILE);
+  const int64_t need = (2 * agg * nb * nb + w * mcp) * 8;
+  if (mcols > 0 && ctx->ev_scratch_bytes < need) {
+    GPX_HIP(hipDeviceSynchronize());
+    if (ctx->ev_scratch) (void)hipFree(ctx->ev_scratch);
+    ctx->ev_scratch = nullptr;
+    ctx->ev_scratch_bytes = 0;
+    GPX_HIP(hipMalloc((void**)&ctx->ev_scratch, (size_t)need));
+    ctx->ev_scratch_bytes = need;
+  }
+  return 0;
+}
+
 // Round 4: the explicit inverse of the diagonal block of panel k, built AHEAD of the panel solve.  It depends on the factored
 // block alone (in G at doff: available when the column broadcast lands, typically a millisecond before the column has its last
 // update), but gpx_dist2_panel_trsm used to build it inside the solve: eight small dependent kernels on the panel chain --
@@ -1176,6 +1197,12 @@ int gpx_program_run(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const int64_
     gpx_mat* h0 = reinterpret_cast<gpx_mat*>((uintptr_t)o[1]);
     gpx_mat* h1 = reinterpret_cast<gpx_mat*>((uintptr_t)o[2]);
     gpx_mat* h2 = reinterpret_cast<gpx_mat*>((uintptr_t)o[3]);
+    // the rows carry raw handles recorded earlier: a matrix freed since then (or a context closed under a kept Program) must be
+    // an error here, not a use-after-free in a kernel
+    if ((h0 && !ctx->live_mats.count(h0)) || (h1 && !ctx->live_mats.count(h1)) || (h2 && !ctx->live_mats.count(h2))) {
+      gpx_set_error("program op %lld (opcode %lld): a matrix handle of the recorded row is no longer alive", (long long)i, (long long)o[0]);
+      return -1;
+    }
     const int64_t* a = o + 4;
     int r = 0;
     switch ((int)o[0]) {
@@ -1197,7 +1224,13 @@ int gpx_program_run(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const int64_
           return -1;
         }
         const gpx_mat* G[GPX_SEG_MAX];
-        for (int s = 0; s < nseg; ++s) G[s] = reinterpret_cast<const gpx_mat*>((uintptr_t)extra[a[11] + s]);
+        for (int s = 0; s < nseg; ++s) {
+          G[s] = reinterpret_cast<const gpx_mat*>((uintptr_t)extra[a[11] + s]);
+          if (!ctx->live_mats.count(G[s])) {
+            gpx_set_error("program op %lld: a packed panel buffer of the segment list is no longer alive", (long long)i);
+            return -1;
+          }
+        }
         r = gpx_dist2_update_multi(ctx, h0, a[0], a[1], a[2], a[3], a[4], (int)a[5], (int)a[6], (int)a[7], (int)a[8], a[9], nseg,
                                    G, extra + a[11] + nseg, below);
         break;

@@ -701,6 +701,10 @@ class DeviceOps2D(Emitter, DeviceOps):
     def alloc_vec(self, n):
         return _dev.DeviceMatrix.zeros(self.ctx, max(int(n), 1), 1, pad=False)
 
+    def reserve(self, nb, agg, mcols):
+        """the context's panel-solve / streamed-evaluation scratches, sized before the first step (never mid-step)"""
+        check(self.ctx.lib.gpx_dist2_reserve(self.ctx.h, int(nb), int(agg), int(mcols)))
+
     def kfill_local(self, spec, X, A, nugget, geo):
         nug, nlen = _dev._nugget_args(nugget, X.shape[0])
         # tests: hold the assembly of ONE rank back ("ms@rank"), so that a missing dependency on it shows every time
@@ -1290,6 +1294,8 @@ class DistFitIvar2D:
         self.acc_c = self.ops.alloc_vec(self.geo.local_cols(self.geo.pc))
         self.scal = self.ops.alloc_vec(8)
         self.B = self.ops.alloc_cross(self.n, hi - lo) if (self.streamed and hi > lo) else None
+        if hasattr(self.ops, "reserve"):
+            self.ops.reserve(nb, self.agg, (hi - lo) if self.B is not None else 0)
         # recorded programs (device ops + a recordable communicator only; GPX_DIST_RECORD=0 interprets every step)
         self.programs = None
         self.recordable = (type(self.ops) is DeviceOps2D and getattr(comm, "recordable", False)

@@ -140,6 +140,9 @@ int gpx_dist2_kfill(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, 
 /* diagonal owner: factor the w x w block at local (lr, lc) into the D region of the panel buffer G (offset doff) */
 int gpx_dist2_diag_factor(gpx_ctx* ctx, gpx_mat* A, int64_t lr, int64_t lc, int64_t w, gpx_mat* G, int64_t doff,
                           int64_t nb, int64_t base, int64_t n_valid);
+/* size the context's scratches of the distributed loops up front (panel-solve inverse: 2 nb^2 doubles; streamed evaluation:
+ * 2 agg nb^2 + agg nb mcols doubles) so that the enqueue path never reallocates mid-step; called by the runners' constructors */
+int gpx_dist2_reserve(gpx_ctx* ctx, int64_t nb, int64_t agg, int64_t mcols);
 /* holders of block column k, as soon as the diagonal block has arrived in G (doff): its explicit inverse, kept for the panel
  * solves of this step (gpx_dist2_panel_trsm then multiplies with it instead of building it on the panel chain; the block row the
  * next diagonal needs takes the same one-product path instead of the leaf recursion) */

@@ -171,6 +171,25 @@ def run_api(args, gpu):
         want = fd[key] * 2 * nz if key == "noise" else fd[key]
         assert abs(dd[key] - want) <= 2e-6 * abs(want), key
     same("lml grad", [llg] + [dd[k_] for k_ in golden.index[c]["keys"]])
+    # ---- edges: fewer evaluation points than ranks; a rank-deficient covariance (all ranks agree on the failure and take the
+    #      replicated path with its drop policy, gp.py:181's pinv answer); FITC (replicated) ----
+    c = "se_iso_d3_n96"
+    ge = GP(make_kernel(golden.index[c]["kernel"]), golden.noise(c))
+    ge.train(golden(c, "X"), golden(c, "y"))
+    m1, v1 = ge.evaluate(golden(c, "Z")[:1], compvar=1)
+    assert rel(m1, golden(c, "mean")[:1]) <= 1e-10 and rel(v1, golden(c, "absvar")[:1]) <= 1e-10
+    same("one evaluation point", m1, v1)
+    if gpu and "rankdef" in golden.index:
+        import warnings
+        c = "rankdef"
+        gr = GP(make_kernel(golden.index[c]["kernel"]), 0.0)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            gr.train(golden(c, "X"), golden(c, "y"))
+            mr, vr = gr.evaluate(golden(c, "Z"), compvar=1)
+        assert gr.dropped >= 1
+        assert rel(mr, golden(c, "mean")) <= 1e-8 and rel(vr, golden(c, "absvar")) <= 1e-8
+        same("rank-deficient", mr, vr)
     # ---- the SPMD contract is CHECKED: a rank that passes different data raises on every rank ----
     if sess.world > 1:
         Xbad = Xg.copy()

@@ -260,3 +260,29 @@ def test_fit_ivar_reports_non_positive_definite(dev, ctx):
             dev.fit_ivar(ctx, sp, K, X, Z)
     finally:
         dev.potrf_policy(ctx, 0.0, False)
+
+
+def test_recorded_program_refuses_a_freed_matrix():
+    """the rows of a recorded program carry raw matrix handles; a matrix freed after the recording must make the replay
+    fail with an error (the context keeps the set of live handles), not run a kernel on released memory."""
+    from gpexp_amd import device as dev, dist
+    from gpexp_amd._lib import GpxError
+    ctx = dev.context()
+    a, b = dev.alloc_vector(ctx, 256), dev.alloc_vector(ctx, 256)
+    prog = dist.Program()
+    prog.emit(dist.OP["COPY"], (a, b), (0, 0, 128))
+    prog.run(ctx)
+    ctx.sync()
+    b.free()
+    with pytest.raises(GpxError, match="no longer alive"):
+        prog.run(ctx)
+
+
+def test_distributed_scratches_are_reserved_by_the_constructor():
+    """the panel-solve and streamed-evaluation scratches are sized when the runner is built (gpx_dist2_reserve), so a
+    step never reallocates them with work in flight; a second reserve with smaller sizes is a no-op."""
+    from gpexp_amd import device as dev
+    ctx = dev.context()
+    assert ctx.lib.gpx_dist2_reserve(ctx.h, 512, 4, 4096) == 0
+    assert ctx.lib.gpx_dist2_reserve(ctx.h, 256, 2, 1024) == 0
+    assert ctx.lib.gpx_dist2_reserve(ctx.h, 100, 2, 1024) < 0     # nb must be a multiple of 128
