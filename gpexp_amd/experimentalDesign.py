@@ -347,8 +347,24 @@ def performGreedyIVARExperimentalDesign(gaussianProcess, candidates, mcPoints, n
         idx, costs = sess.greedy_ivar(gp.kernel._spec(), gp._L, gp._X, candidates, mcPoints, float(gp.noise), int(nPoints))
     else:
         ctx = _dev.context()
-        idx, costs = _dev.greedy_ivar(ctx, gp.kernel._spec(), gp._L, gp._X, _dev.points(ctx, candidates),
-                                      _dev.points(ctx, np.asarray(mcPoints, dtype=float)), float(gp.noise), int(nPoints))
+        n, m, nmc = gp.pts.shape[0], len(candidates), len(mcPoints)
+        resident = 8.0 * (m + 128) * (n + nmc + int(nPoints) + 512)       # W_C, cov(Z, C), the picks' rows (+ padding)
+        if not hasattr(ctx, "_hbm_bytes"):
+            ctx._hbm_bytes = ctx.info()["hbm_bytes"]
+        if resident + 16.0 * (n + 128) * (nmc + 128) + 8.0 * n * n > 0.8 * ctx._hbm_bytes:
+            # the resident state does not fit beside the factor: the refit loop it replaces (chunked over the candidates)
+            idx, costs, X = [], [], np.array(gp.pts, dtype=float, copy=True)
+            g2 = copy.copy(gp)
+            for _ in range(int(nPoints)):
+                g2.addNodesAndComputeCovariance(X)
+                best, c = greedyIVARStep(g2, candidates, mcPoints)
+                idx.append(int(best))
+                costs.append(float(c[best]))
+                X = np.vstack((X, candidates[best:best + 1]))
+            idx, costs = np.array(idx, dtype=np.int64), np.array(costs)
+        else:
+            idx, costs = _dev.greedy_ivar(ctx, gp.kernel._spec(), gp._L, gp._X, _dev.points(ctx, candidates),
+                                          _dev.points(ctx, np.asarray(mcPoints, dtype=float)), float(gp.noise), int(nPoints))
     if returnCosts:
         return idx, costs
     return candidates[list(idx), :]
