@@ -364,8 +364,8 @@ def multi_gpu_replay(ctx, dev, spec, Xh, yh, Zh, noise, K, X, fit_ms, step_ms, g
     dev.kfill_into(ctx, spec, X, K, nugget=noise)      # (the isolated fill launches above left an unfactored matrix in K)
     dev.potrf(ctx, K)
     ctx.sync()
-    fit = dist_replay.paced_grid(ctx, spec, Xh, yh, Zh[:1024], noise, K, X, grid, nb=nb, streamed=False, iters=4, steps=2, rows=[0])
-    both = dist_replay.paced_grid(ctx, spec, Xh, yh, Zh, noise, K, X, grid, nb=nb, streamed=True, iters=5, steps=2, rows=[0])
+    fit = dist_replay.paced_grid(ctx, spec, Xh, yh, Zh[:1024], noise, K, X, grid, nb=nb, streamed=False, iters=4, steps=2)
+    both = dist_replay.paced_grid(ctx, spec, Xh, yh, Zh, noise, K, X, grid, nb=nb, streamed=True, iters=5, steps=2)
     if "error" in fit or "error" in both:
         return {"error": fit.get("error") or both.get("error")}
 
@@ -378,7 +378,7 @@ def multi_gpu_replay(ctx, dev, spec, Xh, yh, Zh, noise, K, X, fit_ms, step_ms, g
                 "holder_latency_ms_first_mid_last": r["holder_latency_ms_first_mid_last"],
                 "bytes_received_per_step": r["bytes_received_per_fit"], "variance_check_rel": r["variance_check_rel"]}
     out = {"grid": "%dx%d" % grid, "nb": nb,
-           "method": "paced single-rank replays on one GPU, one per process column (process row 0), foreign panels held back by the "
+           "method": "paced single-rank replays on one GPU, every rank of the grid in turn, foreign panels held back by the "
                      "measured latency of their holder column, iterated; see scripts/dist_replay.py paced_grid",
            "fit_only": brief(fit), "fit_ivar": brief(both),
            "single_gpu_fit_ms": fit_ms, "single_gpu_step_ms": step_ms,
