@@ -100,6 +100,7 @@ _SIGS = {
     "gpx_vec_op": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, C.c_int]),
     "gpx_comm_grid": (C.c_int, [c_vp, C.c_int, C.c_int]),
     "gpx_comm_bcast_grp": (C.c_int, [c_vp, c_vp, c_i64, c_i64, C.c_int, C.c_int]),
+    "gpx_comm_bcast_grp2": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, C.c_int, C.c_int]),
     "gpx_comm_reduce_grp": (C.c_int, [c_vp, c_vp, c_i64, c_i64, C.c_int, C.c_int]),
     "gpx_comm_allreduce": (C.c_int, [c_vp, c_vp, c_i64, c_i64]),
     "gpx_comm_allreduce_host": (C.c_int, [c_vp, c_dp, c_i64]),

@@ -233,6 +233,26 @@ int gpx_comm_bcast_grp(gpx_ctx* ctx, gpx_mat* buf, int64_t offset, int64_t count
   return 0;
 }
 
+// out-of-place form: the root sends sbuf[soff ..], EVERY member (the root too) receives into rbuf[roff ..].  Round 4: the block
+// row the next diagonal needs travels into a buffer of its own, so that the panel broadcast -- which lands the same bytes on the
+// panel buffer a moment later -- never has to wait for the kernel that is reading them (that wait sat on the chain across ranks).
+int gpx_comm_bcast_grp2(gpx_ctx* ctx, const gpx_mat* sbuf, int64_t soff, gpx_mat* rbuf, int64_t roff, int64_t count, int root, int grp) {
+  GPX_ARG(sbuf && rbuf, "buffer is NULL");
+  GPX_TRY(need_group(ctx, grp));
+  GPX_ARG(soff >= 0 && roff >= 0 && count >= 0 && (soff + count) * 8 <= sbuf->bytes && (roff + count) * 8 <= rbuf->bytes,
+          "broadcast range exceeds a buffer");
+  GPX_ARG(root >= 0 && root < ctx->grp_size[grp], "root outside the group");
+  if (count == 0) return 0;
+  rbuf->bbox_ok = 0;
+  if (ctx->grp_size[grp] == 1) {   // alone in the group: the "receive" is a local copy
+    GPX_HIP(hipMemcpyAsync(rbuf->p + roff, sbuf->p + soff, (size_t)count * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+  }
+  ProfScope ps(ctx, GPX_PROF_COMM, 0.0, 8.0 * (double)count);
+  GPX_NCCL(g_rccl.Broadcast(sbuf->p + soff, rbuf->p + roff, (size_t)count, ncclFloat64, root, (ncclComm_t)ctx->grp[grp], ctx->stream));
+  return 0;
+}
+
 // in-place sum of buf[offset .. offset+count) over a group, result on the group rank `root` (others keep their input)
 int gpx_comm_reduce_grp(gpx_ctx* ctx, gpx_mat* buf, int64_t offset, int64_t count, int root, int grp) {
   GPX_ARG(buf != nullptr, "buffer is NULL");
@@ -1240,6 +1260,7 @@ int gpx_program_run(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const int64_
       case GPX_OP_PACK_ROWS: r = gpx_dist2_pack_rows(ctx, h0, a[0], a[1], a[2], h1, a[3], a[4], a[5], a[6]); break;
       case GPX_OP_PACK_DIAG: r = gpx_dist2_pack_diag(ctx, h0, a[0], a[1], a[2], h1, a[3]); break;
       case GPX_OP_BCAST_GRP: r = gpx_comm_bcast_grp(ctx, h0, a[0], a[1], (int)a[2], (int)a[3]); break;
+      case GPX_OP_BCAST_GRP2: r = gpx_comm_bcast_grp2(ctx, h0, a[0], h1, a[1], a[2], (int)a[3], (int)a[4]); break;
       case GPX_OP_REDUCE_GRP: r = gpx_comm_reduce_grp(ctx, h0, a[0], a[1], (int)a[2], (int)a[3]); break;
       case GPX_OP_ALLREDUCE: r = gpx_comm_allreduce(ctx, h0, a[0], a[1]); break;
       case GPX_OP_PANEL_BCAST: {

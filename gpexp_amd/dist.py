@@ -94,7 +94,7 @@ def merge_argmin(values, indices):
 # ---- recorded programs (include/gpx.h: gpx_program_run) -----------------------------------------------------------
 OP = dict(STREAM=1, RECORD=2, WAIT=3, BEGIN=4, DIAG_FACTOR=5, PANEL_TRSM=6, UPDATE=7, UPDATE_MULTI=8, UNPACK_ROWS=9,
           UNPACK_DIAG=10, PACK_ROWS=11, PACK_DIAG=12, BCAST_GRP=13, REDUCE_GRP=14, ALLREDUCE=15, PANEL_BCAST=16, IVAR_STEP=17,
-          TRSV_DIAG=18, GEMV=19, LOGDET_ACC=20, VEC_OP=21, SPIN=22, COPY=23, IVAR_GROUP=24, FWD_GROUP=25, PANEL_INV=26)
+          TRSV_DIAG=18, GEMV=19, LOGDET_ACC=20, VEC_OP=21, SPIN=22, COPY=23, IVAR_GROUP=24, FWD_GROUP=25, PANEL_INV=26, BCAST_GRP2=27)
 
 
 class Program:
@@ -244,6 +244,10 @@ class RcclComm(Emitter):
 
     def bcast_grp(self, buf, offset, count, root, grp):
         self._emit(OP["BCAST_GRP"], (buf,), (offset, count, root, grp))
+
+    def bcast_grp2(self, sbuf, soff, rbuf, roff, count, root, grp):
+        """out-of-place broadcast: the root sends sbuf[soff ..], every member receives into rbuf[roff ..]"""
+        self._emit(OP["BCAST_GRP2"], (sbuf, rbuf), (soff, roff, count, root, grp))
 
     def reduce_grp(self, buf, offset, count, root, grp):
         self._emit(OP["REDUCE_GRP"], (buf,), (offset, count, root, grp))
@@ -846,11 +850,14 @@ def default_agg(streamed=True, world=8):
 
 def ring_size(agg):
     """Packed panel buffers the loop cycles through: a panel's buffer is read until the bulk update of ITS group has run,
-    which may finish one group late (it runs beside the next group's chain) -- two groups of buffers."""
-    return 2 * agg
+    which may finish one group late (it runs beside the next group's chain) -- at least two groups of buffers.  Round 4: at
+    least GPX_DIST_RING (8) of them whatever the group size: the communication stream may not overwrite a buffer before the bulk
+    update that reads it has run, so a SHORT ring ties the chain across ranks to the slowest rank's backlog of bulk updates
+    (paced replay, two panels per update: with 4 buffers the last panel reached the two busiest ranks 8 ms after the others)."""
+    return max(2 * agg, int(os.environ.get("GPX_DIST_RING", "8")))
 
 
-def dist2_potrf(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, window=0):
+def dist2_potrf(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, window=0, E=None):
     """2-D block-cyclic right-looking Cholesky of the distributed matrix A (in place: A ends as the block-cyclic factor)
     with look-ahead, a CRITICAL-PATH-FIRST diagonal chain and AGGREGATED trailing updates.  G = ring of packed panel
     buffers (geo.buf_elems() doubles each, len(G) >= ring_size(agg), or 2 with agg = 1); L (optional) = full-size matrix
@@ -875,7 +882,7 @@ def dist2_potrf(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, window=0
     order on every rank of every communicator), MAIN (near updates), BULK (aggregated updates), BACK (copies into L, then the
     streamed-evaluation hook `on_stored(k)`).  A panel buffer is rewritten one ring later, after everything that reads it.
     Returns 0 or the 1-based index of the first non-positive pivot (agreed by all)."""
-    dist2_potrf_enqueue(ops, comm, geo, A, G, L=L, on_stored=on_stored, agg=agg, window=window)
+    dist2_potrf_enqueue(ops, comm, geo, A, G, L=L, on_stored=on_stored, agg=agg, window=window, E=E)
     return dist2_potrf_finish(ops, comm, None if window else L)
 
 
@@ -888,7 +895,7 @@ def dist2_potrf_finish(ops, comm, L=None):
     return min(bad) if bad else 0
 
 
-def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, window=0):
+def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, window=0, E=None):
     """The asynchronous part of dist2_potrf: pure enqueue, no host read -- recordable (Program).
 
     window > 0: L is not a full-size replica but a WINDOW of `window` block columns (padded N rows x window * nb columns);
@@ -900,6 +907,14 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
     q = default_agg() if agg is None else int(agg)
     R = len(G)
     assert R >= (ring_size(q) if q > 1 else 2), "panel-buffer ring too short for the aggregation depth"
+    # E (optional, round 4): a ring of small buffers (len(G) of them, nb x row-stride doubles) that receive the block row the
+    # NEXT diagonal needs (L[k+1, k], sent along its process row ahead of the panel).  Without it that block lands in the panel
+    # buffer, where the panel broadcast writes the same bytes again a moment later -- and the communication stream of the next
+    # diagonal's owner has to hold the panel broadcast back until the kernel reading the block is done.  The panel
+    # broadcast is a collective: one rank entering it late delays every rank -- 1.0-1.3 ms on each step, on the chain across
+    # ranks (paced replay: the last panel reached the diagonal owners of process row 1 8 ms after everybody else).
+    if E is not None and (len(E) < len(G) or not hasattr(comm, "bcast_grp2")):
+        E = None
     window = int(window)
     assert window == 0 or (L is not None and on_stored is not None and window % q == 0 and window >= 2 * q), \
         "a window of the factor needs the streamed evaluation that consumes it, and two whole groups of column slots"
@@ -1043,7 +1058,10 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
                 ops.wait(_ev2(E_EARLYSOLVED, k))
             else:
                 wait_free()
-            comm.bcast_grp(g, early_off, h1 * geo.gld, kc, ROW)          # L[k+1, k] along the process row of block row k+1
+            if E is not None:
+                comm.bcast_grp2(g, early_off, E[k % R], 0, h1 * geo.gld, kc, ROW)   # ... into the early buffer of this step
+            else:
+                comm.bcast_grp(g, early_off, h1 * geo.gld, kc, ROW)      # L[k+1, k] along the process row of block row k+1
             ops.record(_ev2(E_EARLY, k))
             if pc == c1:                                                 # owner of the next diagonal block
                 ops.stream(PANEL)
@@ -1055,7 +1073,10 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
                     # update could land on the block before the fill wrote it and be overwritten -- seen on the first
                     # step of a fresh process only, when the fill kernel's first launch is slow (1 run in 12)
                     ops.wait(_ev2(E_COLREADY, 0))
-                ops.update(A, ((k + 1) // Pr) * nb, h1, ((k + 1) // Pc) * nb, h1, g, early_off, early_off, w, nb)
+                if E is not None:
+                    ops.update(A, ((k + 1) // Pr) * nb, h1, ((k + 1) // Pc) * nb, h1, E[k % R], 0, 0, w, nb)
+                else:
+                    ops.update(A, ((k + 1) // Pr) * nb, h1, ((k + 1) // Pc) * nb, h1, g, early_off, early_off, w, nb)
                 ops.record(_ev2(E_DIAGREADY, k + 1))
         ops.stream(PANEL)
         ops.record(_ev2(E_PANELDONE, k))
@@ -1068,7 +1089,7 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
         # Ranks of process row r1 that are no column holders already HAVE L[k+1, k] (row broadcast above) and their PANEL
         # stream may be reading it (early diagonal update) while the panel broadcast lands the same bytes on it again:
         # order the overwrite behind that read instead of relying on the bytes being identical.
-        if nxt and pr == r1 and pc == c1 and not holder:
+        if nxt and pr == r1 and pc == c1 and not holder and E is None:
             ops.wait(_ev2(E_DIAGREADY, k + 1))
         comm.panel_bcast(g, geo.pieces(k))                               # every piece to every rank, all links
         ops.record(_ev2(E_ARRIVED, k))
@@ -1265,7 +1286,10 @@ class DistFitIvar2D:
         lo, hi = eval_slice(self.m, comm.rank, comm.world)
         self.Zloc = self.ops.points(Zh[lo:hi]) if hi > lo else None
         self.A = self.ops.alloc_local(self.geo)
-        self.G = [self.ops.alloc_buf(self.geo) for _ in range(ring_size(self.agg) if self.agg > 1 else 2)]
+        self.G = [self.ops.alloc_buf(self.geo) for _ in range(ring_size(self.agg))]
+        # early buffers (one per ring slot): the block row the next diagonal needs, received out of the panel buffer's way
+        self.E = ([self.ops.alloc_vec(nb * self.geo.gld) for _ in self.G]
+                  if os.environ.get("GPX_DIST_EARLY_BUF", "1") == "1" and hasattr(comm, "bcast_grp2") else None)
         # The finished factor: with the STREAMED evaluation nothing reads a panel after its group's solve step, so the rank
         # keeps a window of two groups of block columns (N x 2 agg nb) instead of an N x N replica (`replicate`, or
         # GPX_DIST_REPLICATE=1, forces the replica; the C5 gradient needs it).
@@ -1322,7 +1346,7 @@ class DistFitIvar2D:
         hook = self._hook()
         L = None if (self.window and hook is None) else self.L       # a rank without evaluation points keeps no window
         dist2_potrf_enqueue(self.ops, self.comm, self.geo, self.A, self.G, L=L, on_stored=hook, agg=self.agg,
-                            window=self.window if hook is not None else 0)
+                            window=self.window if hook is not None else 0, E=self.E)
 
     def _enqueue_solve(self):
         ops, geo = self.ops, self.geo

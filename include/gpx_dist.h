@@ -121,6 +121,8 @@ int gpx_dist_finish(gpx_ctx* ctx, gpx_mat* K);
 /* sub-communicators: group 0 = world, 1 = the rank's process row, 2 = its process column (ncclCommSplit) */
 int gpx_comm_grid(gpx_ctx* ctx, int Pr, int Pc);
 int gpx_comm_bcast_grp(gpx_ctx* ctx, gpx_mat* buf, int64_t offset, int64_t count, int root, int grp);
+/* out-of-place: the root sends sbuf[soff ..], every member receives into rbuf[roff ..] (ncclBroadcast with two pointers) */
+int gpx_comm_bcast_grp2(gpx_ctx* ctx, const gpx_mat* sbuf, int64_t soff, gpx_mat* rbuf, int64_t roff, int64_t count, int root, int grp);
 /* in-place sum inside a group, result on group rank `root` (ncclReduce) / over all ranks, result everywhere (ncclAllReduce) */
 int gpx_comm_reduce_grp(gpx_ctx* ctx, gpx_mat* buf, int64_t offset, int64_t count, int root, int grp);
 int gpx_comm_allreduce(gpx_ctx* ctx, gpx_mat* buf, int64_t offset, int64_t count);
@@ -194,7 +196,7 @@ enum {
   GPX_OP_STREAM = 1, GPX_OP_RECORD, GPX_OP_WAIT, GPX_OP_BEGIN, GPX_OP_DIAG_FACTOR, GPX_OP_PANEL_TRSM, GPX_OP_UPDATE,
   GPX_OP_UPDATE_MULTI, GPX_OP_UNPACK_ROWS, GPX_OP_UNPACK_DIAG, GPX_OP_PACK_ROWS, GPX_OP_PACK_DIAG, GPX_OP_BCAST_GRP,
   GPX_OP_REDUCE_GRP, GPX_OP_ALLREDUCE, GPX_OP_PANEL_BCAST, GPX_OP_IVAR_STEP, GPX_OP_TRSV_DIAG, GPX_OP_GEMV, GPX_OP_LOGDET_ACC,
-  GPX_OP_VEC_OP, GPX_OP_SPIN, GPX_OP_COPY, GPX_OP_IVAR_GROUP, GPX_OP_FWD_GROUP, GPX_OP_PANEL_INV
+  GPX_OP_VEC_OP, GPX_OP_SPIN, GPX_OP_COPY, GPX_OP_IVAR_GROUP, GPX_OP_FWD_GROUP, GPX_OP_PANEL_INV, GPX_OP_BCAST_GRP2
 };
 int gpx_program_run(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const int64_t* extra, int64_t nextra, double* host_ms);
 /* The same program as a hipGraph: captured once (after it has run once the ordinary way; every stream it uses must fork from

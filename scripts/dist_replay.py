@@ -120,6 +120,8 @@ def paced_grid(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, nb=512, agg=None, st
                 for k, v in own.items():
                     newlat[k] = max(newlat.get(k, 0.0), v)
                 last[rank] = dict(paced=pace is not None, ms_per_step=res["ms_per_step"], own_latency_sum_ms=float(sum(own.values())),
+                                  last_arrived_ms=res.get("last_arrived_ms"), last_step_ms=res.get("last_step_ms"),
+                                  foreign_excess_ms=res.get("foreign_excess_ms"), foreign_excess_worst=res.get("foreign_excess_worst"),
                                   bytes_received_per_fit=res["bytes_received_per_fit"], check=res["variance_check_rel"])
         # damped fixed point: a rank's holder latency falls when its foreign panels arrive later (it is less busy), which makes
         # the next sweep's pacing shorter and the latencies rise again -- the plain iteration oscillates (fit + IVAR at 2 x 4:
@@ -133,6 +135,10 @@ def paced_grid(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, nb=512, agg=None, st
                 replayed_ranks=sorted(last), iterations=hist, chain_ms=float(sum(lat.values())), chain_ms_by_process_column=per_col,
                 paced_step_ms_max=max(v["ms_per_step"] for v in last.values()),
                 paced_step_ms={str(r): round(v["ms_per_step"], 3) for r, v in last.items()},
+                last_panel_arrived_ms={str(r): (round(v["last_arrived_ms"], 3) if v["last_arrived_ms"] is not None else None)
+                                       for r, v in last.items()},
+                foreign_excess_ms={str(r): v.get("foreign_excess_ms") for r, v in last.items()},
+                foreign_excess_worst={str(r): v.get("foreign_excess_worst") for r, v in last.items()},
                 holder_latency_ms_first_mid_last=[round(lat[1], 3), round(lat[nblk // 2], 3), round(lat[nblk - 1], 3)],
                 variance_check_rel=max(v["check"] for v in last.values()),
                 bytes_received_per_fit=max(v["bytes_received_per_fit"] for v in last.values()))
@@ -173,7 +179,7 @@ def replay_rank(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=512, agg=N
         ts.append(1e3 * (time.perf_counter() - t0))
         host.append(run.host_ms.get("factor", 0.0))
     geo = run.geo
-    lat = own_step_latencies(ctx, geo)[0] if want_latencies else None
+    lat, arr_all = own_step_latencies(ctx, geo) if want_latencies else (None, None)
     res = dict(grid=gs, rank=rank, pr=geo.pr, pc=geo.pc, N=n, M=m, nb=nb, agg=run.agg, steps_k=geo.nblk,
                streamed_ivar=bool(streamed), factor_window_panels=run.window, ms_per_step=float(np.median(ts)), ms_all=ts,
                host_issue_ms_per_fit=float(np.median(host)), host_issue_us_per_panel_step=1e3 * float(np.median(host)) / geo.nblk,
@@ -183,6 +189,13 @@ def replay_rank(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=512, agg=N
                variance_check_rel=check, single_gpu_potrf_ms=single_potrf_ms)
     if want_latencies:
         res["own_latency_ms"] = lat
+        res["last_arrived_ms"] = arr_all[-1] if arr_all else None      # (of the LAST timed step) the rest of the step is the rank's tail
+        if arr_all and pace_us is not None:      # what a FOREIGN step costs this rank beyond its pacing (the stand-in copies, waits)
+            gaps = [arr_all[k] - (arr_all[k - 1] if k else 0.0) for k in range(len(arr_all))]
+            fk = [k for k in range(len(arr_all)) if k % geo.Pc != geo.pc]
+            res["foreign_excess_ms"] = float(sum(gaps[k] - pace_us[k] * 1e-3 for k in fk))
+            res["foreign_excess_worst"] = sorted(((round(gaps[k] - pace_us[k] * 1e-3, 3), k) for k in fk), reverse=True)[:6]
+        res["last_step_ms"] = ts[-1]
     if profile:
         # per-class kernel time of one more, instrumented, step (row by row: profiler events cannot live inside a graph)
         run.force_interpret = True

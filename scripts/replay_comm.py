@@ -62,6 +62,14 @@ class ReplayComm(Emitter):
             assert grp == ROW and count == geo.height(k + 1) * geo.gld
             self._rows(buf, offset, geo.height(k + 1), k + 1, 1, k)
 
+    def bcast_grp2(self, sbuf, soff, rbuf, roff, count, root, grp):
+        """the early block row into its own buffer (row communicator only)"""
+        geo, k = self.geo, self.k
+        assert grp == ROW and count == geo.height(k + 1) * geo.gld
+        if count == 0:
+            return
+        self._rows(rbuf, roff, geo.height(k + 1), k + 1, 1, k)      # (the root keeps a copy too, as ncclBroadcast gives it)
+
     def panel_bcast(self, buf, pieces):
         geo, k = self.geo, self.k
         if self.pace_us is not None and geo.pc != k % geo.Pc and int(self.pace_us[k]) > 0:

@@ -127,6 +127,11 @@ class HostStagedComm:
             return
         self._write(buf, offset, self.group.bcast_array_grp(self._read(buf, offset, count), root, grp))
 
+    def bcast_grp2(self, sbuf, soff, rbuf, roff, count, root, grp):
+        if count == 0:
+            return
+        self._write(rbuf, roff, self.group.bcast_array_grp(self._read(sbuf, soff, count), root, grp))
+
     def reduce_grp(self, buf, offset, count, root, grp):
         if count == 0:
             return

@@ -365,6 +365,10 @@ class NumpyComm:
         seg = np.ascontiguousarray(buf.a[offset:offset + count])
         buf.a[offset:offset + count] = self.group.bcast_array_grp(seg, root, grp)
 
+    def bcast_grp2(self, sbuf, soff, rbuf, roff, count, root, grp):
+        seg = np.ascontiguousarray(sbuf.a[soff:soff + count])
+        rbuf.a[roff:roff + count] = self.group.bcast_array_grp(seg, root, grp)
+
     def reduce_grp(self, buf, offset, count, root, grp):
         seg = np.ascontiguousarray(buf.a[offset:offset + count])
         buf.a[offset:offset + count] = self.group.reduce_array_grp(seg, root, grp)

@@ -36,9 +36,10 @@ def record_rank(n, nb, Pr, Pc, rank, agg, bulk, streamed, monkeypatch, window=0)
     prog = dist.Program()
     ops.prog = comm.prog = prog
     A, L, B = FakeMat(), FakeMat(), FakeMat()
-    G = [FakeMat() for _ in range(dist.ring_size(agg) if agg > 1 else 2)]
+    G = [FakeMat() for _ in range(dist.ring_size(agg))]
     hook = dist.streamed_ivar_hook(ops, geo, L, B, agg, window, stream=dist.EVAL, fwd=FakeMat() if window else None) if streamed else None
-    dist.dist2_potrf_enqueue(ops, comm, geo, A, G, L=L, on_stored=hook, agg=agg, window=window)
+    E = [FakeMat() for _ in G]          # the product path: the early block row travels into buffers of its own
+    dist.dist2_potrf_enqueue(ops, comm, geo, A, G, L=L, on_stored=hook, agg=agg, window=window, E=E)
     return geo, prog, G
 
 
@@ -70,6 +71,8 @@ def collectives(prog):
         a = r[4:]
         if op == "BCAST_GRP":
             out.append((a[3], "bcast", a[1], a[2]))
+        elif op == "BCAST_GRP2":
+            out.append((a[4], "bcast", a[2], a[3]))
         elif op == "REDUCE_GRP":
             out.append((a[3], "reduce", a[1], a[2]))
         elif op == "ALLREDUCE":
