@@ -1260,10 +1260,10 @@ class DistFitIvar2D:
 
     Memory per rank: the local share of the working matrix (N^2 / W), the ring of packed panel buffers (2 agg x N x nb), the
     rank's slab of the cross matrix (N x M / W) -- and the finished factor in one of two forms:
-      streamed evaluation (default from 4 ranks)  a WINDOW of 2 agg block columns (N x 2 agg nb: 1.07 GB at C4): every panel
+      streamed evaluation (default from 4 ranks AND N >= 98304; round 3: from 4 ranks)  a WINDOW of 2 agg block columns (N x 2 agg nb: 1.07 GB at C4): every panel
           reaches every rank for the trailing update anyway, the evaluation's solve step consumes it right then, nothing reads
           it later.  The factor itself stays distributed (block-cyclic A); N per node is bounded by A / W + B, not by N^2.
-      evaluation after the fit (1-2 ranks), C5   a REPLICATED copy (N^2: 8.6 GB at C4, 34 GB at C5 of the 288 GB), against
+      evaluation after the fit (the default below N = 98304), C5, the class API   a REPLICATED copy (N^2: 8.6 GB at C4, 34 GB at C5 of the 288 GB), against
           which the evaluation / the gradient slabs run with no exchange."""
 
     def __init__(self, ctx, comm, spec, Xh, yh, Zh, noise, nb=512, ops=None, streamed=None, grid=None, agg=None,
@@ -1274,8 +1274,15 @@ class DistFitIvar2D:
         comm.set_grid(Pr, Pc)
         self.n, self.noise = Xh.shape[0], float(noise)
         self.geo = Grid2D(self.n, nb, Pr, Pc, comm.rank)
+        # Evaluation streamed underneath the factorisation (against a window of the factor: no N x N replica) or after it
+        # (against the rank's replica).  Round 3 streamed from 4 ranks because a rank's BUSY time was lower that way; the paced
+        # replay of round 4 says the opposite for the time of the GRID: the streamed solve's GEMMs slow the chain
+        # across ranks (2 x 4 at C4: 121-133 ms streamed against 53 + 62 + 4 = 119 ms fit-then-evaluate; 2 x 2: 206 against 200).
+        # Streaming remains the memory-saving form: default from N = GPX_DIST_STREAM_MIN_N (98304: a replica of 77 GB), where a
+        # rank's own work also dwarfs the chain.  GPX_DIST_STREAM_IVAR=0/1 overrides.
         env = os.environ.get("GPX_DIST_STREAM_IVAR")
-        self.streamed = (comm.world >= 4) if streamed is None else bool(streamed)
+        big = Xh.shape[0] >= int(os.environ.get("GPX_DIST_STREAM_MIN_N", "98304"))
+        self.streamed = (comm.world >= 4 and big) if streamed is None else bool(streamed)
         if env is not None:
             self.streamed = env == "1"
         self.agg = default_agg(self.streamed and Zh.shape[0] > 0, comm.world) if agg is None else int(agg)
