@@ -933,8 +933,21 @@ int gpx_dist2_panel_trsm_keep(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, 
 // the same with the inverse gpx_dist2_panel_inv built for THIS step's diagonal block (the caller vouches for that: the panel
 // loop calls the two back to back on the PANEL stream); falls back to the leaf recursion for a ragged / single-leaf block
 int gpx_dist2_panel_trsm_inv(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t lc, int64_t w, gpx_mat* G, int64_t doff,
-                             int64_t roff, int64_t nb, int64_t dslot) {
-  return panel_trsm_impl(ctx, A, lr0, m, lc, w, G, doff, roff, nb, dslot, 1);
+                             int64_t roff, int64_t nb, int64_t dslot, int copy_back) {
+  return panel_trsm_impl(ctx, A, lr0, m, lc, w, G, doff, roff, nb, dslot, copy_back ? 1 : 2);
+}
+
+// the solved rows from the packed buffer back into the local matrix (the block-cyclic factor the substitution sweeps read):
+// the second half of gpx_dist2_panel_trsm_inv(copy_back = 0), issued BEHIND the event that releases the panel broadcast -- the
+// broadcast reads the packed buffer only, the copy has no business on the chain across ranks
+int gpx_dist2_panel_copyback(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t lc, int64_t w, const gpx_mat* G, int64_t roff,
+                             int64_t nb) {
+  GPX_ARG(ctx && G, "NULL argument");
+  GPX_TRY(check_local(A, lr0, m, lc, w));
+  const int64_t gld = gpx_g_ld(nb);
+  GPX_ARG(w <= nb && roff >= 0 && (roff + m * gld) * 8 <= G->bytes, "region outside G");
+  if (m == 0) return 0;
+  return gpx_copy2d(ctx, G->p + roff, gld, A->p + lr0 * A->ld + lc, A->ld, m, w);
 }
 
 static int panel_trsm_impl(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t lc, int64_t w, gpx_mat* G, int64_t doff,
@@ -952,7 +965,7 @@ static int panel_trsm_impl(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int
     const char* e = getenv("GPX_DIST2_INV_MIN");  // rows from which the explicit inverse is used, in units of nb; 0 = never
     inv_min = e ? atoll(e) : 2;
   }
-  const bool prepared = use_prepared && w == nb && w > GPX_TILE;
+  const bool prepared = use_prepared != 0 && w == nb && w > GPX_TILE;   // use_prepared == 2: the caller copies back later
   GPX_ARG(!prepared || (ctx->d2_inv_src == D && ctx->d2_inv_nb == nb), "panel solve: no inverse was prepared for this diagonal block");
   if (prepared || (inv_min > 0 && m >= inv_min * nb && w == nb && w > GPX_TILE)) {
     GPX_TRY(d2_scratch_ensure(ctx, nb));
@@ -982,6 +995,7 @@ static int panel_trsm_impl(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int
       A->dinv_ok[(size_t)dslot] = 1;
     }
     GPX_TRY(launch_gemm_tri(ctx, X, A->ld, inv, w, G->p + roff, gld, m, w, w, true, false, false, 2));
+    if (prepared && use_prepared == 2) return 0;     // gpx_dist2_panel_copyback follows behind the broadcast's event
     return gpx_copy2d(ctx, G->p + roff, gld, X, A->ld, m, w);
   }
   GPX_TRY(chol_trsm_right(ctx, D, nb, D + nb * nb, X, A->ld, m, w));
@@ -1232,9 +1246,10 @@ int gpx_program_run(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const int64_
       case GPX_OP_BEGIN: r = gpx_dist_begin(ctx); break;
       case GPX_OP_DIAG_FACTOR: r = gpx_dist2_diag_factor(ctx, h0, a[0], a[1], a[2], h1, a[3], a[4], a[5], a[6]); break;
       case GPX_OP_PANEL_TRSM:
-        r = a[8] ? gpx_dist2_panel_trsm_inv(ctx, h0, a[0], a[1], a[2], a[3], h1, a[4], a[5], a[6], a[7] - 1)
+        r = a[8] ? gpx_dist2_panel_trsm_inv(ctx, h0, a[0], a[1], a[2], a[3], h1, a[4], a[5], a[6], a[7] - 1, a[8] == 1)
                  : gpx_dist2_panel_trsm_keep(ctx, h0, a[0], a[1], a[2], a[3], h1, a[4], a[5], a[6], a[7] - 1);
         break;
+      case GPX_OP_PANEL_COPYBACK: r = gpx_dist2_panel_copyback(ctx, h0, a[0], a[1], a[2], a[3], h1, a[4], a[5]); break;
       case GPX_OP_UPDATE: r = gpx_dist2_update(ctx, h0, a[0], a[1], a[2], a[3], h1, a[4], a[5], a[6], a[7]); break;
       case GPX_OP_UPDATE_MULTI: {
         // a: lr0, m, lc0, n, nb, Pr, Pc, pr, pc, piece_stride, nseg | below_diag << 8, extra offset of [G handles..., ks...]

@@ -94,7 +94,7 @@ def merge_argmin(values, indices):
 # ---- recorded programs (include/gpx.h: gpx_program_run) -----------------------------------------------------------
 OP = dict(STREAM=1, RECORD=2, WAIT=3, BEGIN=4, DIAG_FACTOR=5, PANEL_TRSM=6, UPDATE=7, UPDATE_MULTI=8, UNPACK_ROWS=9,
           UNPACK_DIAG=10, PACK_ROWS=11, PACK_DIAG=12, BCAST_GRP=13, REDUCE_GRP=14, ALLREDUCE=15, PANEL_BCAST=16, IVAR_STEP=17,
-          TRSV_DIAG=18, GEMV=19, LOGDET_ACC=20, VEC_OP=21, SPIN=22, COPY=23, IVAR_GROUP=24, FWD_GROUP=25, PANEL_INV=26, BCAST_GRP2=27)
+          TRSV_DIAG=18, GEMV=19, LOGDET_ACC=20, VEC_OP=21, SPIN=22, COPY=23, IVAR_GROUP=24, FWD_GROUP=25, PANEL_INV=26, BCAST_GRP2=27, PANEL_COPYBACK=28)
 
 
 class Program:
@@ -752,10 +752,15 @@ class DeviceOps2D(Emitter, DeviceOps):
         block has arrived: off the panel chain)"""
         self._emit(OP["PANEL_INV"], (G,), (doff, nb, w))
 
-    def panel_trsm(self, A, lr0, m, lc, w, G, doff, roff, nb, dslot=None, prepared=False):
+    def panel_trsm(self, A, lr0, m, lc, w, G, doff, roff, nb, dslot=None, prepared=False, copy_back=True):
         """dslot (owner of the diagonal block only): its local block row -- the explicit inverse the solve builds is kept in A
-        for the distributed substitution's diagonal solves.  prepared: panel_inv ran for this step's diagonal block."""
-        self._emit(OP["PANEL_TRSM"], (A, G), (lr0, m, lc, w, doff, roff, nb, 0 if dslot is None else dslot + 1, int(bool(prepared))))
+        for the distributed substitution's diagonal solves.  prepared: panel_inv ran for this step's diagonal block; copy_back =
+        False (with prepared, full-width blocks): the solved rows go into the packed buffer only, panel_copyback follows."""
+        flag = 0 if not prepared else (1 if copy_back else 2)
+        self._emit(OP["PANEL_TRSM"], (A, G), (lr0, m, lc, w, doff, roff, nb, 0 if dslot is None else dslot + 1, flag))
+
+    def panel_copyback(self, A, lr0, m, lc, w, G, roff, nb):
+        self._emit(OP["PANEL_COPYBACK"], (A, G), (lr0, m, lc, w, roff, nb))
 
     def update(self, A, lr0, m, lc0, n, G, aoff, boff, w, nb):
         self._emit(OP["UPDATE"], (A, G), (lr0, m, lc0, n, aoff, boff, w, nb))
@@ -938,6 +943,7 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
     at_step = getattr(comm, "at_step", None)
     hoist_inv = os.environ.get("GPX_DIST2_HOIST_INV", "1") == "1" and hasattr(ops, "panel_inv")
     gate_bulk = os.environ.get("GPX_DIST_GATE_BULK", "1") == "1"
+    late_copyback = os.environ.get("GPX_DIST2_LATE_COPYBACK", "1") == "1"
 
     def group_end(k):
         return min((k // q + 1) * q - 1, nblk - 1)
@@ -1044,7 +1050,10 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
             lr0, m = geo.row_off(pr, geo.li0(pr, k)), geo.piece_rows(pr, k)
             roff = geo.piece_off(pr) + geo.dsz
             dslot = (k // Pr) if owner else None                         # the owner keeps the block's explicit inverse
-            pk = dict(prepared=True) if hoist_inv else {}
+            # (full-width blocks with the inverse at hand: the solved rows go to the packed buffer only and are copied back into
+            # the local matrix BEHIND the events that release the two broadcasts -- the copies are not the chain's business)
+            late = late_copyback and hoist_inv and w == nb and nb > TILE and hasattr(ops, "panel_copyback")
+            pk = dict(prepared=True, copy_back=not late) if hoist_inv else {}
             if nxt and pr == r1:                                         # block row k+1 first: the next diagonal needs it
                 ops.panel_trsm(A, lr0, h1, lc, w, g, geo.piece_off(kr), roff, nb, **pk)
                 ops.record(_ev2(E_EARLYSOLVED, k))
@@ -1052,6 +1061,8 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
             else:
                 ops.panel_trsm(A, lr0, m, lc, w, g, geo.piece_off(kr), roff, nb, dslot, **pk)
             ops.record(_ev2(E_PIECE, k))
+            if late and m > 0:
+                ops.panel_copyback(A, lr0, m, lc, w, g, roff, nb)
         if nxt and pr == r1:
             ops.stream(COMM)
             if holder:

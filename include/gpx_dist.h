@@ -159,7 +159,11 @@ int gpx_dist2_panel_trsm_keep(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, 
 /* the same with the inverse gpx_dist2_panel_inv prepared for this step's diagonal block (one triangular-operand product, also
  * for a single block row) */
 int gpx_dist2_panel_trsm_inv(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t lc, int64_t w, gpx_mat* G, int64_t doff,
-                             int64_t roff, int64_t nb, int64_t dslot);
+                             int64_t roff, int64_t nb, int64_t dslot, int copy_back);
+/* copy_back == 0 above: the solved rows go into the packed buffer only; this copies them into the local matrix afterwards (behind
+ * the event that releases the panel broadcast: off the chain across ranks) */
+int gpx_dist2_panel_copyback(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t lc, int64_t w, const gpx_mat* G, int64_t roff,
+                             int64_t nb);
 /* A[lr0:lr0+m, lc0:lc0+n] -= G[aoff] (m x w) * G[boff] (n x w)^T : trailing update of one local block column */
 int gpx_dist2_update(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t lc0, int64_t n, const gpx_mat* G,
                      int64_t aoff, int64_t boff, int64_t w, int64_t nb);
@@ -196,7 +200,7 @@ enum {
   GPX_OP_STREAM = 1, GPX_OP_RECORD, GPX_OP_WAIT, GPX_OP_BEGIN, GPX_OP_DIAG_FACTOR, GPX_OP_PANEL_TRSM, GPX_OP_UPDATE,
   GPX_OP_UPDATE_MULTI, GPX_OP_UNPACK_ROWS, GPX_OP_UNPACK_DIAG, GPX_OP_PACK_ROWS, GPX_OP_PACK_DIAG, GPX_OP_BCAST_GRP,
   GPX_OP_REDUCE_GRP, GPX_OP_ALLREDUCE, GPX_OP_PANEL_BCAST, GPX_OP_IVAR_STEP, GPX_OP_TRSV_DIAG, GPX_OP_GEMV, GPX_OP_LOGDET_ACC,
-  GPX_OP_VEC_OP, GPX_OP_SPIN, GPX_OP_COPY, GPX_OP_IVAR_GROUP, GPX_OP_FWD_GROUP, GPX_OP_PANEL_INV, GPX_OP_BCAST_GRP2
+  GPX_OP_VEC_OP, GPX_OP_SPIN, GPX_OP_COPY, GPX_OP_IVAR_GROUP, GPX_OP_FWD_GROUP, GPX_OP_PANEL_INV, GPX_OP_BCAST_GRP2, GPX_OP_PANEL_COPYBACK
 };
 int gpx_program_run(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const int64_t* extra, int64_t nextra, double* host_ms);
 /* The same program as a hipGraph: captured once (after it has run once the ordinary way; every stream it uses must fork from

@@ -205,7 +205,10 @@ class NumpyOps2D(NumpyOps):
         assert not self.poison or not np.isnan(self._D(G, doff, nb)[:w, :w][np.tril_indices(w)]).any(), \
             "the inverse is built from a diagonal block that has not arrived"
 
-    def panel_trsm(self, A, lr0, m, lc, w, G, doff, roff, nb, dslot=None, prepared=False):
+    def panel_copyback(self, A, lr0, m, lc, w, G, roff, nb):
+        pass      # (the double's panel_trsm writes both places at once)
+
+    def panel_trsm(self, A, lr0, m, lc, w, G, doff, roff, nb, dslot=None, prepared=False, copy_back=True):
         self._inside(A, lr0, m, lc, w)
         if m == 0:
             return
