@@ -110,6 +110,10 @@ _SIGS = {
     "gpx_dist2_kfill": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_dp, c_i64, c_vp, c_i64, C.c_int, C.c_int,
                                   C.c_int, C.c_int]),
     "gpx_dist2_diag_factor": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64]),
+    "gpx_dist2_diag_stage": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64]),
+    "gpx_dist2_diag_update": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64]),
+    "gpx_dist2_diag_factor_staged": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64]),
+    "gpx_dist2_diag_store": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64]),
     "gpx_dist2_reserve": (C.c_int, [c_vp, c_i64, c_i64, c_i64]),
     "gpx_dist2_panel_inv": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64]),
     "gpx_dist2_panel_trsm": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64]),

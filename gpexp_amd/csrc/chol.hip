@@ -289,8 +289,9 @@ __device__ __forceinline__ void leaf_panel_wave(double* __restrict__ S, double* 
 
 __global__ __launch_bounds__(256, 2) void leaf_kernel(double* __restrict__ A, int64_t ld, double* __restrict__ inv,
                                                    int64_t base_index, int64_t n_valid, int* __restrict__ info,
-                                                   double piv_min, int skip) {
+                                                   double piv_min, int skip, int hiprio) {
   __shared__ double S[36 * BSZ];
+  if (hiprio) __builtin_amdgcn_s_setprio(3);   // gpx_chain_prio: beside resident GEMM waves the CU serves this chain first
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int g = lane >> 4, q = lane & 15;
@@ -421,8 +422,9 @@ __device__ __forceinline__ void leaf_mul_right_wave(double* __restrict__ Xs, dou
 // X (m x 128, ld ldx) <- X * inv^T.  grid = m / ST workgroups.
 template <int ST>
 __global__ __launch_bounds__(256, 2) void leaf_mul_right_kernel(double* __restrict__ X, int64_t ldx,
-                                                                const double* __restrict__ inv) {
+                                                                const double* __restrict__ inv, int hiprio) {
   extern __shared__ double lsm[];
+  if (hiprio) __builtin_amdgcn_s_setprio(3);
   double* Xs = lsm;  // [ST][129]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, q = lane & 15;
   double* Xg = X + (int64_t)blockIdx.x * ST * ldx;
@@ -494,8 +496,9 @@ __device__ __forceinline__ void leaf_mul_left_wave(double* __restrict__ Bs, doub
 // B (128 x m, ld ldb) <- inv * B.  grid = m / ST workgroups (ST columns each).
 template <int ST>
 __global__ __launch_bounds__(256, 2) void leaf_mul_left_kernel(double* __restrict__ B, int64_t ldb,
-                                                               const double* __restrict__ inv) {
+                                                               const double* __restrict__ inv, int hiprio) {
   extern __shared__ double lsm[];
+  if (hiprio) __builtin_amdgcn_s_setprio(3);
   double* Bs = lsm;  // [128][ST + 1]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, q = lane & 15;
   double* Bg = B + (int64_t)blockIdx.x * ST;
@@ -749,13 +752,13 @@ static int launch_leaf_mul_right(gpx_ctx* ctx, double* X, int64_t ldx, const dou
     const size_t sh = (size_t)(ST * LS) * sizeof(double);
     static bool once = false;
     if (!once) { GPX_TRY(leaf_mul_allow_lds(leaf_mul_right_kernel<ST>, sh)); once = true; }
-    hipLaunchKernelGGL(leaf_mul_right_kernel<ST>, dim3((unsigned)(m / ST)), dim3(256), sh, ctx->stream, X, ldx, inv);
+    hipLaunchKernelGGL(leaf_mul_right_kernel<ST>, dim3((unsigned)(m / ST)), dim3(256), sh, ctx->stream, X, ldx, inv, gpx_chain_prio(ctx));
   } else {
     constexpr int ST = 64;
     const size_t sh = (size_t)(ST * LS) * sizeof(double);
     static bool once = false;
     if (!once) { GPX_TRY(leaf_mul_allow_lds(leaf_mul_right_kernel<ST>, sh)); once = true; }
-    hipLaunchKernelGGL(leaf_mul_right_kernel<ST>, dim3((unsigned)(m / ST)), dim3(256), sh, ctx->stream, X, ldx, inv);
+    hipLaunchKernelGGL(leaf_mul_right_kernel<ST>, dim3((unsigned)(m / ST)), dim3(256), sh, ctx->stream, X, ldx, inv, gpx_chain_prio(ctx));
   }
   GPX_HIP(hipGetLastError());
   return 0;
@@ -770,13 +773,13 @@ static int launch_leaf_mul_left(gpx_ctx* ctx, double* B, int64_t ldb, const doub
     const size_t sh = (size_t)(NB * (ST + 1)) * sizeof(double);
     static bool once = false;
     if (!once) { GPX_TRY(leaf_mul_allow_lds(leaf_mul_left_kernel<ST>, sh)); once = true; }
-    hipLaunchKernelGGL(leaf_mul_left_kernel<ST>, dim3((unsigned)(m / ST)), dim3(256), sh, ctx->stream, B, ldb, inv);
+    hipLaunchKernelGGL(leaf_mul_left_kernel<ST>, dim3((unsigned)(m / ST)), dim3(256), sh, ctx->stream, B, ldb, inv, gpx_chain_prio(ctx));
   } else {
     constexpr int ST = 64;
     const size_t sh = (size_t)(NB * (ST + 1)) * sizeof(double);
     static bool once = false;
     if (!once) { GPX_TRY(leaf_mul_allow_lds(leaf_mul_left_kernel<ST>, sh)); once = true; }
-    hipLaunchKernelGGL(leaf_mul_left_kernel<ST>, dim3((unsigned)(m / ST)), dim3(256), sh, ctx->stream, B, ldb, inv);
+    hipLaunchKernelGGL(leaf_mul_left_kernel<ST>, dim3((unsigned)(m / ST)), dim3(256), sh, ctx->stream, B, ldb, inv, gpx_chain_prio(ctx));
   }
   GPX_HIP(hipGetLastError());
   return 0;
@@ -785,7 +788,7 @@ static int launch_leaf_mul_left(gpx_ctx* ctx, double* B, int64_t ldb, const doub
 int launch_leaf(gpx_ctx* ctx, double* A, int64_t ld, double* inv, int64_t base_index, int64_t n_valid) {
   ProfScope ps(ctx, GPX_PROF_LEAF, 2.0 * NB * NB * NB / 3.0, 0.0);
   hipLaunchKernelGGL(leaf_kernel, dim3(1), dim3(256), 0, ctx->stream, A, ld, inv, base_index, n_valid, ctx->d_info,
-                     ctx->piv_min, ctx->piv_skip);
+                     ctx->piv_min, ctx->piv_skip, gpx_chain_prio(ctx));
   GPX_HIP(hipGetLastError());
   return 0;
 }
@@ -1246,6 +1249,23 @@ static int binv_build_rec(gpx_ctx* ctx, const double* L, int64_t ld, int64_t sl,
   return launch_gemm_batched(ctx, Bi, ib, ib * ib, tmp, s1, ib * ib, R, ib, ib * ib, s2, s1, s2, false, true, batch);
 }
 
+// ONE block whose order is 128 times a power of two (the 512-order diagonal blocks of the distributed factorisation, a small
+// factor's single block): level by level, every combine of a level in one batched launch -- 2 log2(w / 128) launches instead of
+// 2 (w / 128 - 1) (512: 4 instead of 6), same products.  They sit on the diagonal chain of the distributed factorisation.
+static int binv_build_levels(gpx_ctx* ctx, const double* L, int64_t ld, double* binv, int64_t ib, int64_t w, double* tmp,
+                             int64_t lo, int64_t hi) {
+  for (int64_t sz = 2 * NB; sz <= w; sz *= 2) {
+    if (sz <= lo) continue;
+    if (sz > hi) break;
+    const int64_t s1 = sz / 2, nbat = w / sz, sl = sz * (ld + 1), sb = sz * (ib + 1);
+    // T = C A^-1 ; R = 0 - B^-1 T   (binv_build_rec)
+    GPX_TRY(launch_gemm_batched(ctx, L + s1 * ld, ld, sl, binv, ib, sb, tmp, s1, s1 * s1, s1, s1, s1, false, false, nbat));
+    GPX_TRY(launch_gemm_batched(ctx, binv + s1 * (ib + 1), ib, sb, tmp, s1, s1 * s1, binv + s1 * ib, ib, sb, s1, s1, s1, false, true,
+                                nbat));
+  }
+  return 0;
+}
+
 // explicit inverses of the ib-order diagonal blocks covering n rows (a multiple of 128; the last block may be shorter) that
 // start at Ld on the diagonal; invd / binv point at that position too; tmp >= ceil(n / ib) * ib * ib doubles; (lo, hi): see
 // binv_build_rec
@@ -1256,6 +1276,12 @@ static int binv_build_range(gpx_ctx* ctx, const double* Ld, int64_t ld, const do
   if (lo == 0)
     hipLaunchKernelGGL(binv_init_kernel, dim3((unsigned)((rows * (ib / 2) + 255) / 256)), dim3(256), 0, ctx->stream, invd, binv,
                        ib, n);
+  static const bool levels = env_i64("GPX_BINV_LEVELS", 1) != 0;
+  if (levels && nfull == 1 && tail == 0 && ib <= 1024 && ((ib / NB) & (ib / NB - 1)) == 0) {
+    GPX_TRY(binv_build_levels(ctx, Ld, ld, binv, ib, ib, tmp, lo, hi));
+    GPX_HIP(hipGetLastError());
+    return 0;
+  }
   if (nfull > 0) GPX_TRY(binv_build_rec(ctx, Ld, ld, ib * (ld + 1), binv, ib, 0, ib, tmp, nfull, lo, hi));
   if (tail > 0)
     GPX_TRY(binv_build_rec(ctx, Ld + nfull * ib * (ld + 1), ld, 0, binv + nfull * ib * ib, ib, 0, tail, tmp, 1, lo, hi));

@@ -828,27 +828,93 @@ int gpx_dist2_kfill(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, 
 // diagonal owner of step k: copy the w x w block at local (lr, lc) into the D region of G (offset doff), factor it there
 // (leaf inverses behind it), keep the inverses in A->aux (by local row) and write L_kk back into A.  `base` = global index
 // of the block's first row (pivot report), n_valid = number of real points.  Asynchronous on the selected stream.
-int gpx_dist2_diag_factor(gpx_ctx* ctx, gpx_mat* A, int64_t lr, int64_t lc, int64_t w, gpx_mat* G, int64_t doff,
-                          int64_t nb, int64_t base, int64_t n_valid) {
-  GPX_ARG(ctx && G, "NULL argument");
+// = gpx_dist2_diag_stage + gpx_dist2_diag_factor_staged + gpx_dist2_diag_store below, which the panel loop issues separately
+// (round 4) so that only the factorisation itself sits between the arrival of the block row the diagonal waits for and the
+// broadcast of the factor: the copy INTO the packed buffer runs before that arrival (the block's last update is then applied
+// to the copy, gpx_dist2_diag_update), the copies OUT of it behind the event that releases the broadcast -- three launches less
+// on the chain across ranks, whose per-step latency, summed, is the factorisation time of a multi-rank run.
+static int diag_region_check(const gpx_mat* A, int64_t lr, int64_t lc, int64_t w, const gpx_mat* G, int64_t doff, int64_t nb) {
+  GPX_ARG(G, "NULL argument");
   GPX_TRY(check_local(A, lr, w, lc, w));
   GPX_ARG(w <= nb && nb % GPX_TILE == 0 && doff >= 0 && (doff + gpx_dist2_diag_elems(nb)) * 8 <= G->bytes, "D region outside G");
-  if (!A->aux) {
+  return 0;
+}
+
+int gpx_dist2_diag_stage(gpx_ctx* ctx, const gpx_mat* A, int64_t lr, int64_t lc, int64_t w, gpx_mat* G, int64_t doff, int64_t nb) {
+  GPX_ARG(ctx, "NULL argument");
+  GPX_TRY(diag_region_check(A, lr, lc, w, G, doff, nb));
+  return gpx_copy2d(ctx, A->p + lr * A->ld + lc, A->ld, G->p + doff, nb, w, w);
+}
+
+// staged block (h x h at doff of G, row stride nb) -= S[soff](h x w, packed row stride) * the same^T: the LAST update of a
+// diagonal block (by the block row that came ahead of its panel), applied to the staged copy
+int gpx_dist2_diag_update(gpx_ctx* ctx, gpx_mat* G, int64_t doff, int64_t h, const gpx_mat* S, int64_t soff, int64_t w, int64_t nb) {
+  GPX_ARG(ctx && G && S, "NULL argument");
+  const int64_t gld = gpx_g_ld(nb);
+  GPX_ARG(nb > 0 && nb % GPX_TILE == 0 && h > 0 && h <= nb && h % GPX_TILE == 0 && w > 0 && w <= nb && w % 16 == 0 && doff >= 0 &&
+              soff >= 0 && (doff + gpx_dist2_diag_elems(nb)) * 8 <= G->bytes && (soff + h * gld) * 8 <= S->bytes, "operand outside its buffer");
+  return launch_gemm(ctx, S->p + soff, gld, S->p + soff, gld, G->p + doff, nb, h, h, w, true, true, false);
+}
+
+int gpx_dist2_diag_factor_staged(gpx_ctx* ctx, gpx_mat* A, int64_t lr, int64_t lc, int64_t w, gpx_mat* G, int64_t doff,
+                                 int64_t nb, int64_t base, int64_t n_valid) {
+  GPX_ARG(ctx, "NULL argument");
+  GPX_TRY(diag_region_check(A, lr, lc, w, G, doff, nb));
+  if (!A->aux) {   // (the store below needs it; allocated here, ahead of the chain)
     A->aux_bytes = A->prows * GPX_TILE * 8;
     void* p;
     GPX_TRY(gpx_dev_alloc(ctx, A->aux_bytes, &p));
     A->aux = (double*)p;
   }
-  double* D = G->p + doff;
-  double* Dinv = D + nb * nb;
-  double* Ablk = A->p + lr * A->ld + lc;
   if (A->dinv && A->dinv_nb == nb && (size_t)(lr / nb) < A->dinv_ok.size()) A->dinv_ok[(size_t)(lr / nb)] = 0;  // a new factor
-  GPX_TRY(gpx_copy2d(ctx, Ablk, A->ld, D, nb, w, w));
-  GPX_TRY(chol_potrf_nozero(ctx, D, nb, w, Dinv, base, n_valid));
-  GPX_TRY(gpx_copy2d(ctx, D, nb, Ablk, A->ld, w, w));
-  GPX_HIP(hipMemcpyAsync(A->aux + (lr / GPX_TILE) * GPX_TILE * GPX_TILE, Dinv, (size_t)((w / GPX_TILE) * GPX_TILE * GPX_TILE * 8),
-                         hipMemcpyDeviceToDevice, ctx->stream));
+  double* D = G->p + doff;
+  return chol_potrf_nozero(ctx, D, nb, w, D + nb * nb, base, n_valid);
+}
+
+static int keep_inverse(gpx_ctx* ctx, gpx_mat* A, int64_t dslot, int64_t nb, const double* inv) {
+  const int64_t slots = (A->prows + nb - 1) / nb;
+  GPX_ARG(dslot < slots, "diagonal slot outside the local matrix");
+  if (!A->dinv || A->dinv_nb != nb) {
+    if (A->dinv) gpx_dev_release(ctx, A->dinv, A->dinv_bytes);
+    A->dinv = nullptr;
+    void* pd;
+    GPX_TRY(gpx_dev_alloc(ctx, slots * 2 * nb * nb * 8, &pd));
+    A->dinv = (double*)pd;
+    A->dinv_bytes = slots * 2 * nb * nb * 8;
+    A->dinv_nb = nb;
+    A->dinv_ok.assign((size_t)slots, 0);
+  }
+  double* slot = A->dinv + dslot * 2 * nb * nb;   // [inverse | its transpose: the transposed sweep reads rows too]
+  GPX_HIP(hipMemcpyAsync(slot, inv, (size_t)(nb * nb * 8), hipMemcpyDeviceToDevice, ctx->stream));
+  GPX_TRY(chol_block_transpose(ctx, slot, slot + nb * nb, nb));
+  A->dinv_ok[(size_t)dslot] = 1;
   return 0;
+}
+
+// the factored block and its leaf inverses from the packed buffer into the local matrix (what the distributed substitution
+// reads); dslot >= 0: and the explicit inverse gpx_dist2_panel_inv built for THIS block (still in the context's scratch: same
+// stream, before the next gpx_dist2_panel_inv) into the local matrix's slot for the substitution's diagonal solves
+int gpx_dist2_diag_store(gpx_ctx* ctx, gpx_mat* A, int64_t lr, int64_t lc, int64_t w, const gpx_mat* G, int64_t doff, int64_t nb,
+                         int64_t dslot) {
+  GPX_ARG(ctx, "NULL argument");
+  GPX_TRY(diag_region_check(A, lr, lc, w, G, doff, nb));
+  GPX_ARG(A->aux != nullptr, "diag_store: the block was not factored through gpx_dist2_diag_factor_staged");
+  const double* D = G->p + doff;
+  GPX_TRY(gpx_copy2d(ctx, D, nb, A->p + lr * A->ld + lc, A->ld, w, w));
+  GPX_HIP(hipMemcpyAsync(A->aux + (lr / GPX_TILE) * GPX_TILE * GPX_TILE, D + nb * nb, (size_t)((w / GPX_TILE) * GPX_TILE * GPX_TILE * 8),
+                         hipMemcpyDeviceToDevice, ctx->stream));
+  if (dslot >= 0 && w == nb && w > GPX_TILE) {
+    GPX_ARG(ctx->d2_scratch && ctx->d2_inv_src == D && ctx->d2_inv_nb == nb, "diag_store: no inverse was prepared for this diagonal block");
+    GPX_TRY(keep_inverse(ctx, A, dslot, nb, ctx->d2_scratch));
+  }
+  return 0;
+}
+
+int gpx_dist2_diag_factor(gpx_ctx* ctx, gpx_mat* A, int64_t lr, int64_t lc, int64_t w, gpx_mat* G, int64_t doff,
+                          int64_t nb, int64_t base, int64_t n_valid) {
+  GPX_TRY(gpx_dist2_diag_stage(ctx, A, lr, lc, w, G, doff, nb));
+  GPX_TRY(gpx_dist2_diag_factor_staged(ctx, A, lr, lc, w, G, doff, nb, base, n_valid));
+  return gpx_dist2_diag_store(ctx, A, lr, lc, w, G, doff, nb, -1);
 }
 
 // holders of block column k (ranks with pc == k % Pc): X = A[lr0 : lr0+m, lc : lc+w] <- X L_kk^-T (L_kk and its leaf
@@ -976,24 +1042,8 @@ static int panel_trsm_impl(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int
       ctx->d2_inv_src = D;
       ctx->d2_inv_nb = nb;
     }
-    if (dslot >= 0) {
-      const int64_t slots = (A->prows + nb - 1) / nb;
-      GPX_ARG(dslot < slots, "diagonal slot outside the local matrix");
-      if (!A->dinv || A->dinv_nb != nb) {
-        if (A->dinv) gpx_dev_release(ctx, A->dinv, A->dinv_bytes);
-        A->dinv = nullptr;
-        void* pd;
-        GPX_TRY(gpx_dev_alloc(ctx, slots * 2 * nb * nb * 8, &pd));
-        A->dinv = (double*)pd;
-        A->dinv_bytes = slots * 2 * nb * nb * 8;
-        A->dinv_nb = nb;
-        A->dinv_ok.assign((size_t)slots, 0);
-      }
-      double* slot = A->dinv + dslot * 2 * nb * nb;   // [inverse | its transpose: the transposed sweep reads rows too]
-      GPX_HIP(hipMemcpyAsync(slot, inv, (size_t)(nb * nb * 8), hipMemcpyDeviceToDevice, ctx->stream));
-      GPX_TRY(chol_block_transpose(ctx, slot, slot + nb * nb, nb));
-      A->dinv_ok[(size_t)dslot] = 1;
-    }
+    // (use_prepared == 2: gpx_dist2_diag_store keeps the inverse, behind the broadcast's event -- not on the chain)
+    if (dslot >= 0 && use_prepared != 2) GPX_TRY(keep_inverse(ctx, A, dslot, nb, inv));
     GPX_TRY(launch_gemm_tri(ctx, X, A->ld, inv, w, G->p + roff, gld, m, w, w, true, false, false, 2));
     if (prepared && use_prepared == 2) return 0;     // gpx_dist2_panel_copyback follows behind the broadcast's event
     return gpx_copy2d(ctx, G->p + roff, gld, X, A->ld, m, w);
@@ -1250,6 +1300,10 @@ int gpx_program_run(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const int64_
                  : gpx_dist2_panel_trsm_keep(ctx, h0, a[0], a[1], a[2], a[3], h1, a[4], a[5], a[6], a[7] - 1);
         break;
       case GPX_OP_PANEL_COPYBACK: r = gpx_dist2_panel_copyback(ctx, h0, a[0], a[1], a[2], a[3], h1, a[4], a[5]); break;
+      case GPX_OP_DIAG_STAGE: r = gpx_dist2_diag_stage(ctx, h0, a[0], a[1], a[2], h1, a[3], a[4]); break;
+      case GPX_OP_DIAG_UPDATE: r = gpx_dist2_diag_update(ctx, h0, a[0], a[1], h1, a[2], a[3], a[4]); break;
+      case GPX_OP_DIAG_FACTOR_STAGED: r = gpx_dist2_diag_factor_staged(ctx, h0, a[0], a[1], a[2], h1, a[3], a[4], a[5], a[6]); break;
+      case GPX_OP_DIAG_STORE: r = gpx_dist2_diag_store(ctx, h0, a[0], a[1], a[2], h1, a[3], a[4], a[5] - 1); break;
       case GPX_OP_UPDATE: r = gpx_dist2_update(ctx, h0, a[0], a[1], a[2], a[3], h1, a[4], a[5], a[6], a[7]); break;
       case GPX_OP_UPDATE_MULTI: {
         // a: lr0, m, lc0, n, nb, Pr, Pc, pr, pc, piece_stride, nseg | below_diag << 8, extra offset of [G handles..., ks...]

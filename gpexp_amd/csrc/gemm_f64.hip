@@ -363,6 +363,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64
                                                           int tail_tn) {
   constexpr int tri = TRI;
   __shared__ Smem<BT, TE> sm;
+  // (64-tile launches have no tail: tail_tn < 0 there marks a launch on the chain stream, gpx_chain_prio.  Compile-time guarded:
+  // the 128-tile instantiations stay exactly the hand-scheduled kernel.)
+  if (TE == 64 && tail_tn < 0) __builtin_amdgcn_s_setprio(3);
   const int w = blockIdx.x;
   if (TE == 128 && w >= main_wgs) {
     const int wt = w - main_wgs;
@@ -404,8 +407,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64
 template <bool BT, bool ACC>
 __global__ __launch_bounds__(256, 2) void gemm_f64_batched_kernel(const double* A, int64_t lda, int64_t sa,
                                                                   const double* B, int64_t ldb, int64_t sb, double* C,
-                                                                  int64_t ldc, int64_t sc, int nk, int tiles_n) {
+                                                                  int64_t ldc, int64_t sc, int nk, int tiles_n, int hiprio) {
   __shared__ Smem<BT, 64> sm;
+  if (hiprio) __builtin_amdgcn_s_setprio(3);
   const int64_t b = blockIdx.y;
   const int by = blockIdx.x / tiles_n, bx = blockIdx.x - by * tiles_n;
   gemm_tile<BT, ACC, 64>(sm, A + b * sa, lda, B + b * sb, ldb, C + b * sc, ldc, nk, by, bx);
@@ -562,7 +566,7 @@ int launch_gemm_batched(gpx_ctx* ctx, const double* A, int64_t lda, int64_t sa, 
   ProfScope ps(ctx, GPX_PROF_GEMM, 2.0 * (double)m * (double)n * (double)k * (double)batch, 0.0);
 #define GPX_B(BT_, ACC_)                                                                                          \
   hipLaunchKernelGGL((gemm_f64_batched_kernel<BT_, ACC_>), grid, dim3(256), 0, ctx->stream, A, lda, sa, B, ldb, sb, C, \
-                     ldc, sc, nk, tn)
+                     ldc, sc, nk, tn, gpx_chain_prio(ctx))
   if (bt) {
     if (accumulate) GPX_B(true, true); else GPX_B(true, false);
   } else {
@@ -629,12 +633,13 @@ int launch_gemm_tri(gpx_ctx* ctx, const double* A, int64_t lda, const double* B,
   GPX_ARG(p.wgs + tail_wgs < ((int64_t)1 << 31), "gemm: grid too large");
   dim3 grid((unsigned)(p.wgs + tail_wgs));
   const int nk = (int)(k / KB);
+  const int hiprio = gpx_chain_prio(ctx);
   // algorithmic flops: a triangular operand halves the k range on average (+ the diagonal blocks)
   const double kflops = tri == 3 ? (double)k * (2.0 / 3.0) : (tri ? 0.5 * (double)k + 64.0 : (double)k);
   ProfScope ps(ctx, GPX_PROF_GEMM, 2.0 * tiles128 * 128.0 * 128.0 * kflops, 0.0);
 #define GPX_KT(BT_, ACC_, LOW_, TE_, TRI_)                                                                          \
   hipLaunchKernelGGL((gemm_f64_kernel<BT_, ACC_, LOW_, TE_, TRI_>), grid, dim3(256), 0, ctx->stream, A, lda, B, ldb, C, \
-                     ldc, nk, p.tm, p.tn, p.sbc, p.sb_shift, (int)p.wgs, (int)m_main, (int)tail_tn)
+                     ldc, nk, p.tm, p.tn, p.sbc, p.sb_shift, (int)p.wgs, (int)m_main, (TE_ == 64 && hiprio) ? -1 : (int)tail_tn)
   if (tri != 0) {  // the operand forms the explicit inverses use
 #define GPX_GT(BT_, ACC_, LOW_, TRI_)        \
   do {                                       \

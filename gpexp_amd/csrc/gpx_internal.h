@@ -234,6 +234,14 @@ int launch_kfill_rows(gpx_ctx* ctx, const KParams& kp, const double* X, int64_t 
                       int64_t ld);
 
 // gemm_f64.hip:  C[m x n] = (accumulate ? C - A*op(B) : A*op(B)),  m,n multiples of 128, k multiple of 16
+// Kernels of the latency-bound chains (the diagonal block's factorisation and inversion, the panel stream of the distributed
+// loop) run BESIDE chip-filling updates and share their CUs with resident GEMM waves; launched on the context's chain stream
+// (streams[1]) they raise their waves' issue priority (s_setprio 3) so that the CU's arbiter serves them first.  GPX_CHAIN_PRIO=0
+// switches it off (A/B).
+static inline int gpx_chain_prio(const gpx_ctx* ctx) {
+  static const int on = [] { const char* e = getenv("GPX_CHAIN_PRIO"); return e ? atoi(e) : 1; }();
+  return (on && ctx->stream == ctx->streams[1]) ? 1 : 0;
+}
 int launch_gemm(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
                 int64_t m, int64_t n, int64_t k, bool bt, bool accumulate, bool lower);
 

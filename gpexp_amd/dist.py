@@ -94,7 +94,8 @@ def merge_argmin(values, indices):
 # ---- recorded programs (include/gpx.h: gpx_program_run) -----------------------------------------------------------
 OP = dict(STREAM=1, RECORD=2, WAIT=3, BEGIN=4, DIAG_FACTOR=5, PANEL_TRSM=6, UPDATE=7, UPDATE_MULTI=8, UNPACK_ROWS=9,
           UNPACK_DIAG=10, PACK_ROWS=11, PACK_DIAG=12, BCAST_GRP=13, REDUCE_GRP=14, ALLREDUCE=15, PANEL_BCAST=16, IVAR_STEP=17,
-          TRSV_DIAG=18, GEMV=19, LOGDET_ACC=20, VEC_OP=21, SPIN=22, COPY=23, IVAR_GROUP=24, FWD_GROUP=25, PANEL_INV=26, BCAST_GRP2=27, PANEL_COPYBACK=28)
+          TRSV_DIAG=18, GEMV=19, LOGDET_ACC=20, VEC_OP=21, SPIN=22, COPY=23, IVAR_GROUP=24, FWD_GROUP=25, PANEL_INV=26, BCAST_GRP2=27, PANEL_COPYBACK=28,
+          DIAG_STAGE=29, DIAG_UPDATE=30, DIAG_FACTOR_STAGED=31, DIAG_STORE=32)
 
 
 class Program:
@@ -747,6 +748,20 @@ class DeviceOps2D(Emitter, DeviceOps):
     def diag_factor(self, A, lr, lc, w, G, doff, nb, base, n_valid):
         self._emit(OP["DIAG_FACTOR"], (A, G), (lr, lc, w, doff, nb, base, n_valid))
 
+    # the same in parts (round 4: only the factorisation itself stays on the chain across ranks, see dist2_potrf_enqueue)
+    def diag_stage(self, A, lr, lc, w, G, doff, nb):
+        self._emit(OP["DIAG_STAGE"], (A, G), (lr, lc, w, doff, nb))
+
+    def diag_update(self, G, doff, h, S, soff, w, nb):
+        """staged block (h x h) -= S[soff](h x w packed rows) times their transpose"""
+        self._emit(OP["DIAG_UPDATE"], (G, S), (doff, h, soff, w, nb))
+
+    def diag_factor_staged(self, A, lr, lc, w, G, doff, nb, base, n_valid):
+        self._emit(OP["DIAG_FACTOR_STAGED"], (A, G), (lr, lc, w, doff, nb, base, n_valid))
+
+    def diag_store(self, A, lr, lc, w, G, doff, nb, dslot=None):
+        self._emit(OP["DIAG_STORE"], (A, G), (lr, lc, w, doff, nb, 0 if dslot is None else dslot + 1))
+
     def panel_inv(self, G, doff, nb, w):
         """explicit inverse of the factored diagonal block in G at doff, kept for this step's panel solves (built as soon as the
         block has arrived: off the panel chain)"""
@@ -944,6 +959,13 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
     hoist_inv = os.environ.get("GPX_DIST2_HOIST_INV", "1") == "1" and hasattr(ops, "panel_inv")
     gate_bulk = os.environ.get("GPX_DIST_GATE_BULK", "1") == "1"
     late_copyback = os.environ.get("GPX_DIST2_LATE_COPYBACK", "1") == "1"
+    # Round 4, the diagonal chain (potrf(k) -> broadcast -> inverse -> block row k+1 solved -> broadcast -> last update of block
+    # (k+1, k+1) -> potrf(k+1)) is ~20 small dependent launches per step, and their latencies -- 2-3 times the idle-chip figure
+    # beside the trailing updates -- summed over the steps ARE the factorisation time of a grid (scripts/dist_replay.py
+    # --paced-grid).  Staged: the owner of the next diagonal block copies it into the packed buffer BEFORE the block row it waits
+    # for arrives, applies that last update to the copy, factors the copy in place, and copies factor + leaf inverses back into
+    # the local matrix behind the event that releases the panel broadcast: three launches less per step on that chain.
+    staged = os.environ.get("GPX_DIST2_STAGED_DIAG", "1") == "1" and hasattr(ops, "diag_stage")
 
     def group_end(k):
         return min((k // q + 1) * q - 1, nblk - 1)
@@ -1015,10 +1037,10 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
         if at_step is not None:
             at_step(geo, k)
 
-        def wait_free():
-            """everything that read this buffer one ring ago is done (near updates + group-end updates of that panel's group,
-            the copy into L, the panel stream's solves)"""
-            old = k - R
+        def wait_free(kk=k):
+            """everything that read the buffer of step kk one ring ago is done (near updates + group-end updates of that panel's
+            group, the copy into L, the panel stream's solves)"""
+            old = kk - R
             if old >= 0:
                 ge = group_end(old)
                 ops.wait(_ev2(E_UPD, last_chunk_step.get(ge, ge)))
@@ -1031,8 +1053,13 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
         if owner:
             ops.stream(PANEL)
             ops.wait(_ev2(E_DIAGREADY, k))
-            wait_free()
-            ops.diag_factor(A, lr, lc, w, g, geo.piece_off(kr), nb, k * nb, geo.n)
+            if not staged:
+                wait_free()
+                ops.diag_factor(A, lr, lc, w, g, geo.piece_off(kr), nb, k * nb, geo.n)
+            else:
+                if k == 0:                                               # (later blocks were staged one step earlier, below)
+                    ops.diag_stage(A, lr, lc, w, g, geo.piece_off(kr), nb)
+                ops.diag_factor_staged(A, lr, lc, w, g, geo.piece_off(kr), nb, k * nb, geo.n)
             ops.record(_ev2(E_DFACT, k))
         if holder:
             ops.stream(COMM)
@@ -1050,17 +1077,21 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
             lr0, m = geo.row_off(pr, geo.li0(pr, k)), geo.piece_rows(pr, k)
             roff = geo.piece_off(pr) + geo.dsz
             dslot = (k // Pr) if owner else None                         # the owner keeps the block's explicit inverse
+            keep_late = owner and staged and hoist_inv                    # ... behind E_PIECE (diag_store) instead of ahead of the solve
             # (full-width blocks with the inverse at hand: the solved rows go to the packed buffer only and are copied back into
             # the local matrix BEHIND the events that release the two broadcasts -- the copies are not the chain's business)
             late = late_copyback and hoist_inv and w == nb and nb > TILE and hasattr(ops, "panel_copyback")
             pk = dict(prepared=True, copy_back=not late) if hoist_inv else {}
+            ds = None if keep_late else dslot
             if nxt and pr == r1:                                         # block row k+1 first: the next diagonal needs it
                 ops.panel_trsm(A, lr0, h1, lc, w, g, geo.piece_off(kr), roff, nb, **pk)
                 ops.record(_ev2(E_EARLYSOLVED, k))
-                ops.panel_trsm(A, lr0 + h1, m - h1, lc, w, g, geo.piece_off(kr), roff + h1 * geo.gld, nb, dslot, **pk)
+                ops.panel_trsm(A, lr0 + h1, m - h1, lc, w, g, geo.piece_off(kr), roff + h1 * geo.gld, nb, ds, **pk)
             else:
-                ops.panel_trsm(A, lr0, m, lc, w, g, geo.piece_off(kr), roff, nb, dslot, **pk)
+                ops.panel_trsm(A, lr0, m, lc, w, g, geo.piece_off(kr), roff, nb, ds, **pk)
             ops.record(_ev2(E_PIECE, k))
+            if owner and staged:
+                ops.diag_store(A, lr, lc, w, g, geo.piece_off(kr), nb, dslot if keep_late else None)
             if late and m > 0:
                 ops.panel_copyback(A, lr0, m, lc, w, g, roff, nb)
         if nxt and pr == r1:
@@ -1076,7 +1107,8 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
             ops.record(_ev2(E_EARLY, k))
             if pc == c1:                                                 # owner of the next diagonal block
                 ops.stream(PANEL)
-                ops.wait(_ev2(E_EARLY, k))
+                if not staged:
+                    ops.wait(_ev2(E_EARLY, k))
                 if k >= 1:
                     ops.wait(_ev2(E_COL2, k + 1))                        # contributions of the panels before k
                 else:
@@ -1084,10 +1116,15 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
                     # update could land on the block before the fill wrote it and be overwritten -- seen on the first
                     # step of a fresh process only, when the fill kernel's first launch is slow (1 run in 12)
                     ops.wait(_ev2(E_COLREADY, 0))
-                if E is not None:
-                    ops.update(A, ((k + 1) // Pr) * nb, h1, ((k + 1) // Pc) * nb, h1, E[k % R], 0, 0, w, nb)
+                src, soff = (E[k % R], 0) if E is not None else (g, early_off)
+                if staged:
+                    g1, doff1 = G[(k + 1) % R], geo.piece_off(r1)
+                    wait_free(k + 1)
+                    ops.diag_stage(A, ((k + 1) // Pr) * nb, ((k + 1) // Pc) * nb, h1, g1, doff1, nb)
+                    ops.wait(_ev2(E_EARLY, k))
+                    ops.diag_update(g1, doff1, h1, src, soff, w, nb)
                 else:
-                    ops.update(A, ((k + 1) // Pr) * nb, h1, ((k + 1) // Pc) * nb, h1, g, early_off, early_off, w, nb)
+                    ops.update(A, ((k + 1) // Pr) * nb, h1, ((k + 1) // Pc) * nb, h1, src, soff, soff, w, nb)
                 ops.record(_ev2(E_DIAGREADY, k + 1))
         ops.stream(PANEL)
         ops.record(_ev2(E_PANELDONE, k))

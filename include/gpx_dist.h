@@ -142,6 +142,17 @@ int gpx_dist2_kfill(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, 
 /* diagonal owner: factor the w x w block at local (lr, lc) into the D region of the panel buffer G (offset doff) */
 int gpx_dist2_diag_factor(gpx_ctx* ctx, gpx_mat* A, int64_t lr, int64_t lc, int64_t w, gpx_mat* G, int64_t doff,
                           int64_t nb, int64_t base, int64_t n_valid);
+/* the same in three parts, which the panel loop issues separately so that only the factorisation itself sits on the chain across
+ * ranks: _stage copies the block into the D region BEFORE the block row it still waits for has arrived, _diag_update applies that
+ * last update (S[soff]: h x w packed rows, times their transpose) to the staged copy, _factor_staged factors it in place, and
+ * _store -- issued behind the event that releases the broadcast -- copies factor and leaf inverses into the local matrix (dslot
+ * >= 0: and keeps the explicit inverse gpx_dist2_panel_inv built for this block, for gpx_dist2_trsv_diag) */
+int gpx_dist2_diag_stage(gpx_ctx* ctx, const gpx_mat* A, int64_t lr, int64_t lc, int64_t w, gpx_mat* G, int64_t doff, int64_t nb);
+int gpx_dist2_diag_update(gpx_ctx* ctx, gpx_mat* G, int64_t doff, int64_t h, const gpx_mat* S, int64_t soff, int64_t w, int64_t nb);
+int gpx_dist2_diag_factor_staged(gpx_ctx* ctx, gpx_mat* A, int64_t lr, int64_t lc, int64_t w, gpx_mat* G, int64_t doff,
+                                 int64_t nb, int64_t base, int64_t n_valid);
+int gpx_dist2_diag_store(gpx_ctx* ctx, gpx_mat* A, int64_t lr, int64_t lc, int64_t w, const gpx_mat* G, int64_t doff, int64_t nb,
+                         int64_t dslot);
 /* size the context's scratches of the distributed loops up front (panel-solve inverse: 2 nb^2 doubles; streamed evaluation:
  * 2 agg nb^2 + agg nb mcols doubles) so that the enqueue path never reallocates mid-step; called by the runners' constructors */
 int gpx_dist2_reserve(gpx_ctx* ctx, int64_t nb, int64_t agg, int64_t mcols);
@@ -200,7 +211,8 @@ enum {
   GPX_OP_STREAM = 1, GPX_OP_RECORD, GPX_OP_WAIT, GPX_OP_BEGIN, GPX_OP_DIAG_FACTOR, GPX_OP_PANEL_TRSM, GPX_OP_UPDATE,
   GPX_OP_UPDATE_MULTI, GPX_OP_UNPACK_ROWS, GPX_OP_UNPACK_DIAG, GPX_OP_PACK_ROWS, GPX_OP_PACK_DIAG, GPX_OP_BCAST_GRP,
   GPX_OP_REDUCE_GRP, GPX_OP_ALLREDUCE, GPX_OP_PANEL_BCAST, GPX_OP_IVAR_STEP, GPX_OP_TRSV_DIAG, GPX_OP_GEMV, GPX_OP_LOGDET_ACC,
-  GPX_OP_VEC_OP, GPX_OP_SPIN, GPX_OP_COPY, GPX_OP_IVAR_GROUP, GPX_OP_FWD_GROUP, GPX_OP_PANEL_INV, GPX_OP_BCAST_GRP2, GPX_OP_PANEL_COPYBACK
+  GPX_OP_VEC_OP, GPX_OP_SPIN, GPX_OP_COPY, GPX_OP_IVAR_GROUP, GPX_OP_FWD_GROUP, GPX_OP_PANEL_INV, GPX_OP_BCAST_GRP2, GPX_OP_PANEL_COPYBACK,
+  GPX_OP_DIAG_STAGE, GPX_OP_DIAG_UPDATE, GPX_OP_DIAG_FACTOR_STAGED, GPX_OP_DIAG_STORE
 };
 int gpx_program_run(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const int64_t* extra, int64_t nextra, double* host_ms);
 /* The same program as a hipGraph: captured once (after it has run once the ordinary way; every stream it uses must fork from

@@ -196,6 +196,46 @@ class NumpyOps2D(NumpyOps):
             inv[q * 128 * 128:(q + 1) * 128 * 128] = np.linalg.inv(L11[q * 128:(q + 1) * 128, q * 128:(q + 1) * 128]).ravel()
         self.aux[("A", lr)] = inv[:(w // 128) * 128 * 128].copy()
 
+    # the same in parts (dist2_potrf_enqueue, staged): the block is copied into the packed buffer ahead of its last update
+    def diag_stage(self, A, lr, lc, w, G, doff, nb):
+        self._inside(A, lr, w, lc, w)
+        blk = A.a[lr:lr + w, lc:lc + w]
+        assert not self.poison or not np.isnan(np.tril(blk)).any(), "owner stages a diagonal block it never assembled/updated"
+        D = self._D(G, doff, nb)
+        D[:] = np.nan if self.poison else 0.0
+        D[:w, :w] = np.tril(blk) + np.tril(blk, -1).T
+
+    def diag_update(self, G, doff, h, S, soff, w, nb):
+        gld = nb + dist.G_SKEW
+        assert soff + h * gld <= S.a.size
+        rows = S.a[soff:soff + h * gld].reshape(h, gld)[:, :w]
+        assert not self.poison or not np.isnan(rows).any(), "the staged diagonal block is updated by a block row that never arrived"
+        self._D(G, doff, nb)[:h, :h] -= rows @ rows.T
+
+    def diag_factor_staged(self, A, lr, lc, w, G, doff, nb, base, n_valid):
+        D = self._D(G, doff, nb)
+        blk = D[:w, :w].copy()
+        assert not self.poison or not np.isnan(np.tril(blk)).any(), "owner factors a diagonal block that was never staged"
+        try:
+            L11 = np.linalg.cholesky(np.tril(blk) + np.tril(blk, -1).T)
+        except (np.linalg.LinAlgError, ValueError):
+            if self._info == 0:
+                self._info = base + 1
+            L11 = np.eye(w)
+        D[:] = 0.0
+        D[:w, :w] = L11
+        inv = G.a[doff + nb * nb: doff + nb * nb + (nb // 128) * 128 * 128]
+        inv[:] = 0.0
+        for q in range(w // 128):
+            inv[q * 128 * 128:(q + 1) * 128 * 128] = np.linalg.inv(L11[q * 128:(q + 1) * 128, q * 128:(q + 1) * 128]).ravel()
+
+    def diag_store(self, A, lr, lc, w, G, doff, nb, dslot=None):
+        self._inside(A, lr, w, lc, w)
+        L11 = self._D(G, doff, nb)[:w, :w]
+        assert not self.poison or not np.isnan(L11).any(), "the stored diagonal block was never factored"
+        A.a[lr:lr + w, lc:lc + w] = L11
+        self.aux[("A", lr)] = G.a[doff + nb * nb: doff + nb * nb + (w // 128) * 128 * 128].copy()
+
     @staticmethod
     def _inside(A, lr0, m, lc, w):
         """The C primitives reject blocks outside the local matrix (NumPy slicing would not)."""
