@@ -155,6 +155,8 @@ _SIGS = {
     "gpx_dbg_guard_selftest": (C.c_int, [c_vp]),
     "gpx_dbg_spin": (C.c_int, [c_vp, C.c_int]),
     "gpx_dbg_spin_us": (C.c_int, [c_vp, c_i64]),
+    "gpx_dbg_stamp": (C.c_int, [c_vp, C.c_int]),
+    "gpx_dbg_spin_until": (C.c_int, [c_vp, C.c_int, c_i64]),
     "gpx_dbg_event_elapsed": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp]),
 }
 

@@ -454,6 +454,7 @@ int gpx_create(int device, gpx_ctx** out) {
   c->trsv_scratch = nullptr;
   c->trsv_scratch_bytes = 0;
   c->d2_scratch = nullptr;
+  c->dbg_stamps = nullptr;
   c->d2_scratch_bytes = 0;
   c->d2_inv_src = nullptr;
   c->d2_inv_nb = 0;
@@ -478,6 +479,40 @@ int gpx_dbg_spin_us(gpx_ctx* ctx, int64_t us) {
   GPX_ARG(ctx && us >= 0 && us <= 500000, "spin: 0..500000 us");
   if (us == 0) return 0;
   hipLaunchKernelGGL(dbg_spin_kernel, dim3(1), dim3(64), 0, ctx->stream, (long long)((double)us * spin_ticks_per_us(ctx)));
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
+
+// Paced replay, second form: a STAMP of the wall clock taken on the selected stream (slot < 1024), and a spin that ends `us`
+// microseconds after a stamp (at once when that moment has passed; never longer than 0.5 s).  A foreign delivery of the
+// single-rank replay is released at "arrival of the previous panel + what its producer took", whatever this rank's
+// communication stream did in between (scripts/replay_comm.py).
+constexpr int GPX_DBG_STAMPS = 1024;
+__global__ void dbg_stamp_kernel(long long* slot) { *slot = wall_clock64(); }
+__global__ void dbg_spin_until_kernel(const long long* slot, long long ticks, long long cap) {
+  const long long t0 = wall_clock64(), target = *slot + ticks;
+  while (wall_clock64() < target && wall_clock64() - t0 < cap) {}
+}
+static int dbg_stamps_ensure(gpx_ctx* ctx) {
+  if (!ctx->dbg_stamps) {
+    GPX_HIP(hipMalloc((void**)&ctx->dbg_stamps, GPX_DBG_STAMPS * sizeof(long long)));
+    GPX_HIP(hipMemset(ctx->dbg_stamps, 0, GPX_DBG_STAMPS * sizeof(long long)));
+  }
+  return 0;
+}
+int gpx_dbg_stamp(gpx_ctx* ctx, int slot) {
+  GPX_ARG(ctx && slot >= 0 && slot < GPX_DBG_STAMPS, "stamp: slot 0..1023");
+  GPX_TRY(dbg_stamps_ensure(ctx));
+  hipLaunchKernelGGL(dbg_stamp_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->dbg_stamps + slot);
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
+int gpx_dbg_spin_until(gpx_ctx* ctx, int slot, int64_t us) {
+  GPX_ARG(ctx && slot >= 0 && slot < GPX_DBG_STAMPS && us <= 500000, "spin_until: slot 0..1023, at most 500000 us");
+  if (us <= 0) return 0;
+  GPX_TRY(dbg_stamps_ensure(ctx));
+  hipLaunchKernelGGL(dbg_spin_until_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->dbg_stamps + slot,
+                     (long long)((double)us * spin_ticks_per_us(ctx)), (long long)(500000.0 * spin_ticks_per_us(ctx)));
   GPX_HIP(hipGetLastError());
   return 0;
 }
@@ -522,6 +557,7 @@ int gpx_destroy(gpx_ctx* ctx) {
   (void)hipFree(ctx->d_scal);
   if (ctx->trsv_scratch) (void)hipFree(ctx->trsv_scratch);
   if (ctx->d2_scratch) (void)hipFree(ctx->d2_scratch);
+  if (ctx->dbg_stamps) (void)hipFree(ctx->dbg_stamps);
   if (ctx->ev_scratch) (void)hipFree(ctx->ev_scratch);
   for (auto ev : ctx->sync_events) (void)hipEventDestroy(ev);
   for (auto ev : ctx->la_events) (void)hipEventDestroy(ev);

@@ -1352,7 +1352,11 @@ int gpx_program_run(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const int64_
       case GPX_OP_GEMV: r = gpx_dist2_gemv(ctx, h0, a[0], a[1], a[2], a[3], h1, a[4], h2, a[5], (int)a[6]); break;
       case GPX_OP_LOGDET_ACC: r = gpx_dist2_logdet_acc(ctx, h0, a[0], a[1], a[2], a[3], h1); break;
       case GPX_OP_VEC_OP: r = gpx_vec_op(ctx, h0, a[0], h1, a[1], a[2], (int)a[3]); break;
-      case GPX_OP_SPIN: r = a[1] ? gpx_dbg_spin_us(ctx, a[0]) : gpx_dbg_spin(ctx, (int)a[0]); break;   // a1 != 0: a0 in microseconds
+      case GPX_OP_SPIN:   // a1 = 0: a0 ms; 1: a0 us; 2: stamp slot a0; 3: spin until a2 us after the stamp in slot a0
+        r = a[1] == 3 ? gpx_dbg_spin_until(ctx, (int)a[0], a[2])
+            : a[1] == 2 ? gpx_dbg_stamp(ctx, (int)a[0])
+            : a[1] ? gpx_dbg_spin_us(ctx, a[0]) : gpx_dbg_spin(ctx, (int)a[0]);
+        break;
       case GPX_OP_COPY: {  // h0[a0 : a0+a2] <- h1[a1 : a1+a2], device to device (replay stand-in for a point-to-point transfer)
         if (!h0 || !h1 || a[0] < 0 || a[1] < 0 || a[2] < 0 || (a[0] + a[2]) * 8 > h0->bytes || (a[1] + a[2]) * 8 > h1->bytes) {
           gpx_set_error("program op %lld: copy outside its buffers", (long long)i);

@@ -178,6 +178,7 @@ struct gpx_ctx {
   int64_t trsv_scratch_bytes;
   double* d2_scratch;        // 2-D distributed panel solve: explicit inverse of the current diagonal block + build scratch
   int64_t d2_scratch_bytes;  // (2 nb^2 doubles; used on the PANEL stream only, in step order)
+  long long* dbg_stamps;     // gpx_dbg_stamp / gpx_dbg_spin_until: wall-clock stamps taken on a stream (GPX_DBG_STAMPS slots)
   const double* d2_inv_src;  // the packed diagonal block whose inverse d2_scratch holds (gpx_dist2_panel_inv), or NULL
   int64_t d2_inv_nb;
   double* ev_scratch;        // streamed evaluation (gpx_dist_ivar_group_at): block inverses of the group + their build scratch +

@@ -957,7 +957,12 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
     chunked = mode == "chunks"
     at_step = getattr(comm, "at_step", None)
     hoist_inv = os.environ.get("GPX_DIST2_HOIST_INV", "1") == "1" and hasattr(ops, "panel_inv")
-    gate_bulk = os.environ.get("GPX_DIST_GATE_BULK", "1") == "1"
+    # GPX_DIST_GATE_BULK: 0 = the group-end bulk update starts as soon as the group's panels are there; 1 = on the ranks that hold
+    # the NEXT block column, behind their update of that column; 2 = on those ranks, behind their whole holder step (issued one
+    # step later, behind E_PIECE of that step): a chain kernel beside a chip-filling update runs at half its rate or less
+    gate_level = int(os.environ.get("GPX_DIST_GATE_BULK", "2"))
+    gate_bulk = gate_level >= 1
+    deferred_bulk = []           # (group end k, panels) whose bulk update is issued behind this rank's next holder step
     late_copyback = os.environ.get("GPX_DIST2_LATE_COPYBACK", "1") == "1"
     # Round 4, the diagonal chain (potrf(k) -> broadcast -> inverse -> block row k+1 solved -> broadcast -> last update of block
     # (k+1, k+1) -> potrf(k+1)) is ~20 small dependent launches per step, and their latencies -- 2-3 times the idle-chip figure
@@ -1090,6 +1095,17 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
             else:
                 ops.panel_trsm(A, lr0, m, lc, w, g, geo.piece_off(kr), roff, nb, ds, **pk)
             ops.record(_ev2(E_PIECE, k))
+            while deferred_bulk:                                         # the previous group's bulk update, held back until here
+                bk, bks = deferred_bulk.pop(0)
+                ops.stream(bulk_stream)
+                if bulk_stream != MAIN:
+                    ops.wait(_ev2(E_COLREADY, 0))
+                    ops.wait(_ev2(E_ARRIVED, bk))
+                    ops.wait(_ev2(E_PIECE, k))
+                update_cols(bk + 3 + q, nblk - 1, bks)
+                ops.record(_ev2(E_BULK, bk))
+                bulk_recorded.add(bk)
+                ops.stream(PANEL)
             if owner and staged:
                 ops.diag_store(A, lr, lc, w, g, geo.piece_off(kr), nb, dslot if keep_late else None)
             if late and m > 0:
@@ -1187,6 +1203,8 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
                 Ja, Jb, pks, pge = pending.pop(0)
                 update_cols(Ja, Jb, pks)
                 last_chunk_step[k] = k
+            elif k + 3 + q < nblk and gate_level >= 2 and bulk_stream != MAIN and nxt and pc == c1:
+                deferred_bulk.append((k, ks))                            # this rank holds column k+1: issued behind that step's solve
             elif k + 3 + q < nblk:
                 ops.stream(bulk_stream)
                 if bulk_stream != MAIN:

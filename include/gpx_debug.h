@@ -44,6 +44,11 @@ int gpx_dbg_kfill_plan(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhy
                        int* exact, double* center);
 
 int gpx_dbg_spin_us(gpx_ctx* ctx, int64_t us);   /* gpx_dbg_spin in microseconds (<= 500 000) */
+/* a wall-clock stamp taken on the selected stream (slot 0..1023), and a spin on the selected stream that ends `us` microseconds
+ * after that stamp (no launch when us <= 0; at once when the moment has passed; never longer than 0.5 s): the paced replay releases
+ * a foreign delivery at "arrival of the previous panel + what its producer took" (scripts/replay_comm.py) */
+int gpx_dbg_stamp(gpx_ctx* ctx, int slot);
+int gpx_dbg_spin_until(gpx_ctx* ctx, int slot, int64_t us);
 /* ms between the last records of two pipeline events (gpx_event_record ids; GPX_EVENT_TIMING=1 in the environment makes them
  * carry time stamps): the per-step timeline of the distributed loop's strands without a profiler in the way
  * (scripts/dist_timeline.py).  Returns 1 when an event of the pair was never recorded / has not completed. */

@@ -45,6 +45,11 @@ def own_step_latencies(ctx, geo):
         return None, None
     own = [k for k in range(geo.nblk) if k % geo.Pc == geo.pc]
     lat = {k: arr[k] - (arr[k - 1] if k > 0 else 0.0) for k in own}
+    # the diagonal chain's two hand-overs, where THIS rank produces them: the diagonal block factored (owner of (k, k)) and block
+    # row k+1 of panel k solved (holder of column k in the process row of block row k+1), ms after the arrival of panel k-1
+    own_step_latencies.dfact = {k: at(dist.E_DFACT, k) - (arr[k - 1] if k > 0 else 0.0) for k in own if k % geo.Pr == geo.pr}
+    own_step_latencies.early = {k: at(dist.E_EARLYSOLVED, k) - (arr[k - 1] if k > 0 else 0.0)
+                                for k in own if k + 1 < geo.nblk and (k + 1) % geo.Pr == geo.pr}
     if os.environ.get("GPX_REPLAY_DETAIL") == "1":   # where an own holder step spends its latency
         print("# own holder steps: k, [ARRIVED(k-1)] -> near update of column k done (COLREADY) -> diagonal factored (DFACT) -> "
               "panel solved (PIECE) -> delivered (ARRIVED); ms relative to ARRIVED(k-1)", file=sys.stderr)
@@ -75,6 +80,8 @@ def paced_replay(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=512, agg=
         res = replay_rank(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=nb, agg=agg, streamed=streamed, steps=steps,
                           profile=False, pace_us=pace, want_latencies=True)
         lat = res.pop("own_latency_ms")
+        res.pop("own_dfact_ms", None)
+        res.pop("own_early_ms", None)
         if lat is None:
             return dict(error="the pipeline's events carry no time stamps (set GPX_EVENT_TIMING=1 before the first use)")
         hist.append(dict(paced=pace is not None, ms_per_step=res["ms_per_step"], own_latency_sum_ms=float(sum(lat.values())),
@@ -86,7 +93,7 @@ def paced_replay(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=512, agg=
                 bytes_received_per_fit=res["bytes_received_per_fit"], variance_check_rel=res["variance_check_rel"])
 
 
-def paced_grid(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, nb=512, agg=None, streamed=False, iters=3, steps=2, rows=None):
+def paced_grid(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, nb=512, agg=None, streamed=False, iters=5, steps=2, rows=None):
     """The factorisation time of the WHOLE Pr x Pc grid estimated on ONE GPU.  Step k+1's panel solve needs step k's panel, so
     the factorisation time of a real run is the SUM over the steps of what the step's holder column needs from the arrival of
     panel k-1 to the delivery of panel k -- not any rank's busy time (a replay in which every foreign panel arrives at once keeps
@@ -100,16 +107,22 @@ def paced_grid(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, nb=512, agg=None, st
     rows = list(range(Pr)) if rows is None else list(rows)
     nblk = None
     lat = {}           # step k -> holder latency (ms), max over the replayed ranks of the holder column
+    dfl, eal = {}, {}  # step k -> ms after the arrival of panel k-1 at which the diagonal block was factored / block row k+1 solved
     hist = []
     last = {}
+    diag_paced = os.environ.get("GPX_REPLAY_PACE_DIAG", "1") == "1" and len(rows) == Pr
     for it in range(iters):
-        newlat = {}
+        newlat, newdf, newea = {}, {}, {}
         for pc in range(Pc):
             for pr in rows:
                 rank = pr * Pc + pc
                 pace = None
                 if nblk is not None and len(lat) == nblk:
-                    pace = np.array([max(lat[k], 0.0) * 1e3 for k in range(nblk)]).astype(np.int64)
+                    us = lambda d: np.array([max(d.get(k, 0.0), 0.0) * 1e3 for k in range(nblk)]).astype(np.int64)  # noqa: E731
+                    # (sweep 1 paces the panels alone: the figures of the unpaced sweep 0 are those of a rank that is never idle,
+                    # several times the fixed point's, and holding the diagonal chain back by them too keeps them there)
+                    dp = diag_paced and it >= 2
+                    pace = dict(panel=us(lat), dfact=us(dfl) if dp else None, early=us(eal) if dp else None)
                 res = replay_rank(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=nb, agg=agg, streamed=streamed, steps=steps,
                                   profile=False, pace_us=pace, want_latencies=True)
                 own = res.pop("own_latency_ms")
@@ -119,6 +132,8 @@ def paced_grid(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, nb=512, agg=None, st
                 agg_used = res["agg"]
                 for k, v in own.items():
                     newlat[k] = max(newlat.get(k, 0.0), v)
+                newdf.update(res.pop("own_dfact_ms") or {})
+                newea.update(res.pop("own_early_ms") or {})
                 last[rank] = dict(paced=pace is not None, ms_per_step=res["ms_per_step"], own_latency_sum_ms=float(sum(own.values())),
                                   last_arrived_ms=res.get("last_arrived_ms"), last_step_ms=res.get("last_step_ms"),
                                   foreign_excess_ms=res.get("foreign_excess_ms"), foreign_excess_worst=res.get("foreign_excess_worst"),
@@ -126,12 +141,13 @@ def paced_grid(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, nb=512, agg=None, st
         # damped fixed point: a rank's holder latency falls when its foreign panels arrive later (it is less busy), which makes
         # the next sweep's pacing shorter and the latencies rise again -- the plain iteration oscillates (fit + IVAR at 2 x 4:
         # 215, 72, 110, 93, 102 ms of chain); from the second paced sweep on the pacing moves half-way
-        lat = newlat if it < 2 else {k: 0.5 * (lat[k] + newlat[k]) for k in newlat}
+        damp = lambda old, new: new if it < (3 if diag_paced else 2) else {k: 0.5 * (old.get(k, new[k]) + new[k]) for k in new}  # noqa: E731
+        lat, dfl, eal = damp(lat, newlat), damp(dfl, newdf), damp(eal, newea)
         hist.append(dict(iteration=it, chain_ms=float(sum(lat.values())),
                          rank_step_ms={str(r): round(v["ms_per_step"], 3) for r, v in last.items()},
                          paced=all(v["paced"] for v in last.values())))
     per_col = [float(sum(v for k, v in lat.items() if k % Pc == pc)) for pc in range(Pc)]
-    return dict(grid="%dx%d" % grid, nb=nb, agg=agg_used, streamed_ivar=bool(streamed),
+    return dict(grid="%dx%d" % grid, nb=nb, agg=agg_used, streamed_ivar=bool(streamed), diagonal_chain_paced=bool(diag_paced),
                 replayed_ranks=sorted(last), iterations=hist, chain_ms=float(sum(lat.values())), chain_ms_by_process_column=per_col,
                 paced_step_ms_max=max(v["ms_per_step"] for v in last.values()),
                 paced_step_ms={str(r): round(v["ms_per_step"], 3) for r, v in last.items()},
@@ -189,8 +205,12 @@ def replay_rank(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=512, agg=N
                variance_check_rel=check, single_gpu_potrf_ms=single_potrf_ms)
     if want_latencies:
         res["own_latency_ms"] = lat
+        res["own_dfact_ms"] = getattr(own_step_latencies, "dfact", None) if lat is not None else None
+        res["own_early_ms"] = getattr(own_step_latencies, "early", None) if lat is not None else None
         res["last_arrived_ms"] = arr_all[-1] if arr_all else None      # (of the LAST timed step) the rest of the step is the rank's tail
         if arr_all and pace_us is not None:      # what a FOREIGN step costs this rank beyond its pacing (the stand-in copies, waits)
+            if isinstance(pace_us, dict):
+                pace_us = pace_us["panel"]
             gaps = [arr_all[k] - (arr_all[k - 1] if k else 0.0) for k in range(len(arr_all))]
             fk = [k for k in range(len(arr_all)) if k % geo.Pc != geo.pc]
             res["foreign_excess_ms"] = float(sum(gaps[k] - pace_us[k] * 1e-3 for k in fk))
@@ -229,6 +249,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--paced-grid", action="store_true", help="whole-grid estimate: every process column replayed, paced by the "
                                                              "holder latencies of the step's own column, iterated (paced_grid)")
+    ap.add_argument("--iters", type=int, default=5, help="sweeps of --paced-grid (the first one is unpaced)")
     ap.add_argument("--rows", default="", help="process rows replayed by --paced-grid (default: all)")
     ap.add_argument("--paced", action="store_true", help="paced replay: foreign panels arrive at the latency this rank shows in its "
                                                         "own holder steps (estimate of the whole grid's factorisation time)")
@@ -261,7 +282,7 @@ def main():
         if args.paced_grid:
             res = paced_grid(ctx, spec, Xh, yh, Zh, noise, Lref, X, (Pr, Pc), nb=args.nb, agg=args.agg,
                              streamed=(world >= 4 and not args.no_stream),
-                             rows=[int(v) for v in args.rows.split(",")] if args.rows else None)
+                             rows=[int(v) for v in args.rows.split(",")] if args.rows else None, iters=args.iters)
             res["single_gpu_potrf_ms"] = single_potrf_ms
             print(json.dumps(res), flush=True)
             continue

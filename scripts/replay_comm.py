@@ -31,7 +31,14 @@ class ReplayComm(Emitter):
         # panel solve needs step k's panel, so a real run's factorisation time is the SUM of the holders' per-step latencies.
         # With pacing set to the latencies this rank shows in its own holder steps (scripts/dist_replay.py iterates to a fixed
         # point), the replayed step reproduces that chain on one GPU.  xGMI transfer time is still not in it.
-        self.pace_us = pace_us
+        # pace_us may also be a dict(panel=..., dfact=..., early=...) of per-step arrays (us after the arrival of panel k-1 at
+        # which the PRODUCER had panel k delivered / diagonal block k factored / block row k+1 of panel k solved): the two small
+        # broadcasts of the DIAGONAL chain -- L_kk down its process column, L[k+1, k] along its process row -- are then held back
+        # too, each until "arrival of panel k-1 (a wall-clock stamp on this stream) + the producer's figure" (gpx_dbg_spin_until).
+        # With the panels alone paced they arrive the moment this rank asks, and a replayed owner factors its diagonal block
+        # earlier than any real grid could hand it the block row it needs.
+        self.pace = pace_us if isinstance(pace_us, dict) else None
+        self.pace_us = None if self.pace is not None else pace_us
 
     def set_grid(self, Pr, Pc):
         assert Pr * Pc == self.world
@@ -39,6 +46,16 @@ class ReplayComm(Emitter):
 
     def at_step(self, geo, k):
         self.geo, self.k = geo, k
+        if k == 0 and self.pace is not None:
+            self._emit(OP["SPIN"], (), (0, 2))           # stamp slot 0: the step starts (slot k + 1: panel k has arrived)
+
+    def _hold(self, kind):
+        """foreign delivery of step k: not before the stamp of panel k-1's arrival + the producer's figure"""
+        if self.pace is None or self.pace.get(kind) is None:
+            return
+        us = int(self.pace[kind][self.k])
+        if us > 0:
+            self._emit(OP["SPIN"], (), (self.k, 3, us))
 
     def _rows(self, buf, off, m, first_block, stride, k):
         geo = self.geo
@@ -57,9 +74,11 @@ class ReplayComm(Emitter):
             return
         if grp == COL:
             assert offset == geo.piece_off(k % geo.Pr) and count == geo.dsz
+            self._hold("dfact")
             self._diag(buf, offset, k)
         else:
             assert grp == ROW and count == geo.height(k + 1) * geo.gld
+            self._hold("early")
             self._rows(buf, offset, geo.height(k + 1), k + 1, 1, k)
 
     def bcast_grp2(self, sbuf, soff, rbuf, roff, count, root, grp):
@@ -68,12 +87,16 @@ class ReplayComm(Emitter):
         assert grp == ROW and count == geo.height(k + 1) * geo.gld
         if count == 0:
             return
+        if geo.pc != root:
+            self._hold("early")
         self._rows(rbuf, roff, geo.height(k + 1), k + 1, 1, k)      # (the root keeps a copy too, as ncclBroadcast gives it)
 
     def panel_bcast(self, buf, pieces):
         geo, k = self.geo, self.k
         if self.pace_us is not None and geo.pc != k % geo.Pc and int(self.pace_us[k]) > 0:
             self._emit(OP["SPIN"], (), (int(self.pace_us[k]), 1))      # the foreign holder's latency (COMM stream, in order)
+        if geo.pc != k % geo.Pc:
+            self._hold("panel")
         for off, cnt, root in pieces:
             if root == self.rank or cnt == 0:
                 continue
@@ -87,6 +110,8 @@ class ReplayComm(Emitter):
                 assert off == geo.piece_off(p) + geo.dsz and cnt == m * geo.gld
             if m > 0:
                 self._rows(buf, off, m, p + geo.li0(p, k) * geo.Pr, geo.Pr, k)
+        if self.pace is not None:
+            self._emit(OP["SPIN"], (), (k + 1, 2))       # stamp: panel k has arrived
 
     def reduce_grp(self, *a):
         raise NotImplementedError("the substitution sweeps are not replayable on one rank")
