@@ -364,8 +364,8 @@ def multi_gpu_replay(ctx, dev, spec, Xh, yh, Zh, noise, K, X, fit_ms, step_ms, g
     dev.kfill_into(ctx, spec, X, K, nugget=noise)      # (the isolated fill launches above left an unfactored matrix in K)
     dev.potrf(ctx, K)
     ctx.sync()
-    fit = dist_replay.paced_grid(ctx, spec, Xh, yh, Zh[:1024], noise, K, X, grid, nb=nb, streamed=False, iters=4, steps=2)
-    both = dist_replay.paced_grid(ctx, spec, Xh, yh, Zh, noise, K, X, grid, nb=nb, streamed=True, iters=5, steps=2)
+    fit = dist_replay.paced_grid(ctx, spec, Xh, yh, Zh[:1024], noise, K, X, grid, nb=nb, streamed=False, iters=6, steps=2)
+    both = dist_replay.paced_grid(ctx, spec, Xh, yh, Zh, noise, K, X, grid, nb=nb, streamed=True, iters=8, steps=2)
     if "error" in fit or "error" in both:
         return {"error": fit.get("error") or both.get("error")}
     # the OTHER schedule of the step: factorisation, then each rank evaluates its M / 8 slice against its replica (the product

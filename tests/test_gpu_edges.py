@@ -286,3 +286,25 @@ def test_distributed_scratches_are_reserved_by_the_constructor():
     assert ctx.lib.gpx_dist2_reserve(ctx.h, 512, 4, 4096) == 0
     assert ctx.lib.gpx_dist2_reserve(ctx.h, 256, 2, 1024) == 0
     assert ctx.lib.gpx_dist2_reserve(ctx.h, 100, 2, 1024) < 0     # nb must be a multiple of 128
+
+
+def test_stamp_and_spin_until_pace_a_stream():
+    """The paced replay's two debug entries: a spin that ends `us` after a wall-clock stamp taken on the stream -- at once when the
+    moment has passed, and never a launch for us <= 0 -- is what holds a foreign delivery back (scripts/replay_comm.py)."""
+    import time
+    from gpexp_amd import device as dev
+    ctx = dev.context()
+    lib = ctx.lib
+    assert lib.gpx_dbg_stamp(ctx.h, 5) == 0 and lib.gpx_dbg_spin_until(ctx.h, 5, 0) == 0
+    ctx.sync()
+    t0 = time.perf_counter()
+    assert lib.gpx_dbg_stamp(ctx.h, 7) == 0
+    assert lib.gpx_dbg_spin_until(ctx.h, 7, 20000) == 0        # 20 ms after the stamp
+    ctx.sync()
+    first = time.perf_counter() - t0
+    assert 0.019 < first < 0.2, first
+    t0 = time.perf_counter()
+    assert lib.gpx_dbg_spin_until(ctx.h, 7, 20000) == 0        # that moment has passed: returns at once
+    ctx.sync()
+    assert time.perf_counter() - t0 < 0.01
+    assert lib.gpx_dbg_stamp(ctx.h, 1024) < 0 and lib.gpx_dbg_spin_until(ctx.h, -1, 5) < 0
