@@ -50,6 +50,14 @@ def own_step_latencies(ctx, geo):
     own_step_latencies.dfact = {k: at(dist.E_DFACT, k) - (arr[k - 1] if k > 0 else 0.0) for k in own if k % geo.Pr == geo.pr}
     own_step_latencies.early = {k: at(dist.E_EARLYSOLVED, k) - (arr[k - 1] if k > 0 else 0.0)
                                 for k in own if k + 1 < geo.nblk and (k + 1) % geo.Pr == geo.pr}
+    if os.environ.get("GPX_REPLAY_DETAIL") == "1":   # how far the strands that release a panel buffer run behind its arrival
+        for kind, nm in ((dist.E_STORED, "copied into the replica (BACK)"), (dist.E_UPD, "near updates (MAIN)"),
+                         (dist.E_BULK, "bulk update of the group (EVAL / BULK)"), (dist.E_PANELDONE, "panel stream")):
+            lags = [(at(kind, k) - arr[k], k) for k in range(geo.nblk) if at(kind, k) is not None and at(kind, k) > 0]
+            if lags:
+                print("# lag behind the panel's arrival, %-40s mean %6.3f ms, max %6.3f ms at k = %d, in steps of the chain: max %.1f"
+                      % (nm + ":", sum(v for v, _ in lags) / len(lags), max(lags)[0], max(lags)[1],
+                         max(v / max(arr[min(k + 1, geo.nblk - 1)] - arr[k], 1e-3) for v, k in lags if k + 1 < geo.nblk)), file=sys.stderr)
     if os.environ.get("GPX_REPLAY_DETAIL") == "1":   # where an own holder step spends its latency
         print("# own holder steps: k, [ARRIVED(k-1)] -> near update of column k done (COLREADY) -> diagonal factored (DFACT) -> "
               "panel solved (PIECE) -> delivered (ARRIVED); ms relative to ARRIVED(k-1)", file=sys.stderr)
