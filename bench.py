@@ -390,6 +390,10 @@ def multi_gpu_replay(ctx, dev, spec, Xh, yh, Zh, noise, K, X, fit_ms, step_ms, g
                 "chain_ms": r["chain_ms"], "chain_ms_by_process_column": r["chain_ms_by_process_column"],
                 "chain_ms_per_iteration": [h["chain_ms"] for h in r["iterations"]],
                 "paced_step_ms": r["paced_step_ms"], "paced_step_ms_max": r["paced_step_ms_max"],
+                "diagonal_chain_paced": r.get("diagonal_chain_paced"),
+                # what the stand-in device copies of the receives cost the slowest rank's communication stream (in the paced step)
+                "standin_copy_ms_max": max([v for v in (r.get("foreign_excess_ms") or {}).values() if v is not None] or [None],
+                                           key=lambda v: -1.0 if v is None else v),
                 "holder_latency_ms_first_mid_last": r["holder_latency_ms_first_mid_last"],
                 "bytes_received_per_step": r["bytes_received_per_fit"], "variance_check_rel": r["variance_check_rel"]}
     out = {"grid": "%dx%d" % grid, "nb": nb,

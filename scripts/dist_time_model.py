@@ -1,72 +1,62 @@
-"""Time model of the 2-D block-cyclic fit (gpexp_amd/dist.py), round 3: the per-rank GPU time and the host issue
-time are MEASURED (single-rank replay of rank (pr, pc)'s exact kernel sequence on one MI355X, scripts/dist_replay.py ->
-profiles/r03_dist_replay_fit_only.json / _fit_ivar.json); only the xGMI terms are still assumptions, because RCCL with more
-than one rank has never run on the build's hardware (one GPU per lease).
+"""Node PROJECTION of the 2-D block-cyclic fit from the paced replay, round 4.  MEASURED (on one MI355X): the chain
+across ranks and every rank's kernels, with each receive standing in as a device copy of the same bytes
+(bench.py `multi_gpu_replay`, or a `scripts/dist_replay.py --paced-grid` line).  MODELLED (RCCL with more than one rank has never
+run on the build's hardware -- one GPU per lease): what xGMI adds.  The two are kept apart in the output.
 
-    python scripts/dist_time_model.py [profiles/r03_dist_replay_fit_only.json profiles/r03_dist_replay_fit_ivar.json]
+    python scripts/dist_time_model.py [profiles/r04_bench_n1.json]
 
-Per grid: the slowest replayed rank's GPU time per step (every receive already costs its device copy there, so staging is in),
-its host issue time, the bytes that rank receives per fit, and two bracketing projections of the step on a real node:
-  overlapped  max(GPU time, communication time): transfers hidden behind compute (what the stream plumbing is built for)
-  exposed     GPU time + communication time: nothing hidden
-with communication time = bytes received / (links used x 153 GB/s x 0.8) + 2 latency hops x 25 us x panel steps.  Links used:
-the all-link panel broadcast (gpx_comm_panel_bcast) delivers over all W-1 links of the receiver; at 2 ranks there is one link."""
+Model.  The panel of step k is on the chain: panel k+1's solve needs it.  In the replay its pieces arrive as device copies on the
+communication stream, in order, behind the pacing spin -- `foreign_copy_ms`, what those copies cost a rank over a factorisation, is
+measured (the replay's `foreign_excess_ms`).  On a node the same bytes come over the receiver's links instead:
+    transfer(k) = bytes_in(k) / (links x 153 GB/s x eff) + 2 phases x hop latency       (gpx_comm_panel_bcast: scatter + all-gather
+                                                                                         over all W - 1 links of the receiver)
+and the two small broadcasts of the diagonal chain (L_kk down the process column, L[k+1, k] along the process row; 2.6 and 2.1 MB
+at nb = 512) cost one hop each: latency + bytes / (one link x eff).  The projection replaces the stand-in copies by the modelled
+transfers and adds the small hops to every step (pessimistic: the diagonal chain is not the longer one in every step):
+    projected = paced step - foreign_copy_ms + sum_k transfer(k) + steps x (hop(L_kk) + hop(L[k+1, k]))
+for eff in {0.8, 0.5} and hop latency in {10, 25} us.  None of it is a measurement of xGMI."""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-f_fit = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_dist_replay_fit_only.json")
-f_all = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r03_dist_replay_fit_ivar.json")
-LINK, EFF, LAT = 153e9, 0.8, 25e-6
-# The GLOBAL diagonal chain, which no single-rank replay contains (a rank executes only the diagonal blocks it owns; the others'
-# arrive as copies): per panel step the potrf of one nb = 512 block (4 leaves + strip multiplies + rank-128 updates: 0.30 ms
-# measured), the early solve of block row k+1 (0.08 ms) and two small broadcasts -- a lower bound of the factorisation at any grid.
-CHAIN_STEP = 0.30e-3 + 0.08e-3 + 2 * LAT
+path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r04_bench_n1.json")
+LINK = 153e9
 
+line = None
+for ln in open(path):
+    if ln.startswith("{"):
+        line = json.loads(ln)
+rep = line.get("multi_gpu_replay", line)          # a bench line, or a paced_grid line itself
+fit = rep.get("fit_only", rep)
+Pr, Pc = (int(v) for v in rep.get("grid", "2x4").split("x"))
+W, nb = Pr * Pc, int(rep.get("nb", 512))
+N = int(line.get("config", {}).get("N", 32768)) if "config" in line else 32768
+steps = (N + nb - 1) // nb
+paced = float(fit["paced_step_ms_max"])
+single = float(rep.get("single_gpu_fit_ms", rep.get("single_gpu_potrf_ms", 0.0)))
+excess = fit.get("foreign_excess_ms") or {}
+copy_ms = fit.get("standin_copy_ms_max") or (max(excess.values()) if excess else 7.0)  # measured where the line carries it
+bytes_in = float(fit.get("bytes_received_per_step", fit.get("bytes_received_per_fit", 0.0)))
 
-def worst(path):
-    out = {}
-    for r in json.load(open(path)):
-        g = r["grid"]
-        if g not in out or r["ms_per_step"] > out[g]["ms_per_step"]:
-            out[g] = r
-    return out
-
-
-fit, full = worst(f_fit), worst(f_all)
-single_potrf = next(iter(fit.values()))["single_gpu_potrf_ms"]
-print("inputs: %s, %s" % (os.path.basename(f_fit), os.path.basename(f_all)))
-print("single-GPU potrf in the same run: %.1f ms (this box; boxes of the pool differ by up to 10 %%)\n" % single_potrf)
-print("FACTORISATION alone (kfill + dist2_potrf; evaluation set of 1024 points)")
-print("%-5s %6s | %12s %10s %9s %8s | %11s %11s | %18s" % ("grid", "ranks", "GPU ms/step", "host ms", "GB recv", "comm ms", "overlapped",
-                                                            "exposed", "speed-up vs 1 GPU"))
-for g in ("1x1", "1x2", "2x2", "2x4"):
-    if g not in fit:
-        continue
-    r = fit[g]
-    W = int(g[0]) * int(g[2])
-    links = max(W - 1, 1)
-    comm = (r["bytes_received_per_fit"] / (links * LINK * EFF) + 2 * LAT * r["steps_k"]) if W > 1 else 0.0
-    t = r["ms_per_step"] * 1e-3
-    chain = CHAIN_STEP * r["steps_k"] if W > 1 else 0.0
-    lo, hi = max(t, comm, chain), max(t, chain) + comm
-    print("%-5s %6d | %12.1f %10.1f %9.2f %8.1f | %8.1f ms %8.1f ms | %6.1fx .. %5.1fx   (global chain floor %.1f ms)" %
-          (g, W, 1e3 * t, r["host_issue_ms_per_fit"], r["bytes_received_per_fit"] / 1e9, 1e3 * comm, 1e3 * lo, 1e3 * hi,
-           single_potrf / (1e3 * hi), single_potrf / (1e3 * lo), 1e3 * chain))
-print("\nFIT + IVAR over M = 32768 (the bench step without alpha / logdet; IVAR streamed from 4 ranks)")
-print("%-5s %6s | %12s %9s %8s | %11s %11s" % ("grid", "ranks", "GPU ms/step", "GB recv", "comm ms", "overlapped", "exposed"))
-for g in ("1x1", "1x2", "2x2", "2x4"):
-    if g not in full:
-        continue
-    r = full[g]
-    W = int(g[0]) * int(g[2])
-    links = max(W - 1, 1)
-    comm = (r["bytes_received_per_fit"] / (links * LINK * EFF) + 2 * LAT * r["steps_k"]) if W > 1 else 0.0
-    t = r["ms_per_step"] * 1e-3
-    extra = "" if r["streamed_ivar"] else "  (+ IVAR after the fit: ~487 ms / %d ranks, not in this replay)" % W
-    print("%-5s %6d | %12.1f %9.2f %8.1f | %8.1f ms %8.1f ms%s" % (g, W, 1e3 * t, r["bytes_received_per_fit"] / 1e9, 1e3 * comm,
-                                                                 1e3 * max(t, comm), 1e3 * (t + comm), extra))
-print("\nalpha / log det behind the step: 2.8 ms of launches (streamed grids: backward sweep only, 128 small collectives) or 3.6 ms "
-      "(grids with a replica: local sweeps, no exchange) -- scripts/probe_dist_solve.py")
-print("NOT measured: xGMI transfer time, RCCL launch latency, waiting for peers.  Measured: everything a rank's GPU and host do.")
+print("input: %s   grid %dx%d, N = %d, nb = %d, %d panel steps" % (os.path.basename(path), Pr, Pc, N, nb, steps))
+print("MEASURED  paced step of the slowest rank %.1f ms (chain %.1f ms), stand-in copies of the receives in it ~%.1f ms, %.2f GB received "
+      "per rank and fit, single-GPU fit %.1f ms -> %.2fx" % (paced, float(fit["chain_ms"]), copy_ms, bytes_in / 1e9, single, single / paced))
+print("MODELLED  (assumptions in the header; not a measurement)")
+print("%-28s %12s %12s %12s %10s" % ("links eff / hop latency", "panels ms", "small hops ms", "projected ms", "vs 1 GPU"))
+dsz = (nb * nb + nb * 128) * 8.0           # L_kk + its leaf inverses
+early = nb * nb * 8.0                       # L[k+1, k]
+for eff in (0.8, 0.5):
+    for lat in (10e-6, 25e-6):
+        # bytes a rank receives in step k: the panel's (N - (k+1) nb) x nb doubles minus its own piece (1 / W of it on average)
+        panels = sum(max(N - (k + 1) * nb, 0) * nb * 8.0 * (W - 1) / W / ((W - 1) * LINK * eff) + 2 * lat for k in range(steps))
+        hops = steps * ((lat + dsz / (LINK * eff)) * (1 if Pr > 1 else 0) + (lat + early / (LINK * eff)) * (1 if Pc > 1 else 0))
+        proj = paced - copy_ms + 1e3 * panels + 1e3 * hops
+        print("%-28s %12.1f %12.1f %12.1f %9.2fx" % ("%.1f / %2.0f us" % (eff, lat * 1e6), 1e3 * panels, 1e3 * hops, proj,
+                                                   single / proj if single else float("nan")))
+ivar = rep.get("ivar_slice_after_fit_ms")
+if ivar:
+    step1 = float(rep.get("single_gpu_step_ms", 0.0))
+    print("\nfit + IVAR (evaluation after the fit against the rank's replica: no exchange but the final all-gather of M values):")
+    print("MEASURED  %.1f + %.1f ms = %.1f ms -> %.2fx of the single-GPU step (%.1f ms); the projection adds the same xGMI terms as above"
+          % (paced, float(ivar), float(rep["fit_then_ivar_ms"]), step1 / float(rep["fit_then_ivar_ms"]), step1))
