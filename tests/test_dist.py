@@ -107,6 +107,20 @@ def test_panel_loop_2d_schedules_gloo_cpu(world, n, nb, grid, agg, bulk):
     assert "world=%d" % world in out
 
 
+@pytest.mark.parametrize("world,n,nb,env", [
+    (4, 1500, 128, {"GPX_DIST2_STAGED_DIAG": "0"}),                              # diagonal block factored out of the local matrix (round 3)
+    (4, 1500, 128, {"GPX_DIST_GATE_BULK": "0"}), (8, 1700, 128, {"GPX_DIST_GATE_BULK": "1"}),
+    (4, 1500, 128, {"GPX_DIST2_HOIST_INV": "0", "GPX_DIST2_LATE_COPYBACK": "0"}),
+    (2, 1300, 128, {"GPX_DIST_EARLY_BUF": "0", "GPX_DIST_AGG": "1"})])
+def test_panel_loop_2d_round4_knobs_gloo_cpu(world, n, nb, env):
+    """Round 4 moved work off the chain across ranks step by step, each step behind a switch (staged diagonal block, deferred bulk
+    update, hoisted inverse + late copy-back, the early block row's own buffer): the older forms stay valid schedules -- same
+    factor, same dependency checks of the NumPy double (NaN-poisoned buffers, asserted reads), distributed substitution."""
+    out = launch(world, ["--mode", "cpu2d", "--npts", str(n), "--blk", str(nb), "--grid", ""], dict(env, GPX_DIST_SOLVE="dist"),
+                 timeout=900)
+    assert "world=%d" % world in out
+
+
 @pytest.mark.parametrize("world,n,nb", [(2, 700, 128), (4, 900, 128), (8, 1100, 128)])
 def test_c5_sharded_gradient_and_mi_gloo_cpu(world, n, nb):
     """BASELINE config C5 in its multi-GPU form, host logic over gloo with NumPy doubles: distributed fit,
