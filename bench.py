@@ -180,7 +180,7 @@ def bench_c5(args, ctx, dev, world, rank, stdout_fd):
         fc_timer, fc = first_contact_watchdog(rank, world) if world > 1 else (None, {})
         comm = dist.init_from_env(ctx)
         fc["phase"] = "the runner's constructor (ncclCommSplit)"
-        runner = dist.DistFitGrad2D(ctx, comm, spec, Xh, yh, noise, nb=int(os.environ.get("GPX_DIST_NB", "512")), cand=Ch, nsel=8)
+        runner = dist.DistFitGrad2D(ctx, comm, spec, Xh, yh, noise, nb=None, cand=Ch, nsel=8)
         fc["phase"] = "the first all-gather behind the constructor"
         comm.barrier()
         if fc_timer is not None:
@@ -360,12 +360,14 @@ def multi_gpu_replay(ctx, dev, spec, Xh, yh, Zh, noise, K, X, fit_ms, step_ms, g
         sys.path.insert(0, scripts)
     import dist_replay
     t0 = time.perf_counter()
-    nb = int(os.environ.get("GPX_DIST_NB", "512"))
+    from gpexp_amd import dist as _d
+    nb = _d.default_nb(len(Xh), grid[0] * grid[1], False)        # what the product's runners choose at this size and world
+    nb_streamed = _d.default_nb(len(Xh), grid[0] * grid[1], True)
     dev.kfill_into(ctx, spec, X, K, nugget=noise)      # (the isolated fill launches above left an unfactored matrix in K)
     dev.potrf(ctx, K)
     ctx.sync()
     fit = dist_replay.paced_grid(ctx, spec, Xh, yh, Zh[:1024], noise, K, X, grid, nb=nb, streamed=False, iters=6, steps=2)
-    both = dist_replay.paced_grid(ctx, spec, Xh, yh, Zh, noise, K, X, grid, nb=nb, streamed=True, iters=8, steps=2)
+    both = dist_replay.paced_grid(ctx, spec, Xh, yh, Zh, noise, K, X, grid, nb=nb_streamed, streamed=True, iters=8, steps=2)
     if "error" in fit or "error" in both:
         return {"error": fit.get("error") or both.get("error")}
     # the OTHER schedule of the step: factorisation, then each rank evaluates its M / 8 slice against its replica (the product
@@ -396,7 +398,7 @@ def multi_gpu_replay(ctx, dev, spec, Xh, yh, Zh, noise, K, X, fit_ms, step_ms, g
                                            key=lambda v: -1.0 if v is None else v),
                 "holder_latency_ms_first_mid_last": r["holder_latency_ms_first_mid_last"],
                 "bytes_received_per_step": r["bytes_received_per_fit"], "variance_check_rel": r["variance_check_rel"]}
-    out = {"grid": "%dx%d" % grid, "nb": nb,
+    out = {"grid": "%dx%d" % grid, "nb": nb, "nb_streamed": nb_streamed,
            "method": "paced single-rank replays on one GPU, every rank of the grid in turn, foreign panels held back by the "
                      "measured latency of their holder column, iterated; see scripts/dist_replay.py paced_grid",
            "fit_only": brief(fit), "fit_ivar_streamed": brief(both),
@@ -533,8 +535,9 @@ def main():
         fc["phase"] = "the runner's constructor (ncclCommSplit)"
         # default: north_star's 2-D block-cyclic layout (Pr x Pc grid, gpexp_amd/dist.py); GPX_DIST_LAYOUT=1d selects the
         # round-1 block-column layout (every rank holds the full matrix, one ncclBroadcast per panel)
-        nb = int(os.environ.get("GPX_DIST_NB", "512"))
         want_2d = os.environ.get("GPX_DIST_LAYOUT", "2d") != "1d"
+        nb1d = int(os.environ.get("GPX_DIST_NB", "512"))       # block-column width of the 1-D fallback layout
+        nb = dist.default_nb(N, world, False) if want_2d else nb1d
         runner, err = None, ""
         if want_2d:
             try:
@@ -552,7 +555,7 @@ def main():
             runner = None
             want_2d = False
         if runner is None:
-            runner = dist.DistFitIvar(ctx, comm, spec, Xh, yh, Zh, noise, nb=nb)
+            runner = dist.DistFitIvar(ctx, comm, spec, Xh, yh, Zh, noise, nb=nb1d)
             layout = "1-D block-cyclic columns" + ("" if os.environ.get("GPX_DIST_LAYOUT") == "1d" else " (2-D setup failed)")
         else:
             layout = "2-D block-cyclic %dx%d grid, nb=%d, %d panels per trailing update" % (runner.geo.Pr, runner.geo.Pc, nb, runner.agg)
@@ -575,7 +578,7 @@ def main():
                 first = preflight
                 del runner
                 want_2d = False
-                runner = dist.DistFitIvar(ctx, comm, spec, Xh, yh, Zh, noise, nb=nb)
+                runner = dist.DistFitIvar(ctx, comm, spec, Xh, yh, Zh, noise, nb=nb1d)
                 layout = "1-D block-cyclic columns (the 2-D preflight failed)"
                 preflight = dist_preflight(ctx, comm, dist, dev, spec, d, nb=min(nb, 256), two_d=False)
                 preflight["failed_2d_preflight"] = first

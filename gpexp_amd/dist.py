@@ -858,14 +858,33 @@ EV_FORK, EV_PRE, EV_JOIN0 = 1, 2, 3            # event ids below 14 are free (id
 ALL_SIDE_STREAMS = (PANEL, COMM, BACK, EVAL, BULK)
 
 
-def default_agg(streamed=True, world=8):
+def default_agg(streamed=True, world=8, nb=512):
     """Panels per aggregated trailing update (GPX_DIST_AGG; K = agg * nb per launch).  4 -> K = 2048 at nb = 512 where the
     evaluation is streamed underneath the factorisation (the rank is throughput-bound: longer K, fewer launches); 2 for the
     factorisation alone, whose time on a real grid is the chain ACROSS ranks: shorter-lived bulk tiles give the chain's kernels
-    their slots sooner (paced replay of the 2 x 4 grid at C4: 51 ms with 2, 54 with 4 or 1; fit + IVAR: 113 with either)."""
+    their slots sooner (paced replay of the 2 x 4 grid at C4: 51 ms with 2, 54 with 4 or 1; fit + IVAR: 113 with either).  Blocks
+    of 1024 (default_nb) carry half as many: the same K."""
     # (1-2 ranks: each rank carries half or all of the trailing updates -- throughput-bound like the streamed case; world-1 RCCL
     # bench 695 ms with 4 panels per update, 710 with 2)
-    return max(1, min(8, int(os.environ.get("GPX_DIST_AGG", "4" if (streamed or world < 4) else "2"))))
+    dflt = 4 if (streamed or world < 4) else 2
+    if nb >= 1024:
+        dflt = max(1, dflt // 2)
+    return max(1, min(8, int(os.environ.get("GPX_DIST_AGG", str(dflt)))))
+
+
+def default_nb(n, world=8, streamed=False):
+    """Block size of the 2-D block-cyclic layout (GPX_DIST_NB).  512 from N = 8192 (256 / 128 below: at least a few block steps
+    per rank).  Eight ranks and more, factorisation without a streamed evaluation, N >= 16384: 1024 -- the time of such a grid is
+    the chain ACROSS ranks, a sum over the block steps of ~20 small dependent launches and two hops, and half as many steps
+    with twice the work each is shorter (paced replay of the 2 x 4 grid at C4, all ranks, diagonal chain paced: 44.6 ms against
+    48-50 at 512; 2048: 47.8, the panel solves and near updates of a step then outweigh what the fewer steps save; a 2 x 2 grid is
+    throughput-bound and indifferent: 61.5 / 61.8 ms -- profiles/r04_dist_paced_sweeps2.txt)."""
+    env = os.environ.get("GPX_DIST_NB")
+    if env:
+        return int(env)
+    if n >= 16384 and world >= 8 and not streamed:
+        return 1024
+    return 512 if n >= 8192 else (256 if n >= 2048 else 128)
 
 
 def ring_size(agg):
@@ -1332,14 +1351,13 @@ class DistFitIvar2D:
       evaluation after the fit (the default below N = 98304), C5, the class API   a REPLICATED copy (N^2: 8.6 GB at C4, 34 GB at C5 of the 288 GB), against
           which the evaluation / the gradient slabs run with no exchange."""
 
-    def __init__(self, ctx, comm, spec, Xh, yh, Zh, noise, nb=512, ops=None, streamed=None, grid=None, agg=None,
+    def __init__(self, ctx, comm, spec, Xh, yh, Zh, noise, nb=None, ops=None, streamed=None, grid=None, agg=None,
                  fit_only=False, replicate=None):
         self.ctx, self.comm, self.spec = ctx, comm, spec
         self.ops = ops or DeviceOps2D(ctx)
         Pr, Pc = grid or choose_grid(comm.world)
         comm.set_grid(Pr, Pc)
         self.n, self.noise = Xh.shape[0], float(noise)
-        self.geo = Grid2D(self.n, nb, Pr, Pc, comm.rank)
         # Evaluation streamed underneath the factorisation (against a window of the factor: no N x N replica) or after it
         # (against the rank's replica).  Round 3 streamed from 4 ranks because a rank's BUSY time was lower that way; the paced
         # replay of round 4 (DESIGN 6.2) says the opposite for the time of the GRID: the streamed solve's GEMMs slow the chain
@@ -1351,7 +1369,11 @@ class DistFitIvar2D:
         self.streamed = (comm.world >= 4 and big) if streamed is None else bool(streamed)
         if env is not None:
             self.streamed = env == "1"
-        self.agg = default_agg(self.streamed and Zh.shape[0] > 0, comm.world) if agg is None else int(agg)
+        # (nb = None: default_nb -- decided from N, the world size and the evaluation schedule alone: the same on every rank)
+        nb = default_nb(self.n, comm.world, self.streamed and Zh.shape[0] > 0) if nb is None else int(nb)
+        self.nb = nb
+        self.geo = Grid2D(self.n, nb, Pr, Pc, comm.rank)
+        self.agg = default_agg(self.streamed and Zh.shape[0] > 0, comm.world, nb) if agg is None else int(agg)
         self.fit_only = bool(fit_only)       # replay: factorisation (+ streamed evaluation) only
         self.yh = np.ascontiguousarray(yh, dtype=np.float64)
         self.m = Zh.shape[0]
@@ -1595,7 +1617,7 @@ class DistFitGrad2D(DistFitIvar2D):
     with its traces sharded over the ranks (dist_lml_grad) and -- optionally -- a greedy MI design over `cand` candidates with
     the scoring sharded (dist_mi_greedy)."""
 
-    def __init__(self, ctx, comm, spec, Xh, yh, noise, nb=512, cand=None, nsel=8, be=None, **kw):
+    def __init__(self, ctx, comm, spec, Xh, yh, noise, nb=None, cand=None, nsel=8, be=None, **kw):
         super().__init__(ctx, comm, spec, Xh, yh, np.zeros((0, Xh.shape[1])), noise, nb=nb, streamed=False, **kw)
         self.cand, self.nsel, self.be = cand, int(nsel), be
         self.times = {}
@@ -1669,9 +1691,8 @@ class Session:
     def use_eval(self, m):
         return self.world > 1 and m >= max(self.min_m, self.world)
 
-    @staticmethod
-    def nb_for(n):
-        return 512 if n >= 8192 else (256 if n >= 2048 else 128)
+    def nb_for(self, n):
+        return default_nb(n, self.world, False)
 
     # ---- the SPMD contract, checked ----
     def agree(self, what, *arrays):

@@ -46,6 +46,18 @@ def launch(world, extra, env_extra=None, timeout=600):
     return r.stdout
 
 
+def test_default_block_size_and_aggregation():
+    """default_nb / default_agg: decided from (N, world, evaluation schedule) alone -- the same on every rank -- and the product of
+    the two (the k range of a trailing update) stays 2048 where a rank is throughput-bound and 1024 where the chain across ranks
+    bounds the grid."""
+    from gpexp_amd import dist
+    assert [dist.default_nb(n, 8) for n in (1000, 2048, 8192, 16384, 32768)] == [128, 256, 512, 1024, 1024]
+    assert dist.default_nb(32768, 4) == 512 and dist.default_nb(32768, 8, streamed=True) == 512 and dist.default_nb(131072, 8, True) == 512
+    for world, streamed in ((1, False), (2, False), (4, False), (8, False), (8, True)):
+        nb = dist.default_nb(32768, world, streamed)
+        assert dist.default_agg(streamed, world, nb) * nb == (2048 if (streamed or world < 4) else 1024)
+
+
 def test_index_logic():
     from gpexp_amd import dist
     assert dist.padded(1) == 128 and dist.padded(128) == 128 and dist.padded(129) == 256
@@ -171,7 +183,8 @@ def test_grid_logic():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,n,nb,grid", [(2, 1500, 256, ""), (4, 2100, 256, ""), (3, 1900, 128, ""), (4, 900, 512, "4x1")])
+@pytest.mark.parametrize("world,n,nb,grid", [(2, 1500, 256, ""), (4, 2100, 256, ""), (3, 1900, 128, ""), (4, 900, 512, "4x1"),
+                                             (4, 4300, 1024, "")])
 def test_distributed_fit_ivar_2d_shared_gpu(world, n, nb, grid):
     """The 2-D path on the real HIP primitives (ranks share the GPU, host-staged exchange): replicated factor, alpha,
     log-likelihood and IVAR equal the single-GPU path; both evaluation schedules; repeatable bit for bit."""
