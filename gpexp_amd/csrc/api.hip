@@ -1023,7 +1023,8 @@ int gpx_refit_rows(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, c
     if ((r = gpx_dev_alloc(ctx, K->aux_bytes, &pa)) != 0) break;
     K->aux = (double*)pa;
     if (keep > 0) {
-      if ((r = gpx_copy2d(ctx, Lold->p, Lold->ld, K->p, K->ld, keep, keep)) != 0) break;
+      // (the lower triangle only: nothing reads a factor above its diagonal, and the new matrix starts zeroed)
+      if ((r = gpx_copy2d_lower(ctx, Lold->p, Lold->ld, K->p, K->ld, keep)) != 0) break;
       if (hipMemcpyAsync(K->aux, Lold->aux, (size_t)keep * GPX_TILE * 8, hipMemcpyDeviceToDevice, ctx->stream) !=
           hipSuccess) { r = -2; gpx_set_error("refit_rows: copy of the leaf inverses failed"); break; }
     }

@@ -105,12 +105,15 @@ namespace {
 // 512-column stripe (all loads first): with one 4 KB row per workgroup the panel copies of the distributed loop were
 // dispatch-bound at ~190 GB/s (profiles/r03_dist_replay_trace_2x4.txt, round-3 first trace: 20 ms of copies per step).
 constexpr int COPY_RPB = 8;
+// lower_row0 >= 0: only the part on / below the diagonal of a square block whose first row is lower_row0 rows above this launch's
+// (to the next 512-column boundary): column groups entirely above the diagonal return at once
 __global__ __launch_bounds__(256) void copy2d_kernel(const double* __restrict__ src, int64_t lds_,
                                                      double* __restrict__ dst, int64_t ldd, int64_t rows,
-                                                     int64_t cols) {
+                                                     int64_t cols, int64_t lower_row0) {
   const int64_t c2 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
   const int64_t r0 = (int64_t)blockIdx.y * COPY_RPB;
   if (c2 >= cols) return;
+  if (lower_row0 >= 0 && (int64_t)blockIdx.x * 512 > lower_row0 + r0 + COPY_RPB - 1) return;
   double2 v[COPY_RPB];
 #pragma unroll
   for (int i = 0; i < COPY_RPB; ++i)
@@ -122,17 +125,27 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const double* __restrict__ 
 
 }  // namespace
 
-int gpx_copy2d(gpx_ctx* ctx, const double* src, int64_t lds_, double* dst, int64_t ldd, int64_t rows, int64_t cols) {
+static int copy2d_impl(gpx_ctx* ctx, const double* src, int64_t lds_, double* dst, int64_t ldd, int64_t rows, int64_t cols,
+                       bool lower) {
   if (rows <= 0 || cols <= 0) return 0;
   // grid.y is limited to 65535 row groups per launch
   for (int64_t r0 = 0; r0 < rows; r0 += 65535 * (int64_t)COPY_RPB) {
     const int64_t rr = rows - r0 < 65535 * (int64_t)COPY_RPB ? rows - r0 : 65535 * (int64_t)COPY_RPB;
     dim3 grid((unsigned)((cols / 2 + 255) / 256), (unsigned)((rr + COPY_RPB - 1) / COPY_RPB));
     hipLaunchKernelGGL(copy2d_kernel, grid, dim3(256), 0, ctx->stream, src + r0 * lds_, lds_, dst + r0 * ldd, ldd, rr,
-                       cols);
+                       cols, lower ? r0 : (int64_t)-1);
   }
   GPX_HIP(hipGetLastError());
   return 0;
+}
+
+int gpx_copy2d(gpx_ctx* ctx, const double* src, int64_t lds_, double* dst, int64_t ldd, int64_t rows, int64_t cols) {
+  return copy2d_impl(ctx, src, lds_, dst, ldd, rows, cols, false);
+}
+
+// the lower triangle of an n x n block (to 512-column granularity above the diagonal): what a factor's consumers read
+int gpx_copy2d_lower(gpx_ctx* ctx, const double* src, int64_t lds_, double* dst, int64_t ldd, int64_t n) {
+  return copy2d_impl(ctx, src, lds_, dst, ldd, n, n, true);
 }
 
 

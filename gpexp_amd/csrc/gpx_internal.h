@@ -230,6 +230,7 @@ int launch_kfill_cyclic(gpx_ctx* ctx, const KParams& kp, const double* X, int64_
                         int64_t nugget_len, double nugget_scalar, double* out, int64_t prows, int64_t pcols, int64_t ld,
                         int64_t nb, int Pr, int pr, int Pc, int pc);
 int gpx_copy2d(gpx_ctx* ctx, const double* src, int64_t lds_, double* dst, int64_t ldd, int64_t rows, int64_t cols);
+int gpx_copy2d_lower(gpx_ctx* ctx, const double* src, int64_t lds_, double* dst, int64_t ldd, int64_t n);
 int launch_kfill_rows(gpx_ctx* ctx, const KParams& kp, const double* X, int64_t n, int64_t row0, const double* d_nugget,
                       int64_t nugget_len, double nugget_scalar, double* out, int64_t prows_band, int64_t pcols,
                       int64_t ld);

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gpexp_amd import device as dev
 ctx = dev.context()
-for n, b in ((4096, 64), (8192, 64), (16384, 128), (16384, 1024)):
+for n, b in ((4096, 64), (8192, 64), (16384, 128), (16384, 512), (16384, 1024)):
     rng = np.random.default_rng(n)
     d = 8
     X = rng.uniform(-1, 1, (n, d))
