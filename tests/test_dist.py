@@ -104,7 +104,7 @@ def test_panel_loop_2d_fewer_points_than_ranks_gloo_cpu():
 
 
 @pytest.mark.parametrize("world,n,nb,grid,agg,bulk", [(4, 2100, 128, "", 4, "chunks"), (4, 1500, 128, "", 2, "chunks"),
-                                                     (2, 1700, 128, "", 3, "eval"), (8, 2100, 128, "", 8, "eval"),
+                                                     (2, 1700, 128, "", 3, "eval"), (8, 1500, 128, "", 8, "eval"),
                                                      (4, 1500, 128, "", 1, "main"), (6, 1500, 128, "", 4, "bulk"),
                                                      (2, 1700, 128, "", 5, "chunks"), (1, 1900, 128, "", 4, "eval")])
 def test_panel_loop_2d_schedules_gloo_cpu(world, n, nb, grid, agg, bulk):
@@ -121,7 +121,7 @@ def test_panel_loop_2d_schedules_gloo_cpu(world, n, nb, grid, agg, bulk):
 
 @pytest.mark.parametrize("world,n,nb,env", [
     (4, 1500, 128, {"GPX_DIST2_STAGED_DIAG": "0"}),                              # diagonal block factored out of the local matrix (round 3)
-    (4, 1500, 128, {"GPX_DIST_GATE_BULK": "0"}), (8, 1700, 128, {"GPX_DIST_GATE_BULK": "1"}),
+    (4, 1500, 128, {"GPX_DIST_GATE_BULK": "0"}), (4, 1300, 128, {"GPX_DIST_GATE_BULK": "1"}),
     (4, 1500, 128, {"GPX_DIST2_HOIST_INV": "0", "GPX_DIST2_LATE_COPYBACK": "0"}),
     (2, 1300, 128, {"GPX_DIST_EARLY_BUF": "0", "GPX_DIST_AGG": "1"})])
 def test_panel_loop_2d_round4_knobs_gloo_cpu(world, n, nb, env):
