@@ -77,7 +77,7 @@ def pace_from(lat, nblk):
     return np.maximum(np.interp(xs, ks, [lat[k] for k in ks]) * 1e3, 0.0).astype(np.int64)
 
 
-def paced_replay(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=512, agg=None, streamed=False, iters=3, steps=2):
+def paced_replay(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=None, agg=None, streamed=False, iters=3, steps=2):
     """The factorisation time of the WHOLE grid estimated on one GPU: replay `rank` with every foreign panel held back by the
     latency this rank shows in its own holder steps, and iterate (the latencies depend on how busy the rank is, which depends
     on the pacing).  Needs GPX_EVENT_TIMING=1 in the environment before the context's first event.  Returns a dict."""
@@ -95,13 +95,13 @@ def paced_replay(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=512, agg=
         hist.append(dict(paced=pace is not None, ms_per_step=res["ms_per_step"], own_latency_sum_ms=float(sum(lat.values())),
                          chain_estimate_ms=float(sum(lat.values())) * grid[1]))
         pace = pace_from(lat, res["steps_k"])
-    return dict(grid=res["grid"], rank=rank, nb=nb, streamed_ivar=bool(streamed), iterations=hist,
+    return dict(grid=res["grid"], rank=rank, nb=res["nb"], streamed_ivar=bool(streamed), iterations=hist,
                 unpaced_rank_busy_ms=hist[0]["ms_per_step"], paced_step_ms=hist[-1]["ms_per_step"],
                 own_latency_ms_first_last=[round(lat[min(lat)], 3), round(lat[max(lat)], 3)],
                 bytes_received_per_fit=res["bytes_received_per_fit"], variance_check_rel=res["variance_check_rel"])
 
 
-def paced_grid(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, nb=512, agg=None, streamed=False, iters=5, steps=2, rows=None):
+def paced_grid(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, nb=None, agg=None, streamed=False, iters=5, steps=2, rows=None):
     """The factorisation time of the WHOLE Pr x Pc grid estimated on ONE GPU.  Step k+1's panel solve needs step k's panel, so
     the factorisation time of a real run is the SUM over the steps of what the step's holder column needs from the arrival of
     panel k-1 to the delivery of panel k -- not any rank's busy time (a replay in which every foreign panel arrives at once keeps
@@ -137,7 +137,7 @@ def paced_grid(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, nb=512, agg=None, st
                 if own is None:
                     return dict(error="the pipeline's events carry no time stamps (set GPX_EVENT_TIMING=1 before the first use)")
                 nblk = res["steps_k"]
-                agg_used = res["agg"]
+                agg_used, nb = res["agg"], res["nb"]
                 for k, v in own.items():
                     newlat[k] = max(newlat.get(k, 0.0), v)
                 newdf.update(res.pop("own_dfact_ms") or {})
@@ -168,7 +168,7 @@ def paced_grid(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, nb=512, agg=None, st
                 bytes_received_per_fit=max(v["bytes_received_per_fit"] for v in last.values()))
 
 
-def replay_rank(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=512, agg=None, streamed=True, steps=3, profile=True,
+def replay_rank(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=None, agg=None, streamed=True, steps=3, profile=True,
                 single_potrf_ms=None, pace_us=None, want_latencies=False):
     """One process plays `rank` of the Pr x Pc `grid` against the complete factor `Lref` resident on this GPU: records the
     rank's program, checks what it computed against the single-GPU path, times `steps` steps.  Returns the result dict."""
@@ -204,6 +204,7 @@ def replay_rank(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=512, agg=N
         host.append(run.host_ms.get("factor", 0.0))
     geo = run.geo
     lat, arr_all = own_step_latencies(ctx, geo) if want_latencies else (None, None)
+    nb = run.nb
     res = dict(grid=gs, rank=rank, pr=geo.pr, pc=geo.pc, N=n, M=m, nb=nb, agg=run.agg, steps_k=geo.nblk,
                streamed_ivar=bool(streamed), factor_window_panels=run.window, ms_per_step=float(np.median(ts)), ms_all=ts,
                host_issue_ms_per_fit=float(np.median(host)), host_issue_us_per_panel_step=1e3 * float(np.median(host)) / geo.nblk,
@@ -250,7 +251,7 @@ def main():
     ap.add_argument("--n", type=int, default=32768)
     ap.add_argument("--m", type=int, default=32768)
     ap.add_argument("--d", type=int, default=8)
-    ap.add_argument("--nb", type=int, default=512)
+    ap.add_argument("--nb", type=int, default=0, help="block size (default: what the product's runner chooses, dist.default_nb)")
     ap.add_argument("--agg", type=int, default=None, help="panels per trailing update (default: 4 with the streamed evaluation, 2 without)")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--no-stream", action="store_true", help="factorisation alone (no evaluation streamed underneath, as the C5 fit)")
@@ -288,7 +289,7 @@ def main():
         Pr, Pc = (int(v) for v in gs.split("x"))
         world = Pr * Pc
         if args.paced_grid:
-            res = paced_grid(ctx, spec, Xh, yh, Zh, noise, Lref, X, (Pr, Pc), nb=args.nb, agg=args.agg,
+            res = paced_grid(ctx, spec, Xh, yh, Zh, noise, Lref, X, (Pr, Pc), nb=(args.nb or None), agg=args.agg,
                              streamed=(world >= 4 and not args.no_stream),
                              rows=[int(v) for v in args.rows.split(",")] if args.rows else None, iters=args.iters)
             res["single_gpu_potrf_ms"] = single_potrf_ms
@@ -297,12 +298,12 @@ def main():
         ranks = sorted({(world - 1 if r == "last" else int(r)) for r in args.ranks.split(",") if r == "last" or int(r) < world})
         for rank in ranks:
             if args.paced:
-                res = paced_replay(ctx, spec, Xh, yh, Zh, noise, Lref, X, (Pr, Pc), rank, nb=args.nb, agg=args.agg,
+                res = paced_replay(ctx, spec, Xh, yh, Zh, noise, Lref, X, (Pr, Pc), rank, nb=(args.nb or None), agg=args.agg,
                                    streamed=(world >= 4 and not args.no_stream))
                 res["single_gpu_potrf_ms"] = single_potrf_ms
                 print(json.dumps(res), flush=True)
                 continue
-            res = replay_rank(ctx, spec, Xh, yh, Zh, noise, Lref, X, (Pr, Pc), rank, nb=args.nb, agg=args.agg,
+            res = replay_rank(ctx, spec, Xh, yh, Zh, noise, Lref, X, (Pr, Pc), rank, nb=(args.nb or None), agg=args.agg,
                               streamed=(world >= 4 and not args.no_stream), steps=args.steps, single_potrf_ms=single_potrf_ms)
             results.append(res)
             print(json.dumps(res), flush=True)
