@@ -1023,7 +1023,8 @@ int gpx_refit_rows(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, c
     if ((r = gpx_dev_alloc(ctx, K->aux_bytes, &pa)) != 0) break;
     K->aux = (double*)pa;
     if (keep > 0) {
-      // (the lower triangle only: nothing reads a factor above its diagonal, and the new matrix starts zeroed)
+      // (the lower triangle only, to the 512-column boundary above the diagonal -- every diagonal tile whole: nothing reads a
+      // factor's blocks above those; a full factorisation leaves the assembled K there, this one whatever the pool handed out)
       if ((r = gpx_copy2d_lower(ctx, Lold->p, Lold->ld, K->p, K->ld, keep)) != 0) break;
       if (hipMemcpyAsync(K->aux, Lold->aux, (size_t)keep * GPX_TILE * 8, hipMemcpyDeviceToDevice, ctx->stream) !=
           hipSuccess) { r = -2; gpx_set_error("refit_rows: copy of the leaf inverses failed"); break; }
