@@ -759,9 +759,13 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         line = {
-            "metric": "GP-fit+IVAR-eval points/s at N=%d d=%d (wall-time in ms_per_step)" % (N, d),
+            "metric": "GP-fit+IVAR-eval points/s at N=%d d=%d (wall-time in ms_per_step); value = (N+M)/t_step, SURVEY 8d's "
+                      "N/t_fit and M/t_IVAR are points_per_s_fit / points_per_s_ivar right behind it" % (N, d),
             "value": (N + M) / (dt / args.steps),
             "unit": "points/s",
+            "points_per_s_fit": (N / (fit_ms * 1e-3)) if fit_ms else None,
+            "points_per_s_ivar": (M / (ivar_ms * 1e-3)) if ivar_ms else None,
+            "fit_ms": fit_ms, "ivar_ms": ivar_ms,
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -795,9 +799,6 @@ def main():
                                    traffic=None),
             "roofline_kcross": dict(hbm(kc), kernel="kfill_rectn_kernel (rectangular N x M cross matrix, every element "
                                                    "computed)", traffic=None),
-            "fit_ms": fit_ms, "ivar_ms": ivar_ms,
-            "points_per_s_fit": (N / (fit_ms * 1e-3)) if fit_ms else None,
-            "points_per_s_ivar": (M / (ivar_ms * 1e-3)) if ivar_ms else None,
             "phase_note": "fit_ms (kfill + potrf + potrs + logdet) and ivar_ms are timed separately after the timed region "
                           "(inside it the alpha sweeps run underneath the IVAR GEMMs); roofline_kfill / roofline_kcross are "
                           "one isolated launch each between two host syncs, host clock, median of 5 (kernel duration + "

@@ -574,12 +574,6 @@ def dist_greedy_ivar(ctx, comm, spec, L, X, cand_host, mc_host, noise, nsel, wan
     return (idx, costs, allc) if want_all else (idx, costs)
 
 
-def dist_greedy_var(ctx, comm, spec, cand_host, nsel, keep=()):
-    """Greedy maximum-variance design is O(M*n) per step and sequential in the steps: every rank runs the identical
-    deterministic selection on the full candidate set (no exchange) -- "replicas" for this sub-path, by design."""
-    return _dev.greedy_var(ctx, spec, _dev.points(ctx, cand_host), nsel, keep=keep)
-
-
 # =====================================================================================================================
 # 2-D block-cyclic fit (north_star; SURVEY.md 8e) -- the default multi-GPU path
 # =====================================================================================================================

@@ -53,7 +53,8 @@ X, Z = dev.points(ctx, Xh), dev.points(ctx, Zh)
 L = dev.potrf(ctx, dev.kfill(ctx, sp, X, nugget=0.1))
 _, t = best(lambda: dev.ivar_grad(ctx, sp, L, X, Z))
 report("gpx_ivar_grad", "costFunctionGP_IVAR.derivative v1 (experimentalDesign.py:168-179)", dict(N=N, M=M, d=d), t,
-       flops=2.0 * N * N * M, note="two triangular solves on the N x M cross matrix + the contraction with dK/dx (fused reduction)")
+       flops=3.0 * N * N * M, note="ONE count, in SURVEY 8d's units (a triangular solve of an N x M block = N^2 M): beta = K^-1 K(X,Z) "
+       "is two solves (2 N^2 M), S = beta beta^T as a lower SYRK is N^2 M more; tr(dK/dx S) needs S")
 _, t = best(lambda: dev.var_grad_newpt(ctx, sp, L, X, Z))
 report("gpx_var_grad_newpt", "GP.evaluateVarianceDerivWRTnewpt (gp.py:261-280)", dict(N=N, M=M, d=d), t, flops=2.0 * N * N * M)
 Nv, Mv = (1024, 1024) if quick else (2048, 4096)
@@ -85,8 +86,9 @@ Mm = 2048 if quick else 8192
 Cm = dev.points(ctx, rng.uniform(-1, 1, (Mm, d5)))
 _, t = best(lambda: dev.mi_greedy(ctx, sp5, Cm, 0.1, 8, 0))
 report("gpx_mi_greedy", "costFunctionGP_MI + performGreedyMIExperimentalDesign (experimentalDesign.py:223-285, 753-785)",
-       dict(candidates=Mm, picks=8, d=d5), t, flops=Mm ** 3 / 3.0 + 2.0 * Mm ** 3 / 3.0 + Mm ** 3,
-       note="fit + full inverse of the M x M candidate covariance (MFMA), then 7 rank-one down-dates of it (HBM: 16 M^2 bytes each)")
+       dict(candidates=Mm, picks=8, d=d5), t, flops=Mm ** 3 / 3.0 + 2.0 * Mm ** 3 / 3.0,
+       note="SURVEY 8d count: potrf M^3/3 + potri 2 M^3/3 = M^3 (round 4 charged a dense M^3 product on top that the code no "
+            "longer executes); then 7 rank-one down-dates (HBM: 16 M^2 bytes each)")
 # ---- f4: FITC
 Nf = 8192 if quick else 32768
 nu = Nf // 8

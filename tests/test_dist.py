@@ -2,7 +2,8 @@
 the 2-D block-cyclic path (north_star) at world 2, 4, 6 and 8 on 1x2 / 2x2 / 2x3 / 2x4 grids with ragged N, and the 1-D
 block-column path at world 2 and 3.  GPU (-m gpu): real kernels, 2 to 6 ranks sharing the GPU through the host-staged
 communicator, and the RCCL communicator (ncclCommSplit, grouped send/recv) with world_size 1 -- RCCL with more than one
-rank needs more than one GPU and has not run anywhere yet."""
+rank needs more than one GPU: the `*_real_rccl` cases at the end switch themselves on when the box shows that many devices
+(one rank per device, GPX_COMM=rccl, same comparisons as the host-staged ones) and are collected-and-skipped otherwise."""
 import os
 import socket
 import subprocess
@@ -357,3 +358,86 @@ def test_distributed_fit_ivar_shared_gpu(world, n, nb):
 def test_rccl_communicator_world1():
     out = launch(1, ["--mode", "gpu", "--npts", "900", "--mpts", "300", "--blk", "256"], {"GPX_COMM": "rccl"})
     assert "RcclComm" in out
+
+
+# ---- real RCCL, one rank per device: switched on by the number of visible devices ------------------------------------------
+_VISIBLE = []
+
+
+def visible_gpus():
+    """HIP devices this box shows, counted in a CHILD process (hipGetDeviceCount through ctypes on libamdhip64): the test
+    runner itself is not asked to initialise a device for a decision about skipping, and nothing is exec-ed from a process that
+    holds one.  0 when there is no HIP runtime or no device."""
+    if not _VISIBLE:
+        code = ("import ctypes\n"
+                "try:\n"
+                "    h = ctypes.CDLL('libamdhip64.so')\n"
+                "    n = ctypes.c_int(0)\n"
+                "    print(n.value if h.hipGetDeviceCount(ctypes.byref(n)) == 0 else 0)\n"
+                "except OSError:\n"
+                "    print(0)\n")
+        try:
+            r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+            _VISIBLE.append(int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else 0)
+        except (OSError, ValueError, subprocess.TimeoutExpired):
+            _VISIBLE.append(0)
+    return _VISIBLE[0]
+
+
+def need_gpus(world):
+    n = visible_gpus()
+    if n < world:
+        pytest.skip("real RCCL at world %d needs %d visible devices, this box shows %d (RCCL refuses two ranks on one device)"
+                    % (world, world, n))
+
+
+RCCL_ENV = {"GPX_COMM": "rccl", "NCCL_DEBUG": "WARN"}     # no GPX_FORCE_DEVICE: rank r opens device LOCAL_RANK
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n,nb,grid", [(2, 1500, 256, ""), (4, 2100, 256, ""), (4, 4300, 1024, ""), (8, 4300, 256, ""),
+                                             (8, 2500, 128, "4x2")])
+def test_distributed_fit_ivar_2d_real_rccl(world, n, nb, grid):
+    """test_distributed_fit_ivar_2d_shared_gpu with the product communicator: ncclCommSplit row / column communicators, the
+    grouped send/recv panel broadcast, group broadcasts and all-reduces between REAL ranks; replicated factor, alpha,
+    log-likelihood and IVAR against the single-GPU path on every rank (L 1e-12, alpha 1e-10, the rest 1e-11)."""
+    need_gpus(world)
+    out = launch(world, ["--mode", "gpu2d", "--npts", str(n), "--mpts", "777", "--blk", str(nb), "--grid", grid], RCCL_ENV,
+                 timeout=900)
+    assert "RcclComm" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_class_api_golden_fixtures_real_rccl(world):
+    """The reference's fixtures through the class API over RCCL: 1e-10, indices exact, bit-identical arrays on every rank."""
+    need_gpus(world)
+    out = launch(world, ["--mode", "gpu-api"], RCCL_ENV, timeout=900)
+    assert "gpu-api world=%d cases=9" % world in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_class_api_c4_lite_reference_fixture_real_rccl(world):
+    """The N = 8192 reference fixture through the class API with the session's default thresholds over RCCL."""
+    need_gpus(world)
+    out = launch(world, ["--mode", "gpu-api-c4lite"], RCCL_ENV, timeout=900)
+    assert "gpu-api-c4lite world=%d" % world in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n,m,nb", [(2, 1500, 300, 256), (4, 2100, 517, 256), (8, 2900, 700, 128)])
+def test_c5_distributed_gradient_and_mi_real_rccl(world, n, m, nb):
+    """Config C5 over RCCL: sharded gradient == single-GPU gpx_lml_grad (1e-10), sharded MI picks == gpx_mi_greedy."""
+    need_gpus(world)
+    out = launch(world, ["--mode", "gpu-c5", "--npts", str(n), "--mpts", str(m), "--blk", str(nb)], RCCL_ENV, timeout=900)
+    assert "gpu-c5 world=%d" % world in out
+
+
+def test_real_rccl_cases_are_collected_and_gate_on_the_device_count():
+    """CPU side of the switch: the counter answers (0 here), and a case asked for more devices than that skips with the reason."""
+    n = visible_gpus()
+    assert isinstance(n, int) and n >= 0
+    with pytest.raises(pytest.skip.Exception) as e:
+        need_gpus(n + 1)
+    assert "visible devices" in str(e.value)
