@@ -39,6 +39,7 @@ __device__ __forceinline__ double readlane_d(double v, int srclane) {
 constexpr int LB = 16;          // block edge
 constexpr int TS17 = LB + 1;    // row stride inside a 16 x 16 block (odd: conflict-free fragment reads)
 constexpr int BSZ = LB * TS17;  // doubles per stored block
+constexpr int LEAF_CB = LB * LB + 64 + LB;  // leaf_diag_fast's broadcast buffer
 
 // LDS image of the leaf (round 3): only the 36 blocks on / below the diagonal, block (I, J) at sb_off(I, J), element (r, c)
 // at r * 17 + c -- 78 336 bytes instead of the 149 KB of the full 128 x 129 image + 8 inverse blocks.  That is what lets
@@ -49,71 +50,13 @@ constexpr int BSZ = LB * TS17;  // doubles per stored block
 // holds A_pp until it is factored; L_pp then goes straight to global memory and the slot is reused for T_p = L_pp^-1.
 __device__ __forceinline__ constexpr int sb_off(int I, int J) { return (I * (I + 1) / 2 + J) * BSZ; }
 
-// one block column K of X = L^-1, entirely in registers; rows of blocks I = K..7
-template <int K>
-__device__ __forceinline__ void leaf_inverse_column(const double* S, double* __restrict__ inv, int g, int q) {
-  d4 xb[8 - K];
-#pragma unroll
-  for (int v = 0; v < 4; ++v) xb[0][v] = S[sb_off(K, K) + (g + 4 * v) * TS17 + q];
-#pragma unroll
-  for (int v = 0; v < 4; ++v) inv[(LB * K + g + 4 * v) * NB + LB * K + q] = xb[0][v];
-#pragma unroll
-  for (int I = K + 1; I < 8; ++I) {
-    d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int J = K; J < I; ++J) {
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const double a = S[sb_off(I, J) + q * TS17 + 4 * s4 + g];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xb[J - K][s4], acc, 0, 0, 0);
-      }
-    }
-    d4 r = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      const double a = -S[sb_off(I, I) + q * TS17 + 4 * s4 + g];
-      r = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[s4], r, 0, 0, 0);
-    }
-    xb[I - K] = r;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) inv[(LB * I + g + 4 * v) * NB + LB * K + q] = r[v];
-  }
-}
-
-// lane N of the caller's 16-lane row, broadcast to the row (64-bit DPP supports exactly this: row_newbcast)
-template <int N>
-__device__ __forceinline__ double row_bcast(double v) {
-  return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + N, 0xf, 0xf, true);  // bound_ctrl: no 'old' value to materialise
-}
-__device__ __forceinline__ double row_bcast_n(double v, int n) {  // n is a constant after unrolling
-  switch (n) {
-    case 0: return row_bcast<0>(v);
-    case 1: return row_bcast<1>(v);
-    case 2: return row_bcast<2>(v);
-    case 3: return row_bcast<3>(v);
-    case 4: return row_bcast<4>(v);
-    case 5: return row_bcast<5>(v);
-    case 6: return row_bcast<6>(v);
-    case 7: return row_bcast<7>(v);
-    case 8: return row_bcast<8>(v);
-    case 9: return row_bcast<9>(v);
-    case 10: return row_bcast<10>(v);
-    case 11: return row_bcast<11>(v);
-    case 12: return row_bcast<12>(v);
-    case 13: return row_bcast<13>(v);
-    case 14: return row_bcast<14>(v);
-    default: return row_bcast<15>(v);
-  }
-}
-
-// (1) of the leaf: factor the 16x16 diagonal block p (LDS block D = S + sb_off(p, p)) and invert the factor, one wave, in
-// registers.  Lane q of every 16-lane row owns row q of the block and column q of the inverse (the four rows of the wave work
-// redundantly); L[c][j] reaches the other lanes through a DPP row broadcast, and one broadcast feeds both the
-// right-looking update of the factor and the forward substitution of the inverse.  sqrt and 1/sqrt of the pivot come from
-// v_rsq_f64 + two coupled Goldschmidt steps + a residual correction: 8 dependent fp64 ops instead of sqrt + division.
-// Column j of L_pp is final after step j: it goes straight to global memory (Ag = the block's first element there, zeros
-// above the diagonal), and row j of the inverse T_p replaces the block in LDS -- every lane has read its row of A_pp into
-// registers before the first store.
+// (1) of the leaf, GENERAL form: factor the 16x16 diagonal block p (LDS block D = S + sb_off(p, p)) and invert the factor, one
+// wave.  Since round 5 this is the RARE path -- leaf_diag_fast below factors every block whose pivots are sound -- so it is
+// written for few registers, not for speed (rounds 1-4 kept rows and inverse columns in 64 + 32 VGPRs and set the whole
+// kernel's allocation): rows and inverse columns stay in LDS (D and the 16 x 16 scratch X: X[c][q] at X[16 c + q]), lane q of
+// every 16-lane row works on row q / column q (the four rows redundantly: same values to the same addresses), the loop over the
+// pivots is not unrolled.  Column j of L_pp is final after step j: it goes to global memory (Ag = the block's first element
+// there, zeros above the diagonal), and row j of the inverse T_p replaces row j of the block in LDS (dead by then).
 //
 // Pivot policy (piv_min, skip): a pivot <= piv_min is "bad".  skip == 0: it is replaced by 1.0 and its global index is
 // reported (first one wins) -- the caller sees a non-positive-definite matrix.  skip != 0 (the rank-deficient retry of
@@ -121,21 +64,16 @@ __device__ __forceinline__ double row_bcast_n(double v, int n) {  // n is a cons
 // against the factor returns 0 in that component, exactly as if the point were not in the training set; this is what
 // numpy.linalg.pinv (gp.py:181) makes of an exactly duplicated point.  Dropped pivots are counted in info[1].
 __device__ __forceinline__ void leaf_diag(double* __restrict__ D, double* __restrict__ Ag, int64_t ld, int c0, int q, int lane,
-                                          int64_t base_index, int64_t n_valid, int* __restrict__ info, double piv_min,
-                                          int skip) {
-  double a[LB], sacc[LB];
-#pragma unroll
-  for (int c = 0; c < LB; ++c) {
-    a[c] = (c <= q) ? D[q * TS17 + c] : 0.0;
-    sacc[c] = (c == q) ? 1.0 : 0.0;
-  }
-  int first_bad = LB;  // first column with a non-positive (or NaN) pivot; wave-uniform
-  int nbad = 0;
+                                       int64_t base_index, int64_t n_valid, int* __restrict__ info, double piv_min, int skip,
+                                       double* __restrict__ X) {
+#pragma unroll 1
+  for (int c = 0; c < LB; ++c) X[LB * c + q] = (c == q) ? 1.0 : 0.0;
+  int first_bad = LB, nbad = 0;  // wave-uniform
   double* const grow = Ag + (int64_t)q * ld;
-#pragma unroll
+#pragma unroll 1
   for (int j = 0; j < LB; ++j) {
-    double piv = row_bcast_n(a[j], j);
-    const bool ok = piv > piv_min;  // branch-free on the pivot chain: a bad pivot is replaced by 1.0 and reported after the loop
+    double piv = D[j * TS17 + j];
+    const bool ok = piv > piv_min;
     first_bad = (!ok && first_bad == LB) ? j : first_bad;
     nbad += (!ok && base_index + c0 + j < n_valid) ? 1 : 0;
     piv = ok ? piv : 1.0;
@@ -147,22 +85,19 @@ __device__ __forceinline__ void leaf_diag(double* __restrict__ D, double* __rest
     r = fma(-g, h, 0.5);
     g = fma(g, r, g);
     h = fma(h, r, h);
-    g = fma(fma(-g, g, piv), h, g);  // sqrt(piv)
+    g = fma(fma(-g, g, piv), h, g);                 // sqrt(piv)
     const double rs = (ok || !skip) ? h + h : 0.0;  // 1/sqrt(piv); 0 drops the point (see the pivot policy above)
-    const double aj = (q == j) ? g : a[j] * rs;
-    const double xj = sacc[j] * rs;
-    const double naj = -aj, nxj = -xj;
-#pragma unroll
+    const double aj = (q == j) ? g : ((q > j) ? D[q * TS17 + j] * rs : 0.0);
+    const double xj = X[LB * j + q] * rs;
+    grow[j] = aj;
+    if (q > j) D[q * TS17 + j] = aj;  // the scaled column, for the other rows' updates below
+#pragma unroll 1
     for (int c = j + 1; c < LB; ++c) {
-      const double l = row_bcast_n(aj, c);  // L[c][j]
-      a[c] = fma(l, naj, a[c]);
-      sacc[c] = fma(l, nxj, sacc[c]);
+      const double l = D[c * TS17 + j];  // L[c][j]: written above by lane c of this wave (LDS operations execute in order)
+      if (q >= c) D[q * TS17 + c] = fma(-l, aj, D[q * TS17 + c]);
+      X[LB * c + q] = fma(-l, xj, X[LB * c + q]);
     }
-    // column j of the factor and row j of the inverse are final: out now, their registers are free
-    if (lane < LB) {
-      grow[j] = (j <= q) ? aj : 0.0;
-      D[j * TS17 + q] = xj;
-    }
+    D[j * TS17 + q] = xj;  // row j of the inverse over row j of the block: (j, c < j) and (j, j) are dead, (j, c > j) never read
   }
   if (first_bad < LB && lane == 0 && base_index + c0 + first_bad < n_valid) {
     if (skip)
@@ -170,6 +105,100 @@ __device__ __forceinline__ void leaf_diag(double* __restrict__ D, double* __rest
     else
       atomicCAS(info, 0, (int)(base_index + c0 + first_bad + 1));
   }
+}
+
+// (1'), round 5: the same 16x16 step in ONE THIRD of the instructions.  A single wave on a SIMD issues an fp64 VALU instruction
+// every ~8.6 cycles whether it depends on the previous one or not (profiles/r01_dfma_peak.txt: 8.65 cycles per v_fma_f64 at one
+// wave per SIMD and eight independent chains), so leaf_diag's 390 cycles per pivot were its ~40 instructions per pivot, not
+// its dependency chain.  What is removed:
+//   * the four 16-lane rows no longer work redundantly: lanes 0..15 hold the rows of the block (v[c] = A[q][c]), lanes 32..47
+//     the columns of the inverse (v[c] = Y[c][q]), so ONE v_fma_f64 per (pivot, column) updates both (there were two);
+//   * the column entries L[c][j] reach every lane as BROADCAST READS of a small LDS buffer (one ds_read_b128 per two columns,
+//     issued beside the VALU) instead of one DPP move each; only the pivot and the entry the next pivot waits for come
+//     through v_readlane;
+//   * the square roots leave the loop: the elimination runs in LDL^T form (only w = 1/d_j on the chain: v_rcp_f64 + two
+//     Newton steps), every lane keeps ITS pivot d_q, and 1/sqrt(d_q) is formed once, lane-parallel, after the last step;
+//     L[q][j] = a_qj / sqrt(d_j), T[j][q] = Y[j][q] / sqrt(d_j);
+//   * no selects for the pivot policy: the block is factored as if it were positive definite and NOTHING is stored until the
+//     pivots have been checked; a pivot <= piv_min (or NaN) sends the caller to leaf_diag, which re-reads the untouched block.
+// CB (LEAF_CB doubles): 16 x 16 (column j of the unscaled factor at CB[16 j + row]) + 64 junk slots (the lanes that hold no row
+// write there) + 16 for the 1/sqrt broadcast; touched by wave 0 only -- LDS operations of one wave execute in order, no barrier.
+__device__ __forceinline__ bool leaf_diag_fast(double* __restrict__ D, double* __restrict__ Ag, int64_t ld, int q, int lane,
+                                               double piv_min, double* __restrict__ CB) {
+  const bool rowlane = lane < LB, collane = (lane >> 4) == 2;
+  double v[LB];
+#pragma unroll
+  for (int c = 0; c < LB; ++c) v[c] = rowlane ? ((c <= q) ? D[q * TS17 + c] : 0.0) : ((collane && c == q) ? 1.0 : 0.0);
+  double* const cbw = rowlane ? CB + q : CB + LB * LB + lane;  // + 16 j per column
+  const double2* const cbr = reinterpret_cast<const double2*>(CB);
+  double ntz_prev = 0.0;
+#pragma unroll
+  for (int j = 0; j < LB; ++j) {
+    // the entries of column j-1 for the far updates of pivot j-1: all reads in flight before the first use (one wait, not eight)
+    double2 u[LB / 2];
+    if (j > 0) {
+#pragma unroll
+      for (int c2 = (j + 1) / 2; c2 < LB / 2; ++c2) u[c2] = cbr[(LB / 2) * (j - 1) + c2];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // v[j] is final: pivot, the entry below it, and the column out for the broadcast reads of the NEXT iteration
+    const double piv = readlane_d(v[j], j);
+    const double unext = readlane_d(v[j], j + 1 < LB ? j + 1 : j);
+    cbw[LB * j] = v[j];
+    double w = __builtin_amdgcn_rcp(piv);  // ~2^-24 relative (ISA manual: 2^29 ulp); w (1 + e + e^2) leaves e^3 = 2^-72
+    double e = fma(-piv, w, 1.0);
+    e = fma(e, e, e);
+    w = fma(w, e, w);
+    const double ntz = -(v[j] * w);  // rows: -a_qj / d_j;  inverse columns: -Y[j][q] / d_j
+    if (j + 1 < LB) v[j + 1] = fma(ntz, unext, v[j + 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    // the far updates of pivot j-1 (columns j+1 ..; column j got it as that iteration's `unext` update)
+    if (j > 0) {
+#pragma unroll
+      for (int c2 = (j + 1) / 2; c2 < LB / 2; ++c2) {
+        if (2 * c2 >= j + 1) v[2 * c2] = fma(ntz_prev, u[c2].x, v[2 * c2]);
+        if (2 * c2 + 1 >= j + 1) v[2 * c2 + 1] = fma(ntz_prev, u[c2].y, v[2 * c2 + 1]);
+      }
+    }
+    ntz_prev = ntz;
+  }
+  // every row lane's pivot d_q went into the broadcast buffer at step q; all of them must be sound before anything is stored
+  const double dq = CB[(LB + 1) * q];
+  if (__builtin_amdgcn_ballot_w64(!(dq > piv_min)) != 0) return false;
+  double rs;
+  {
+    const double y = __builtin_amdgcn_rsq(dq);
+    double g = dq * y, h = 0.5 * y;
+    double r = fma(-g, h, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    r = fma(-g, h, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    g = fma(fma(-g, g, dq), h, g);  // sqrt(d_q)
+    r = fma(-g, h + h, 1.0);        // 1/sqrt(d_q) corrected against the corrected root
+    rs = fma(h + h, r, h + h);
+  }
+  CB[LB * LB + 64 + q] = rs;  // (the four lanes of a column write the same value)
+  double2 r2[LB / 2];  // all eight broadcast reads in flight at once
+  const double2* const rsr = reinterpret_cast<const double2*>(CB + LB * LB + 64);
+#pragma unroll
+  for (int c2 = 0; c2 < LB / 2; ++c2) r2[c2] = rsr[c2];
+#pragma unroll
+  for (int c2 = 0; c2 < LB / 2; ++c2) {  // zero above the diagonal by construction
+    v[2 * c2] *= r2[c2].x;
+    v[2 * c2 + 1] *= r2[c2].y;
+  }
+  if (rowlane) {
+    double* const grow = Ag + (int64_t)q * ld;
+#pragma unroll
+    for (int c2 = 0; c2 < LB / 2; ++c2) *reinterpret_cast<double2*>(grow + 2 * c2) = double2{v[2 * c2], v[2 * c2 + 1]};
+  }
+  if (collane) {
+#pragma unroll
+    for (int c = 0; c < LB; ++c) D[c * TS17 + q] = v[c];
+  }
+  return true;
 }
 
 // The 28 blocks (I,K), 1 <= K <= I <= 7, of the trailing matrix live in REGISTERS (MFMA accumulator layout) from the
@@ -240,24 +269,152 @@ __device__ __forceinline__ void leaf_scale(double* __restrict__ S, int p, int wa
   }
 }
 
+// ---- the 128-order inverse, built ROW BLOCK BY ROW BLOCK underneath the factorisation (round 5) ---------------------------
+// X = L^-1: X[R][K] = -T_R * sum_{J=K}^{R-1} L[R][J] X[J][K] (K < R), X[R][R] = T_R.  Rounds 1-4 built X column by column AFTER
+// the factorisation (4.9 us of the leaf's 37).  But waves 1..3 idle while wave 0 factors a diagonal block (1.8 us per step), and
+// everything row R needs but T_R is final one step earlier.  So each of waves 1..3 owns block columns of X (balanced over the
+// last steps, where the rows are long: {0,5,7} / {1,4} / {2,3,6}), keeps them in registers in MFMA accumulator layout (= the
+// B-operand layout of the next product), and inside the window of step P -- while wave 0 factors block P --
+//   (a) finishes row P-1:   X[P-1][K] = -T_{P-1} * acc_K      (T_{P-1} has been in LDS since barrier [B] of step P-1)
+//   (b) forms row P's sums: acc_K = sum_J L[P][J] X[J][K]     (block row P of L is final since step P-1)
+// and stores every block of X as it completes.  Left for the end: row 7's finish, 4 MFMAs per column.
+__device__ constexpr int inv_owner(int K) { return (K == 0 || K == 5 || K == 7) ? 1 : ((K == 1 || K == 4) ? 2 : 3); }
+
+template <int W, int R>
+__device__ __forceinline__ void inv_finish_row(const double* __restrict__ S, double* __restrict__ inv, d4 (&xb)[8][8],
+                                               d4 (&acc)[8], int g, int q) {
+#pragma unroll
+  for (int K = 0; K <= R; ++K) {
+    if (inv_owner(K) != W) continue;
+    d4 r;
+    if (K == R) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) r[v] = S[sb_off(R, R) + (g + 4 * v) * TS17 + q];
+    } else {
+      r = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const double a = -S[sb_off(R, R) + q * TS17 + 4 * s4 + g];
+        r = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[K][s4], r, 0, 0, 0);
+      }
+    }
+    xb[K][R - K] = r;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) inv[(LB * R + g + 4 * v) * NB + LB * K + q] = r[v];
+  }
+}
+
+template <int W, int P>
+__device__ __forceinline__ void inv_row_sums(const double* __restrict__ S, d4 (&xb)[8][8], d4 (&acc)[8], int g, int q) {
+  // the products of one J share the A fragments of L[P][J]; the accumulators of different K interleave
+#pragma unroll
+  for (int K = 0; K < P; ++K)
+    if (inv_owner(K) == W) acc[K] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int J = 0; J < P; ++J) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const double a = S[sb_off(P, J) + q * TS17 + 4 * s4 + g];
+#pragma unroll
+      for (int K = 0; K <= J; ++K)
+        if (inv_owner(K) == W) acc[K] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xb[K][J - K][s4], acc[K], 0, 0, 0);
+    }
+  }
+}
+
+// block column PC of L (blocks (I, PC), I > PC: final once scaled) from LDS to global memory, by the 192 threads of waves 1..3
+template <int PC>
+__device__ __forceinline__ void leaf_store_column(const double* __restrict__ S, double* __restrict__ A, int64_t ld, int tt) {
+  constexpr int R0 = LB * (PC + 1), NIT = ((NB - R0) * 8 + 191) / 192;
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int idx = tt + 192 * i, r = R0 + (idx >> 3), c2 = idx & 7;
+    if (r < NB) {
+      const double* sp = S + sb_off(r >> 4, PC) + (r & 15) * TS17 + 2 * c2;
+      *reinterpret_cast<double2*>(A + (int64_t)r * ld + LB * PC + 2 * c2) = double2{sp[0], sp[1]};
+    }
+  }
+}
+
+// The 35 lower blocks other than (0, 0), column by column (the columns step 0 needs first), and the 28 upper ones
+__device__ constexpr int kLowI[35] = {1, 2, 3, 4, 5, 6, 7, 1, 2, 3, 4, 5, 6, 7, 2, 3, 4, 5, 6, 7, 3, 4, 5, 6, 7, 4, 5, 6, 7, 5, 6, 7, 6, 7, 7};
+__device__ constexpr int kLowJ[35] = {0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 6, 6, 7};
+
+// waves 1..3, while wave 0 factors block (0, 0): wave W brings blocks W-1, W+2, ... of that list into LDS -- two 16-byte loads per
+// lane and block, all 24 in flight at once (one round trip to memory; rounds 1-4: every thread 32 loads in two batches, wave 0
+// waiting with the others)
+template <int W>
+__device__ __forceinline__ void leaf_load_blocks(double* __restrict__ S, const double* __restrict__ A, int64_t ld, int lane) {
+  constexpr int NBK = (35 - (W - 1) + 2) / 3;
+  double2 v[NBK][2];
+  const int rr = lane >> 3, c = 2 * (lane & 7);
+#pragma unroll
+  for (int k = 0; k < NBK; ++k) {
+    const int b = (W - 1) + 3 * k;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      v[k][h] = *reinterpret_cast<const double2*>(A + (int64_t)(LB * kLowI[b] + rr + 8 * h) * ld + LB * kLowJ[b] + c);
+  }
+#pragma unroll
+  for (int k = 0; k < NBK; ++k) {
+    const int b = (W - 1) + 3 * k;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      double* sp = S + sb_off(kLowI[b], kLowJ[b]) + (rr + 8 * h) * TS17 + c;
+      sp[0] = v[k][h].x;
+      sp[1] = v[k][h].y;
+    }
+  }
+}
+
+// zeros into the blocks above the diagonal of A and of the inverse (the mirror images of the list above, (0, 0)'s aside): stores
+// only, issued in the window of step 5 (the early windows carry the big deferred updates)
+template <int W>
+__device__ __forceinline__ void leaf_zero_upper(double* __restrict__ A, int64_t ld, double* __restrict__ inv, int lane) {
+  const int rr = lane >> 3, c = 2 * (lane & 7);
+#pragma unroll
+  for (int b = W - 1; b < 35; b += 3) {
+    if (kLowI[b] == kLowJ[b]) continue;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = LB * kLowJ[b] + rr + 8 * h, cc = LB * kLowI[b] + c;  // block (J, I): above the diagonal
+      *reinterpret_cast<double2*>(A + (int64_t)r * ld + cc) = double2{0.0, 0.0};
+      *reinterpret_cast<double2*>(inv + r * NB + cc) = double2{0.0, 0.0};
+    }
+  }
+}
+
 // Per step p, every wave passes the same three barriers:
-//   [A] column p is in LDS        wave 0: factor + invert diagonal block p      waves 1..3: DEFERRED part of update p-1
+//   [A] column p is in LDS        wave 0: factor + invert diagonal block p
+//                                 waves 1..3 (the WINDOW of step p): DEFERRED part of update p-1, block column p-1 of L out to
+//                                 global memory, row p-1 of the 128-order inverse finished, row p's sums formed
 //   [B] T[p] ready                all: scale the blocks below the diagonal
 //   [C] column p scaled           waves 1..3: PRIORITY part of update p (column p+1 -> LDS)
 template <int W>
-__device__ __forceinline__ void leaf_factor(double* __restrict__ S, int g, int q) {
+__device__ __forceinline__ void leaf_factor(double* __restrict__ S, double* __restrict__ A, int64_t ld,
+                                            double* __restrict__ inv, int t, int g, int q) {
   constexpr int NS = leaf_nslots(W);
   d4 blk[NS];
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const LeafBlk bk = leaf_blk(3 * s + (W - 1));
-#pragma unroll
-    for (int v = 0; v < 4; ++v) blk[s][v] = S[sb_off(bk.I, bk.K) + (g + 4 * v) * TS17 + q];
-  }
+  d4 xb[8][8], acc[8];  // only this wave's block columns of the inverse are ever touched (constant indices: scalarised)
+  const int tt = t - 64;
+  leaf_load_blocks<W>(S, A, ld, t & 63);
 #define GPX_LEAF_STEP(P_)                                                     \
   do {                                                                        \
-    if (P_ > 0) leaf_update_deferred<W, (P_ > 0 ? P_ - 1 : 0), NS>(S, blk, g, q); \
+    if (P_ > 0) {                                                             \
+      leaf_update_deferred<W, (P_ > 0 ? P_ - 1 : 0), NS>(S, blk, g, q);       \
+      leaf_store_column<(P_ > 0 ? P_ - 1 : 0)>(S, A, ld, tt);                 \
+      if (P_ == 5) leaf_zero_upper<W>(A, ld, inv, t & 63);                    \
+      inv_finish_row<W, (P_ > 0 ? P_ - 1 : 0)>(S, inv, xb, acc, g, q);        \
+      inv_row_sums<W, P_>(S, xb, acc, g, q);                                  \
+    }                                                                         \
     __syncthreads(); /* [B] */                                                \
+    if (P_ == 0) { /* the whole block is in LDS now: this wave's trailing blocks into registers */ \
+      _Pragma("unroll") for (int s = 0; s < NS; ++s) {                        \
+        const LeafBlk bk = leaf_blk(3 * s + (W - 1));                         \
+        _Pragma("unroll") for (int v = 0; v < 4; ++v)                         \
+          blk[s][v] = S[sb_off(bk.I, bk.K) + (g + 4 * v) * TS17 + q];         \
+      }                                                                       \
+    }                                                                         \
     leaf_scale(S, P_, W, g, q);                                               \
     __syncthreads(); /* [C] */                                                \
     if (P_ < 7) leaf_update_priority<W, (P_ < 7 ? P_ : 6), NS>(S, blk, g, q);  \
@@ -272,89 +429,65 @@ __device__ __forceinline__ void leaf_factor(double* __restrict__ S, int g, int q
   GPX_LEAF_STEP(6);
   GPX_LEAF_STEP(7);
 #undef GPX_LEAF_STEP
+  inv_finish_row<W, 7>(S, inv, xb, acc, g, q);
 }
 
 // wave 0: the diagonal blocks
 __device__ __forceinline__ void leaf_panel_wave(double* __restrict__ S, double* __restrict__ A, int64_t ld, int g, int q,
                                                 int lane, int64_t base_index, int64_t n_valid, int* __restrict__ info,
-                                                double piv_min, int skip) {
+                                                double piv_min, int skip, int fast, double* __restrict__ CB,
+                                                long long* __restrict__ stamps) {
   for (int p = 0; p < 8; ++p) {
-    leaf_diag(S + sb_off(p, p), A + (int64_t)(LB * p) * ld + LB * p, ld, LB * p, q, lane, base_index, n_valid, info, piv_min, skip);
+    double* const Dp = S + sb_off(p, p);
+    double* const Ap = A + (int64_t)(LB * p) * ld + LB * p;
+    if (stamps && lane == 0) stamps[2 + 3 * p] = (long long)__builtin_amdgcn_s_memtime();
+    if (!fast || !leaf_diag_fast(Dp, Ap, ld, q, lane, piv_min, CB))
+      leaf_diag(Dp, Ap, ld, LB * p, q, lane, base_index, n_valid, info, piv_min, skip, CB);
+    if (stamps && lane == 0) stamps[3 + 3 * p] = (long long)__builtin_amdgcn_s_memtime();
     __syncthreads();  // [B]
     leaf_scale(S, p, 0, g, q);
     __syncthreads();  // [C]
+    if (stamps && lane == 0) stamps[4 + 3 * p] = (long long)__builtin_amdgcn_s_memtime();
     __syncthreads();  // [A] of the next step
   }
 }
 
 __global__ __launch_bounds__(256, 2) void leaf_kernel(double* __restrict__ A, int64_t ld, double* __restrict__ inv,
                                                    int64_t base_index, int64_t n_valid, int* __restrict__ info,
-                                                   double piv_min, int skip, int hiprio) {
+                                                   double piv_min, int skip, int hiprio, int fast,
+                                                   long long* __restrict__ stamps) {
+  // stamps (debug, gpx_dbg_leaf_stamps; nullptr in the product path): s_memtime of wave 0 at 0 = start, 1 = block (0, 0)
+  // loaded, 2 + 3p / 3 + 3p / 4 + 3p = diagonal step p begins / its 16 x 16 factor + inverse done / column p scaled,
+  // 27 = wave 0 leaves; 28 / 29 = the 100 MHz wall clock at start / at the end of the LAST wave (written by wave 1)
   __shared__ double S[36 * BSZ];
+  __shared__ __attribute__((aligned(16))) double CB[LEAF_CB];
   if (hiprio) __builtin_amdgcn_s_setprio(3);   // gpx_chain_prio: beside resident GEMM waves the CU serves this chain first
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int g = lane >> 4, q = lane & 15;
-  // global -> LDS in two batches of 16 loads per thread (two round trips to memory instead of 64); blocks above the diagonal
-  // are neither loaded nor stored
-  {
-    const int r0 = t >> 6, c = 2 * (t & 63), J = c >> 4, cc = c & 15;
-    const double* ap = A + (int64_t)r0 * ld + c;
-#pragma unroll 1
+  if (stamps && t == 0) { stamps[0] = (long long)__builtin_amdgcn_s_memtime(); stamps[28] = (long long)wall_clock64(); }
+  if (wave == 0) {
+    // round 5: wave 0 fetches ONLY block (0, 0) and starts factoring it; the other 35 blocks arrive underneath
+    double2 v[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) v[h] = *reinterpret_cast<const double2*>(A + (int64_t)((lane >> 3) + 8 * h) * ld + 2 * (lane & 7));
+#pragma unroll
     for (int h = 0; h < 2; ++h) {
-      double2 v[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int r = 64 * h + r0 + 4 * i;
-        v[i] = double2{0.0, 0.0};
-        if (J <= (r >> 4)) v[i] = *reinterpret_cast<const double2*>(ap + (int64_t)(4 * i) * ld);
-      }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int r = 64 * h + r0 + 4 * i, I = r >> 4;
-        if (J <= I) {
-          double* sp = S + sb_off(I, J) + (r & 15) * TS17 + cc;
-          sp[0] = v[i].x;
-          sp[1] = v[i].y;
-        }
-      }
-      ap += 64 * ld;
+      double* sp = S + sb_off(0, 0) + ((lane >> 3) + 8 * h) * TS17 + 2 * (lane & 7);
+      sp[0] = v[h].x;
+      sp[1] = v[h].y;
     }
+    if (stamps && t == 0) stamps[1] = (long long)__builtin_amdgcn_s_memtime();
+    leaf_panel_wave(S, A, ld, g, q, lane, base_index, n_valid, info, piv_min, skip, fast, CB, stamps);
+    if (stamps && t == 0) stamps[27] = (long long)__builtin_amdgcn_s_memtime();
+    return;
   }
-  __syncthreads();
   switch (wave) {
-    case 0: leaf_panel_wave(S, A, ld, g, q, lane, base_index, n_valid, info, piv_min, skip); break;
-    case 1: leaf_factor<1>(S, g, q); break;
-    case 2: leaf_factor<2>(S, g, q); break;
-    default: leaf_factor<3>(S, g, q); break;
+    case 1: leaf_factor<1>(S, A, ld, inv, t, g, q); break;
+    case 2: leaf_factor<2>(S, A, ld, inv, t, g, q); break;
+    default: leaf_factor<3>(S, A, ld, inv, t, g, q); break;
   }
-  // write the off-diagonal blocks of L back (the diagonal blocks went out of leaf_diag), zero above the diagonal blocks, and
-  // zero the upper blocks of the inverse; the other blocks of the inverse are written below
-  {
-    const int r0 = t >> 6, c = 2 * (t & 63), J = c >> 4, cc = c & 15;
-    double* ap = A + (int64_t)r0 * ld + c;
-    double* ip = inv + r0 * NB + c;
-#pragma unroll 4
-    for (int i = 0; i < 32; ++i) {
-      const int r = r0 + 4 * i, I = r >> 4;
-      if (J < I) {
-        const double* sp = S + sb_off(I, J) + (r & 15) * TS17 + cc;
-        *reinterpret_cast<double2*>(ap) = double2{sp[0], sp[1]};
-      } else if (J > I) {
-        *reinterpret_cast<double2*>(ap) = double2{0.0, 0.0};
-        *reinterpret_cast<double2*>(ip) = double2{0.0, 0.0};
-      }
-      ap += 4 * ld;
-      ip += 4 * NB;
-    }
-  }
-  // inverse: wave w builds block columns w and 7-w (balanced: 140+4 / 108+12 / 80+24 / 56+40 MFMAs)
-  switch (wave) {
-    case 0: leaf_inverse_column<0>(S, inv, g, q); leaf_inverse_column<7>(S, inv, g, q); break;
-    case 1: leaf_inverse_column<1>(S, inv, g, q); leaf_inverse_column<6>(S, inv, g, q); break;
-    case 2: leaf_inverse_column<2>(S, inv, g, q); leaf_inverse_column<5>(S, inv, g, q); break;
-    default: leaf_inverse_column<3>(S, inv, g, q); leaf_inverse_column<4>(S, inv, g, q); break;
-  }
+  if (stamps && t == 64) stamps[29] = (long long)wall_clock64();
 }
 
 // ---- leaf multiplies: X <- X * inv^T (right) and B <- inv * B (left), in place -----------------------------------
@@ -787,9 +920,28 @@ static int launch_leaf_mul_left(gpx_ctx* ctx, double* B, int64_t ldb, const doub
 
 int launch_leaf(gpx_ctx* ctx, double* A, int64_t ld, double* inv, int64_t base_index, int64_t n_valid) {
   ProfScope ps(ctx, GPX_PROF_LEAF, 2.0 * NB * NB * NB / 3.0, 0.0);
+  static const int fast = getenv("GPX_LEAF_DIAG") ? atoi(getenv("GPX_LEAF_DIAG")) : 1;  // 0: round 1-4's leaf_diag throughout
   hipLaunchKernelGGL(leaf_kernel, dim3(1), dim3(256), 0, ctx->stream, A, ld, inv, base_index, n_valid, ctx->d_info,
-                     ctx->piv_min, ctx->piv_skip, gpx_chain_prio(ctx));
+                     ctx->piv_min, ctx->piv_skip, gpx_chain_prio(ctx), fast, (long long*)nullptr);
   GPX_HIP(hipGetLastError());
+  return 0;
+}
+
+// debug (gpx_debug.h): one leaf launch on the leading 128 x 128 block of K with the phase stamps of leaf_kernel copied out
+extern "C" int gpx_dbg_leaf_stamps(gpx_ctx* ctx, gpx_mat* K, int fast, int64_t* out30) {
+  GPX_ARG(ctx && K && out30 && K->prows >= NB && K->pcols >= NB, "leaf stamps: bad arguments");
+  long long* d = nullptr;
+  double* inv = nullptr;
+  GPX_HIP(hipMalloc((void**)&d, 30 * sizeof(long long)));
+  GPX_HIP(hipMalloc((void**)&inv, NB * NB * sizeof(double)));
+  GPX_HIP(hipMemsetAsync(d, 0, 30 * sizeof(long long), ctx->stream));
+  hipLaunchKernelGGL(leaf_kernel, dim3(1), dim3(256), 0, ctx->stream, K->p, K->ld, inv, (int64_t)0, (int64_t)NB, ctx->d_info,
+                     ctx->piv_min, ctx->piv_skip, 0, fast, d);
+  GPX_HIP(hipGetLastError());
+  GPX_HIP(hipStreamSynchronize(ctx->stream));
+  GPX_HIP(hipMemcpy(out30, d, 30 * sizeof(long long), hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  (void)hipFree(inv);
   return 0;
 }
 

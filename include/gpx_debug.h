@@ -54,6 +54,11 @@ int gpx_dbg_spin_until(gpx_ctx* ctx, int slot, int64_t us);
  * (scripts/dist_timeline.py).  Returns 1 when an event of the pair was never recorded / has not completed. */
 int gpx_dbg_event_elapsed(gpx_ctx* ctx, int id0, int id1, double* ms);
 
+/* One launch of the 128 x 128 Cholesky leaf on the leading block of K (in place) with the kernel's phase time stamps
+   (s_memtime of its first wave: 0 start, 1 loaded, 2+3p / 3+3p / 4+3p per diagonal step p, 26 written back, 27 inverse
+   done; shader clocks; 28 / 29: the constant 100 MHz clock at start / end).  fast = 1: round 5's diagonal step, 0: the general one throughout.  scripts/probe_leaf.py. */
+int gpx_dbg_leaf_stamps(gpx_ctx* ctx, gpx_mat* K, int fast, int64_t* out30);
+
 #ifdef __cplusplus
 }
 #endif
