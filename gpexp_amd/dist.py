@@ -840,15 +840,15 @@ class DeviceOps2D(Emitter, DeviceOps):
 
 # event kinds of the 2-D pipeline (per step k)
 (E_COLREADY, E_DFACT, E_DBC, E_PIECE, E_ARRIVED, E_STORED, E_UPD, E_DIAGREADY, E_EARLYSOLVED, E_EARLY, E_COL2,
- E_PANELDONE, E_BULK, E_IVAR) = range(14)
-N_EVENT_KINDS = 14
+ E_PANELDONE, E_BULK, E_IVAR, E_PIECE0, E_ARR0, E_COLREADY0) = range(17)   # the last three: FIRST row chunk of a panel (round 5)
+N_EVENT_KINDS = 17
 
 
 def _ev2(kind, k):
     return N_EVENT_KINDS * (k + 1) + kind
 
 
-EV_FORK, EV_PRE, EV_JOIN0 = 1, 2, 3            # event ids below 14 are free (ids of step k start at 14 (k + 1))
+EV_FORK, EV_PRE, EV_JOIN0 = 1, 2, 3            # event ids below N_EVENT_KINDS are free (ids of step k start at N_EVENT_KINDS (k + 1))
 ALL_SIDE_STREAMS = (PANEL, COMM, BACK, EVAL, BULK)
 
 
@@ -984,6 +984,48 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
     # for arrives, applies that last update to the copy, factors the copy in place, and copies factor + leaf inverses back into
     # the local matrix behind the event that releases the panel broadcast: three launches less per step on that chain.
     staged = os.environ.get("GPX_DIST2_STAGED_DIAG", "1") == "1" and hasattr(ops, "diag_stage")
+    # Round 5: the panel travels in TWO ROW CHUNKS.  Per step the holder column used to add
+    # [near update of column k] + [panel solve] + [hand-over] to the chain across ranks, each over the WHOLE piece (early steps
+    # at C4 on a 2 x 4 grid: 0.88 + 0.36 + 0.33 ms).  But chunk c of panel k+1 needs chunk c of panel k only (the same local
+    # rows: updated by it, then solved) -- plus the diagonal block, which has its own early path.  So the piece of every process
+    # row is cut at a local row S: chunk 0 = the rows above S (solved, broadcast, applied to column k+1 first), chunk 1 = the
+    # rest, one stage behind on each of the three streams (PANEL solve / COMM broadcast / MAIN near update).  S stays put for
+    # `chunk_hold` steps (chunk 0 shrinks from the top as the factorisation moves down) and is then re-centred; a step whose
+    # chunk 0 is not covered by the previous step's chunk-0 update waits for the whole column (one bubble per re-centring).
+    # Chunk 0 always holds the first block row of its piece: that is the block row the near updates multiply with.
+    nchunk = int(os.environ.get("GPX_DIST_PANEL_CHUNKS", "2"))
+    chunk_hold = max(1, int(os.environ.get("GPX_DIST_CHUNK_HOLD", "4")))
+    chunk_min = int(os.environ.get("GPX_DIST_CHUNK_MIN_BLOCKS", "4"))     # pieces shorter than this many block rows stay whole
+
+    def chunk_rows0(p, k):
+        """rows of piece p of panel k that travel in chunk 0 (all of them where the panel is not cut)"""
+        m = geo.piece_rows(p, k)
+        if nchunk < 2 or m == 0:
+            return m
+        k0 = (k // chunk_hold) * chunk_hold
+        m0 = geo.piece_rows(p, k0)
+        if m0 < chunk_min * nb:
+            return m
+        S = geo.row_off(p, geo.li0(p, k0)) + ((m0 // 2 + nb - 1) // nb) * nb         # local row of the cut
+        s = S - geo.row_off(p, geo.li0(p, k))
+        return min(max(s, min(m, nb)), m)
+
+    def chunk_pieces(k, c):
+        """(offset, count, world root) of the regions chunk c of panel k delivers; the diagonal region travels with chunk 0"""
+        kr_, kc_ = k % Pr, k % Pc
+        out = []
+        for p in range(Pr):
+            m, s = geo.piece_rows(p, k), chunk_rows0(p, k)
+            r0, r1 = (0, s) if c == 0 else (s, m)
+            if c == 0 and p == kr_:
+                out.append((geo.piece_off(p), geo.dsz + r1 * geo.gld, p * Pc + kc_))
+            elif r1 > r0:
+                out.append((geo.piece_off(p) + geo.dsz + r0 * geo.gld, (r1 - r0) * geo.gld, p * Pc + kc_))
+        return out
+
+    def chunk_hi0(k):
+        """one past the last LOCAL row (this process row) that chunk 0 of panel k solves / updates"""
+        return geo.row_off(pr, geo.li0(pr, k)) + chunk_rows0(pr, k)
 
     def group_end(k):
         return min((k // q + 1) * q - 1, nblk - 1)
@@ -1000,13 +1042,17 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
         n = sum(geo.height(lj * Pc + pc) for lj in range(lja, ljb + 1))
         return lja * nb, n, lja * Pc + pc
 
-    def update_cols(Ja, Jb, ks, below_diag=False):
+    def update_cols(Ja, Jb, ks, below_diag=False, rows=None):
+        """rows = (lo, hi): only the local rows in [lo, hi) (a row chunk of the panel; block-aligned)"""
         lc0, n, J0 = my_col_range(Ja, Jb)
         if n == 0:
             return
         li = geo.blocks_before(pr, Pr, J0 + (1 if below_diag else 0))   # first local block row with I >= J0 (> J0)
         lr0 = geo.row_off(pr, li)
-        m = geo.local_rows(pr) - lr0
+        hi = geo.local_rows(pr)
+        if rows is not None:
+            lr0, hi = max(lr0, rows[0]), min(hi, rows[1])
+        m = hi - lr0
         if m > 0:
             ops.update_multi(A, lr0, m, lc0, n, geo, [G[kk % R] for kk in ks], list(ks), below_diag)
 
@@ -1091,8 +1137,13 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
             ops.wait(_ev2(E_DBC, k))
             if hoist_inv:
                 ops.panel_inv(g, geo.piece_off(kr), nb, w)                # needs the diagonal block only: ahead of the column
-            ops.wait(_ev2(E_COLREADY, k))
             lr0, m = geo.row_off(pr, geo.li0(pr, k)), geo.piece_rows(pr, k)
+            s0 = chunk_rows0(pr, k)                                      # rows of this rank's piece in chunk 0
+            two = bool(chunk_pieces(k, 1))                               # the panel travels in two chunks (all ranks agree)
+            # chunk 0's rows have column k's update through panel k-1 once THAT panel's chunk-0 update ran (E_COLREADY0) -- if it
+            # covered them: after a re-centring of the cut it did not, and the solve waits for the whole column
+            covered = k >= 1 and bool(chunk_pieces(k - 1, 1)) and lr0 + s0 <= chunk_hi0(k - 1)
+            ops.wait(_ev2(E_COLREADY0 if covered else E_COLREADY, k))
             roff = geo.piece_off(pr) + geo.dsz
             dslot = (k // Pr) if owner else None                         # the owner keeps the block's explicit inverse
             keep_late = owner and staged and hoist_inv                    # ... behind E_PIECE (diag_store) instead of ahead of the solve
@@ -1101,12 +1152,18 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
             late = late_copyback and hoist_inv and w == nb and nb > TILE and hasattr(ops, "panel_copyback")
             pk = dict(prepared=True, copy_back=not late) if hoist_inv else {}
             ds = None if keep_late else dslot
+            e1 = 0
             if nxt and pr == r1:                                         # block row k+1 first: the next diagonal needs it
+                e1 = h1
                 ops.panel_trsm(A, lr0, h1, lc, w, g, geo.piece_off(kr), roff, nb, **pk)
                 ops.record(_ev2(E_EARLYSOLVED, k))
-                ops.panel_trsm(A, lr0 + h1, m - h1, lc, w, g, geo.piece_off(kr), roff + h1 * geo.gld, nb, ds, **pk)
-            else:
-                ops.panel_trsm(A, lr0, m, lc, w, g, geo.piece_off(kr), roff, nb, ds, **pk)
+            c0 = s0 if two else m                                        # chunk 0 ends here (>= e1: it holds the first block row)
+            ops.panel_trsm(A, lr0 + e1, c0 - e1, lc, w, g, geo.piece_off(kr), roff + e1 * geo.gld, nb, ds, **pk)
+            ops.record(_ev2(E_PIECE0, k))
+            if two:
+                if covered:
+                    ops.wait(_ev2(E_COLREADY, k))
+                ops.panel_trsm(A, lr0 + c0, m - c0, lc, w, g, geo.piece_off(kr), roff + c0 * geo.gld, nb, **pk)
             ops.record(_ev2(E_PIECE, k))
             while deferred_bulk:                                         # the previous group's bulk update, held back until here
                 bk, bks = deferred_bulk.pop(0)
@@ -1159,8 +1216,9 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
         ops.record(_ev2(E_PANELDONE, k))
         # ---- panel chain ----------------------------------------------------------------------------------------
         ops.stream(COMM)
+        two = bool(chunk_pieces(k, 1))
         if holder:
-            ops.wait(_ev2(E_PIECE, k))
+            ops.wait(_ev2(E_PIECE0 if two else E_PIECE, k))
         else:
             wait_free()
         # Ranks of process row r1 that are no column holders already HAVE L[k+1, k] (row broadcast above) and their PANEL
@@ -1168,7 +1226,22 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
         # order the overwrite behind that read instead of relying on the bytes being identical.
         if nxt and pr == r1 and pc == c1 and not holder and E is None:
             ops.wait(_ev2(E_DIAGREADY, k + 1))
-        comm.panel_bcast(g, geo.pieces(k))                               # every piece to every rank, all links
+        at_chunk = getattr(comm, "at_chunk", None)                        # (measurement communicators: which chunk comes next)
+        if two:
+            if at_chunk is not None:
+                at_chunk(0, False)
+            comm.panel_bcast(g, chunk_pieces(k, 0))                      # chunk 0 of every piece (+ the diagonal region) ...
+            ops.record(_ev2(E_ARR0, k))
+            if holder:
+                ops.wait(_ev2(E_PIECE, k))
+            if at_chunk is not None:
+                at_chunk(1, True)
+            comm.panel_bcast(g, chunk_pieces(k, 1))                      # ... and the rest, one stage behind
+        else:
+            if at_chunk is not None:
+                at_chunk(0, True)
+            comm.panel_bcast(g, geo.pieces(k))                           # every piece to every rank, all links
+            ops.record(_ev2(E_ARR0, k))
         ops.record(_ev2(E_ARRIVED, k))
         ops.stream(BACK)
         ops.wait(_ev2(E_ARRIVED, k))
@@ -1186,9 +1259,19 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
             on_stored(k)
         # ---- trailing updates -----------------------------------------------------------------------------------
         ops.stream(MAIN)
-        ops.wait(_ev2(E_ARRIVED, k))
         g0 = (k // q) * q
-        update_cols(k + 1, k + 1, [k], below_diag=True)                  # look-ahead: releases panel k+1's solve
+        if two and nxt and pc == c1:
+            # this rank solves panel k+1: its column k+1 gets panel k chunk by chunk (the B operand -- block row k+1 of the panel
+            # -- is the first block row of its piece and travels with chunk 0)
+            cut = chunk_hi0(k)
+            ops.wait(_ev2(E_ARR0, k))
+            update_cols(k + 1, k + 1, [k], below_diag=True, rows=(0, cut))
+            ops.record(_ev2(E_COLREADY0, k + 1))
+            ops.wait(_ev2(E_ARRIVED, k))
+            update_cols(k + 1, k + 1, [k], below_diag=True, rows=(cut, geo.local_rows(pr)))
+        else:
+            ops.wait(_ev2(E_ARRIVED, k))
+            update_cols(k + 1, k + 1, [k], below_diag=True)              # look-ahead: releases panel k+1's solve
         if nxt and pc == c1:
             ops.record(_ev2(E_COLREADY, k + 1))
         update_cols(k + 2, k + 2, list(range(g0, k + 1)))                # two ahead: up to date through panel k

@@ -45,6 +45,11 @@ def own_step_latencies(ctx, geo):
         return None, None
     own = [k for k in range(geo.nblk) if k % geo.Pc == geo.pc]
     lat = {k: arr[k] - (arr[k - 1] if k > 0 else 0.0) for k in own}
+    # round 5: the panel travels in two row chunks; the first one's arrivals form a chain of their own (chunk 0 of panel k needs
+    # chunk 0 of panel k-1 only)
+    arr0 = [at(dist.E_ARR0, k) for k in range(geo.nblk)]
+    own_step_latencies.lat0 = (None if any(a is None for a in arr0) else
+                               {k: arr0[k] - (arr0[k - 1] if k > 0 else 0.0) for k in own})
     # the diagonal chain's two hand-overs, where THIS rank produces them: the diagonal block factored (owner of (k, k)) and block
     # row k+1 of panel k solved (holder of column k in the process row of block row k+1), ms after the arrival of panel k-1
     own_step_latencies.dfact = {k: at(dist.E_DFACT, k) - (arr[k - 1] if k > 0 else 0.0) for k in own if k % geo.Pr == geo.pr}
@@ -88,13 +93,14 @@ def paced_replay(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=None, agg
         res = replay_rank(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=nb, agg=agg, streamed=streamed, steps=steps,
                           profile=False, pace_us=pace, want_latencies=True)
         lat = res.pop("own_latency_ms")
+        lat0 = res.pop("own_latency0_ms", None)
         res.pop("own_dfact_ms", None)
         res.pop("own_early_ms", None)
         if lat is None:
             return dict(error="the pipeline's events carry no time stamps (set GPX_EVENT_TIMING=1 before the first use)")
         hist.append(dict(paced=pace is not None, ms_per_step=res["ms_per_step"], own_latency_sum_ms=float(sum(lat.values())),
                          chain_estimate_ms=float(sum(lat.values())) * grid[1]))
-        pace = pace_from(lat, res["steps_k"])
+        pace = dict(panel=pace_from(lat, res["steps_k"]), panel0=pace_from(lat0 or lat, res["steps_k"]), dfact=None, early=None)
     return dict(grid=res["grid"], rank=rank, nb=res["nb"], streamed_ivar=bool(streamed), iterations=hist,
                 unpaced_rank_busy_ms=hist[0]["ms_per_step"], paced_step_ms=hist[-1]["ms_per_step"],
                 own_latency_ms_first_last=[round(lat[min(lat)], 3), round(lat[max(lat)], 3)],
@@ -115,12 +121,13 @@ def paced_grid(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, nb=None, agg=None, s
     rows = list(range(Pr)) if rows is None else list(rows)
     nblk = None
     lat = {}           # step k -> holder latency (ms), max over the replayed ranks of the holder column
+    lat0 = {}          # the same for the FIRST row chunk of the panel (round 5)
     dfl, eal = {}, {}  # step k -> ms after the arrival of panel k-1 at which the diagonal block was factored / block row k+1 solved
     hist = []
     last = {}
     diag_paced = os.environ.get("GPX_REPLAY_PACE_DIAG", "1") == "1" and len(rows) == Pr
     for it in range(iters):
-        newlat, newdf, newea = {}, {}, {}
+        newlat, newdf, newea, newlat0 = {}, {}, {}, {}
         for pc in range(Pc):
             for pr in rows:
                 rank = pr * Pc + pc
@@ -130,7 +137,8 @@ def paced_grid(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, nb=None, agg=None, s
                     # (sweep 1 paces the panels alone: the figures of the unpaced sweep 0 are those of a rank that is never idle,
                     # several times the fixed point's, and holding the diagonal chain back by them too keeps them there)
                     dp = diag_paced and it >= 2
-                    pace = dict(panel=us(lat), dfact=us(dfl) if dp else None, early=us(eal) if dp else None)
+                    pace = dict(panel=us(lat), panel0=us(lat0 if len(lat0) == nblk else lat), dfact=us(dfl) if dp else None,
+                                early=us(eal) if dp else None)
                 res = replay_rank(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=nb, agg=agg, streamed=streamed, steps=steps,
                                   profile=False, pace_us=pace, want_latencies=True)
                 own = res.pop("own_latency_ms")
@@ -140,6 +148,8 @@ def paced_grid(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, nb=None, agg=None, s
                 agg_used, nb = res["agg"], res["nb"]
                 for k, v in own.items():
                     newlat[k] = max(newlat.get(k, 0.0), v)
+                for k, v in (res.pop("own_latency0_ms", None) or own).items():
+                    newlat0[k] = max(newlat0.get(k, 0.0), v)
                 newdf.update(res.pop("own_dfact_ms") or {})
                 newea.update(res.pop("own_early_ms") or {})
                 last[rank] = dict(paced=pace is not None, ms_per_step=res["ms_per_step"], own_latency_sum_ms=float(sum(own.values())),
@@ -150,7 +160,7 @@ def paced_grid(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, nb=None, agg=None, s
         # the next sweep's pacing shorter and the latencies rise again -- the plain iteration oscillates (fit + IVAR at 2 x 4:
         # 215, 72, 110, 93, 102 ms of chain); from the second paced sweep on the pacing moves half-way
         damp = lambda old, new: new if it < (3 if diag_paced else 2) else {k: 0.5 * (old.get(k, new[k]) + new[k]) for k in new}  # noqa: E731
-        lat, dfl, eal = damp(lat, newlat), damp(dfl, newdf), damp(eal, newea)
+        lat, dfl, eal, lat0 = damp(lat, newlat), damp(dfl, newdf), damp(eal, newea), damp(lat0, newlat0)
         hist.append(dict(iteration=it, chain_ms=float(sum(lat.values())),
                          rank_step_ms={str(r): round(v["ms_per_step"], 3) for r, v in last.items()},
                          paced=all(v["paced"] for v in last.values())))
@@ -214,6 +224,7 @@ def replay_rank(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=None, agg=
                variance_check_rel=check, single_gpu_potrf_ms=single_potrf_ms)
     if want_latencies:
         res["own_latency_ms"] = lat
+        res["own_latency0_ms"] = getattr(own_step_latencies, "lat0", None) if lat is not None else None
         res["own_dfact_ms"] = getattr(own_step_latencies, "dfact", None) if lat is not None else None
         res["own_early_ms"] = getattr(own_step_latencies, "early", None) if lat is not None else None
         res["last_arrived_ms"] = arr_all[-1] if arr_all else None      # (of the LAST timed step) the rest of the step is the rank's tail

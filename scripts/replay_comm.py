@@ -44,18 +44,26 @@ class ReplayComm(Emitter):
         assert Pr * Pc == self.world
         self.grid = (Pr, Pc)
 
+    CH0 = 512   # stamp slots CH0 + k + 1: chunk 0 of panel k has arrived (slot k + 1: all of panel k); gpx_debug.h has 1024 slots
+
     def at_step(self, geo, k):
         self.geo, self.k = geo, k
+        self.chunk, self.last_chunk = 0, True
         if k == 0 and self.pace is not None:
             self._emit(OP["SPIN"], (), (0, 2))           # stamp slot 0: the step starts (slot k + 1: panel k has arrived)
+            self._emit(OP["SPIN"], (), (self.CH0, 2))
 
-    def _hold(self, kind):
-        """foreign delivery of step k: not before the stamp of panel k-1's arrival + the producer's figure"""
+    def at_chunk(self, c, last):
+        """round 5: the panel loop announces which row chunk of panel k the next panel_bcast delivers, and whether it is the last"""
+        self.chunk, self.last_chunk = int(c), bool(last)
+
+    def _hold(self, kind, base=0):
+        """foreign delivery of step k: not before the stamp of panel k-1's arrival (chunk 0: of ITS chunk 0's) + the producer's figure"""
         if self.pace is None or self.pace.get(kind) is None:
             return
         us = int(self.pace[kind][self.k])
         if us > 0:
-            self._emit(OP["SPIN"], (), (self.k, 3, us))
+            self._emit(OP["SPIN"], (), (base + self.k, 3, us))
 
     def _rows(self, buf, off, m, first_block, stride, k):
         geo = self.geo
@@ -93,25 +101,33 @@ class ReplayComm(Emitter):
 
     def panel_bcast(self, buf, pieces):
         geo, k = self.geo, self.k
-        if self.pace_us is not None and geo.pc != k % geo.Pc and int(self.pace_us[k]) > 0:
+        foreign = geo.pc != k % geo.Pc
+        if self.pace_us is not None and foreign and self.chunk == 0 and int(self.pace_us[k]) > 0:
             self._emit(OP["SPIN"], (), (int(self.pace_us[k]), 1))      # the foreign holder's latency (COMM stream, in order)
-        if geo.pc != k % geo.Pc:
-            self._hold("panel")
+        if foreign:
+            if self.chunk == 0:
+                self._hold("panel0", self.CH0)
+            if self.last_chunk:
+                self._hold("panel")
         for off, cnt, root in pieces:
             if root == self.rank or cnt == 0:
                 continue
             p = root // geo.Pc
-            m = geo.piece_rows(p, k)
-            if p == k % geo.Pr:
-                assert off == geo.piece_off(p) and cnt == geo.dsz + m * geo.gld
+            rel = off - geo.piece_off(p)
+            if rel == 0:                                   # the diagonal region leads the piece of the holder's process row
+                assert p == k % geo.Pr and cnt >= geo.dsz and (cnt - geo.dsz) % geo.gld == 0
                 self._diag(buf, off, k)
-                off += geo.dsz
-            else:
-                assert off == geo.piece_off(p) + geo.dsz and cnt == m * geo.gld
+                off, cnt, rel = off + geo.dsz, cnt - geo.dsz, geo.dsz
+            assert rel >= geo.dsz and (rel - geo.dsz) % geo.gld == 0 and cnt % geo.gld == 0
+            r0, m = (rel - geo.dsz) // geo.gld, cnt // geo.gld   # rows [r0, r0 + m) of piece p: a whole number of blocks above them
+            assert r0 % geo.nb == 0 and r0 + m <= geo.piece_rows(p, k)
             if m > 0:
-                self._rows(buf, off, m, p + geo.li0(p, k) * geo.Pr, geo.Pr, k)
+                self._rows(buf, off, m, p + (geo.li0(p, k) + r0 // geo.nb) * geo.Pr, geo.Pr, k)
         if self.pace is not None:
-            self._emit(OP["SPIN"], (), (k + 1, 2))       # stamp: panel k has arrived
+            if self.chunk == 0:
+                self._emit(OP["SPIN"], (), (self.CH0 + k + 1, 2))   # stamp: chunk 0 of panel k has arrived
+            if self.last_chunk:
+                self._emit(OP["SPIN"], (), (k + 1, 2))              # stamp: panel k has arrived
 
     def reduce_grp(self, *a):
         raise NotImplementedError("the substitution sweeps are not replayable on one rank")

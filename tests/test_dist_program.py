@@ -99,7 +99,14 @@ def test_recorded_programs_event_discipline_and_collective_order(Pr, Pc, n, nb, 
     # world communicator: identical sequences on every rank
     world = {r: [c for c in seq if c[0] == dist.WORLD] for r, seq in progs.items()}
     assert all(world[r] == world[0] for r in range(W)), "ranks disagree on the order of the world collectives"
-    assert len(world[0]) == dist.num_blocks(n, nb), "one panel broadcast per panel"
+    # round 5: a panel travels in one or two row chunks (the same cut on every rank: the sequences above agree), and the chunks of
+    # a panel deliver exactly the regions of its pieces
+    nblk = dist.num_blocks(n, nb)
+    assert nblk <= len(world[0]) <= 2 * nblk, "one or two panel broadcasts per panel"
+    if nblk >= 12 and min(Pr, Pc) >= 1 and dist.Grid2D(n, nb, Pr, Pc, 0).piece_rows(0, 0) >= 4 * nb:
+        assert len(world[0]) > nblk, "no panel was cut into row chunks"
+    assert sum(sum(c[2]) for c in world[0]) == sum(cnt for k in range(nblk) for _, cnt, _ in geo.pieces(k)), \
+        "the chunks of the panels do not add up to their pieces"
     # row / column communicators: identical sequences inside each group
     for grp, members in [(dist.ROW, [[p * Pc + q for q in range(Pc)] for p in range(Pr)]),
                          (dist.COL, [[p * Pc + q for p in range(Pr)] for q in range(Pc)])]:
