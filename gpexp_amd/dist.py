@@ -35,6 +35,7 @@ The index arithmetic (ownership, slices, piece offsets, update ranges) is plain 
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -1517,6 +1518,8 @@ class DistFitIvar2D:
     def _enqueue_factor(self):
         hook = self._hook()
         L = None if (self.window and hook is None) else self.L       # a rank without evaluation points keeps no window
+        if getattr(self, "cyclic_only", False):                      # the factor stays block-cyclic in A: nothing is copied
+            L, hook = None, None
         dist2_potrf_enqueue(self.ops, self.comm, self.geo, self.A, self.G, L=L, on_stored=hook, agg=self.agg,
                             window=self.window if hook is not None else 0, E=self.E)
 
@@ -1574,7 +1577,7 @@ class DistFitIvar2D:
             ops.stream(MAIN)                                       # (the program forks every stream off MAIN behind this)
             ops.vec_op(self.yv, 0, self.y0, 0, geo.np, 0)
         self._run("factor", self._enqueue_factor)
-        info = dist2_potrf_finish(ops, comm, None if self.window else self.L)
+        info = dist2_potrf_finish(ops, comm, None if (self.window or getattr(self, "cyclic_only", False)) else self.L)
         if info:
             from ._lib import NotPositiveDefinite
             raise NotPositiveDefinite(info)
@@ -1814,9 +1817,18 @@ class Session:
         run.spec = spec
         run.X = run.ops.points(nodes)
         run.noise = nugget if isinstance(nugget, np.ndarray) else float(nugget)
+        # Round 5: the caller gets the runner's replica ITSELF, not a gpx_mat_clone of it (8.6 GB copied at C4 on every call,
+        # every likelihood evaluation of an optimiser loop included, and two N x N matrices resident per rank).  A factor that
+        # is still referenced when the next fit of this size comes (GP.train keeps it; loglikeParams(remember=False) drops it at
+        # once) stays with its holder: the runner then takes a fresh matrix and re-records its program (the recorded rows carry
+        # the matrix handle).  2 = the runner's own reference + getrefcount's argument.
+        if sys.getrefcount(run.L) > 2:
+            run.L = run.ops.alloc_matrix(run.n)
+            run.programs, run._runs = None, {}
+            self.stats["replicas_handed_over"] = self.stats.get("replicas_handed_over", 0) + 1
         run.fit()
         self.stats["fits"] += 1
-        return run.X, self.be.clone(self.ctx, run.L)
+        return run.X, run.L
 
     # ---- evaluation ----
     def gather(self, local, m, width=1):

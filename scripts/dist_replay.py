@@ -188,10 +188,11 @@ def replay_rank(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=None, agg=
     n, m = Xh.shape[0], Zh.shape[0]
     comm = ReplayComm(ctx, world, rank, Lref, pace_us=pace_us)
     run = dist.DistFitIvar2D(ctx, comm, spec, Xh, yh, Zh, noise, nb=nb, grid=(Pr, Pc), agg=agg, streamed=streamed, fit_only=True)
+    run.cyclic_only = os.environ.get("GPX_REPLAY_NO_REPLICA") == "1"    # factorisation without any copy of the finished panels
     _, part = run.step()          # records the program, first run
     ctx.sync()
     check = 0.0
-    if not run.window:
+    if not run.window and not run.cyclic_only:
         # the replicated factor this rank assembled from its own solves and the staged pieces must BE the factor
         Zc = dev.points(ctx, Zh[:512])
         _, v1 = dev.posterior(ctx, spec, run.L, X, None, Zc, want_mean=False)
