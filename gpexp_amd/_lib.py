@@ -120,6 +120,8 @@ _SIGS = {
     "gpx_dist2_panel_trsm_keep": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64]),
     "gpx_dist2_panel_trsm_inv": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, C.c_int]),
     "gpx_dist2_panel_copyback": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64]),
+    "gpx_dist2_panel_pack": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64]),
+    "gpx_dist2_diag_pack": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64]),
     "gpx_dist2_update": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64]),
     "gpx_dist2_update_multi": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_i64,
                                          C.c_int, C.POINTER(c_vp), c_ip, C.c_int]),

@@ -1029,6 +1029,31 @@ int gpx_dist2_panel_copyback(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, i
   return gpx_copy2d(ctx, G->p + roff, gld, A->p + lr0 * A->ld + lc, A->ld, m, w);
 }
 
+// Round 5, the factor RE-STREAMED (gpexp_amd/dist.py dist2_restream_enqueue: evaluation against a rank that kept no replica of
+// the factor -- the block-cyclic local matrix is all there is): the inverse of gpx_dist2_panel_copyback / gpx_dist2_diag_store.
+// Rows [lr0, lr0 + m) of local block column lc (a piece of finished panel k) from the local matrix into the packed buffer ...
+int gpx_dist2_panel_pack(gpx_ctx* ctx, const gpx_mat* A, int64_t lr0, int64_t m, int64_t lc, int64_t w, gpx_mat* G, int64_t roff,
+                         int64_t nb) {
+  GPX_ARG(ctx && G, "NULL argument");
+  GPX_TRY(check_local(A, lr0, m, lc, w));
+  const int64_t gld = gpx_g_ld(nb);
+  GPX_ARG(w <= nb && roff >= 0 && (roff + m * gld) * 8 <= G->bytes, "region outside G");
+  if (m == 0) return 0;
+  return gpx_copy2d(ctx, A->p + lr0 * A->ld + lc, A->ld, G->p + roff, gld, m, w);
+}
+
+// ... and the factored diagonal block with its leaf inverses into the D region (owner of the block)
+int gpx_dist2_diag_pack(gpx_ctx* ctx, const gpx_mat* A, int64_t lr, int64_t lc, int64_t w, gpx_mat* G, int64_t doff, int64_t nb) {
+  GPX_ARG(ctx, "NULL argument");
+  GPX_TRY(diag_region_check(A, lr, lc, w, G, doff, nb));
+  GPX_ARG(A->aux != nullptr, "diag_pack: the local matrix holds no factored diagonal block");
+  double* D = G->p + doff;
+  GPX_TRY(gpx_copy2d(ctx, A->p + lr * A->ld + lc, A->ld, D, nb, w, w));
+  GPX_HIP(hipMemcpyAsync(D + nb * nb, A->aux + (lr / GPX_TILE) * GPX_TILE * GPX_TILE, (size_t)((w / GPX_TILE) * GPX_TILE * GPX_TILE * 8),
+                         hipMemcpyDeviceToDevice, ctx->stream));
+  return 0;
+}
+
 static int panel_trsm_impl(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t lc, int64_t w, gpx_mat* G, int64_t doff,
                            int64_t roff, int64_t nb, int64_t dslot, int use_prepared) {
   GPX_ARG(ctx && G, "NULL argument");
@@ -1317,6 +1342,8 @@ int gpx_program_run(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const int64_
       case GPX_OP_DIAG_UPDATE: r = gpx_dist2_diag_update(ctx, h0, a[0], a[1], h1, a[2], a[3], a[4]); break;
       case GPX_OP_DIAG_FACTOR_STAGED: r = gpx_dist2_diag_factor_staged(ctx, h0, a[0], a[1], a[2], h1, a[3], a[4], a[5], a[6]); break;
       case GPX_OP_DIAG_STORE: r = gpx_dist2_diag_store(ctx, h0, a[0], a[1], a[2], h1, a[3], a[4], a[5] - 1); break;
+      case GPX_OP_PANEL_PACK: r = gpx_dist2_panel_pack(ctx, h0, a[0], a[1], a[2], a[3], h1, a[4], a[5]); break;
+      case GPX_OP_DIAG_PACK: r = gpx_dist2_diag_pack(ctx, h0, a[0], a[1], a[2], h1, a[3], a[4]); break;
       case GPX_OP_UPDATE: r = gpx_dist2_update(ctx, h0, a[0], a[1], a[2], a[3], h1, a[4], a[5], a[6], a[7]); break;
       case GPX_OP_UPDATE_MULTI: {
         // a: lr0, m, lc0, n, nb, Pr, Pc, pr, pc, piece_stride, nseg | below_diag << 8, extra offset of [G handles..., ks...]

@@ -96,7 +96,7 @@ def merge_argmin(values, indices):
 OP = dict(STREAM=1, RECORD=2, WAIT=3, BEGIN=4, DIAG_FACTOR=5, PANEL_TRSM=6, UPDATE=7, UPDATE_MULTI=8, UNPACK_ROWS=9,
           UNPACK_DIAG=10, PACK_ROWS=11, PACK_DIAG=12, BCAST_GRP=13, REDUCE_GRP=14, ALLREDUCE=15, PANEL_BCAST=16, IVAR_STEP=17,
           TRSV_DIAG=18, GEMV=19, LOGDET_ACC=20, VEC_OP=21, SPIN=22, COPY=23, IVAR_GROUP=24, FWD_GROUP=25, PANEL_INV=26, BCAST_GRP2=27, PANEL_COPYBACK=28,
-          DIAG_STAGE=29, DIAG_UPDATE=30, DIAG_FACTOR_STAGED=31, DIAG_STORE=32)
+          DIAG_STAGE=29, DIAG_UPDATE=30, DIAG_FACTOR_STAGED=31, DIAG_STORE=32, PANEL_PACK=33, DIAG_PACK=34)
 
 
 class Program:
@@ -357,6 +357,11 @@ class DeviceOps:
 
     def ivar_step(self, K, k, nb, B):
         check(self.ctx.lib.gpx_dist_ivar_step(self.ctx.h, K.h, int(k), int(nb), B.h))
+
+    def cross_mean(self, spec, X, Z, alpha):
+        """K(Z, X) alpha on the host: the posterior mean of a slice of evaluation points without the factor (its own small fill:
+        the solve overwrites K(X, Z) in place)."""
+        return _dev.matvec(self.ctx, _dev.kfill(self.ctx, spec, Z, Z=X), as_f64(alpha))
 
     def variances(self, spec, Z, B, n):
         """k(z,z) - column sums of squares of the solved cross matrix (signed, as evaluateVariance)."""
@@ -771,6 +776,14 @@ class DeviceOps2D(Emitter, DeviceOps):
 
     def panel_copyback(self, A, lr0, m, lc, w, G, roff, nb):
         self._emit(OP["PANEL_COPYBACK"], (A, G), (lr0, m, lc, w, roff, nb))
+
+    def panel_pack(self, A, lr0, m, lc, w, G, roff, nb):
+        """rows of a FINISHED panel from the local matrix into the packed buffer (re-streamed factor, dist2_restream_enqueue)"""
+        self._emit(OP["PANEL_PACK"], (A, G), (lr0, m, lc, w, roff, nb))
+
+    def diag_pack(self, A, lr, lc, w, G, doff, nb):
+        """the factored diagonal block + its leaf inverses from the local matrix into the D region of the packed buffer"""
+        self._emit(OP["DIAG_PACK"], (A, G), (lr, lc, w, doff, nb))
 
     def update(self, A, lr0, m, lc0, n, G, aoff, boff, w, nb):
         self._emit(OP["UPDATE"], (A, G), (lr0, m, lc0, n, aoff, boff, w, nb))
@@ -1330,6 +1343,74 @@ def dist2_potrf_enqueue(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, 
         ops.wait(EV_JOIN0 + i_)
 
 
+def dist2_restream_enqueue(ops, comm, geo, A, G, L, on_stored=None, agg=None, window=0):
+    """The FINISHED block-cyclic factor A once more to every rank, panel by panel -- the evaluation phase of a process that keeps
+    no replica of the factor (round 5; SURVEY 8e(1) "above N = 16384 keep L distributed"; the role of the fork inside
+    GP.evaluateVariance, gp.py:244-258).  Per panel k: the holder column packs its pieces out of the local matrix (the owner adds
+    the diagonal block and its leaf inverses), the panel broadcast delivers every piece to every rank, the pieces are copied into
+    L -- a WINDOW of `window` block columns consumed group by group by `on_stored` (streamed_ivar_hook: one right-looking solve
+    step of the rank's slice of K(X, Z) per group, E_IVAR releases the slot), or with window = 0 a full-size matrix (the replica
+    assembled on demand for the entry points that need a dense factor).  No arithmetic on the factor, no trailing updates: per
+    rank N^2/2 doubles received, nothing resident but A / W, the window and the ring of packed buffers.  Pure enqueue."""
+    nb, Pr, Pc, pr, pc = geo.nb, geo.Pr, geo.Pc, geo.pr, geo.pc
+    nblk = geo.nblk
+    q = default_agg() if agg is None else int(agg)
+    R = len(G)
+    window = int(window)
+    assert window == 0 or (L is not None and on_stored is not None and window % q == 0 and window >= 2 * q)
+    at_step = getattr(comm, "at_step", None)
+    ops.stream(MAIN)
+    ops.record(EV_FORK)
+    for s_ in ALL_SIDE_STREAMS:
+        ops.stream(s_)
+        ops.wait(EV_FORK)
+    for k in range(nblk):
+        kr, kc = k % Pr, k % Pc
+        g = G[k % R]
+        w = geo.height(k)
+        lr, lc = (k // Pr) * nb, (k // Pc) * nb
+        holder = pc == kc
+        if at_step is not None:
+            at_step(geo, k)
+        if holder:
+            ops.stream(PANEL)
+            if k >= R:
+                ops.wait(_ev2(E_STORED, k - R))                           # the buffer's previous panel has been copied out
+            if pr == kr:
+                ops.diag_pack(A, lr, lc, w, g, geo.piece_off(kr), nb)
+            lr0, m = geo.row_off(pr, geo.li0(pr, k)), geo.piece_rows(pr, k)
+            if m > 0:
+                ops.panel_pack(A, lr0, m, lc, w, g, geo.piece_off(pr) + geo.dsz, nb)
+            ops.record(_ev2(E_PIECE, k))
+        ops.stream(COMM)
+        if holder:
+            ops.wait(_ev2(E_PIECE, k))
+        elif k >= R:
+            ops.wait(_ev2(E_STORED, k - R))
+        comm.panel_bcast(g, geo.pieces(k))
+        ops.record(_ev2(E_ARRIVED, k))
+        ops.stream(BACK)
+        ops.wait(_ev2(E_ARRIVED, k))
+        if L is not None:
+            col = (k % window) * nb if window else k * nb
+            if window and k >= window:
+                ops.wait(_ev2(E_IVAR, min(((k - window) // q + 1) * q - 1, nblk - 1)))   # the step that read this column slot
+            ops.unpack_diag(g, geo.piece_off(kr), w, nb, L, k * nb, col if window else None)
+            for p in range(Pr):
+                m = geo.piece_rows(p, k)
+                if m > 0:
+                    ops.unpack_rows(g, geo.piece_off(p) + geo.dsz, m, w, nb, L, p + geo.li0(p, k) * Pr, Pr, col)
+        ops.record(_ev2(E_STORED, k))
+        if on_stored is not None:
+            on_stored(k)
+    for i_, s_ in enumerate(ALL_SIDE_STREAMS):                           # JOIN
+        ops.stream(s_)
+        ops.record(EV_JOIN0 + i_)
+    ops.stream(MAIN)
+    for i_ in range(len(ALL_SIDE_STREAMS)):
+        ops.wait(EV_JOIN0 + i_)
+
+
 def dist2_potrs(ops, comm, geo, A, yv, acc_r, acc_c, out, skip_forward=False):
     """alpha = K^-1 y on the block-cyclic factor A: block forward substitution (partial sums reduced along the process
     row of the diagonal owner, the solved block broadcast down its process column), then the transposed sweep with the
@@ -1430,7 +1511,7 @@ class DistFitIvar2D:
           which the evaluation / the gradient slabs run with no exchange."""
 
     def __init__(self, ctx, comm, spec, Xh, yh, Zh, noise, nb=None, ops=None, streamed=None, grid=None, agg=None,
-                 fit_only=False, replicate=None):
+                 fit_only=False, replicate=None, cyclic=False):
         self.ctx, self.comm, self.spec = ctx, comm, spec
         self.ops = ops or DeviceOps2D(ctx)
         Pr, Pc = grid or choose_grid(comm.world)
@@ -1473,7 +1554,15 @@ class DistFitIvar2D:
         if not self.streamed:
             self.replicate = True
         self.window = 0 if self.replicate else 2 * self.agg
-        if self.window:
+        # cyclic (round 5, the class API's distributed-factor mode): the finished factor stays block-cyclic in A -- no replica,
+        # no window until an evaluation asks for one; alpha / log det by distributed substitution, evaluation by re-streaming the
+        # panels (cyclic_posterior), a dense replica only on demand (assemble_dense)
+        self.cyclic_only = bool(cyclic)
+        self.generation = 0              # fits of this runner so far: a CyclicFactor knows which one it belongs to
+        self._win = None
+        if self.cyclic_only:
+            self.replicate, self.window, self.L = False, 0, None
+        elif self.window:
             self.L = self.ops.alloc_window(self.n, self.window * nb)
         else:
             self.L = self.ops.alloc_matrix(self.n)
@@ -1576,6 +1665,7 @@ class DistFitIvar2D:
         if self.fused_fwd:
             ops.stream(MAIN)                                       # (the program forks every stream off MAIN behind this)
             ops.vec_op(self.yv, 0, self.y0, 0, geo.np, 0)
+        self.generation += 1
         self._run("factor", self._enqueue_factor)
         info = dist2_potrf_finish(ops, comm, None if (self.window or getattr(self, "cyclic_only", False)) else self.L)
         if info:
@@ -1616,6 +1706,102 @@ class DistFitIvar2D:
             part = float(np.sum(ops.posterior_var(self.spec, self.L, self.X, self.Zloc)))
         iv = abs(ordered_sum(comm.allgather(np.array([part]))[:, 0]) / max(self.m, 1))
         return ll, iv
+
+
+    # ---- round 5: the block-cyclic factor as THE factor (no replica) ------------------------------------------------------------
+    def solve_for(self, y):
+        """(alpha = K^-1 y on the host, log det K) from the block-cyclic factor by distributed substitution (dist2_potrs) --
+        identical on every rank (the blocks of alpha are assembled by collectives)."""
+        self.yh = np.ascontiguousarray(y, dtype=np.float64)
+        ypad = np.zeros(self.geo.np)
+        ypad[:self.n] = self.yh
+        self.ops.vec_from_host(self.y0, ypad)
+        self._run("solve", self._enqueue_solve)
+        logdet = float(self.comm.allreduce_host(np.array([self.ops.vec_to_host(self.scal, 1)[0]]))[0])
+        return self.ops.vec_to_host(self.alpha, self.n), logdet
+
+    def resident_bytes(self):
+        """what this rank holds for the factor: its share of the matrix, the ring of packed buffers (+ early buffers), the window"""
+        geo = self.geo
+        b = 8 * geo.local_rows(geo.pr) * geo.local_cols(geo.pc) + 8 * len(self.G) * geo.buf_elems()
+        if self.E is not None:
+            b += 8 * len(self.E) * self.nb * geo.gld
+        if self._win is not None:
+            b += 8 * geo.np * 2 * self.agg * self.nb
+        if self.L is not None:
+            b += 8 * geo.np * (self.window * self.nb if self.window else geo.np)
+        return int(b)
+
+    def cyclic_posterior(self, Zloc, alpha=None, want_mean=True, want_var=True):
+        """(mean, signed variance) at this rank's slice `Zloc` (host, may be empty) of the evaluation points against the
+        block-cyclic factor: K(X, Zloc) is solved group by group against a WINDOW of the factor while the panels are re-streamed
+        (dist2_restream_enqueue).  A COLLECTIVE when want_var: every rank must call it, also with an empty slice."""
+        ops, comm, geo = self.ops, self.comm, self.geo
+        mloc = int(Zloc.shape[0])
+        Z = ops.points(Zloc) if mloc else None
+        mean = var = None
+        if want_mean:
+            mean = ops.cross_mean(self.spec, self.X, Z, alpha) if mloc else np.zeros(0)
+        if want_var:
+            q, B, hook, win = self.agg, None, None, None
+            if mloc:
+                B = ops.alloc_cross(self.n, mloc)
+                if hasattr(ops, "reserve"):
+                    ops.reserve(self.nb, q, mloc)
+                ops.stream(MAIN)
+                ops.cross_fill(self.spec, self.X, Z, B)
+                if self._win is None:
+                    self._win = ops.alloc_window(self.n, 2 * q * self.nb)
+                win = self._win
+                hook = streamed_ivar_hook(ops, geo, win, B, q, 2 * q)
+            dist2_restream_enqueue(ops, comm, geo, self.A, self.G, win, on_stored=hook, agg=q, window=2 * q if mloc else 0)
+            ops.info()                                   # synchronises every stream
+            var = ops.variances(self.spec, Z, B, self.n) if mloc else np.zeros(0)
+        return mean, var
+
+    def assemble_dense(self):
+        """A replica of the factor assembled on demand (a COLLECTIVE: the panels are re-streamed into a full-size matrix) for the
+        entry points that need a dense factor on every rank (greedy designs, the gradient slabs, compvar = 2, point derivatives).
+        The returned matrix is an ordinary factored matrix and belongs to the caller."""
+        ops = self.ops
+        L = ops.alloc_matrix(self.n)
+        ops.stream(MAIN)
+        ops.begin()
+        dist2_restream_enqueue(ops, self.comm, self.geo, self.A, self.G, L, on_stored=None, agg=self.agg, window=0)
+        ops.info()
+        ops.finish(L)
+        return L
+
+
+class CyclicFactor:
+    """What Session.factor hands the class API in the distributed-factor mode (GPX_DIST_FACTOR=cyclic): the fit of one
+    (kernel, nodes, nugget) whose factor lives block-cyclic on the ranks.  solve / posterior run distributed; dense() assembles a
+    replica once for everything else.  The runner's matrix is reused by the NEXT fit of the same size: a factor that is asked
+    after that re-fits itself first (same inputs, same result)."""
+    is_cyclic = True
+
+    def __init__(self, sess, run, spec, nodes, nugget):
+        self.sess, self.run, self.spec = sess, run, spec
+        self.nodes, self.nugget = nodes, nugget
+        self.generation = run.generation
+        self._dense = None
+
+    def _current(self):
+        if self.run.generation != self.generation:
+            self.sess._refit(self)
+        return self.run
+
+    def solve(self, y):
+        return self._current().solve_for(y)
+
+    def posterior(self, Zloc, alpha, want_mean, want_var):
+        return self._current().cyclic_posterior(Zloc, alpha, want_mean, want_var)
+
+    def dense(self):
+        if self._dense is None:
+            self._dense = self._current().assemble_dense()
+            self.sess.stats["dense_assembled"] = self.sess.stats.get("dense_assembled", 0) + 1
+        return self._dense
 
 
 # =====================================================================================================================
@@ -1754,7 +1940,15 @@ class Session:
         self.min_m = int(os.environ.get("GPX_DIST_MIN_M", "4096")) if min_m is None else int(min_m)
         self.check = (os.environ.get("GPX_DIST_CHECK", "1") == "1") if check is None else bool(check)
         self._runner = None          # (key, DistFitIvar2D): buffers + recorded programs of the last problem size
+        self._scratch_runner = None  # the same for fits nobody keeps (likelihood evaluations) in the distributed-factor mode
         self.stats = dict(fits=0, evals=0, grads=0)
+        # Round 5, distributed-factor mode (GPX_DIST_FACTOR=cyclic | replica; default: cyclic from GPX_DIST_CYCLIC_MIN_N = 65536
+        # training points, where two N x N replicas per rank stop being cheap): the fit leaves the factor block-cyclic on the
+        # ranks -- N^2 / W per rank + the ring of packed panel buffers -- and the class API works on THAT: coeff / log-marginal by
+        # distributed substitution, evaluate / evaluateVariance / the IVAR cost by re-streaming the panels against a window
+        # (dist2_restream_enqueue); a dense replica is assembled only when an entry point needs one (CyclicFactor.dense).
+        self.factor_mode = os.environ.get("GPX_DIST_FACTOR", "auto")
+        self.cyclic_min_n = int(os.environ.get("GPX_DIST_CYCLIC_MIN_N", "65536"))
 
     @property
     def rank(self):
@@ -1773,6 +1967,9 @@ class Session:
 
     def nb_for(self, n):
         return default_nb(n, self.world, False)
+
+    def use_cyclic(self, n):
+        return self.factor_mode == "cyclic" or (self.factor_mode == "auto" and n >= self.cyclic_min_n)
 
     # ---- the SPMD contract, checked ----
     def agree(self, what, *arrays):
@@ -1805,14 +2002,46 @@ class Session:
         self._runner = (key, run)
         return run
 
-    def factor(self, spec, nodes, nugget):
-        """Distributed assembly + factorisation of K(nodes) + diag(nugget) -> (X, L): the device point set and this rank's own
-        copy of the replicated factor (an ordinary factored matrix: every single-GPU entry point works on it).  Raises
+    def _get_cyclic_runner(self, n, d, nb, keep):
+        slot = "_runner_c" if keep else "_scratch_runner"
+        key = (int(n), int(d), int(nb))
+        cur = getattr(self, slot, None)
+        if cur is not None and cur[0] == key:
+            return cur[1]
+        setattr(self, slot, None)
+        run = DistFitIvar2D(self.ctx, self.comm, None, np.zeros((n, d)), np.zeros(n), np.zeros((0, d)), 0.0, nb=nb,
+                            ops=self.ops_factory(), streamed=False, cyclic=True)
+        setattr(self, slot, (key, run))
+        return run
+
+    def _fit_cyclic(self, run, spec, nodes, nugget):
+        run.spec = spec
+        run.X = run.ops.points(nodes)
+        run.noise = nugget if isinstance(nugget, np.ndarray) else float(nugget)
+        run.fit()
+        self.stats["fits"] += 1
+
+    def _refit(self, fac):
+        """the runner of a kept CyclicFactor has been used by a later fit: the same fit once more (deterministic)"""
+        self._fit_cyclic(fac.run, fac.spec, fac.nodes, fac.nugget)
+        fac.generation = fac.run.generation
+        fac._dense = None
+        self.stats["cyclic_refits"] = self.stats.get("cyclic_refits", 0) + 1
+
+    def factor(self, spec, nodes, nugget, keep=True):
+        """Distributed assembly + factorisation of K(nodes) + diag(nugget) -> (X, L): the device point set and the factor --
+        this rank's replica (an ordinary factored matrix: every single-GPU entry point works on it) or, in the distributed-factor
+        mode, a CyclicFactor.  keep = False: the caller drops the factor at once (a likelihood evaluation).  Raises
         NotPositiveDefinite on every rank alike (the pivot index is agreed by an all-gather)."""
         nodes = as_f64(nodes)
         n, d = nodes.shape
         self.agree("the training set / hyper-parameters", nodes, np.asarray(nugget, dtype=float), spec.hyp,
                    np.array([spec.kind, spec.d]))
+        if self.use_cyclic(n):
+            run = self._get_cyclic_runner(n, d, self.nb_for(n), keep)
+            self._fit_cyclic(run, spec, nodes, nugget)
+            nug = nugget.copy() if isinstance(nugget, np.ndarray) else nugget
+            return run.X, CyclicFactor(self, run, spec, nodes.copy(), nug)
         run = self._get_runner(n, d, self.nb_for(n))
         run.spec = spec
         run.X = run.ops.points(nodes)
@@ -1850,12 +2079,17 @@ class Session:
         be, ctx = self.be, self.ctx
         newpt = as_f64(newpt)
         m = newpt.shape[0]
-        if not self.use_eval(m):
+        cyc = getattr(L, "is_cyclic", False)
+        if not self.use_eval(m) and not cyc:
             return be.posterior(ctx, spec, L, X, alpha, be.points(ctx, newpt), want_mean=want_mean, want_var=want_var)
         self.agree("the evaluation points", newpt)
         lo, hi = eval_slice(m, self.rank, self.world)
         cols = []
-        if hi > lo:
+        if cyc:      # the factor is block-cyclic on the ranks: every rank takes part in the re-stream, also with an empty slice
+            mean, var = L.posterior(newpt[lo:hi], alpha, want_mean, want_var)
+            if hi > lo:
+                cols = [c for c in (mean if want_mean else None, var if want_var else None) if c is not None]
+        elif hi > lo:
             mean, var = be.posterior(ctx, spec, L, X, alpha, be.points(ctx, newpt[lo:hi]), want_mean=want_mean,
                                      want_var=want_var)
             cols = [c for c in (mean if want_mean else None, var if want_var else None) if c is not None]
@@ -1872,6 +2106,12 @@ class Session:
         m = mc.shape[0]
         lo, hi = eval_slice(m, self.rank, self.world)
         part = 0.0
+        if getattr(L, "is_cyclic", False):     # block-cyclic factor: the slice's variances by the re-streamed solve (collective)
+            self.agree("the Monte-Carlo points", mc)
+            _, var = L.posterior(as_f64(mc[lo:hi]), None, False, True)
+            part = float(np.sum(var))
+            self.stats["evals"] += 1
+            return ordered_sum(self.comm.allgather(np.array([part]))[:, 0]) / max(m, 1)
         if hi > lo:
             Z = getattr(cache, "_mc_slice_dev", None) if cache is not None else None
             if Z is None:

@@ -77,11 +77,11 @@ class costFunctionGP_IVAR(costFunctionBase):
             gp.addNodesAndComputeCovariance(inputPoints)
         else:
             gp.addNodesAndComputeCovariance(inputPoints, self.space.noiseFunc(inputPoints))
-        if gp._L is None:   # FITC model: the same mean through the Woodbury precision (gp.py:246-255), as the reference
+        if not gp._has_factor():   # FITC model: the same mean through the Woodbury precision (gp.py:246-255), as the reference
             return np.abs(np.mean(gp.evaluateVariance(self.mcPoints)))
         sess = _dist.session()
-        if sess is not None and sess.use_eval(self.nMC):          # MC points sharded over the ranks, partial sums in rank order
-            return np.abs(sess.ivar(gp.kernel._spec(), gp._L, gp._X, self.mcPoints, cache=self))
+        if sess is not None and (gp._Lc is not None or sess.use_eval(self.nMC)):   # MC points sharded over the ranks, partial sums in rank order
+            return np.abs(sess.ivar(gp.kernel._spec(), gp._Lc or gp._L, gp._X, self.mcPoints, cache=self))
         cost = _dev.ivar(_dev.context(), gp.kernel._spec(), gp._L, gp._X, self._mc())
         return np.abs(cost)
 
@@ -321,7 +321,7 @@ def greedyIVARStep(gaussianProcess, candidates, mcPoints):
     (gp.addNodesAndComputeCovariance / train): returns (best_index, costs) where
     costs[j] = costFunctionGP_IVAR(gp, n+1, space, mcPoints=mcPoints).evaluate(vstack(gp.pts, candidates[j]))."""
     gp = gaussianProcess
-    if gp._L is None:
+    if not gp._has_factor():
         raise NotImplementedError("greedyIVARStep needs the dense Cholesky factor (GP built with FITC=... has none)")
     sess = _dist.session()
     if sess is not None and sess.use_eval(len(candidates)):      # candidates sharded, first-minimum merge, costs gathered
@@ -339,7 +339,7 @@ def performGreedyIVARExperimentalDesign(gaussianProcess, candidates, mcPoints, n
     cov(Z, C | design) resident and conditions them on each pick by a rank-one update.  The GP itself is not modified.
     Returns candidates[indices] (as the reference's greedy designs do) or (indices, costs) with returnCosts=True."""
     gp = gaussianProcess
-    if gp._L is None:
+    if not gp._has_factor():
         raise NotImplementedError("performGreedyIVARExperimentalDesign needs the dense Cholesky factor (GP built with FITC=... has none)")
     candidates = np.asarray(candidates, dtype=float)
     sess = _dist.session()

@@ -64,6 +64,8 @@ class GP:
             self.FITC = kwargs['FITC']  # fraction of the nodes used as inducing points (gp.py:69-70, 187)
         self._fitc = None    # device FITC model (gpx_fitc_*)
         self._X = None       # device point set
+        self._Lc = None      # distributed-factor mode (dist.CyclicFactor): the factor lives block-cyclic on the ranks ...
+        self._Ld = None      # ... and a dense factor is assembled only when something asks for `_L`
         self._L = None       # device Cholesky factor of K(pts) + nugget
         self._nugget = None  # nugget that went into _L
         self._K_host = None
@@ -96,13 +98,32 @@ class GP:
     def precisionMatrix(self):
         if self._P_host is None and self._fitc is not None:
             self._P_host = self._fitc.dense(cov=False, prec=True)[1]
-        elif self._P_host is None and self._L is not None:
+        elif self._P_host is None and self._has_factor():
             self._P_host = _dev.potri(_dev.context(), self._L).to_host(tri=2)   # lower triangle valid: mirrored
         return self._P_host
 
     @precisionMatrix.setter
     def precisionMatrix(self, value):
         self._P_host = value
+
+    # the dense device factor.  Under a multi-process launch in the distributed-factor mode (dist.Session.use_cyclic) the fit
+    # leaves a CyclicFactor instead: train / evaluate / evaluateVariance / the likelihood / the IVAR cost work on that, and a
+    # dense replica is assembled the first time anything else reads `_L`.
+    @property
+    def _L(self):
+        if self._Ld is None and self._Lc is not None:
+            self._Ld = self._Lc.dense()
+        return self._Ld
+
+    @_L.setter
+    def _L(self, value):
+        if getattr(value, "is_cyclic", False):
+            self._Lc, self._Ld = value, None
+        else:
+            self._Lc, self._Ld = None, value
+
+    def _has_factor(self):
+        return self._Lc is not None or self._Ld is not None
 
     # ---- helpers --------------------------------------------------------------------------------------------
     def gpPriorMean(self, pts):
@@ -140,8 +161,8 @@ class GP:
                 # (dist.Session.factor).  A non-PD result is agreed by all ranks; they then all take the replicated
                 # single-GPU path below with its rank-deficient policy.
                 try:
-                    Xd, L = sess.factor(spec, nodes, nugget)
-                    if remember:
+                    Xd, L = sess.factor(spec, nodes, nugget, keep=remember)
+                    if remember and not getattr(L, "is_cyclic", False):   # (rows are reused from a DENSE previous factor only)
                         self._remember(nodes, nugget, spec, L)
                     return Xd, L, 0.0
                 except NotPositiveDefinite:
@@ -254,7 +275,10 @@ class GP:
         if self._fitc is not None:
             self.coeff = self._fitc.solve(evals)[0]
             return
-        self.coeff = _dev.potrs(_dev.context(), self._L, evals)
+        if self._Lc is not None:
+            self.coeff = self._Lc.solve(evals)[0]          # distributed substitution on the block-cyclic factor
+        else:
+            self.coeff = _dev.potrs(_dev.context(), self._L, evals)
 
     # ---- prediction ---------------------------------------------------------------------------------------------
     def evaluate(self, newpt, compvar=0):
@@ -273,10 +297,11 @@ class GP:
                 return out, _dev.kfill(ctx, spec, Z, Z=Z).to_host() - kv @ (self.precisionMatrix @ kv.T)
             return out
         sess = _dist.session()
-        if sess is not None and sess.use_eval(newpt.shape[0]):
+        if sess is not None and (self._Lc is not None or sess.use_eval(newpt.shape[0])):
             # evaluation points sharded over the ranks, mean and variance gathered on every rank (the role of
             # parallelizeMcForLoop, parallel_utilities.py:26-80)
-            mean, var = sess.posterior(spec, self._L, self._X, self.coeff, newpt, want_mean=True, want_var=(compvar == 1))
+            mean, var = sess.posterior(spec, self._Lc or self._L, self._X, self.coeff, newpt, want_mean=True,
+                                       want_var=(compvar == 1))
         else:
             mean, var = _dev.posterior(ctx, spec, self._L, self._X, self.coeff, Z, want_mean=True,
                                        want_var=(compvar == 1))
@@ -297,8 +322,9 @@ class GP:
         if self._fitc is not None:
             return self._fitc.posterior(None, _dev.points(ctx, newpt), want_mean=False, want_var=True)[1]
         sess = _dist.session()
-        if sess is not None and sess.use_eval(newpt.shape[0]):    # gp.py:244-258: the reference's own parallel branch
-            return sess.posterior(self.kernel._spec(), self._L, self._X, None, newpt, want_mean=False, want_var=True)[1]
+        if sess is not None and (self._Lc is not None or sess.use_eval(newpt.shape[0])):   # gp.py:244-258: the reference's parallel branch
+            return sess.posterior(self.kernel._spec(), self._Lc or self._L, self._X, None, newpt, want_mean=False,
+                                  want_var=True)[1]
         _, var = _dev.posterior(ctx, self.kernel._spec(), self._L, self._X, None, _dev.points(ctx, newpt),
                                 want_mean=False, want_var=True)
         return var
@@ -307,7 +333,7 @@ class GP:
     def _point_derivative_ready(self, newpt):
         assert self.pts is not None, "must specify training points before running this"
         assert newpt.shape[1] == self.kernel.dimension, "evaluation points for GP is incorrect shape"
-        if self._L is None:
+        if not self._has_factor():
             raise NotImplementedError("variance derivatives need the dense factor (not available with FITC)")
         if not hasattr(self.kernel, "derivative") or (self.kernel._spec().kind == _dev.K_MEHLER
                                                       and self.kernel.dimension != 1):
@@ -363,8 +389,14 @@ class GP:
         nugget = self.noise if noiseIn is None else noiseIn
         X, L, _ = self._factor(pts, nugget, remember=False)
         ctx = _dev.context()
-        alpha = _dev.potrs(ctx, L, evals)
-        out = -0.5 * np.dot(evals, alpha) - 0.5 * _dev.logdet(ctx, L) - len(evals) / 2.0 * np.log(2.0 * np.pi)
+        if getattr(L, "is_cyclic", False):
+            alpha, logdet = L.solve(evals)                 # distributed substitution; a dense factor only for the gradient
+            if returnDeriv == 1:
+                L = L.dense()
+        else:
+            alpha = _dev.potrs(ctx, L, evals)
+            logdet = _dev.logdet(ctx, L)
+        out = -0.5 * np.dot(evals, alpha) - 0.5 * logdet - len(evals) / 2.0 * np.log(2.0 * np.pi)
         if returnDeriv == 1:
             keys = list(self.kernel.hyperParam.keys()) + ['noise']
             sess = _dist.session()

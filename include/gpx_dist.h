@@ -175,6 +175,13 @@ int gpx_dist2_panel_trsm_inv(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, i
  * the event that releases the panel broadcast: off the chain across ranks) */
 int gpx_dist2_panel_copyback(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t lc, int64_t w, const gpx_mat* G, int64_t roff,
                              int64_t nb);
+/* The finished factor RE-STREAMED from the block-cyclic local matrix (a rank that keeps no replica; dist2_restream_enqueue): the
+   inverses of gpx_dist2_panel_copyback / gpx_dist2_diag_store -- rows of a finished panel, and the factored diagonal block with its
+   leaf inverses, from the local matrix into the packed buffer the panel broadcast sends from. */
+int gpx_dist2_panel_pack(gpx_ctx* ctx, const gpx_mat* A, int64_t lr0, int64_t m, int64_t lc, int64_t w, gpx_mat* G, int64_t roff,
+                         int64_t nb);
+int gpx_dist2_diag_pack(gpx_ctx* ctx, const gpx_mat* A, int64_t lr, int64_t lc, int64_t w, gpx_mat* G, int64_t doff, int64_t nb);
+
 /* A[lr0:lr0+m, lc0:lc0+n] -= G[aoff] (m x w) * G[boff] (n x w)^T : trailing update of one local block column */
 int gpx_dist2_update(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64_t lc0, int64_t n, const gpx_mat* G,
                      int64_t aoff, int64_t boff, int64_t w, int64_t nb);
@@ -212,7 +219,7 @@ enum {
   GPX_OP_UPDATE_MULTI, GPX_OP_UNPACK_ROWS, GPX_OP_UNPACK_DIAG, GPX_OP_PACK_ROWS, GPX_OP_PACK_DIAG, GPX_OP_BCAST_GRP,
   GPX_OP_REDUCE_GRP, GPX_OP_ALLREDUCE, GPX_OP_PANEL_BCAST, GPX_OP_IVAR_STEP, GPX_OP_TRSV_DIAG, GPX_OP_GEMV, GPX_OP_LOGDET_ACC,
   GPX_OP_VEC_OP, GPX_OP_SPIN, GPX_OP_COPY, GPX_OP_IVAR_GROUP, GPX_OP_FWD_GROUP, GPX_OP_PANEL_INV, GPX_OP_BCAST_GRP2, GPX_OP_PANEL_COPYBACK,
-  GPX_OP_DIAG_STAGE, GPX_OP_DIAG_UPDATE, GPX_OP_DIAG_FACTOR_STAGED, GPX_OP_DIAG_STORE
+  GPX_OP_DIAG_STAGE, GPX_OP_DIAG_UPDATE, GPX_OP_DIAG_FACTOR_STAGED, GPX_OP_DIAG_STORE, GPX_OP_PANEL_PACK, GPX_OP_DIAG_PACK
 };
 int gpx_program_run(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const int64_t* extra, int64_t nextra, double* host_ms);
 /* The same program as a hipGraph: captured once (after it has run once the ordinary way; every stream it uses must fork from

@@ -88,6 +88,7 @@ def run_api(args, gpu):
         noise = golden.noise(case)
         g = GP(make_kernel(ix["kernel"]), noise if np.ndim(noise) == 0 else 1e-3)
         f0 = sess.stats["fits"]
+        dense0 = sess.stats.get("dense_assembled", 0)
         if np.ndim(noise) == 0:
             ll = g.computeLogLike(X, y)
             g.train(X, y)
@@ -96,9 +97,14 @@ def run_api(args, gpu):
             g.train(X, y, noiseIn=noise)
         assert sess.world == 1 or sess.stats["fits"] == f0 + 2, "the class API did not take the distributed fit"
         e0 = sess.stats["evals"]
+        cyclic = sess.world > 1 and sess.use_cyclic(len(X))
+        if cyclic:    # distributed-factor mode: the fit left a block-cyclic factor, coeff came from the distributed substitution
+            assert g._Lc is not None and g._Ld is None, "the fit did not leave a block-cyclic factor"
         mean, var = g.evaluate(Z, compvar=1)
         signed = g.evaluateVariance(Z)
         mean0 = g.evaluate(Z)
+        if cyclic:    # ... and evaluation re-streamed it: no dense replica was assembled
+            assert g._Ld is None and sess.stats.get("dense_assembled", 0) == dense0, "evaluation assembled a dense replica"
         assert sess.world == 1 or len(Z) < sess.world or sess.stats["evals"] == e0 + 3
         errs = [rel(g.coeff, golden(case, "coeff")), rel(mean, golden(case, "mean")), rel(var, golden(case, "absvar")),
                 rel(signed, golden(case, "var")), abs(ll - float(golden(case, "loglike"))) / abs(float(golden(case, "loglike")))]
@@ -202,9 +208,10 @@ def run_api(args, gpu):
             assert "disagree" in str(e)
     comm.barrier()
     if comm.rank == 0:
-        print("DIST_OK %s world=%d cases=%d worst=%.2e identical_checks=%d fits=%d evals=%d" %
+        print("DIST_OK %s world=%d cases=%d worst=%.2e identical_checks=%d fits=%d evals=%d factor=%s dense_assembled=%d cyclic_refits=%d" %
               ("gpu-api" if gpu else "cpu-api", sess.world, len(GP_CASES), worst, same.n, sess.stats["fits"],
-               sess.stats["evals"]), flush=True)
+               sess.stats["evals"], "cyclic" if sess.world > 1 and sess.use_cyclic(100) else "replica",
+               sess.stats.get("dense_assembled", 0), sess.stats.get("cyclic_refits", 0)), flush=True)
     dist.detach()
     if gpu:
         ctx.close()

@@ -248,6 +248,25 @@ class NumpyOps2D(NumpyOps):
     def panel_copyback(self, A, lr0, m, lc, w, G, roff, nb):
         pass      # (the double's panel_trsm writes both places at once)
 
+    # the finished factor re-streamed out of the local matrix (dist2_restream_enqueue)
+    def panel_pack(self, A, lr0, m, lc, w, G, roff, nb):
+        self._inside(A, lr0, m, lc, w)
+        rows = A.a[lr0:lr0 + m, lc:lc + w]
+        assert not self.poison or not np.isnan(rows).any(), "a holder re-streams rows of a panel it never solved"
+        gld = nb + dist.G_SKEW
+        assert roff + m * gld <= G.a.size
+        G.a[roff:roff + m * gld] = np.nan if self.poison else 0.0
+        G.a[roff:roff + m * gld].reshape(m, gld)[:, :w] = rows
+
+    def diag_pack(self, A, lr, lc, w, G, doff, nb):
+        self._inside(A, lr, w, lc, w)
+        blk = np.tril(A.a[lr:lr + w, lc:lc + w])
+        assert not self.poison or not np.isnan(blk).any(), "the owner re-streams a diagonal block it never factored"
+        D = self._D(G, doff, nb)
+        D[:] = np.nan if self.poison else 0.0
+        D[:w, :w] = blk
+        G.a[doff + nb * nb: doff + nb * nb + (w // 128) * 128 * 128] = self.aux.get(("A", lr), 0.0)
+
     def panel_trsm(self, A, lr0, m, lc, w, G, doff, roff, nb, dslot=None, prepared=False, copy_back=True):
         self._inside(A, lr0, m, lc, w)
         if m == 0:

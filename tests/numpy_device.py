@@ -243,6 +243,17 @@ class ApiOps2D(NumpyOps2D):
     def __init__(self):
         super().__init__(None)
 
+    # the evaluation against a block-cyclic factor (DistFitIvar2D.cyclic_posterior) takes the kernel of the call too
+    def cross_fill(self, spec, X, Z, B):
+        B.a[:] = 0.0
+        B.a[:X.shape[0], :] = orc.cross_matrix(oracle_spec(spec), Z, X).T
+
+    def cross_mean(self, spec, X, Z, alpha):
+        return orc.cross_matrix(oracle_spec(spec), Z, X) @ np.asarray(alpha, dtype=float)
+
+    def variances(self, spec, Z, B, n):
+        return orc.kernel_diag(oracle_spec(spec), Z) - np.sum(B.a[:n] ** 2, axis=0)
+
     def kfill_local(self, spec, X, A, nugget, geo):
         n, nb = X.shape[0], geo.nb
         full = np.eye(geo.np)
