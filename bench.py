@@ -413,6 +413,23 @@ def multi_gpu_replay(ctx, dev, spec, Xh, yh, Zh, noise, K, X, fit_ms, step_ms, g
                             "evaluation streamed underneath the factorisation against a window of the factor (default from N = 98304)",
            "xgmi": "NOT INCLUDED -- receives are device copies of the same bytes, sends cost nothing; the ratios are single-GPU time / "
                    "paced step time of the grid: upper bounds on what 8 GPUs can reach, not a measured scaling figure"}
+    # Round 5: the class API's distributed-factor mode on the same grid -- rank 0 replayed with NO replica of the factor
+    # (block-cyclic local matrix + ring of packed buffers only), its M / 8 slice of the evaluation solved against a window while
+    # the panels are re-streamed (DistFitIvar2D.cyclic_posterior; receives = stand-in device copies), checked against this GPU's
+    # own posterior; and what a rank holds for the factor in either mode
+    try:
+        os.environ["GPX_REPLAY_CYCLIC"] = "1"
+        r = dist_replay.replay_rank(ctx, spec, Xh, yh, Zh, noise, K, X, grid, 0, nb=nb, streamed=False, steps=1, profile=False)
+        df = r["distributed_factor"]
+        out["distributed_factor"] = dict(
+            df, rank=0, unpaced_fit_busy_ms=r["ms_per_step"],
+            resident_factor_bytes_replica_mode=df["resident_factor_bytes"] - df["window_bytes"] + df["replica_would_be_bytes"],
+            note="resident_factor_bytes = local share of the matrix + ring of packed panel buffers + early buffers + window; the "
+                 "replica mode (default below N = 65536) adds one N x N replica per rank (round 4: two, the GP held a clone)")
+    except Exception as e:      # the measurement above stands without it
+        out["distributed_factor"] = {"error": repr(e)}
+    finally:
+        os.environ.pop("GPX_REPLAY_CYCLIC", None)
     out["seconds"] = time.perf_counter() - t0
     return out
 

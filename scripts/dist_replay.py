@@ -187,8 +187,11 @@ def replay_rank(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=None, agg=
     gs = "%dx%d" % (Pr, Pc)
     n, m = Xh.shape[0], Zh.shape[0]
     comm = ReplayComm(ctx, world, rank, Lref, pace_us=pace_us)
-    run = dist.DistFitIvar2D(ctx, comm, spec, Xh, yh, Zh, noise, nb=nb, grid=(Pr, Pc), agg=agg, streamed=streamed, fit_only=True)
-    run.cyclic_only = os.environ.get("GPX_REPLAY_NO_REPLICA") == "1"    # factorisation without any copy of the finished panels
+    cyclic = os.environ.get("GPX_REPLAY_CYCLIC") == "1"     # the class API's distributed-factor mode: no replica, re-streamed evaluation
+    run = dist.DistFitIvar2D(ctx, comm, spec, Xh, yh, Zh[:0] if cyclic else Zh, noise, nb=nb, grid=(Pr, Pc), agg=agg,
+                             streamed=False if cyclic else streamed, fit_only=True, cyclic=cyclic)
+    if os.environ.get("GPX_REPLAY_NO_REPLICA") == "1":
+        run.cyclic_only = True                              # factorisation without any copy of the finished panels
     _, part = run.step()          # records the program, first run
     ctx.sync()
     check = 0.0
@@ -215,6 +218,27 @@ def replay_rank(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=None, agg=
         host.append(run.host_ms.get("factor", 0.0))
     geo = run.geo
     lat, arr_all = own_step_latencies(ctx, geo) if want_latencies else (None, None)
+    cyc = None
+    if cyclic and pace_us is None:
+        # the evaluation of this rank's slice against the block-cyclic factor: panels re-streamed (stand-in copies for the
+        # receives), windowed solve -- checked against the single-GPU path, timed; and what the rank holds for the factor
+        lo, hi = dist.eval_slice(m, rank, world)
+        _, var = run.cyclic_posterior(Zh[lo:hi], None, False, True)
+        _, ref = dev.posterior(ctx, spec, Lref, X, None, dev.points(ctx, Zh[lo:hi]), want_mean=False)
+        err = float(np.max(np.abs(var - ref)) / np.max(np.abs(ref)))
+        assert err < 1e-10, (gs, rank, err)
+        tt = []
+        for _ in range(2):
+            ctx.sync()
+            t0 = time.perf_counter()
+            run.cyclic_posterior(Zh[lo:hi], None, False, True)
+            ctx.sync()
+            tt.append(1e3 * (time.perf_counter() - t0))
+        A8 = 8 * geo.local_rows(geo.pr) * geo.local_cols(geo.pc)
+        cyc = dict(restreamed_ivar_slice_ms=min(tt), slice_points=hi - lo, variance_rel_err=err,
+                   resident_factor_bytes=run.resident_bytes(), local_matrix_bytes=A8,
+                   ring_bytes=8 * len(run.G) * geo.buf_elems(), window_bytes=8 * geo.np * 2 * run.agg * run.nb,
+                   replica_would_be_bytes=8 * geo.np * geo.np, cross_slice_bytes=8 * geo.np * (hi - lo))
     nb = run.nb
     res = dict(grid=gs, rank=rank, pr=geo.pr, pc=geo.pc, N=n, M=m, nb=nb, agg=run.agg, steps_k=geo.nblk,
                streamed_ivar=bool(streamed), factor_window_panels=run.window, ms_per_step=float(np.median(ts)), ms_all=ts,
@@ -223,6 +247,8 @@ def replay_rank(ctx, spec, Xh, yh, Zh, noise, Lref, X, grid, rank, nb=None, agg=
                issue_mode="hipGraph (one launch per step)" if run.use_graph else "rows (one HIP call per row)",
                graph_nodes=run.programs["factor"].graph_nodes, bytes_received_per_fit=comm.bytes_in,
                variance_check_rel=check, single_gpu_potrf_ms=single_potrf_ms)
+    if cyc is not None:
+        res["distributed_factor"] = cyc
     if want_latencies:
         res["own_latency_ms"] = lat
         res["own_latency0_ms"] = getattr(own_step_latencies, "lat0", None) if lat is not None else None
