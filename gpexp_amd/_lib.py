@@ -120,6 +120,7 @@ _SIGS = {
     "gpx_dist2_panel_trsm_keep": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64]),
     "gpx_dist2_panel_trsm_inv": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, C.c_int]),
     "gpx_dist2_panel_copyback": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64]),
+    "gpx_points_set_box": (C.c_int, [c_vp, c_vp, c_dp, c_dp, C.c_int]),
     "gpx_dist2_panel_pack": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64]),
     "gpx_dist2_diag_pack": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64]),
     "gpx_dist2_update": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64]),

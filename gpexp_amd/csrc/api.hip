@@ -247,6 +247,20 @@ static int mat_bbox(gpx_ctx* ctx, const gpx_mat* cm) {
   return 0;
 }
 
+// (gpx_dist.h) a point set that is a SLICE of a larger one takes the larger set's bounding box: the centring and the exact-path
+// decision of every fill it enters (gpx_kparams_sets) then do not depend on how the set was sharded over the ranks (ADVICE r4:
+// the sharded greedy-IVAR state differed from the single-rank one in the last bits, enough to flip a near-tie)
+extern "C" int gpx_points_set_box(gpx_ctx* ctx, gpx_mat* P, const double* lo, const double* hi, int d) {
+  GPX_ARG(ctx && P && lo && hi && d >= 1 && d <= GPX_MAXD && P->cols == d, "points_set_box: bad arguments");
+  for (int k = 0; k < d; ++k) {
+    GPX_ARG(lo[k] <= hi[k], "points_set_box: empty box");
+    P->lo[k] = lo[k];
+    P->hi[k] = hi[k];
+  }
+  P->bbox_ok = 1;
+  return 0;
+}
+
 // S * sensitivity above which the expanded-form distance would cost more than ~2e-14 of relative kernel error
 // (measured: 7.6e-15 at S*sens = 75); sensitivity = max |dk/ds| / sig: 1/2 for SE and Matern-3/2, 1/6 for Matern-5/2
 static double exact_threshold() {
@@ -673,7 +687,14 @@ int gpx_mat_clone(gpx_ctx* ctx, const gpx_mat* src, gpx_mat** out) {
     *out = nullptr;
     GPX_ARG(false, "clone: storage layout of the copy differs from the source");
   }
-  GPX_HIP(hipMemcpyAsync(m->p, src->p, (size_t)src->bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  // (every failure from here on frees the copy and leaves *out NULL -- a half-initialised handle used to leak)
+  auto fail = [&](const char* what) {
+    gpx_set_error("clone: %s failed: %s", what, hipGetErrorString(hipGetLastError()));
+    gpx_mat_free(ctx, m);
+    *out = nullptr;
+    return -2;
+  };
+  if (hipMemcpyAsync(m->p, src->p, (size_t)src->bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) return fail("copy");
   if (src->aux) {
     void* p = nullptr;
     int r = gpx_dev_alloc(ctx, src->aux_bytes, &p);
@@ -684,7 +705,8 @@ int gpx_mat_clone(gpx_ctx* ctx, const gpx_mat* src, gpx_mat** out) {
     }
     m->aux = (double*)p;
     m->aux_bytes = src->aux_bytes;
-    GPX_HIP(hipMemcpyAsync(m->aux, src->aux, (size_t)src->aux_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    if (hipMemcpyAsync(m->aux, src->aux, (size_t)src->aux_bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+      return fail("copy of the leaf inverses");
   }
   m->factored = src->factored;
   m->bbox_ok = src->bbox_ok;
@@ -693,7 +715,7 @@ int gpx_mat_clone(gpx_ctx* ctx, const gpx_mat* src, gpx_mat** out) {
     m->hi[k] = src->hi[k];
   }
   // binv / dinv are caches rebuilt on demand (binv_ib = 0 from gpx_mat_new)
-  GPX_HIP(hipStreamSynchronize(ctx->stream));
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail("synchronisation");
   return 0;
 }
 

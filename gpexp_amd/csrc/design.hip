@@ -207,7 +207,12 @@ __global__ __launch_bounds__(256) void givar_cost_kernel(const double* __restric
                                                          double s0, double inv_nmc, int64_t M, double* __restrict__ cost) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= M) return;
-  cost[j] = fabs((s0 - q[j] / (v[j] + noise)) * inv_nmc);
+  //  a candidate that has been picked with noise == 0 has v -> 0 and q -> 0: 0 / 0.  np.argmin would return the first
+  // NaN, the first-minimum reduction below never selects one -- so such a candidate is taken out of the race explicitly: +inf
+  // (also a denominator at round-off level or below: conditioning on the point again cannot reduce anything)
+  const double den = v[j] + noise;
+  double c = den > 1e-300 ? fabs((s0 - q[j] / den) * inv_nmc) : INFINITY;
+  cost[j] = (c == c) ? c : INFINITY;
 }
 
 __device__ __forceinline__ VI vi_min(VI a, VI b) {
@@ -760,6 +765,11 @@ int gpx_givar_score(gpx_ctx* ctx, gpx_givar* st, double* best_cost, int64_t* bes
   GPX_HIP(hipMemcpyAsync(best_idx, st->redi + 1023, 8, hipMemcpyDeviceToHost, ctx->stream));
   if (all_costs) GPX_HIP(hipMemcpyAsync(all_costs, st->cost, (size_t)st->M * 8, hipMemcpyDeviceToHost, ctx->stream));
   GPX_HIP(hipStreamSynchronize(ctx->stream));
+  // no finite cost on this rank's slice: the caller's merge sees (+inf, M) -- a rank with nothing to offer, as an empty slice
+  if (*best_idx < 0 || *best_idx >= st->M || !(*best_cost < INFINITY)) {
+    *best_idx = st->M;
+    *best_cost = INFINITY;
+  }
   return 0;
 }
 
@@ -767,6 +777,7 @@ int gpx_givar_score(gpx_ctx* ctx, gpx_givar* st, double* best_cost, int64_t* bes
 // broadcast.  Asynchronous.
 int gpx_givar_pack(gpx_ctx* ctx, gpx_givar* st, int64_t s, gpx_mat* buf) {
   GPX_ARG(ctx && st && buf && s >= 0 && s < st->M, "bad arguments");
+  GPX_ARG(ctx->live_mats.count(st->Cm), "givar: the candidate point set the state was begun with has been freed");   // 
   GPX_ARG(buf->bytes >= st->pack * 8, "pivot buffer too small");
   GPX_ARG(st->cur < st->nsel, "all picks applied");
   int64_t w = st->zp > st->np ? st->zp : st->np;
@@ -783,6 +794,7 @@ int gpx_givar_pack(gpx_ctx* ctx, gpx_givar* st, int64_t s, gpx_mat* buf) {
 // every rank: condition its candidates on the pick whose pack is in buf.  Blocking (S0 lives on the host).
 int gpx_givar_apply(gpx_ctx* ctx, gpx_givar* st, const gpx_mat* buf) {
   GPX_ARG(ctx && st && buf && buf->bytes >= st->pack * 8, "bad arguments");
+  GPX_ARG(ctx->live_mats.count(st->Cm), "givar: the candidate point set the state was begun with has been freed");
   GPX_ARG(st->cur < st->nsel, "all picks applied");
   const double* b = buf->p;
   const double* r = b + 2 + st->d;
@@ -816,6 +828,12 @@ int gpx_greedy_ivar(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, 
     double c = 0.0;
     int64_t s = 0;
     if ((r = gpx_givar_score(ctx, st, &c, &s, all_costs ? all_costs + t * st->M : nullptr)) != 0) break;
+    if (s >= st->M) {
+      gpx_set_error("greedy IVAR: pick %lld of %lld: no candidate has a finite cost (every remaining one is already in the design "
+                    "with zero noise, or the state is not finite)", (long long)(t + 1), (long long)nsel);
+      r = -1;
+      break;
+    }
     out_idx[t] = s;
     if (out_cost) out_cost[t] = c;
     if (t + 1 == nsel) break;

@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 from . import _lib
-from ._lib import check, as_f64, dptr, c_vp, c_i64
+from ._lib import check, as_f64, dptr, c_vp, c_i64, GpxError
 
 K_SE, K_MATERN32, K_MATERN52, K_MEHLER = 0, 1, 2, 3
 PROF_CLASSES = ["kfill", "gemm", "leaf", "trsv", "reduce", "greedy", "comm", "kcross"]
@@ -171,6 +171,17 @@ def points(ctx, x):
     x = as_f64(x)
     assert x.ndim == 2
     return DeviceMatrix.from_host(ctx, x, pad=False)
+
+
+def points_slice(ctx, x, lo, hi):
+    """Rows [lo, hi) of the host point set `x` on the device, carrying the bounding box of ALL of x (gpx_points_set_box): what a
+    rank uploads of a sharded candidate / evaluation set, so that its fills use the same centring as the unsharded call."""
+    x = as_f64(x)
+    P = points(ctx, x[lo:hi])
+    if hi > lo and x.shape[0] > 0:
+        blo, bhi = np.ascontiguousarray(x.min(axis=0)), np.ascontiguousarray(x.max(axis=0))
+        check(ctx.lib.gpx_points_set_box(ctx.h, P.h, dptr(blo), dptr(bhi), int(x.shape[1])))
+    return P
 
 
 def _nugget_args(nugget, n):
@@ -477,7 +488,15 @@ def lml_grad(ctx, spec, L, X, alpha, slabs=None):
     if not slabs:
         return lml_grad_full(ctx, spec, L, X, alpha)
     if os.environ.get("GPX_LML_GRAD_FORM", "linv") == "linv" and lml_grad_linv_fits(ctx, n):
-        return lml_grad_from_sums(spec, lml_grad_linv(ctx, spec, L, X, alpha))
+        #  the static size test knows nothing of what else the process holds -- the factor, a cached previous factor,
+        # pooled blocks, a session's replica --, so the 2 N^2 + N^2/4 doubles of scratch can fail to allocate where the slab form
+        # below (no N x N buffer) still runs: an out-of-memory error of the linv form falls through to it
+        try:
+            return lml_grad_from_sums(spec, lml_grad_linv(ctx, spec, L, X, alpha))
+        except GpxError as e:
+            if "hipMalloc" not in str(e) and "memory" not in str(e).lower():
+                raise
+            ctx.trim()
     b = lml_grad_slab_bounds(n, int(slabs))
     sums = np.zeros(spec.d + 2)
     for r0, r1 in zip(b[:-1], b[1:]):

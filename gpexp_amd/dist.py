@@ -545,7 +545,9 @@ def dist_greedy_ivar(ctx, comm, spec, L, X, cand_host, mc_host, noise, nsel, wan
     nsel = int(nsel)
     lo, hi = eval_slice(m, comm.rank, comm.world)
     Z = be.points(ctx, mc_host)
-    st = be.GivarState(ctx, spec, L, X, be.points(ctx, cand_host[lo:hi]), Z, noise, nsel) if hi > lo else None
+    # (the slice carries the bounding box of ALL candidates: same centring, same arithmetic per candidate as on one rank)
+    slice_pts = be.points_slice(ctx, cand_host, lo, hi) if hasattr(be, "points_slice") else be.points(ctx, cand_host[lo:hi])
+    st = be.GivarState(ctx, spec, L, X, slice_pts, Z, noise, nsel) if hi > lo else None
     npad = padded(X.shape[0])
     pack = 2 + spec.d + padded(mc_host.shape[0]) + npad + nsel
     assert st is None or st.pivot_elems == pack
@@ -556,11 +558,14 @@ def dist_greedy_ivar(ctx, comm, spec, L, X, cand_host, mc_host, noise, nsel, wan
     for t in range(nsel):
         if st is not None:
             c, i, loc = st.score(want_all)
-            mine = np.array([c, float(lo + i)])
+            mine = np.array([c, float(lo + i)]) if np.isfinite(c) else np.array([np.inf, float(m)])   # (nothing finite: as an empty slice)
         else:
             loc, mine = np.zeros(0), np.array([np.inf, float(m)])
         pairs = comm.allgather(mine)
         cost, s = merge_argmin(pairs[:, 0], pairs[:, 1].astype(np.int64))
+        if not np.isfinite(cost):            # the same on every rank (the merge is)
+            raise RuntimeError("greedy IVAR: pick %d of %d: no candidate has a finite cost (every remaining one is already in "
+                               "the design with zero noise, or the state is not finite)" % (t + 1, nsel))
         idx[t], costs[t] = s, cost
         if want_all:
             pad = np.zeros(per)
@@ -2141,7 +2146,8 @@ class Session:
         lo, hi = eval_slice(m, self.rank, self.world)
         Z = be.points(ctx, as_f64(mc))
         if hi > lo:
-            best, costs = be.greedy_ivar_step(ctx, spec, L, X, be.points(ctx, cand[lo:hi]), Z, noise)
+            cpts = be.points_slice(ctx, cand, lo, hi) if hasattr(be, "points_slice") else be.points(ctx, cand[lo:hi])
+            best, costs = be.greedy_ivar_step(ctx, spec, L, X, cpts, Z, noise)
             mine = np.array([costs[best], float(lo + best)])
         else:
             costs, mine = np.zeros(0), np.array([np.inf, float(m)])

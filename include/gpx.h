@@ -104,7 +104,12 @@ int gpx_kernel_eval(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp,
                     const double* A, int64_t na, const double* B, int64_t nb, double* out);
 
 /* ---- L2: factorisation and solves (replace numpy.linalg.pinv / slogdet) ---------------------- */
-/* in-place lower Cholesky K = L L^T (strict upper left undefined); replaces pinv at gp.py:181, 400 */
+/* in-place lower Cholesky K = L L^T; replaces pinv at gp.py:181, 400.
+   INVARIANT of every factored matrix (gpx_potrf, gpx_refit_rows, the distributed fits): only the lower triangle is defined.
+   The strict upper part holds whatever the storage held before -- finite leftovers of K after gpx_potrf, possibly NaN / Inf
+   pool contents after gpx_refit_rows (which copies the old factor's lower triangle only).  No entry point reads it: solves,
+   posterior, gradients, gpx_potri and further refits take the lower triangle; gpx_mat_to_host(tri = 1 / 2) masks / mirrors it.
+   tests/test_gpu_refit.py runs them on a refit factor whose pool blocks were NaN-filled. */
 int gpx_potrf(gpx_ctx* ctx, gpx_mat* K);
 /* Pivot policy of every factorisation that follows: a pivot <= piv_min is bad; skip == 0 reports it (status > 0 from
  * gpx_potrf, the default with piv_min = 0), skip != 0 DROPS the point instead -- L_jj = 1, the rest of column j and row j of

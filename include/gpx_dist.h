@@ -36,6 +36,10 @@ int gpx_mat_write(gpx_ctx* ctx, gpx_mat* m, int64_t offset, int64_t count, const
 
 
 /* ---- multi-pick greedy IVAR as a candidate-sharded state machine (gpx_greedy_ivar of gpx.h drives it on one GPU) ---- */
+/* A point set that is one rank's SLICE of a larger set takes the whole set's bounding box (lo / hi: d doubles each), so that the
+   centring and the exact-difference decision of the fills it enters are the same on every sharding as on one rank. */
+int gpx_points_set_box(gpx_ctx* ctx, gpx_mat* P, const double* lo, const double* hi, int d);
+
 /* gpx_greedy_ivar (gpx.h) as a state machine, sharded by CANDIDATES for the multi-GPU form (every rank: its slice of C and the whole of Z):
  * score -> local first minimum; the owner of the merged winner packs its pivot (gpx_givar_pivot_elems doubles: delta, the
  * point, cov(Z, c_s | design) / sqrt(delta), its column of W_C, its coordinates along the earlier picks), the caller broadcasts

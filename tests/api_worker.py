@@ -148,6 +148,15 @@ def run_api(args, gpu):
     assert list(gi) == list(golden(c, "givar_idx")[:4]), (gi, golden(c, "givar_idx"))
     assert rel(gc, golden(c, "givar_cost")[:4]) <= 1e-10
     same("greedy ivar multi-pick", gi, gc)
+    if gpu and sess.world > 1:
+        #  the slices carry the bounding box of ALL candidates, so the sharded state machine does the single-rank
+        # arithmetic candidate by candidate: picks AND every cost of every pick equal the one-GPU call bit for bit
+        L1 = g._L
+        i1, c1, a1 = be.greedy_ivar(ctx, g.kernel._spec(), L1, g._X, be.points(ctx, Ch), be.points(ctx, Zh), float(g.noise), 4,
+                                    want_all=True)
+        id_, cd, ad = dist.dist_greedy_ivar(ctx, comm, g.kernel._spec(), L1, g._X, Ch, Zh, float(g.noise), 4, want_all=True)
+        assert list(i1) == list(id_) and np.array_equal(np.asarray(c1), np.asarray(cd)) and np.array_equal(a1, ad), \
+            "sharded greedy IVAR differs from the single-rank run in the last bits"
     # ---- MI design (experimentalDesign.py:223-285, 753-785): scoring sharded by rows of the inverse ----
     c = "kat6_mi"
     if c in golden.index:

@@ -208,7 +208,10 @@ class _GivarState:
         self.pivot_elems = 2 + self.d + self.zp + self.np_ + self.nsel
 
     def score(self, want_all=False):
-        cost = np.abs((self.s0 - np.sum(self.G ** 2, axis=0) / (self.v + self.noise)) / self.nmc)
+        den = self.v + self.noise
+        with np.errstate(divide="ignore", invalid="ignore"):
+            cost = np.where(den > 1e-300, np.abs((self.s0 - np.sum(self.G ** 2, axis=0) / den) / self.nmc), np.inf)
+        cost = np.where(np.isnan(cost), np.inf, cost)           # (gpx_givar_score: an undefined cost leaves the race)
         i = int(np.argmin(cost))
         return float(cost[i]), i, (cost if want_all else None)
 

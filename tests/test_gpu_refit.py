@@ -130,3 +130,53 @@ def test_greedy_with_derivatives_driver_pins_earlier_batches(dev, ctx, capsys):
     c3 = costFunctionGP_IVAR(gp, 3, space, mcPoints=mc).evaluate(first)
     c6 = costFunctionGP_IVAR(gp, 6, space, mcPoints=mc).evaluate(pts)
     assert c6 < c3
+
+
+def test_refit_factor_with_nan_poisoned_upper_part_feeds_every_consumer(dev):
+    """gpx_refit_rows copies the old factor's LOWER triangle only, so the new factor's strict upper part is whatever the
+    pool handed out.  Under GPX_ALLOC_GUARD=2 every pooled block starts NaN-filled: the refit factor's upper part IS NaN here,
+    and every consumer of a factor -- solve, log det, posterior, the L^-1 gradient form, the explicit inverse, a further refit --
+    must give what it gives on a factor from gpx_potrf (include/gpx.h states the invariant)."""
+    import os
+    old = os.environ.get("GPX_ALLOC_GUARD")
+    os.environ["GPX_ALLOC_GUARD"] = "2"
+    try:
+        ctx = dev.Context(0)                   # the guard mode is read when a context is created
+    finally:
+        if old is None:
+            os.environ.pop("GPX_ALLOC_GUARD", None)
+        else:
+            os.environ["GPX_ALLOC_GUARD"] = old
+    try:
+        rng = np.random.default_rng(99)
+        n, d, keep = 1700, 3, 1024
+        sp = dev.KernelSpec(dev.K_SE, d, [0.5, 0.7, 0.9, 1.2])
+        Xo = rng.uniform(-1, 1, (n, d))
+        Xn = Xo.copy()
+        Xn[keep:] = rng.uniform(-1, 1, (n - keep, d))
+        y = rng.standard_normal(n)
+        Z = dev.points(ctx, rng.uniform(-1, 1, (257, d)))
+        L_old = dev.potrf(ctx, dev.kfill(ctx, sp, dev.points(ctx, Xo), nugget=0.05))
+        Xd = dev.points(ctx, Xn)
+        L_ref = dev.potrf(ctx, dev.kfill(ctx, sp, Xd, nugget=0.05))
+        L_new = dev.refit_rows(ctx, sp, Xd, 0.05, L_old, keep)
+        assert np.isnan(np.triu(L_new.to_host()[:n, :n], 600)).any(), "the guard mode did not poison the refit factor's upper part"
+        a_new, a_ref = dev.potrs(ctx, L_new, y), dev.potrs(ctx, L_ref, y)
+        assert np.all(np.isfinite(a_new)) and rel(a_new, a_ref) <= 1e-10
+        assert dev.logdet(ctx, L_new) == pytest.approx(dev.logdet(ctx, L_ref), rel=1e-12)
+        m1, v1 = dev.posterior(ctx, sp, L_new, Xd, a_new, Z)
+        m0, v0 = dev.posterior(ctx, sp, L_ref, Xd, a_ref, Z)
+        assert rel(m1, m0) <= 1e-10 and rel(v1, v0) <= 1e-9
+        g1, g0 = dev.lml_grad_linv(ctx, sp, L_new, Xd, a_new), dev.lml_grad_linv(ctx, sp, L_ref, Xd, a_ref)
+        assert np.all(np.isfinite(g1)) and rel(g1, g0) <= 1e-9
+        P1, P0 = dev.potri(ctx, L_new).to_host(tri=2)[:n, :n], dev.potri(ctx, L_ref).to_host(tri=2)[:n, :n]
+        assert np.all(np.isfinite(P1)) and rel(P1, P0) <= 1e-9
+        Xn2 = Xn.copy()
+        Xn2[1536:] = rng.uniform(-1, 1, (n - 1536, d))
+        X2 = dev.points(ctx, Xn2)
+        L2 = dev.refit_rows(ctx, sp, X2, 0.05, L_new, 1536)          # a further refit on the refit factor
+        L2_ref = dev.potrf(ctx, dev.kfill(ctx, sp, X2, nugget=0.05))
+        assert rel(np.tril(L2.to_host()[:n, :n]), np.tril(L2_ref.to_host()[:n, :n])) <= 1e-11
+        assert ctx.guard_violations() == 0
+    finally:
+        ctx.close()
