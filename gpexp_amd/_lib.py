@@ -162,6 +162,7 @@ _SIGS = {
     "gpx_dbg_spin_until": (C.c_int, [c_vp, C.c_int, c_i64]),
     "gpx_dbg_event_elapsed": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp]),
     "gpx_dbg_leaf_stamps": (C.c_int, [c_vp, c_vp, C.c_int, C.POINTER(c_i64)]),
+    "gpx_dbg_coop_stamps": (C.c_int, [c_vp, C.POINTER(c_i64)]),
 }
 
 _lib = None

@@ -572,6 +572,7 @@ int gpx_destroy(gpx_ctx* ctx) {
   if (ctx->trsv_scratch) (void)hipFree(ctx->trsv_scratch);
   if (ctx->d2_scratch) (void)hipFree(ctx->d2_scratch);
   if (ctx->dbg_stamps) (void)hipFree(ctx->dbg_stamps);
+  if (ctx->coop_state) (void)hipFree(ctx->coop_state);
   if (ctx->ev_scratch) (void)hipFree(ctx->ev_scratch);
   for (auto ev : ctx->sync_events) (void)hipEventDestroy(ev);
   for (auto ev : ctx->la_events) (void)hipEventDestroy(ev);

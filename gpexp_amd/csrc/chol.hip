@@ -11,6 +11,7 @@
 #include "gpx_internal.h"
 #include <math.h>
 #include <stdlib.h>
+#include <stddef.h>
 
 namespace {
 
@@ -452,16 +453,11 @@ __device__ __forceinline__ void leaf_panel_wave(double* __restrict__ S, double* 
   }
 }
 
-__global__ __launch_bounds__(256, 2) void leaf_kernel(double* __restrict__ A, int64_t ld, double* __restrict__ inv,
-                                                   int64_t base_index, int64_t n_valid, int* __restrict__ info,
-                                                   double piv_min, int skip, int hiprio, int fast,
-                                                   long long* __restrict__ stamps) {
-  // stamps (debug, gpx_dbg_leaf_stamps; nullptr in the product path): s_memtime of wave 0 at 0 = start, 1 = block (0, 0)
-  // loaded, 2 + 3p / 3 + 3p / 4 + 3p = diagonal step p begins / its 16 x 16 factor + inverse done / column p scaled,
-  // 27 = wave 0 leaves; 28 / 29 = the 100 MHz wall clock at start / at the end of the LAST wave (written by wave 1)
-  __shared__ double S[36 * BSZ];
-  __shared__ __attribute__((aligned(16))) double CB[LEAF_CB];
-  if (hiprio) __builtin_amdgcn_s_setprio(3);   // gpx_chain_prio: beside resident GEMM waves the CU serves this chain first
+// one 128 x 128 leaf: every thread of a 256-thread workgroup calls it; returns without a trailing barrier (wave 0 is done with the
+// factor, waves 1..3 with the inverse's last row and their stores)
+__device__ __forceinline__ void leaf_body(double* __restrict__ S, double* __restrict__ CB, double* __restrict__ A, int64_t ld,
+                                          double* __restrict__ inv, int64_t base_index, int64_t n_valid, int* __restrict__ info,
+                                          double piv_min, int skip, int fast, long long* __restrict__ stamps) {
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int g = lane >> 4, q = lane & 15;
@@ -488,6 +484,19 @@ __global__ __launch_bounds__(256, 2) void leaf_kernel(double* __restrict__ A, in
     default: leaf_factor<3>(S, A, ld, inv, t, g, q); break;
   }
   if (stamps && t == 64) stamps[29] = (long long)wall_clock64();
+}
+
+__global__ __launch_bounds__(256, 2) void leaf_kernel(double* __restrict__ A, int64_t ld, double* __restrict__ inv,
+                                                   int64_t base_index, int64_t n_valid, int* __restrict__ info,
+                                                   double piv_min, int skip, int hiprio, int fast,
+                                                   long long* __restrict__ stamps) {
+  // stamps (debug, gpx_dbg_leaf_stamps; nullptr in the product path): s_memtime of wave 0 at 0 = start, 1 = block (0, 0)
+  // loaded, 2 + 3p / 3 + 3p / 4 + 3p = diagonal step p begins / its 16 x 16 factor + inverse done / column p scaled,
+  // 27 = wave 0 leaves; 28 / 29 = the 100 MHz wall clock at start / at the end of the LAST wave (written by wave 1)
+  __shared__ double S[36 * BSZ];
+  __shared__ __attribute__((aligned(16))) double CB[LEAF_CB];
+  if (hiprio) __builtin_amdgcn_s_setprio(3);   // gpx_chain_prio: beside resident GEMM waves the CU serves this chain first
+  leaf_body(S, CB, A, ld, inv, base_index, n_valid, info, piv_min, skip, fast, stamps);
 }
 
 // ---- leaf multiplies: X <- X * inv^T (right) and B <- inv * B (left), in place -----------------------------------
@@ -648,6 +657,187 @@ __global__ __launch_bounds__(256, 2) void leaf_mul_left_kernel(double* __restric
     case 1: leaf_mul_left_wave<ST, 1>(Bs, Bg, ldb, inv, bv, t, g, q); break;
     case 2: leaf_mul_left_wave<ST, 2>(Bs, Bg, ldb, inv, bv, t, g, q); break;
     default: leaf_mul_left_wave<ST, 3>(Bs, Bg, ldb, inv, bv, t, g, q); break;
+  }
+}
+
+// ---- one diagonal block of order <= 1024 factored in ONE launch (round 5) ------------------------------
+// potrf_right_looking spends three launches per 128 columns (leaf, strip multiply, rank-128 update): 22 dependent launches for
+// a 1024-order block, 0.33 ms on an idle chip -- but beside chip-filling trailing updates every one of them waits for a retirement
+// wave of the GEMM's workgroups (0.6-0.95 ms per block on the owner's diagonal chain of the 2-D distributed loop).
+// Here the whole block is ONE kernel of 1 + H workgroups that stay resident and hand work to each other through flags in global
+// memory:
+//   workgroup 0 ("chain")   factors the 128-leaves, one after the other (leaf_body), and nothing else;
+//   workgroups 1..H         strips  X(I, p) <- X(I, p) inv_p^T      in quarters of 32 rows   (leaf_mul_right_wave)
+//                           updates C(I, J) -= L(I, p) L(J, p)^T    in sub-tiles of 64 x 64  (coop_update_tile, K = 128)
+// Every task has ONE owner -- task number modulo H in an enumeration all workgroups share: step p, strips by block row, then
+// updates column by column (so what the next leaf and the next strips wait for comes first).  That enumeration is a topological
+// order of the dependency graph and every workgroup runs its tasks in that order, so the earliest unfinished task's owner is never
+// waiting for anything later: no deadlock whatever the placement, as long as every workgroup eventually gets a slot (nothing
+// else on the device waits for this kernel).  Hand-over = agent-scope release (all waves done, thread 0 fences and adds to the
+// flag) / acquire (thread 0 spins, fences, barrier) -- correct for any placement of the workgroups on the XCDs; the spins give up
+// after ~2 s (abort flag -> the kernel ends, the pivot report carries an error) instead of hanging the device.
+struct CoopState {
+  int leaf_done[8];
+  int strip_cnt[8][8];   // [p][I]: quarters of strip (I, p) done (4 = all)
+  int upd_cnt[8][8];     // [I][J]: 64 x 64 sub-tile updates applied to block (I, J) so far
+  int abort;
+  int pad[7];
+  long long t_wait[8], t_leaf[8], t_done[8];   // chain, 100 MHz wall clock: block p awaited / its leaf starts / its flag is out
+};
+
+__device__ __forceinline__ void coop_signal(int* flag) {
+  __syncthreads();  // every wave's stores are issued and complete (workgroup-scope release)
+  if (threadIdx.x == 0) {
+    __threadfence();  // agent-scope release: this CU's stores leave its L2 slice's dirty state before the flag moves
+    __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// returns false when the kernel is being aborted (a spin ran out somewhere)
+__device__ __forceinline__ bool coop_wait(const int* flag, int target, int* abort_flag) {
+  if (threadIdx.x == 0) {
+    int it = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+      if (++it > (1 << 21)) {
+        __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    __threadfence();  // agent-scope acquire: this CU's L1 forgets what it held
+  }
+  __syncthreads();
+  return __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+}
+
+// C (64 x 64 at Cg, row stride ld) -= A (64 x 128 at Ag) * B (64 x 128 at Bg)^T, all row stride ld; one workgroup; Ls >= 2 * 64 * 65
+__device__ __forceinline__ void coop_update_tile(double* __restrict__ Ls, double* __restrict__ Cg, const double* __restrict__ Ag,
+                                                 const double* __restrict__ Bg, int64_t ld) {
+  constexpr int LDA = 65;
+  double* As = Ls;
+  double* Bs = Ls + 64 * LDA;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, q = lane & 15;
+  const int wm = wave >> 1, wn = wave & 1;
+  d4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+  for (int kh = 0; kh < 2; ++kh) {
+    // stage the 64 x 64 halves of both operands: 8 16-byte loads per thread and operand, all in flight
+    double2 va[8], vb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = t + 256 * i, r = idx >> 5, c = 2 * (idx & 31);
+      va[i] = *reinterpret_cast<const double2*>(Ag + (int64_t)r * ld + 64 * kh + c);
+      vb[i] = *reinterpret_cast<const double2*>(Bg + (int64_t)r * ld + 64 * kh + c);
+    }
+    if (kh) __syncthreads();  // the first half's fragments have been read
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = t + 256 * i, r = idx >> 5, c = 2 * (idx & 31);
+      As[r * LDA + c] = va[i].x;
+      As[r * LDA + c + 1] = va[i].y;
+      Bs[r * LDA + c] = vb[i].x;
+      Bs[r * LDA + c + 1] = vb[i].y;
+    }
+    __syncthreads();
+    const double* ap = As + (32 * wm + q) * LDA + g;
+    const double* bp = Bs + (32 * wn + q) * LDA + g;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const double a0 = ap[4 * s], a1 = ap[16 * LDA + 4 * s];
+      const double b0 = bp[4 * s], b1 = bp[16 * LDA + 4 * s];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        double* cp = Cg + (int64_t)(32 * wm + 16 * i + g + 4 * v) * ld + 32 * wn + 16 * j + q;
+        *cp -= acc[i][j][v];
+      }
+  __syncthreads();  // the LDS images are free for the next task
+}
+
+// 32 rows of a strip: X (32 x 128 at Xg) <- X inv^T, in place; Ls >= 32 * 129
+__device__ __forceinline__ void coop_strip_quarter(double* __restrict__ Ls, double* __restrict__ Xg, int64_t ld,
+                                                   const double* __restrict__ inv) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, q = lane & 15;
+  double2 xv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = t + 256 * i, r = idx >> 6, c = 2 * (idx & 63);
+    xv[i] = *reinterpret_cast<const double2*>(Xg + (int64_t)r * ld + c);
+  }
+  switch (wave) {
+    case 0: leaf_mul_right_wave<32, 0>(Ls, Xg, ld, inv, xv, t, g, q); break;
+    case 1: leaf_mul_right_wave<32, 1>(Ls, Xg, ld, inv, xv, t, g, q); break;
+    case 2: leaf_mul_right_wave<32, 2>(Ls, Xg, ld, inv, xv, t, g, q); break;
+    default: leaf_mul_right_wave<32, 3>(Ls, Xg, ld, inv, xv, t, g, q); break;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256, 1) void potrf_coop_kernel(double* A, int64_t ld, int nl, double* inv, int64_t base_index,
+                                                         int64_t n_valid, int* __restrict__ info, double piv_min, int skip,
+                                                         int hiprio, CoopState* st) {
+  __shared__ double S[36 * BSZ];
+  __shared__ __attribute__((aligned(16))) double CB[LEAF_CB];
+  if (hiprio) __builtin_amdgcn_s_setprio(3);
+  int* const abort_flag = &st->abort;
+  const int H = (int)gridDim.x - 1;
+  if (blockIdx.x == 0) {
+    // the chain: leaf after leaf; block (p, p) is complete once the 3 p lower sub-tile updates of the steps before p are in
+    for (int p = 0; p < nl; ++p) {
+      if (threadIdx.x == 0) st->t_wait[p] = (long long)wall_clock64();
+      if (p > 0 && !coop_wait(&st->upd_cnt[p][p], 3 * p, abort_flag)) break;
+      if (threadIdx.x == 0) st->t_leaf[p] = (long long)wall_clock64();
+      leaf_body(S, CB, A + (int64_t)(NB * p) * (ld + 1), ld, inv + (int64_t)p * NB * NB, base_index + NB * p, n_valid, info, piv_min,
+                skip, 1, nullptr);
+      coop_signal(&st->leaf_done[p]);
+      if (threadIdx.x == 0) st->t_done[p] = (long long)wall_clock64();
+    }
+    if (threadIdx.x == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+      atomicCAS(info, 0, (int)(base_index + 1));   // a spin ran out: the factorisation is reported as failed, not hung
+    return;
+  }
+  const int h = (int)blockIdx.x - 1;
+  int task = 0;   // position in the enumeration every helper walks
+  for (int p = 0; p + 1 < nl; ++p) {
+    const double* invp = inv + (int64_t)p * NB * NB;
+    // strips of step p, block row by block row (row p+1 first: the next leaf's update and the next step's strips need it)
+    for (int I = p + 1; I < nl; ++I)
+      for (int qd = 0; qd < 4; ++qd, ++task) {
+        if (task % H != h) continue;
+        if (!coop_wait(&st->leaf_done[p], 1, abort_flag)) return;
+        if (p > 0 && !coop_wait(&st->upd_cnt[I][p], 4 * p, abort_flag)) return;
+        coop_strip_quarter(S, A + (int64_t)(NB * I + 32 * qd) * ld + NB * p, ld, invp);
+        coop_signal(&st->strip_cnt[p][I]);
+      }
+    // updates of step p, block column by block column, the diagonal block of the column first
+    for (int J = p + 1; J < nl; ++J)
+      for (int I = J; I < nl; ++I)
+        for (int sub = 0; sub < 4; ++sub) {
+          const int a = sub >> 1, b = sub & 1;
+          if (I == J && b > a) continue;   // diagonal block: the lower sub-tiles only
+          const int mine = task++;
+          if (mine % H != h) continue;
+          if (!coop_wait(&st->strip_cnt[p][I], 4, abort_flag)) return;
+          if (I != J && !coop_wait(&st->strip_cnt[p][J], 4, abort_flag)) return;
+          if (p > 0 && !coop_wait(&st->upd_cnt[I][J], (I == J ? 3 : 4) * p, abort_flag)) return;
+          coop_update_tile(S, A + (int64_t)(NB * I + 64 * a) * ld + NB * J + 64 * b, A + (int64_t)(NB * I + 64 * a) * ld + NB * p,
+                           A + (int64_t)(NB * J + 64 * b) * ld + NB * p, ld);
+          coop_signal(&st->upd_cnt[I][J]);
+        }
   }
 }
 
@@ -924,6 +1114,14 @@ int launch_leaf(gpx_ctx* ctx, double* A, int64_t ld, double* inv, int64_t base_i
   hipLaunchKernelGGL(leaf_kernel, dim3(1), dim3(256), 0, ctx->stream, A, ld, inv, base_index, n_valid, ctx->d_info,
                      ctx->piv_min, ctx->piv_skip, gpx_chain_prio(ctx), fast, (long long*)nullptr);
   GPX_HIP(hipGetLastError());
+  return 0;
+}
+
+// debug (gpx_debug.h): the chain's time stamps of the LAST potrf_coop_kernel launch of this context (3 x 8 values, 100 MHz)
+extern "C" int gpx_dbg_coop_stamps(gpx_ctx* ctx, int64_t* out24) {
+  GPX_ARG(ctx && out24 && ctx->coop_state, "coop stamps: no cooperative factorisation has run on this context");
+  GPX_HIP(hipDeviceSynchronize());
+  GPX_HIP(hipMemcpy(out24, (char*)ctx->coop_state + offsetof(CoopState, t_wait), 24 * sizeof(long long), hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -1304,8 +1502,27 @@ int64_t chol_potrf_panel_width(int64_t n) {
   return (blk >= potrf_rl_max() && n >= 2 * blk && n > potrf_rl_max()) ? blk : 0;
 }
 
+// one launch of potrf_coop_kernel for a diagonal block of order 256 .. 1024 (GPX_POTRF_COOP=0: the launch chain of rounds 1-4;
+// GPX_COOP_HELPERS: workgroups beside the chain, default 16)
+static int launch_potrf_coop(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double* invd, int64_t base, int64_t n_valid) {
+  static const int helpers = (int)env_i64("GPX_COOP_HELPERS", 16);
+  if (!ctx->coop_state) GPX_HIP(hipMalloc((void**)&ctx->coop_state, sizeof(CoopState)));
+  GPX_HIP(hipMemsetAsync(ctx->coop_state, 0, sizeof(CoopState), ctx->stream));
+  ProfScope ps(ctx, GPX_PROF_LEAF, (double)n * n * n / 3.0, 0.0);
+  const int H = helpers < 1 ? 1 : (helpers > 64 ? 64 : helpers);
+  hipLaunchKernelGGL(potrf_coop_kernel, dim3(1 + H), dim3(256), 0, ctx->stream, A, ld, (int)(n / NB), invd, base, n_valid,
+                     ctx->d_info, ctx->piv_min, ctx->piv_skip, gpx_chain_prio(ctx), (CoopState*)ctx->coop_state);
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
+
 static int potrf_rec(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double* invd, int64_t base, int64_t n_valid) {
   if (n == NB) return launch_leaf(ctx, A, ld, invd, base, n_valid);
+  // (default OFF: measured -- profiles/r05_potrf_coop_ab.txt -- the one-launch form is no faster than the launch chain on an idle
+  // chip, 0.33 ms per 1024 block either way since the leaf itself takes 21 of a step's ~40 us, and the paced 2 x 4 replay is 1.3 ms
+  // SLOWER with it: 17-29 resident workgroups of 81 KB LDS each take CU slots from the trailing updates the ranks are bound by)
+  static const int64_t coop_on = env_i64("GPX_POTRF_COOP", 0), coop_max = env_i64("GPX_POTRF_COOP_MAX", 1024);
+  if (coop_on && n <= coop_max && n <= 8 * NB) return launch_potrf_coop(ctx, A, ld, n, invd, base, n_valid);
   if (n <= potrf_rl_max()) return potrf_right_looking(ctx, A, ld, n, invd, base, n_valid);
   static const int64_t blk = env_i64("GPX_POTRF_BLOCK", 4096) / NB * NB;  // 0: recursive halving at every level (round 1)
   if (blk >= potrf_rl_max() && n >= 2 * blk) return potrf_blocked(ctx, A, ld, n, invd, base, n_valid, blk);

@@ -136,6 +136,7 @@ struct gpx_ctx {
                              // 4 = evaluation (low priority, unmasked): the streamed IVAR solve beside the factorisation,
                              // 3 = background, 5 = bulk: CU-masked (leave 4 CUs per XCD to the other streams) when the runtime allows
   std::vector<hipEvent_t> sync_events;  // gpx_event_record / gpx_event_wait ids
+  void* coop_state = nullptr;   // flags of potrf_coop_kernel (chol.hip), zeroed on the stream before every launch
   std::unordered_set<const gpx_mat*> live_mats;  // every matrix this context handed out and has not freed (gpx_program_run checks its rows against it)
   // work buffers of a blocked factorisation in flight (set by gpx_potrf around chol_potrf, NULL otherwise): storage of the
   // explicit block inverses being built, order of those blocks, scratch for their build and for the panel solves

@@ -14,6 +14,14 @@ for nb in (256, 512, 1024, 2048):
         dev.kfill_into(ctx, sp, X, K, nugget=0.1); ctx.sync()
         t0 = time.perf_counter(); dev.potrf(ctx, K); ts.append(time.perf_counter() - t0)
     print("potrf(%d): %.3f ms (best of 12, includes one host sync and, from 2048, the block-inverse build)" % (nb, 1e3 * min(ts[2:])), flush=True)
+    if nb <= 1024 and os.environ.get("GPX_POTRF_COOP", "1") != "0":
+        import ctypes as C
+        st = (C.c_int64 * 24)()
+        if ctx.lib.gpx_dbg_coop_stamps(ctx.h, st) == 0:
+            tw, tl, td = list(st[0:8]), list(st[8:16]), list(st[16:24])
+            nl = nb // 128
+            print("   chain (us): " + " | ".join("p%d wait %.1f leaf+flag %.1f" % (p, (tl[p] - tw[p]) / 100.0, (td[p] - tl[p]) / 100.0)
+                                                  for p in range(nl)) + " | total %.1f" % ((td[nl - 1] - tw[0]) / 100.0), flush=True)
 # trailing-update GEMM rates at K = nb (m x m x nb lower): what a rank's share of the update runs at
 for nb in (256, 512, 1024):
     m = 16384
