@@ -76,6 +76,7 @@ _SIGS = {
     "gpx_mi_greedy": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, C.c_double, c_i64, c_i64, c_ip, c_dp]),
     "gpx_lml_grad": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_dp, c_dp]),
     "gpx_lml_grad_slab": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_dp, c_i64, c_i64, c_dp]),
+    "gpx_lml_grad_rows": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_dp, c_i64, c_i64, C.c_int, c_dp]),
     "gpx_lml_grad_linv": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_dp, c_dp]),
     "gpx_mi_begin": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, C.c_double, c_i64, c_i64, c_i64, c_i64, C.POINTER(c_vp)]),
     "gpx_mi_row": (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp]),

@@ -1280,6 +1280,17 @@ int chol_trsm_right_leading(gpx_ctx* ctx, gpx_mat* Lm, int64_t ncols, double* X,
   return trsm_right_binv_rec(ctx, Lm->p, Lm->ld, Lm->binv, ib, X, ldx, m, ncols, 0, (ncols + ib - 1) / ib, T);
 }
 
+// X (m x ncols) <- X L11^-1 (NOT transposed) against the LEADING ncols x ncols block of a complete factor through its block
+// inverses: rows of L^-1 are X = E L11^-1 (the row form of the sharded log-marginal gradient, hyper.hip gpx_lml_grad_rows).
+// ncols a multiple of 128 (a partial last block uses the leading part of its inverse: the inverse of a leading principal block of
+// a triangular matrix is the leading block of its inverse); T >= m * ib doubles.
+int chol_trsm_right_n_leading(gpx_ctx* ctx, gpx_mat* Lm, int64_t ncols, double* X, int64_t ldx, int64_t m, double* T) {
+  GPX_ARG(Lm && Lm->factored && X && T && ncols > 0 && ncols <= Lm->prows && ncols % NB == 0, "trsm leading (n): bad arguments");
+  GPX_TRY(chol_binv_ensure(ctx, Lm));
+  const int64_t ib = Lm->binv_ib, nblk_all = (Lm->prows + ib - 1) / ib;
+  return trsm_right_n_binv_rec(ctx, Lm->p, Lm->ld, Lm->binv + nblk_all * ib * ib, ib, X, ldx, m, ncols, 0, (ncols + ib - 1) / ib, T);
+}
+
 // Blocked right-looking factorisation with panels of width B (4096) and ONE PANEL OF LOOK-AHEAD for large matrices.
 // Per panel k: solve the rows below the diagonal block, then the trailing update A22 -= P P^T with K = B.  The diagonal
 // block of panel k+1 -- a chain of ~100 latency-bound kernels (128-wide leaves, strip multiplies, rank-128 updates: 2.3 ms

@@ -285,6 +285,7 @@ int chol_trtri(gpx_ctx* ctx, const gpx_mat* L, double* Linv, double* tmp);  // L
 int chol_binv_ensure(gpx_ctx* ctx, gpx_mat* L);
 int chol_trsm_right_trailing(gpx_ctx* ctx, gpx_mat* L, int64_t r0, double* X, int64_t ldx, int64_t m, int transposed, double* T);
 int chol_trsm_right_leading(gpx_ctx* ctx, gpx_mat* L, int64_t ncols, double* X, int64_t ldx, int64_t m, double* T);
+int chol_trsm_right_n_leading(gpx_ctx* ctx, gpx_mat* L, int64_t ncols, double* X, int64_t ldx, int64_t m, double* T);
 int chol_block_inverse(gpx_ctx* ctx, const double* D, int64_t ldd, const double* invd, double* inv, int64_t w, double* tmp);
 int64_t chol_binv_order(int64_t n);
 int64_t chol_binv_elems(int64_t n);

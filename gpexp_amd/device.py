@@ -563,6 +563,26 @@ def lml_grad_slab(ctx, spec, L, X, alpha, r0, r1):
     return out
 
 
+def lml_grad_rows_bounds(n, parts):
+    """Row boundaries (multiples of 128, inside the padded order) that cut the ROWS of L^-1 into `parts` slabs of equal work for
+    gpx_lml_grad_rows: rows [r0, r1) cost ~ (r1 - r0) r1^2, so r_i = N (i / parts)^(1/3)."""
+    npad = (max(n, 1) + 127) // 128 * 128
+    b = [int(round(npad * (i / parts) ** (1.0 / 3.0) / 128)) * 128 for i in range(parts + 1)]
+    b[0], b[-1] = 0, npad
+    for i in range(1, parts + 1):
+        b[i] = min(max(b[i], b[i - 1]), npad)
+    return b
+
+
+def lml_grad_rows(ctx, spec, L, X, alpha, r0, r1, nsub=1):
+    """Raw trace sums (d+2) of the log-marginal gradient contributed by the rows [r0, r1) of L^-1 (gpx_lml_grad_rows; the range
+    is worked in `nsub` sub-slabs of equal work whose products accumulate in one matrix, traced once)."""
+    alpha = as_f64(alpha)
+    out = np.empty(spec.d + 2)
+    check(ctx.lib.gpx_lml_grad_rows(ctx.h, *spec.args(), L.h, X.h, dptr(alpha), int(r0), int(r1), int(nsub), dptr(out)))
+    return out
+
+
 def lml_grad_from_sums(spec, sums):
     """[d/d cl_0 .. d/d cl_{d-1}, d/d signalSize, raw d/d noise] from the summed slab traces (as gpx_lml_grad returns them)."""
     d = spec.d

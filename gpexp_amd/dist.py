@@ -1826,11 +1826,20 @@ def dist_lml_grad(ctx, comm, spec, L, X, alpha, be=None, slabs=None):
     # its FIRST row: one slab over all rows costs 2 N^3, many slabs approach 2 N^3 / 3 -- single GPU, N = 65536: 7.8 s with one
     # slab, 3.5 s with 16); about 16 slabs in total, at least one per rank.
     sub = max(1, int(os.environ.get("GPX_C5_SLABS", "16")) // comm.world) if slabs is None else max(1, int(slabs))
-    b = be.lml_grad_slab_bounds(n, comm.world * sub)
+    # Round 5: the ROWS form (GPX_DIST_GRAD_FORM=rows, the default where the backend has it): rank r takes rows of L^-1 -- one
+    # right solve against the leading block of the factor + one large lower SYRK per slab instead of the slab form's two solves
+    # with K = 1024 block inverses (gpx_lml_grad_rows; the slab form measured 54 TF/s at C5, 0.69 of the MFMA roof).
+    rows_form = os.environ.get("GPX_DIST_GRAD_FORM", "rows") == "rows" and hasattr(be, "lml_grad_rows")
     sums = np.zeros(spec.d + 2)
-    for i in range(comm.rank * sub, (comm.rank + 1) * sub):
-        if b[i + 1] > b[i]:
-            sums = sums + be.lml_grad_slab(ctx, spec, L, X, alpha, b[i], b[i + 1])
+    if rows_form:
+        b = be.lml_grad_rows_bounds(n, comm.world)          # one range of rows per rank, `sub` sub-slabs inside (one trace)
+        if b[comm.rank + 1] > b[comm.rank]:
+            sums = sums + be.lml_grad_rows(ctx, spec, L, X, alpha, b[comm.rank], b[comm.rank + 1], sub)
+    else:
+        b = be.lml_grad_slab_bounds(n, comm.world * sub)
+        for i in range(comm.rank * sub, (comm.rank + 1) * sub):
+            if b[i + 1] > b[i]:
+                sums = sums + be.lml_grad_slab(ctx, spec, L, X, alpha, b[i], b[i + 1])
     allsums = comm.allgather(sums)
     tot = np.zeros(spec.d + 2)
     for r in range(comm.world):

@@ -62,6 +62,14 @@ int gpx_givar_end(gpx_ctx* ctx, gpx_givar* st);
 int gpx_lml_grad_slab(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
                       const double* alpha, int64_t r0, int64_t r1, double* sums);
 
+/* The same traces sharded by ROWS [r0, r1) of L^-1 (round 5): one right solve against the leading r1-order block of the factor
+   and one lower SYRK G = X^T X (r1 x r1, K = r1 - r0) instead of the slab form's two solves; work (r1 - r0) r1^2, memory
+   r1^2 + 2 (r1 - r0) r1 doubles; the range is cut into nsub sub-slabs of equal work whose products accumulate in one matrix,
+   traced once.  The partial sums of a partition of the rows add up to gpx_lml_grad's (the slab ending at the
+   padded order adds the alpha alpha^T part).  alpha: host, N doubles; sums: host, d+2 doubles. */
+int gpx_lml_grad_rows(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
+                      const double* alpha, int64_t r0, int64_t r1, int nsub, double* sums);
+
 /* ---- row-sharded greedy MI state (gpx_mi_greedy of gpx.h is the single-GPU form) ------------------------- */
 /* Greedy MI with the candidate SCORING sharded by rows of the inverse (multi-GPU; gpexp_amd/dist.py dist_mi_greedy).  One
  * state per rank: rows [lo, hi) of the M x M inverse are kept current and exactly those candidates are scored.  Per pick:

@@ -638,6 +638,29 @@ class NumpyC5:
             out[d + 1] += T[a, a]
         return out
 
+    def lml_grad_rows_bounds(self, n, parts):
+        from gpexp_amd import device as _real
+        return _real.lml_grad_rows_bounds(n, parts)
+
+    def lml_grad_rows(self, ctx, spec, L, X, alpha, r0, r1, nsub=1):
+        """the rows [r0, r1) of L^-1: their share G = U_R^T U_R of K^-1 (gpx_lml_grad_rows); alpha alpha^T with the last slab"""
+        n, d = X.shape[0], spec.d
+        K0, D = self._k(spec, X, X)
+        U = np.linalg.inv(np.tril(L.a[:n, :n]))
+        R = U[r0:min(r1, n)]
+        npad = L.a.shape[0]
+        T = (np.outer(alpha, alpha) if r1 == npad else np.zeros((n, n))) - R.T @ R
+        out = np.zeros(d + 2)
+        for a in range(n):
+            w = np.full(n - a, 2.0)
+            w[0] = 1.0
+            tk = w * T[a, a:] * K0[a, a:]
+            for q in range(d):
+                out[q] += np.sum(tk * D[a, a:, q] ** 2)
+            out[d] += np.sum(tk)
+            out[d + 1] += T[a, a]
+        return out
+
     def MiState(self, ctx, spec, Cp, noise, nsel, start, lo, hi):
         be = self
 
