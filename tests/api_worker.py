@@ -115,6 +115,24 @@ def run_api(args, gpu):
         nc = golden(case, "cov").shape[0]
         cov = g.evaluate(Z[:nc], compvar=2)[1]
         assert rel(cov, golden(case, "cov")) <= 1e-10
+    # ---- distributed-factor mode: a kept factor whose runner a LATER fit of the same size has used re-fits itself ----
+    if sess.world > 1 and sess.use_cyclic(100):
+        case = "se_ard_d8_n130"
+        ix = golden.index[case]
+        X, y, Z = golden(case, "X"), golden(case, "y"), golden(case, "Z")
+        ga = GP(make_kernel(ix["kernel"]), golden.noise(case))
+        ga.train(X, y)
+        other = dict(ix["kernel"])
+        other["signalSize"] = 2.0 * other["signalSize"]
+        gb = GP(make_kernel(other), 0.5)
+        gb.train(X, y)                                  # same size: the kept runner's matrix now holds gb's factor
+        r0 = sess.stats.get("cyclic_refits", 0)
+        mean, var = ga.evaluate(Z, compvar=1)           # ga's factor is stale -> the same fit once more, then the evaluation
+        assert sess.stats.get("cyclic_refits", 0) == r0 + 1
+        assert rel(mean, golden(case, "mean")) <= 1e-10 and rel(var, golden(case, "absvar")) <= 1e-10
+        mb = gb.evaluate(Z)                             # ... which in turn superseded gb's
+        assert sess.stats.get("cyclic_refits", 0) == r0 + 2 and np.all(np.isfinite(mb))
+        same("stale cyclic factor", mean, var, mb)
     # ---- IVAR cost (experimentalDesign.py:79-117): refit on the design + MC points sharded ----
     c = "kat4_ivar"
     s = golden.index[c]["kernel"]
