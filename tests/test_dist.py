@@ -136,10 +136,10 @@ def test_panel_loop_2d_round4_knobs_gloo_cpu(world, n, nb, env):
 
 @pytest.mark.parametrize("world,n,nb,env", [
     (4, 2100, 128, {"GPX_DIST_CHUNK_MIN_BLOCKS": "1", "GPX_DIST_CHUNK_HOLD": "1"}),    # the cut re-centred at every step
-    (4, 2300, 128, {"GPX_DIST_CHUNK_MIN_BLOCKS": "2", "GPX_DIST_CHUNK_HOLD": "3"}),
-    (8, 2500, 128, {"GPX_DIST_CHUNK_MIN_BLOCKS": "2", "GPX_DIST_CHUNK_HOLD": "2", "GPX_DIST_AGG": "2"}),
+    (4, 1900, 128, {"GPX_DIST_CHUNK_MIN_BLOCKS": "2", "GPX_DIST_CHUNK_HOLD": "3"}),
+    (8, 1500, 128, {"GPX_DIST_CHUNK_MIN_BLOCKS": "2", "GPX_DIST_CHUNK_HOLD": "2", "GPX_DIST_AGG": "2"}),
     (2, 1900, 128, {"GPX_DIST_CHUNK_MIN_BLOCKS": "3", "GPX_DIST_CHUNK_HOLD": "8"}),    # chunk 0 shrinks to its one block row
-    (6, 2300, 128, {"GPX_DIST_PANEL_CHUNKS": "1"})])                                   # rounds 2-4: the panel in one piece
+    (6, 1300, 128, {"GPX_DIST_PANEL_CHUNKS": "1"})])                                   # rounds 2-4: the panel in one piece
 def test_panel_loop_2d_row_chunks_gloo_cpu(world, n, nb, env):
     """Round 5: the panel travels in two row chunks, one stage apart on the solve / broadcast / near-update streams.  Every cut
     rule the loop can meet -- re-centred every step, held until chunk 0 is down to the block row it must keep, pieces too short to
