@@ -1224,9 +1224,11 @@ static int trsm_right_binv_rec(gpx_ctx* ctx, const double* Ld, int64_t ldl, cons
                                int64_t ldx, int64_t m, int64_t n, int64_t b0, int64_t b1, double* T) {
   auto off = [&](int64_t b) { return b * ib < n ? b * ib : n; };
   if (b1 - b0 == 1) {
+    // (round 4 ran tall pieces through an in-place strip kernel -- one workgroup per 128-row strip walking the column tiles from
+    // the last to the first: m / 128 workgroups, 41 TF/s on the useful flops.  With the longest-first tile order of the
+    // triangular-operand GEMM (gemm_f64.hip tile_of, round 5) the 2-D launch reaches 55 TF/s at m = 24576 and the copy back costs
+    // less than the difference: potrf 184.2 -> 181.8 ms at N = 32768; the strip kernel is gone.)
     const int64_t o = off(b0), sz = off(b0 + 1) - o;
-    static const int64_t strip_min = env_i64("GPX_TRMM_STRIP_MIN", 16384);
-    if (strip_min > 0 && m >= strip_min) return launch_trmm_right_inplace(ctx, X + o, ldx, binv + b0 * ib * ib, ib, m, sz);
     GPX_TRY(launch_gemm_tri(ctx, X + o, ldx, binv + b0 * ib * ib, ib, T, ib, m, sz, sz, true, false, false, 2));
     return gpx_copy2d(ctx, T, ib, X + o, ldx, m, sz);
   }
@@ -1237,21 +1239,26 @@ static int trsm_right_binv_rec(gpx_ctx* ctx, const double* Ld, int64_t ldl, cons
 }
 
 // X (m x n) <- X L^-1 (NOT transposed) with the same block inverses: block columns from the last to the first, X_b <- X_b Binv_b
-// as a product with the stored TRANSPOSE of the inverse (binvT, upper triangular, used transposed; dense product: the zero half
-// is multiplied too -- 1/8 of the solve's flops at four blocks), between them X[:, earlier] -= X[:, done] L[done, earlier] with
-// K >= ib.  The leaf-level recursion of chol_trsm_right_n spends its time in K = 128..512 products.
+// -- round 5: as a triangular-operand product with the inverse itself (k x n lower, not transposed: the k range of a column tile
+// starts at its diagonal; `binv` = the lower inverses, `binvT` their transposes, kept for the dense form: GPX_TRSM_N_DENSE=1) --,
+// between them X[:, earlier] -= X[:, done] L[done, earlier] with K >= ib.  The leaf-level recursion of chol_trsm_right_n spends
+// its time in K = 128..512 products.
 static int trsm_right_n_binv_rec(gpx_ctx* ctx, const double* Ld, int64_t ldl, const double* binvT, int64_t ib, double* X,
-                                 int64_t ldx, int64_t m, int64_t n, int64_t b0, int64_t b1, double* T) {
+                                 int64_t ldx, int64_t m, int64_t n, int64_t b0, int64_t b1, double* T, const double* binv = nullptr) {
   auto off = [&](int64_t b) { return b * ib < n ? b * ib : n; };
   if (b1 - b0 == 1) {
     const int64_t o = off(b0), sz = off(b0 + 1) - o;
-    GPX_TRY(launch_gemm(ctx, X + o, ldx, binvT + b0 * ib * ib, ib, T, ib, m, sz, sz, true, false, false));
+    static const int64_t dense = env_i64("GPX_TRSM_N_DENSE", 0);
+    if (binv && !dense)
+      GPX_TRY(launch_gemm_tri(ctx, X + o, ldx, binv + b0 * ib * ib, ib, T, ib, m, sz, sz, false, false, false, 4));
+    else
+      GPX_TRY(launch_gemm(ctx, X + o, ldx, binvT + b0 * ib * ib, ib, T, ib, m, sz, sz, true, false, false));
     return gpx_copy2d(ctx, T, ib, X + o, ldx, m, sz);
   }
   const int64_t mid = (b0 + b1) / 2, o0 = off(b0), om = off(mid), o1 = off(b1);
-  GPX_TRY(trsm_right_n_binv_rec(ctx, Ld, ldl, binvT, ib, X, ldx, m, n, mid, b1, T));
+  GPX_TRY(trsm_right_n_binv_rec(ctx, Ld, ldl, binvT, ib, X, ldx, m, n, mid, b1, T, binv));
   GPX_TRY(launch_gemm(ctx, X + om, ldx, Ld + om * ldl + o0, ldl, X + o0, ldx, m, om - o0, o1 - om, false, true, false));
-  return trsm_right_n_binv_rec(ctx, Ld, ldl, binvT, ib, X, ldx, m, n, b0, mid, T);
+  return trsm_right_n_binv_rec(ctx, Ld, ldl, binvT, ib, X, ldx, m, n, b0, mid, T, binv);
 }
 
 // Both right solves against the TRAILING factor L[r0:, r0:] of a complete factor with block inverses (r0 a multiple of the
@@ -1267,7 +1274,7 @@ int chol_trsm_right_trailing(gpx_ctx* ctx, gpx_mat* Lm, int64_t r0, double* X, i
   const double* binv = Lm->binv + (r0 / ib) * ib * ib;
   const double* binvT = Lm->binv + nblk_all * ib * ib + (r0 / ib) * ib * ib;
   if (transposed) return trsm_right_binv_rec(ctx, Ld, Lm->ld, binv, ib, X, ldx, m, n2, 0, nb2, T);
-  return trsm_right_n_binv_rec(ctx, Ld, Lm->ld, binvT, ib, X, ldx, m, n2, 0, nb2, T);
+  return trsm_right_n_binv_rec(ctx, Ld, Lm->ld, binvT, ib, X, ldx, m, n2, 0, nb2, T, binv);
 }
 
 // X (m x ncols) <- X L11^-T against the LEADING ncols x ncols block of a complete factor, through its block inverses (every
@@ -1288,7 +1295,8 @@ int chol_trsm_right_n_leading(gpx_ctx* ctx, gpx_mat* Lm, int64_t ncols, double* 
   GPX_ARG(Lm && Lm->factored && X && T && ncols > 0 && ncols <= Lm->prows && ncols % NB == 0, "trsm leading (n): bad arguments");
   GPX_TRY(chol_binv_ensure(ctx, Lm));
   const int64_t ib = Lm->binv_ib, nblk_all = (Lm->prows + ib - 1) / ib;
-  return trsm_right_n_binv_rec(ctx, Lm->p, Lm->ld, Lm->binv + nblk_all * ib * ib, ib, X, ldx, m, ncols, 0, (ncols + ib - 1) / ib, T);
+  return trsm_right_n_binv_rec(ctx, Lm->p, Lm->ld, Lm->binv + nblk_all * ib * ib, ib, X, ldx, m, ncols, 0, (ncols + ib - 1) / ib, T,
+                               Lm->binv);
 }
 
 // Blocked right-looking factorisation with panels of width B (4096) and ONE PANEL OF LOOK-AHEAD for large matrices.

@@ -81,6 +81,18 @@ __device__ __forceinline__ bool tile_of(int sblk, int within, int tiles_m, int t
   }
   *by = (sr << sb_shift) + (within >> sb_shift);
   *bx = (sc << sb_shift) + (within & sbm);
+  if (!LOWER && rot == 2) {
+    // Round 5, triangular operand B (tri == 2: the k range of column tile bx ends at its diagonal, so the tiles of a super-block
+    // take 1 .. 8 units of time): column-major inside the super-block, LONGEST column first.  The slots an XCD's short tiles
+    // free early are refilled in id order from its next super-block -- with its long tiles (longest-processing-time-first list
+    // scheduling) instead of a row-major mix: the launch's makespan comes down from ~1.4x to ~1.15x of work / slots.
+    *by = (sr << sb_shift) + (within & sbm);
+    *bx = (sc << sb_shift) + (sbm - (within >> sb_shift));
+  }
+  if (!LOWER && rot == 3) {   // tri == 4: the k range of column tile bx STARTS at its diagonal -- the first columns are the long ones
+    *by = (sr << sb_shift) + (within & sbm);
+    *bx = (sc << sb_shift) + (within >> sb_shift);
+  }
   if (*by >= tiles_m || *bx >= tiles_n) return false;
   if (LOWER && *bx > *by) return false;  // tile strictly above the diagonal
   return true;
@@ -356,6 +368,8 @@ __device__ __forceinline__ void gemm_tile(Smem<BT, TE>& sm, const double* A, int
 // TRI (triangular-operand modes, see launch_gemm_tri) is a TEMPLATE parameter: the dense instantiations must stay exactly
 // the hand-scheduled kernel -- with `tri` as a run-time argument the IVAR solve lost 2 % (490 -> 500 ms), hipcc's
 // scheduling of the k-loop is that sensitive to what surrounds it.
+__device__ int g_tri2_lpt = 1;   // GPX_TRI2_LPT=0 (A/B): the row-major order inside a super-block for triangular-operand launches
+
 template <bool BT, bool ACC, bool LOWER, int TE, int TRI>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64_t lda, const double* B, int64_t ldb,
                                                           double* C, int64_t ldc, int nk, int tiles_m, int tiles_n,
@@ -380,7 +394,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64
   const int xcd = w & 7, q = w >> 3;
   const int sbs2 = 2 * sb_shift;
   int by, bx;
-  if (!tile_of<LOWER>((q >> sbs2) * 8 + xcd, q & ((1 << sbs2) - 1), tiles_m, tiles_n, sb_cols, sb_shift, &by, &bx, tri == 2 || tri == 4))
+  const int lpt_order = (TRI == 2 || TRI == 4) ? g_tri2_lpt : 0;
+  if (!tile_of<LOWER>((q >> sbs2) * 8 + xcd, q & ((1 << sbs2) - 1), tiles_m, tiles_n, sb_cols, sb_shift, &by, &bx,
+                      tri == 2 ? (lpt_order ? 2 : 1) : (tri == 4 ? (lpt_order ? 3 : 1) : 0)))
     return;
   // (Dealing single tiles of a triangular product to XCDs diagonally balances them too, but gives up the super-blocks'
   // operand reuse in L2: measured 11.9 ms against 13.1 dense for 28672 x 4096 x 4096 -- fabric-bound.)
@@ -413,20 +429,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_batched_kernel(const double* 
   const int64_t b = blockIdx.y;
   const int by = blockIdx.x / tiles_n, bx = blockIdx.x - by * tiles_n;
   gemm_tile<BT, ACC, 64>(sm, A + b * sa, lda, B + b * sb, ldb, C + b * sc, ldc, nk, by, bx);
-}
-
-// X (m x n) <- X Linv^T in place, Linv lower triangular of order n (an explicit block inverse): one workgroup per 128-row
-// strip walks the column tiles from the LAST to the first -- tile j of the result needs columns 0 .. 128(j+1) of X, and no
-// later step reads what an earlier one has written, so neither a second buffer nor a copy back is needed.  A strip is a
-// serial chain of n/128 tiles with k = 128 .. n: this only pays while the strips fill the chip (see launch_trmm_right_inplace).
-__global__ __launch_bounds__(256, 2) void trmm_right_inplace_kernel(double* X, int64_t ldx, const double* Linv, int64_t ldi,
-                                                                    int tiles_n) {
-  __shared__ Smem<true, 128> sm;
-  const int by = blockIdx.x;
-  for (int j = tiles_n - 1; j >= 0; --j) {
-    gemm_tile<true, false, 128>(sm, X, ldx, Linv, ldi, X, ldx, (j + 1) * (128 / KB), by, j);
-    __syncthreads();  // the next tile restages the LDS images
-  }
 }
 
 // ---- trailing update of the 2-D block-cyclic factorisation (dist.hip / gpexp_amd/dist.py) ------------------------------------
@@ -541,17 +543,6 @@ Plan make_plan(int64_t m, int64_t n, bool lower, int te) {
 
 }  // namespace
 
-// X (m x n) <- X Linv^T in place (Linv: n x n lower triangular, row stride ldi); m, n multiples of 128
-int launch_trmm_right_inplace(gpx_ctx* ctx, double* X, int64_t ldx, const double* Linv, int64_t ldi, int64_t m, int64_t n) {
-  if (m == 0 || n == 0) return 0;
-  GPX_ARG(m % 128 == 0 && n % 128 == 0 && (ldx % 2) == 0 && (ldi % 2) == 0, "trmm: m, n multiples of 128, even strides");
-  ProfScope ps(ctx, GPX_PROF_GEMM, (double)m * (double)n * ((double)n + 128.0), 0.0);
-  hipLaunchKernelGGL(trmm_right_inplace_kernel, dim3((unsigned)(m / 128)), dim3(256), 0, ctx->stream, X, ldx, Linv, ldi,
-                     (int)(n / 128));
-  GPX_HIP(hipGetLastError());
-  return 0;
-}
-
 // C_b (m x n) = (accumulate ? C_b - A_b*op(B_b) : A_b*op(B_b)) for b = 0..batch-1 with element strides sa, sb, sc between
 // consecutive entries; m, n multiples of 64, k of 16; C_b must not alias A_b or B_b
 int launch_gemm_batched(gpx_ctx* ctx, const double* A, int64_t lda, int64_t sa, const double* B, int64_t ldb, int64_t sb,
@@ -595,6 +586,12 @@ int launch_gemm_tri(gpx_ctx* ctx, const double* A, int64_t lda, const double* B,
   GPX_ARG(m % 128 == 0 && n % 128 == 0 && k % KB == 0 && k > 0, "gemm: m,n must be multiples of 128 and k of 16");
   GPX_ARG((lda % 2) == 0 && (ldb % 2) == 0, "gemm: leading dimensions must be even (16-byte loads)");
   GPX_ARG(!lower || m == n, "gemm: lower-only update needs a square C");
+  static int lpt_set = -1;
+  if (lpt_set < 0) {
+    const char* e5 = getenv("GPX_TRI2_LPT");
+    lpt_set = e5 ? atoi(e5) : 1;
+    if (lpt_set != 1) GPX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tri2_lpt), &lpt_set, sizeof(int)));
+  }
   static int small_max = -1;
   if (small_max < 0) {
     const char* e3 = getenv("GPX_GEMM_SMALL_MAX");    // use 64x64 tiles while the 128-tile count is below this

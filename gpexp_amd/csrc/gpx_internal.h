@@ -248,7 +248,6 @@ static inline int gpx_chain_prio(const gpx_ctx* ctx) {
 int launch_gemm(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
                 int64_t m, int64_t n, int64_t k, bool bt, bool accumulate, bool lower);
 
-int launch_trmm_right_inplace(gpx_ctx* ctx, double* X, int64_t ldx, const double* Linv, int64_t ldi, int64_t m, int64_t n);
 int launch_gemm_tri(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
                     int64_t m, int64_t n, int64_t k, bool bt, bool accumulate, bool lower, int tri);
 int launch_gemm_batched(gpx_ctx* ctx, const double* A, int64_t lda, int64_t sa, const double* B, int64_t ldb, int64_t sb,
