@@ -89,6 +89,10 @@ __device__ __forceinline__ bool tile_of(int sblk, int within, int tiles_m, int t
     *by = (sr << sb_shift) + (within & sbm);
     *bx = (sc << sb_shift) + (sbm - (within >> sb_shift));
   }
+  if (!LOWER && rot == 4) {   // tri == 1: the k range of ROW tile by ends at its diagonal -- the last row tiles of a super-block first
+    *by = (sr << sb_shift) + (sbm - (within >> sb_shift));
+    *bx = (sc << sb_shift) + (within & sbm);
+  }
   if (!LOWER && rot == 3) {   // tri == 4: the k range of column tile bx STARTS at its diagonal -- the first columns are the long ones
     *by = (sr << sb_shift) + (within & sbm);
     *bx = (sc << sb_shift) + (within >> sb_shift);
@@ -394,9 +398,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64
   const int xcd = w & 7, q = w >> 3;
   const int sbs2 = 2 * sb_shift;
   int by, bx;
-  const int lpt_order = (TRI == 2 || TRI == 4) ? g_tri2_lpt : 0;
+  const int lpt_order = (TRI == 1 || TRI == 2 || TRI == 4) ? g_tri2_lpt : 0;
   if (!tile_of<LOWER>((q >> sbs2) * 8 + xcd, q & ((1 << sbs2) - 1), tiles_m, tiles_n, sb_cols, sb_shift, &by, &bx,
-                      tri == 2 ? (lpt_order ? 2 : 1) : (tri == 4 ? (lpt_order ? 3 : 1) : 0)))
+                      tri == 2 ? (lpt_order ? 2 : 1) : (tri == 4 ? (lpt_order ? 3 : 1) : (tri == 1 && lpt_order ? 4 : 0))))
     return;
   // (Dealing single tiles of a triangular product to XCDs diagonally balances them too, but gives up the super-blocks'
   // operand reuse in L2: measured 11.9 ms against 13.1 dense for 28672 x 4096 x 4096 -- fabric-bound.)
