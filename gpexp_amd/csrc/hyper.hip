@@ -474,11 +474,12 @@ int gpx_lml_grad_rows(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp
           "row bounds must be multiples of 128 inside the padded order");
   const int nq = d + 2;
   for (int q = 0; q < nq; ++q) sums[q] = 0.0;
-  // sub-slabs of equal work inside [r0, r1): ends at (r0^3 + (r1^3 - r0^3) i / nsub)^(1/3), rounded to 128
+  // sub-slabs of EQUAL HEIGHT inside [r0, r1), rounded to 128.  A sub-slab [c0, c1) costs (c1 - c0) c1^2 -- every one of its rows
+  // is solved against the leading c1-order block --, so the sum over the sub-slabs exceeds the integral of r^2: by 9.6 % with 16
+  // equal heights over [0, N) (8.7 % is the optimum), by 18 % with cuts of equal integral (the first version: C5 3.34 s)
   std::vector<int64_t> cut((size_t)nsub + 1);
   for (int i = 0; i <= nsub; ++i) {
-    const double c3 = (double)r0 * r0 * r0 + ((double)r1 * r1 * r1 - (double)r0 * r0 * r0) * i / nsub;
-    int64_t c = (int64_t)llround(cbrt(c3) / GPX_TILE) * GPX_TILE;
+    int64_t c = r0 + (int64_t)llround((double)(r1 - r0) * i / nsub / GPX_TILE) * GPX_TILE;
     cut[(size_t)i] = c < r0 ? r0 : (c > r1 ? r1 : c);
   }
   cut[0] = r0;

@@ -563,11 +563,42 @@ def lml_grad_slab(ctx, spec, L, X, alpha, r0, r1):
     return out
 
 
-def lml_grad_rows_bounds(n, parts):
-    """Row boundaries (multiples of 128, inside the padded order) that cut the ROWS of L^-1 into `parts` slabs of equal work for
-    gpx_lml_grad_rows: rows [r0, r1) cost ~ (r1 - r0) r1^2, so r_i = N (i / parts)^(1/3)."""
+def lml_grad_rows_bounds(n, parts, nsub=1):
+    """Row boundaries (multiples of 128, inside the padded order) that cut the ROWS of L^-1 into `parts` ranges of equal COST for
+    gpx_lml_grad_rows when every range is worked in `nsub` sub-slabs of equal height: a sub-slab [c0, c1) costs (c1 - c0) c1^2.
+    Found by bisection on the cost per range (the ranges are laid out greedily from row 0; the cost of a range grows with its
+    end)."""
     npad = (max(n, 1) + 127) // 128 * 128
-    b = [int(round(npad * (i / parts) ** (1.0 / 3.0) / 128)) * 128 for i in range(parts + 1)]
+    nsub = max(1, int(nsub))
+
+    def cost(a, b):
+        h = (b - a) / nsub
+        return sum(h * (a + (j + 1) * h) ** 2 for j in range(nsub))
+
+    def layout(t):
+        b = [0.0]
+        for _ in range(parts):
+            lo, hi = b[-1], float(npad)
+            if cost(b[-1], hi) <= t:
+                b.append(hi)
+                continue
+            for _ in range(60):
+                mid = 0.5 * (lo + hi)
+                if cost(b[-1], mid) < t:
+                    lo = mid
+                else:
+                    hi = mid
+            b.append(hi)
+        return b
+
+    lo, hi = 0.0, cost(0.0, float(npad))
+    for _ in range(60):
+        t = 0.5 * (lo + hi)
+        if layout(t)[-1] >= npad - 1e-6:
+            hi = t
+        else:
+            lo = t
+    b = [int(round(v / 128)) * 128 for v in layout(hi)]
     b[0], b[-1] = 0, npad
     for i in range(1, parts + 1):
         b[i] = min(max(b[i], b[i - 1]), npad)

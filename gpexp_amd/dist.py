@@ -1832,7 +1832,7 @@ def dist_lml_grad(ctx, comm, spec, L, X, alpha, be=None, slabs=None):
     rows_form = os.environ.get("GPX_DIST_GRAD_FORM", "rows") == "rows" and hasattr(be, "lml_grad_rows")
     sums = np.zeros(spec.d + 2)
     if rows_form:
-        b = be.lml_grad_rows_bounds(n, comm.world)          # one range of rows per rank, `sub` sub-slabs inside (one trace)
+        b = be.lml_grad_rows_bounds(n, comm.world, sub)     # one range of rows per rank, `sub` sub-slabs inside (one trace)
         if b[comm.rank + 1] > b[comm.rank]:
             sums = sums + be.lml_grad_rows(ctx, spec, L, X, alpha, b[comm.rank], b[comm.rank + 1], sub)
     else:

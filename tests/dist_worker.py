@@ -638,9 +638,9 @@ class NumpyC5:
             out[d + 1] += T[a, a]
         return out
 
-    def lml_grad_rows_bounds(self, n, parts):
+    def lml_grad_rows_bounds(self, n, parts, nsub=1):
         from gpexp_amd import device as _real
-        return _real.lml_grad_rows_bounds(n, parts)
+        return _real.lml_grad_rows_bounds(n, parts, nsub)
 
     def lml_grad_rows(self, ctx, spec, L, X, alpha, r0, r1, nsub=1):
         """the rows [r0, r1) of L^-1: their share G = U_R^T U_R of K^-1 (gpx_lml_grad_rows); alpha alpha^T with the last slab"""
