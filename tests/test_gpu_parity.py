@@ -134,6 +134,26 @@ def test_gemm_triangular_operands(dev, ctx, tri):
         assert rel(dC.to_host()[il], (U @ U.T)[il]) <= 1e-13
 
 
+@pytest.mark.parametrize("tri,m,n", [(2, 16384, 1024), (2, 2304, 1152), (2, 20480, 512), (4, 16384, 1024), (4, 1920, 640),
+                                     (1, 1024, 16384), (1, 1152, 2304)])
+def test_gemm_triangular_operands_longest_first_tile_order(dev, ctx, tri, m, n):
+    """Round 5: inside a super-block the tiles of a triangular-operand launch are enumerated longest k range first (tile_of,
+    gemm_f64.hip).  The enumeration must still visit every tile exactly once -- for 128-tiles over several super-blocks and XCD
+    rounds (>= 1024 tiles), ragged super-blocks, and the 64-tile form: same result as the dense product of the zero-filled
+    operand, every entry."""
+    rng = np.random.default_rng(1000 * tri + m % 97 + n)
+    if tri == 1:      # A (m x m) lower triangular, C = A B
+        A = np.tril(rng.standard_normal((m, m))); B = rng.standard_normal((m, n)); bt = 0; want = A @ B
+    elif tri == 2:    # B (n x n) lower triangular used transposed, C = A B^T
+        A = rng.standard_normal((m, n)); B = np.tril(rng.standard_normal((n, n))); bt = 1; want = A @ B.T
+    else:             # B (n x n) lower triangular used as it is, C = A B
+        A = rng.standard_normal((m, n)); B = np.tril(rng.standard_normal((n, n))); bt = 0; want = A @ B
+    dC = dev.DeviceMatrix.from_host(ctx, np.full(want.shape, np.nan), pad=False)     # an unvisited tile would stay NaN
+    dev.dbg_gemm_tri(ctx, dev.DeviceMatrix.from_host(ctx, A, pad=False), dev.DeviceMatrix.from_host(ctx, B, pad=False), dC, bt, 0, tri)
+    got = dC.to_host()
+    assert np.all(np.isfinite(got)) and rel(got, want) <= 1e-13
+
+
 def test_gemm_lower_only(dev, ctx):
     rng = np.random.default_rng(6)
     A = rng.standard_normal((384, 64))
