@@ -312,3 +312,45 @@ def test_declared_rccl_abi_matches_the_installed_header():
     r = subprocess.run([hipcc, "-std=c++17", "-fsyntax-only", "-x", "hip", "--offload-arch=gfx950", "-I/opt/rocm/include",
                         os.path.join(ROOT, "tests", "abi", "rccl_abi_check.cpp")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_lml_grad_falls_back_when_the_big_scratch_does_not_fit(monkeypatch):
+    """dev.lml_grad picks the L^-1 form from a static size test, not from free memory -- an out-of-memory error of that
+    form (2 N^2 + N^2 / 4 doubles of scratch) must fall through to the rows form (one N x N accumulator) and then to the slab loop
+    (no N x N buffer), while any OTHER error propagates.  Host logic only: the device entry points are replaced."""
+    import numpy as np
+    from gpexp_amd import device as dev
+    from gpexp_amd._lib import GpxError
+
+    class Ctx:
+        trims = 0
+
+        def trim(self):
+            Ctx.trims += 1
+
+    class Pts:
+        shape = (60000, 3)
+
+    spec = dev.KernelSpec(dev.K_SE, 3, [0.5, 0.5, 0.5, 1.0])
+    calls = []
+
+    def oom(*a, **k):
+        calls.append("oom")
+        raise GpxError("libgpx_hip: hipMalloc(68719476736 bytes) failed: out of memory")
+
+    monkeypatch.setattr(dev, "lml_grad_linv_fits", lambda ctx, n: True)
+    monkeypatch.setattr(dev, "lml_grad_linv", oom)
+    monkeypatch.setattr(dev, "lml_grad_rows", oom)
+    monkeypatch.setattr(dev, "lml_grad_slab", lambda ctx, spec, L, X, a, r0, r1: (calls.append((r0, r1)), np.ones(spec.d + 2))[1])
+    monkeypatch.setenv("GPX_LML_GRAD_FORM", "linv")
+    g = dev.lml_grad(Ctx(), spec, None, Pts(), np.zeros(60000))
+    assert calls[:2] == ["oom", "oom"] and len(calls) > 2 and Ctx.trims == 2 and g.shape == (5,)
+    slabs = [c for c in calls if c != "oom"]
+    assert slabs[0][0] == 0 and slabs[-1][1] == 60032 and all(a[1] == b[0] for a, b in zip(slabs, slabs[1:]))
+
+    def broken(*a, **k):
+        raise GpxError("libgpx_hip: bad argument: X does not match the factor")
+
+    monkeypatch.setattr(dev, "lml_grad_linv", broken)
+    with pytest.raises(GpxError, match="does not match"):
+        dev.lml_grad(Ctx(), spec, None, Pts(), np.zeros(60000))
