@@ -151,6 +151,7 @@ _SIGS = {
     "gpx_profile_get": (C.c_int, [c_vp, C.c_int, c_ip, c_dp, c_dp, c_dp]),
     "gpx_dbg_gemm": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int]),
     "gpx_dbg_gemm_tri": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int]),
+    "gpx_dbg_gemm_ksplit": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int]),
     "gpx_dbg_kfill_plan": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, C.POINTER(C.c_int), c_dp]),
     "gpx_dbg_colreduce_plan": (C.c_int, [c_i64, c_i64, C.POINTER(c_i64), C.POINTER(c_i64)]),
     "gpx_dbg_panel_bcast_plan": (C.c_int, [C.c_int, C.c_int, c_i64, C.c_int, C.POINTER(c_i64), C.POINTER(C.c_int),

@@ -576,6 +576,7 @@ int gpx_destroy(gpx_ctx* ctx) {
   if (ctx->ev_scratch) (void)hipFree(ctx->ev_scratch);
   for (auto ev : ctx->sync_events) (void)hipEventDestroy(ev);
   for (auto ev : ctx->la_events) (void)hipEventDestroy(ev);
+  if (ctx->ev_side) (void)hipEventDestroy(ctx->ev_side);
   for (int i = 0; i < GPX_NSTREAMS; ++i) {
     bool seen = false;   // (GPX_STREAM_ALIAS: an index may share its stream with an earlier one)
     for (int j = 0; j < i; ++j) seen = seen || ctx->streams[j] == ctx->streams[i];
@@ -1045,12 +1046,28 @@ int gpx_refit_rows(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, c
     void* pa;
     if ((r = gpx_dev_alloc(ctx, K->aux_bytes, &pa)) != 0) break;
     K->aux = (double*)pa;
+    // the kept rows are COPIED (device state is immutable once built: shallow copies of a GP share handles), but nothing below
+    // reads the copy -- the strip solve works against the old factor, the new rows are factored on their own -- so it runs on the
+    // low-priority side stream underneath (HBM-bound beside MFMA-bound work: 0.59 ms off the 4.7 at N = 16384) and is joined
+    // before the result is handed out
+    hipStream_t Mst = ctx->stream, Cst = ctx->streams[4];
+    bool side = keep > 0 && Mst == ctx->streams[0] && Cst != Mst;
+    if (side && !ctx->ev_side && hipEventCreateWithFlags(&ctx->ev_side, hipEventDisableTiming) != hipSuccess) side = false;
     if (keep > 0) {
       // (the lower triangle only, to the 512-column boundary above the diagonal -- every diagonal tile whole: nothing reads a
       // factor's blocks above those; a full factorisation leaves the assembled K there, this one whatever the pool handed out)
-      if ((r = gpx_copy2d_lower(ctx, Lold->p, Lold->ld, K->p, K->ld, keep)) != 0) break;
-      if (hipMemcpyAsync(K->aux, Lold->aux, (size_t)keep * GPX_TILE * 8, hipMemcpyDeviceToDevice, ctx->stream) !=
-          hipSuccess) { r = -2; gpx_set_error("refit_rows: copy of the leaf inverses failed"); break; }
+      if (side) {
+        if (hipEventRecord(ctx->ev_side, Mst) != hipSuccess || hipStreamWaitEvent(Cst, ctx->ev_side, 0) != hipSuccess) { r = -2; break; }
+        ctx->stream = Cst;
+      }
+      r = gpx_copy2d_lower(ctx, Lold->p, Lold->ld, K->p, K->ld, keep);
+      if (r == 0 && hipMemcpyAsync(K->aux, Lold->aux, (size_t)keep * GPX_TILE * 8, hipMemcpyDeviceToDevice, ctx->stream) !=
+          hipSuccess) { r = -2; gpx_set_error("refit_rows: copy of the leaf inverses failed"); }
+      if (side) {
+        if (r == 0 && hipEventRecord(ctx->ev_side, Cst) != hipSuccess) r = -2;
+        ctx->stream = Mst;
+      }
+      if (r != 0) break;
     }
     double nscal = 0.0;
     if (nugget_len == 1) nscal = nugget[0];
@@ -1079,10 +1096,11 @@ int gpx_refit_rows(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, c
         if (wide) {
           const int64_t ib = chol_binv_order(Lold->prows), nbat = keep / kc, rem = keep - nbat * kc;
           void *pT = nullptr, *pP = nullptr;
-          const int64_t tb = n2 * ib * 8, pb = nbat * n2 * n2 * 8;
+          const int64_t tcap = std::max<int64_t>(4 * n2 * ib, 2 * n2 * keep);   // (the solve runs its few-row products as slices)
+          const int64_t tb = tcap * 8, pb = nbat * n2 * n2 * 8;
           if ((r = gpx_dev_alloc(ctx, tb, &pT)) != 0) break;
           if ((r = gpx_dev_alloc(ctx, pb, &pP)) != 0) { gpx_dev_release(ctx, pT, tb); break; }
-          r = chol_trsm_right_leading(ctx, const_cast<gpx_mat*>(Lold), keep, A21, K->ld, n2, (double*)pT);
+          r = chol_trsm_right_leading(ctx, const_cast<gpx_mat*>(Lold), keep, A21, K->ld, n2, (double*)pT, tcap);
           if (r == 0)
             r = launch_gemm_batched(ctx, A21, K->ld, kc, A21, K->ld, kc, (double*)pP, n2, n2 * n2, n2, n2, kc, true, false, nbat);
           if (r == 0) r = launch_sub_partials(ctx, (const double*)pP, nbat, n2, A21 + keep, K->ld);
@@ -1093,7 +1111,8 @@ int gpx_refit_rows(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, c
           gpx_dev_release(ctx, pP, pb);
           if (r != 0) break;
         } else {
-          if ((r = chol_trsm_right(ctx, K->p, K->ld, K->aux, A21, K->ld, n2, keep)) != 0) break;
+          // (against the OLD factor: the copy may still be in flight)
+          if ((r = chol_trsm_right(ctx, Lold->p, Lold->ld, Lold->aux, A21, K->ld, n2, keep)) != 0) break;
           if ((r = launch_gemm(ctx, A21, K->ld, A21, K->ld, A21 + keep, K->ld, n2, n2, keep, true, true, true)) != 0) break;
         }
       }
@@ -1101,6 +1120,7 @@ int gpx_refit_rows(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, c
         break;
     }
     int info = 0;
+    if (side && hipStreamWaitEvent(Mst, ctx->ev_side, 0) != hipSuccess) { r = -2; break; }
     if (hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { r = -2; break; }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) { r = -2; break; }
     K->factored = (info == 0);
@@ -1538,6 +1558,20 @@ int gpx_dbg_kfill_plan(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhy
   *exact = kp.exact;
   for (int k = 0; k < d; ++k) center[k] = kp.center[k];
   return 0;
+}
+
+int gpx_dbg_gemm_ksplit(gpx_ctx* ctx, const gpx_mat* A, const gpx_mat* B, gpx_mat* C, int mode, int parts) {
+  GPX_ARG(ctx && A && B && C && mode >= 0 && mode <= 3 && parts > 0, "bad argument");
+  const int64_t m = C->prows, n = C->pcols, k = A->pcols;
+  GPX_ARG(A->prows == m && B->prows == n && B->pcols == k, "operand shapes");
+  void* P;
+  const int64_t pb = (int64_t)parts * m * n * 8;
+  GPX_TRY(gpx_dev_alloc(ctx, pb, &P));
+  int r = mode <= 1 ? launch_gemm_ksplit(ctx, A->p, A->ld, B->p, B->ld, C->p, C->ld, m, n, k, mode == 1, parts, (double*)P)
+                    : launch_gemm_ksplit_small(ctx, A->p, A->ld, B->p, B->ld, C->p, C->ld, m, n, k, mode == 3, parts, (double*)P);
+  (void)hipStreamSynchronize(ctx->stream);
+  gpx_dev_release(ctx, P, pb);
+  return r;
 }
 
 int gpx_dbg_gemm(gpx_ctx* ctx, const gpx_mat* A, const gpx_mat* B, gpx_mat* C, int bt, int accumulate, int lower) {

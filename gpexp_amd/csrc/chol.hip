@@ -1220,8 +1220,24 @@ static int binv_build_range(gpx_ctx* ctx, const double* Ld, int64_t ld, const do
 // cannot be formed in place), between them X[:, later] -= X[:, done] L[later, done]^T with K >= ib.  The leaf-level recursion
 // of chol_trsm_right spends its time in K = 128..512 updates (12-60 TF/s); with 4096-wide panels those were half of the
 // panel solves' 58 ms at N = 32768.
+// FEW rows (m <= 1024: one batch of design points against the kept factor, gpx_refit_rows): the products of the lower levels are
+// m x ib x ib -- 128 64-tiles under a serial k range of 1024, 55-60 us each on half the chip, 2 ms of the 3.6 ms of a
+// 512 x 15872 solve whose flops are 1.6 ms.  Those run as slices of the k range (launch_gemm_ksplit_small): >= 512 workgroups.
+static inline bool trsm_few_rows(int64_t m) {
+  static const int64_t rows = env_i64("GPX_TRSM_FEW_ROWS", 1024);   // (0: one launch per product for every shape, A/B)
+  return m <= rows && m % 64 == 0;
+}
+static inline int64_t slices_for(int64_t m, int64_t n, int64_t k) {
+  if (n % 64 != 0) return 1;
+  const int64_t tiles = (m / 64) * (n / 64);
+  int64_t parts = 1;
+  while (tiles * parts < 512 && k % (2 * parts * 16) == 0 && k / (2 * parts) >= 256) parts *= 2;
+  return parts;
+}
+
 static int trsm_right_binv_rec(gpx_ctx* ctx, const double* Ld, int64_t ldl, const double* binv, int64_t ib, double* X,
-                               int64_t ldx, int64_t m, int64_t n, int64_t b0, int64_t b1, double* T) {
+                               int64_t ldx, int64_t m, int64_t n, int64_t b0, int64_t b1, double* T, int64_t tcap = 0) {
+  const bool few = tcap >= 4 * m * ib && trsm_few_rows(m);   // tcap: doubles T holds when it is more than m ib
   auto off = [&](int64_t b) { return b * ib < n ? b * ib : n; };
   if (b1 - b0 == 1) {
     // (round 4 ran tall pieces through an in-place strip kernel -- one workgroup per 128-row strip walking the column tiles from
@@ -1229,13 +1245,26 @@ static int trsm_right_binv_rec(gpx_ctx* ctx, const double* Ld, int64_t ldl, cons
     // triangular-operand GEMM (gemm_f64.hip tile_of, round 5) the 2-D launch reaches 55 TF/s at m = 24576 and the copy back costs
     // less than the difference: potrf 184.2 -> 181.8 ms at N = 32768; the strip kernel is gone.)
     const int64_t o = off(b0), sz = off(b0 + 1) - o;
+    // (few rows: the k range in slices, dense against the stored inverse, whose upper part is zero; the sum goes straight into X)
+    const int64_t parts = few ? slices_for(m, sz, sz) : 1;
+    if (parts > 1) return launch_gemm_ksplit_small(ctx, X + o, ldx, binv + b0 * ib * ib, ib, X + o, ldx, m, sz, sz, true, parts, T);
     GPX_TRY(launch_gemm_tri(ctx, X + o, ldx, binv + b0 * ib * ib, ib, T, ib, m, sz, sz, true, false, false, 2));
     return gpx_copy2d(ctx, T, ib, X + o, ldx, m, sz);
   }
   const int64_t mid = (b0 + b1) / 2, o0 = off(b0), om = off(mid), o1 = off(b1);
-  GPX_TRY(trsm_right_binv_rec(ctx, Ld, ldl, binv, ib, X, ldx, m, n, b0, mid, T));
-  GPX_TRY(launch_gemm(ctx, X + o0, ldx, Ld + om * ldl + o0, ldl, X + om, ldx, m, o1 - om, om - o0, true, true, false));
-  return trsm_right_binv_rec(ctx, Ld, ldl, binv, ib, X, ldx, m, n, mid, b1, T);
+  GPX_TRY(trsm_right_binv_rec(ctx, Ld, ldl, binv, ib, X, ldx, m, n, b0, mid, T, tcap));
+  const int64_t parts = few ? slices_for(m, o1 - om, om - o0) : 1;
+  // (the upper levels: 128-tiles -- 4 tile rows of them cannot fill the chip either -- over slices of >= 1024 of the k range)
+  int64_t p128 = 1;
+  if (few && parts == 1 && m % 128 == 0 && (o1 - om) % 128 == 0)
+    while ((m / 128) * ((o1 - om) / 128) * p128 < 512 && (om - o0) % (2 * p128 * 16) == 0 && (om - o0) / (2 * p128) >= 1024) p128 *= 2;
+  if (parts > 1 && m * (o1 - om) * parts <= tcap)
+    GPX_TRY(launch_gemm_ksplit_small(ctx, X + o0, ldx, Ld + om * ldl + o0, ldl, X + om, ldx, m, o1 - om, om - o0, false, parts, T));
+  else if (p128 > 1 && m * (o1 - om) * p128 <= tcap)
+    GPX_TRY(launch_gemm_ksplit(ctx, X + o0, ldx, Ld + om * ldl + o0, ldl, X + om, ldx, m, o1 - om, om - o0, false, p128, T));
+  else
+    GPX_TRY(launch_gemm(ctx, X + o0, ldx, Ld + om * ldl + o0, ldl, X + om, ldx, m, o1 - om, om - o0, true, true, false));
+  return trsm_right_binv_rec(ctx, Ld, ldl, binv, ib, X, ldx, m, n, mid, b1, T, tcap);
 }
 
 // X (m x n) <- X L^-1 (NOT transposed) with the same block inverses: block columns from the last to the first, X_b <- X_b Binv_b
@@ -1279,12 +1308,14 @@ int chol_trsm_right_trailing(gpx_ctx* ctx, gpx_mat* Lm, int64_t r0, double* X, i
 
 // X (m x ncols) <- X L11^-T against the LEADING ncols x ncols block of a complete factor, through its block inverses (every
 // product K >= the inverse order instead of the leaf recursion's K = 128..512): the strip solve of gpx_refit_rows, whose few
-// rows (one batch of design points) make short-K products latency-bound.  ncols a multiple of 128; T >= m * ib doubles.
-int chol_trsm_right_leading(gpx_ctx* ctx, gpx_mat* Lm, int64_t ncols, double* X, int64_t ldx, int64_t m, double* T) {
+// rows (one batch of design points) make short-K products latency-bound.  ncols a multiple of 128; T holds tcap >= m * ib
+// doubles (from 4 m ib on the small products of a few-row solve run as slices of their k range, with 2 m ncols the large ones too).
+int chol_trsm_right_leading(gpx_ctx* ctx, gpx_mat* Lm, int64_t ncols, double* X, int64_t ldx, int64_t m, double* T, int64_t tcap) {
   GPX_ARG(Lm && Lm->factored && X && T && ncols > 0 && ncols <= Lm->prows && ncols % NB == 0, "trsm leading: bad arguments");
   GPX_TRY(chol_binv_ensure(ctx, Lm));
   const int64_t ib = Lm->binv_ib;
-  return trsm_right_binv_rec(ctx, Lm->p, Lm->ld, Lm->binv, ib, X, ldx, m, ncols, 0, (ncols + ib - 1) / ib, T);
+  GPX_ARG(tcap >= m * ib, "trsm leading: scratch too small");
+  return trsm_right_binv_rec(ctx, Lm->p, Lm->ld, Lm->binv, ib, X, ldx, m, ncols, 0, (ncols + ib - 1) / ib, T, tcap);
 }
 
 // X (m x ncols) <- X L11^-1 (NOT transposed) against the LEADING ncols x ncols block of a complete factor through its block

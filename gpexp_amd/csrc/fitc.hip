@@ -197,8 +197,12 @@ int gpx_fitc_fit(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, con
     if ((r = gpx_mat_new(ctx, f->nu, f->n, 1, &f->Ks)) != 0) break;
     if ((r = launch_kfill(ctx, kp, S->p, f->nu, X->p, f->n, 0, nullptr, 0, 0.0, f->Kuf->p, f->nup, f->np,
                           f->Kuf->ld)) != 0) break;
-    if ((r = gpx_copy2d(ctx, f->Kuf->p, f->Kuf->ld, f->W->p, f->W->ld, f->nup, f->np)) != 0) break;
-    if ((r = chol_trsm_left(ctx, f->Lu->p, f->Lu->ld, f->Lu->aux, f->W->p, f->W->ld, f->nup, f->np)) != 0) break;
+    // (out of place through Lu's 1024-order block inverses, every product K >= 1024 on 128-tiles: 7.9 ms against 9.3 for the
+    // in-place leaf recursion at nu = 4096, N = 32768.  The solve consumes its right-hand side: a second fill of Kuf into Ks --
+    // which is only written further down -- costs 0.19 ms, the copy it replaces 0.61.)
+    if ((r = launch_kfill(ctx, kp, S->p, f->nu, X->p, f->n, 0, nullptr, 0, 0.0, f->Ks->p, f->nup, f->np,
+                          f->Ks->ld)) != 0) break;
+    if ((r = chol_trsm_left_oop(ctx, f->Lu, f->Ks->p, f->Ks->ld, f->W->p, f->W->ld, f->np)) != 0) break;
     // g = diag(K) + noise - colsum(W^2)
     double *qd, *kd, *part;
     void* pg;
@@ -224,8 +228,22 @@ int gpx_fitc_fit(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, con
     if ((r = gpx_mat_new(ctx, f->nu, f->nu, 1, &f->La)) != 0) break;
     if ((r = launch_kfill(ctx, kp, S->p, f->nu, S->p, f->nu, 1, nullptr, 1, noise, f->La->p, f->nup, f->nup,
                           f->La->ld)) != 0) break;
-    if ((r = launch_gemm(ctx, f->Ks->p, f->Ks->ld, f->Kuf->p, f->Kuf->ld, f->La->p, f->La->ld, f->nup, f->nup, f->np, true,
-                         true, true)) != 0) break;
+    // nu x nu under a k range of N: as slices of the k range when C alone cannot fill the chip with 128-tiles (gemm_f64.hip,
+    // launch_gemm_ksplit: 11.2 -> 9.0 ms at nu = 4096, N = 32768; 1024 or 4096 tiles wanted instead of 2048: no faster)
+    {
+      const int64_t t128 = (f->nup / 128) * (f->nup / 128 + 1) / 2;
+      int64_t parts = 1;
+      while (parts < 16 && t128 * parts < 2048 && f->np % (2 * parts * 16) == 0 && f->np / (2 * parts) >= 4096) parts *= 2;
+      double* P = nullptr;
+      if (parts > 1 && tmp.get(parts * f->nup * f->nup * 8, &P) != 0) parts = 1;   // (no room for the partials: one launch)
+      if (parts > 1)
+        r = launch_gemm_ksplit(ctx, f->Ks->p, f->Ks->ld, f->Kuf->p, f->Kuf->ld, f->La->p, f->La->ld, f->nup, f->nup, f->np, true,
+                               parts, P);
+      else
+        r = launch_gemm(ctx, f->Ks->p, f->Ks->ld, f->Kuf->p, f->Kuf->ld, f->La->p, f->La->ld, f->nup, f->nup, f->np, true, true,
+                        true);
+      if (r != 0) break;
+    }
     if ((r = factor_in_place(ctx, f->La, "Quu + Kuf G^-1 Kfu")) != 0) break;
     if (hipGetLastError() != hipSuccess) { r = -2; break; }
   } while (0);

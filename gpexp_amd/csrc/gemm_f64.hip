@@ -435,6 +435,54 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_batched_kernel(const double* 
   gemm_tile<BT, ACC, 64>(sm, A + b * sa, lda, B + b * sb, ldb, C + b * sc, ldc, nk, by, bx);
 }
 
+// Split-K form for a SMALL C under a LONG k range (FITC: nu x nu x N with nu = N / 8; the rows of a design batch against the
+// kept factor): slice b of the k range (blockIdx.y) writes its own m x n partial product P_b = A[:, slice] B[:, slice]^T (row
+// stride n, consecutive), and ksplit_sub_kernel subtracts the partials from C in slice order -- deterministic, unlike atomics.
+// A 4096^2 lower C is 528 128-tiles for 512 resident workgroups (one full round + 16 tiles alone) or 2080 64-tiles, whose 8
+// flop per operand byte out of L2 hold that kernel at 49 TF/s; four slices of 128-tiles: 2112 workgroups at 16 flop per byte.
+template <bool LOWER>
+__global__ __launch_bounds__(256, 2) void gemm_f64_ksplit_kernel(const double* A, int64_t lda, const double* B, int64_t ldb,
+                                                                 double* P, int64_t n, int64_t sp, int nk_slice, int parts,
+                                                                 int tiles_m, int tiles_n, int sb_cols, int sb_shift) {
+  __shared__ Smem<true, 128> sm;
+  // the jobs (super-block, slice) are dealt to the XCDs round-robin like the super-blocks of gemm_f64_kernel: with the plain
+  // 2-D grid (tile = blockIdx.x, slice = blockIdx.y) XCD c owns the tile columns bx = c mod 8 of EVERY slice -- 80 lower tiles
+  // for XCD 0, 52 for XCD 7 at 4096^2 -- and the launch took 15.0 ms where the 64-tile kernel takes 11.2
+  const int w = blockIdx.x, xcd = w & 7, q = w >> 3, sbs2 = 2 * sb_shift;
+  const int job = (q >> sbs2) * 8 + xcd, within = q & ((1 << sbs2) - 1);
+  int sb, slice;
+  if (LOWER) {   // all slices of the strictly lower super-blocks first, the diagonal ones (slots that exit at once) last
+    const int nsr = (tiles_m + (1 << sb_shift) - 1) >> sb_shift, noff = nsr * (nsr - 1) / 2;
+    if (job < parts * noff) {
+      slice = job / noff;
+      sb = job - slice * noff;
+    } else {
+      const int jj = job - parts * noff;
+      slice = jj / nsr;
+      sb = noff + jj - slice * nsr;
+    }
+  } else {
+    const int nsb = ((tiles_m + (1 << sb_shift) - 1) >> sb_shift) * sb_cols;
+    slice = job / nsb;
+    sb = job - slice * nsb;
+  }
+  if (slice >= parts) return;
+  int by, bx;
+  if (!tile_of<LOWER>(sb, within, tiles_m, tiles_n, sb_cols, sb_shift, &by, &bx)) return;
+  const int64_t k0 = (int64_t)slice * nk_slice * KB;
+  gemm_tile<true, false, 128>(sm, A + k0, lda, B + k0, ldb, P + (int64_t)slice * sp, n, nk_slice, by, bx);
+}
+
+// C[i][j] -= sum_b P_b[i][j] (j <= i when lower; assign: C = the sum), partials added in slice order
+__global__ __launch_bounds__(256) void ksplit_sub_kernel(const double* __restrict__ P, int64_t parts, int64_t m, int64_t n,
+                                                         double* __restrict__ C, int64_t ldc, int lower, int assign) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+  if (j >= n || (lower && j > (i | 127))) return;   // (whole diagonal tiles: the partials hold them)
+  double s = 0.0;
+  for (int64_t b = 0; b < parts; ++b) s += P[(b * m + i) * n + j];
+  C[i * ldc + j] = assign ? s : C[i * ldc + j] - s;
+}
+
 // ---- trailing update of the 2-D block-cyclic factorisation (dist.hip / gpexp_amd/dist.py) ------------------------------------
 // C = the local matrix of rank (pr, pc) from local block (li_first, lj_first) on; local block (li, lj) is global block
 // (I, J) = (li Pr + pr, lj Pc + pc).  For every tile with I > J (or I >= J), in ONE launch,
@@ -568,6 +616,49 @@ int launch_gemm_batched(gpx_ctx* ctx, const double* A, int64_t lda, int64_t sa, 
     if (accumulate) GPX_B(false, true); else GPX_B(false, false);
   }
 #undef GPX_B
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
+
+// C -= A B^T over a long k range as `parts` slices (see gemm_f64_ksplit_kernel); P: parts * m * n doubles of scratch
+int launch_gemm_ksplit(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
+                       int64_t m, int64_t n, int64_t k, bool lower, int64_t parts, double* P) {
+  if (m == 0 || n == 0) return 0;
+  GPX_ARG(P && parts > 0 && parts <= 65535 && m % 128 == 0 && n % 128 == 0 && k % (parts * KB) == 0 && k > 0,
+          "gemm_ksplit: m,n multiples of 128, k a multiple of 16 * parts");
+  GPX_ARG((lda % 2) == 0 && (ldb % 2) == 0 && (!lower || m == n) && m <= 65535, "gemm_ksplit: bad operands");
+  const Plan p = make_plan(m, n, lower, 128);   // (super-block edge 8 / 4 / 2 tiles: within 3 % of each other at 4096^2 x 32768)
+  const int64_t jobs = p.nsb * parts, wgs = (jobs + 7) / 8 * 8 * ((int64_t)1 << (2 * p.sb_shift));
+  GPX_ARG(wgs < ((int64_t)1 << 31), "gemm_ksplit: grid too large");
+  dim3 grid((unsigned)wgs);
+  const int nks = (int)(k / parts / KB);
+  {
+    ProfScope ps(ctx, GPX_PROF_GEMM, (lower ? 1.0 : 2.0) * (double)m * (double)n * (double)k, 0.0);
+    if (lower)
+      hipLaunchKernelGGL((gemm_f64_ksplit_kernel<true>), grid, dim3(256), 0, ctx->stream, A, lda, B, ldb, P, n, m * n, nks,
+                         (int)parts, p.tm, p.tn, p.sbc, p.sb_shift);
+    else
+      hipLaunchKernelGGL((gemm_f64_ksplit_kernel<false>), grid, dim3(256), 0, ctx->stream, A, lda, B, ldb, P, n, m * n, nks,
+                         (int)parts, p.tm, p.tn, p.sbc, p.sb_shift);
+  }
+  hipLaunchKernelGGL(ksplit_sub_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)m), dim3(256), 0, ctx->stream, P, parts, m, n,
+                     C, ldc, lower ? 1 : 0, 0);
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
+
+// The same for products too small for 128-tiles (a few rows against one block of a factor: m x n of 128 64-tiles under a serial
+// k range of 1024 -- 55-60 us on half the chip): C = (assign ? 0 : C) -/+ A B^T as `parts` slices of the k range on 64-tiles
+// (blockIdx.y = slice), the partials summed in slice order.  assign: C = A B^T (C may alias A: the partials are complete before
+// the sum is written).  P: parts * m * n doubles.
+int launch_gemm_ksplit_small(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
+                             int64_t m, int64_t n, int64_t k, bool assign, int64_t parts, double* P) {
+  if (m == 0 || n == 0) return 0;
+  GPX_ARG(P && parts > 0 && k % (parts * KB) == 0 && m <= 65535, "gemm_ksplit_small: bad arguments");
+  const int64_t ks = k / parts;
+  GPX_TRY(launch_gemm_batched(ctx, A, lda, ks, B, ldb, ks, P, n, m * n, m, n, ks, true, false, parts));
+  hipLaunchKernelGGL(ksplit_sub_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)m), dim3(256), 0, ctx->stream, P, parts, m, n,
+                     C, ldc, 0, assign ? 1 : 0);
   GPX_HIP(hipGetLastError());
   return 0;
 }

@@ -151,6 +151,7 @@ struct gpx_ctx {
   int64_t panel_width;
   int panel_count;
   std::vector<hipEvent_t> la_events;    // look-ahead factorisation (chol.hip): column ready / chain done / masked chunk done
+  hipEvent_t ev_side = nullptr;         // fork / join of gpx_refit_rows' copy of the kept rows on the low-priority stream
   int cus;
   // cached device allocations (exact-size reuse)
   std::multimap<int64_t, void*> pool;
@@ -250,6 +251,10 @@ int launch_gemm(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int
 
 int launch_gemm_tri(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
                     int64_t m, int64_t n, int64_t k, bool bt, bool accumulate, bool lower, int tri);
+int launch_gemm_ksplit(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
+                       int64_t m, int64_t n, int64_t k, bool lower, int64_t parts, double* P);
+int launch_gemm_ksplit_small(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
+                             int64_t m, int64_t n, int64_t k, bool assign, int64_t parts, double* P);
 int launch_gemm_batched(gpx_ctx* ctx, const double* A, int64_t lda, int64_t sa, const double* B, int64_t ldb, int64_t sb,
                         double* C, int64_t ldc, int64_t sc, int64_t m, int64_t n, int64_t k, bool bt, bool accumulate,
                         int64_t batch);
@@ -283,7 +288,7 @@ int launch_logdet(gpx_ctx* ctx, const double* L, int64_t ld, int64_t n, double* 
 int chol_trtri(gpx_ctx* ctx, const gpx_mat* L, double* Linv, double* tmp);  // Linv (n x n, ld n) = L^-1; tmp >= (n/2)^2
 int chol_binv_ensure(gpx_ctx* ctx, gpx_mat* L);
 int chol_trsm_right_trailing(gpx_ctx* ctx, gpx_mat* L, int64_t r0, double* X, int64_t ldx, int64_t m, int transposed, double* T);
-int chol_trsm_right_leading(gpx_ctx* ctx, gpx_mat* L, int64_t ncols, double* X, int64_t ldx, int64_t m, double* T);
+int chol_trsm_right_leading(gpx_ctx* ctx, gpx_mat* L, int64_t ncols, double* X, int64_t ldx, int64_t m, double* T, int64_t tcap);
 int chol_trsm_right_n_leading(gpx_ctx* ctx, gpx_mat* L, int64_t ncols, double* X, int64_t ldx, int64_t m, double* T);
 int chol_block_inverse(gpx_ctx* ctx, const double* D, int64_t ldd, const double* invd, double* inv, int64_t w, double* tmp);
 int64_t chol_binv_order(int64_t n);

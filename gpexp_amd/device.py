@@ -672,5 +672,9 @@ def dbg_gemm_tri(ctx, A, B, Cm, bt, accumulate, tri):
     check(ctx.lib.gpx_dbg_gemm_tri(ctx.h, A.h, B.h, Cm.h, int(bt), int(accumulate), int(tri)))
 
 
+def dbg_gemm_ksplit(ctx, A, B, Cm, mode, parts):
+    check(ctx.lib.gpx_dbg_gemm_ksplit(ctx.h, A.h, B.h, Cm.h, int(mode), int(parts)))
+
+
 def dbg_gemm(ctx, A, B, Cm, bt, accumulate, lower=False):
     check(ctx.lib.gpx_dbg_gemm(ctx.h, A.h, B.h, Cm.h, int(bt), int(accumulate), int(lower)))

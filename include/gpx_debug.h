@@ -16,6 +16,10 @@ int gpx_dbg_gemm(gpx_ctx* ctx, const gpx_mat* A, const gpx_mat* B, gpx_mat* C, i
 /* triangular-operand GEMM modes: tri = 1 (A lower triangular, k == m), 2 (B lower-triangular n x k used transposed, bt),
  * 3 (lower C = U U^T with A = B = U upper triangular, bt); the structurally zero part of every tile's k range is skipped */
 int gpx_dbg_gemm_tri(gpx_ctx* ctx, const gpx_mat* A, const gpx_mat* B, gpx_mat* C, int bt, int accumulate, int tri);
+/* the same product as `parts` slices of the k range whose partial products are summed in slice order (B (n x k) used
+ * transposed): mode 0 = C -= A B^T on 128-tiles, 1 = the same on/below the diagonal tiles only (square C), 2 = C -= A B^T on
+ * 64-tiles (the few-row products of gpx_refit_rows), 3 = C = A B^T on 64-tiles (C may alias A) */
+int gpx_dbg_gemm_ksplit(gpx_ctx* ctx, const gpx_mat* A, const gpx_mat* B, gpx_mat* C, int mode, int parts);
 /* GPX_CHAOS=<seed> in the environment at gpx_create (debug): every launch site holds its stream back by a random 0.1-3 ms with
  * probability 1/4; results must not change (a dependency between the context's streams that is only met by lucky timing would). */
 /* queues a kernel that spins for ~ms milliseconds (<= 500) on the selected stream: lets a test hold one stream back so that a

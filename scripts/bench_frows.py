@@ -3,7 +3,7 @@
 entry point with its size, best-of-3 time, the algorithmic work and the achieved rate against the roof that bounds it.
 Run it under `rocprofv3 --kernel-trace --stats` for the per-kernel table (profiles/r03_frows_kernel_stats.csv).
 
-    python scripts/bench_frows.py [--quick]
+    python scripts/bench_frows.py [--quick] [--only f1,design,mi,fitc,refit]
 """
 import json
 import os
@@ -18,6 +18,11 @@ from gpexp_amd import device as dev  # noqa: E402
 PEAK_TF, PEAK_GBS = 78.6, 8000.0
 ctx = dev.context()
 quick = "--quick" in sys.argv
+only = set(sys.argv[sys.argv.index("--only") + 1].split(",")) if "--only" in sys.argv else None
+
+
+def want(section):
+    return only is None or section in only
 
 
 def best(f, reps=3):
@@ -45,72 +50,77 @@ def report(name, replaces, size, t, flops=None, nbytes=None, note=""):
 
 rng = np.random.default_rng(8192)
 d = 8
-# ---- f1: gradients of the posterior variance w.r.t. point locations (gp.py:261-341, experimentalDesign.py:168-179)
-N, M = (2048, 8192) if quick else (8192, 32768)
-Xh, Zh = rng.uniform(-1, 1, (N, d)), rng.uniform(-1, 1, (M, d))
 sp = dev.KernelSpec(dev.K_SE, d, list(0.4 + 0.05 * np.arange(d)) + [1.0])
-X, Z = dev.points(ctx, Xh), dev.points(ctx, Zh)
-L = dev.potrf(ctx, dev.kfill(ctx, sp, X, nugget=0.1))
-_, t = best(lambda: dev.ivar_grad(ctx, sp, L, X, Z))
-report("gpx_ivar_grad", "costFunctionGP_IVAR.derivative v1 (experimentalDesign.py:168-179)", dict(N=N, M=M, d=d), t,
-       flops=3.0 * N * N * M, note="ONE count, in SURVEY 8d's units (a triangular solve of an N x M block = N^2 M): beta = K^-1 K(X,Z) "
-       "is two solves (2 N^2 M), S = beta beta^T as a lower SYRK is N^2 M more; tr(dK/dx S) needs S")
-_, t = best(lambda: dev.var_grad_newpt(ctx, sp, L, X, Z))
-report("gpx_var_grad_newpt", "GP.evaluateVarianceDerivWRTnewpt (gp.py:261-280)", dict(N=N, M=M, d=d), t, flops=2.0 * N * N * M)
-Nv, Mv = (1024, 1024) if quick else (2048, 4096)
-Xv, Zv = dev.points(ctx, Xh[:Nv]), dev.points(ctx, Zh[:Mv])
-Lv = dev.potrf(ctx, dev.kfill(ctx, sp, Xv, nugget=0.1))
-_, t = best(lambda: dev.var_grad(ctx, sp, Lv, Xv, Zv), reps=2)
-report("gpx_var_grad", "GP.evaluateVarianceDerivative (gp.py:282-341)", dict(N=Nv, M=Mv, d=d), t, flops=2.0 * (d + 1) * Nv * Nv * Mv,
-       nbytes=8.0 * Nv * d * Mv,
-       note="the (N d) x M result goes to the HOST by contract (that is what the reference returns): %.2f GB over PCIe dominate; "
-            "one N x N matrix dK_l is refilled per coordinate (not d of them)" % (8.0 * Nv * d * Mv / 1e9))
-del L, Lv
+# ---- f1: gradients of the posterior variance w.r.t. point locations (gp.py:261-341, experimentalDesign.py:168-179)
+if want("f1"):
+    N, M = (2048, 8192) if quick else (8192, 32768)
+    Xh, Zh = rng.uniform(-1, 1, (N, d)), rng.uniform(-1, 1, (M, d))
+    X, Z = dev.points(ctx, Xh), dev.points(ctx, Zh)
+    L = dev.potrf(ctx, dev.kfill(ctx, sp, X, nugget=0.1))
+    _, t = best(lambda: dev.ivar_grad(ctx, sp, L, X, Z))
+    report("gpx_ivar_grad", "costFunctionGP_IVAR.derivative v1 (experimentalDesign.py:168-179)", dict(N=N, M=M, d=d), t,
+           flops=3.0 * N * N * M, note="ONE count, in SURVEY 8d's units (a triangular solve of an N x M block = N^2 M): beta = K^-1 K(X,Z) "
+           "is two solves (2 N^2 M), S = beta beta^T as a lower SYRK is N^2 M more; tr(dK/dx S) needs S")
+    _, t = best(lambda: dev.var_grad_newpt(ctx, sp, L, X, Z))
+    report("gpx_var_grad_newpt", "GP.evaluateVarianceDerivWRTnewpt (gp.py:261-280)", dict(N=N, M=M, d=d), t, flops=2.0 * N * N * M)
+    Nv, Mv = (1024, 1024) if quick else (2048, 4096)
+    Xv, Zv = dev.points(ctx, Xh[:Nv]), dev.points(ctx, Zh[:Mv])
+    Lv = dev.potrf(ctx, dev.kfill(ctx, sp, Xv, nugget=0.1))
+    _, t = best(lambda: dev.var_grad(ctx, sp, Lv, Xv, Zv), reps=2)
+    report("gpx_var_grad", "GP.evaluateVarianceDerivative (gp.py:282-341)", dict(N=Nv, M=Mv, d=d), t, flops=2.0 * (d + 1) * Nv * Nv * Mv,
+           nbytes=8.0 * Nv * d * Mv,
+           note="the (N d) x M result goes to the HOST by contract (that is what the reference returns): %.2f GB over PCIe dominate; "
+                "one N x N matrix dK_l is refilled per coordinate (not d of them)" % (8.0 * Nv * d * Mv / 1e9))
+    del L, Lv
 # ---- a13-a15 / 8c: design kernels at C3 / C5 sizes
-N3, M3, nmc = (4096, 16384, 1024) if quick else (16384, 65536, 4096)
-rng = np.random.default_rng(16384)
-X3h, C3h, Z3h = rng.uniform(-1, 1, (N3, d)), rng.uniform(-1, 1, (M3, d)), rng.uniform(-1, 1, (nmc, d))
-X3, C3, Z3 = dev.points(ctx, X3h), dev.points(ctx, C3h), dev.points(ctx, Z3h)
-K3 = dev.potrf(ctx, dev.kfill(ctx, sp, X3, nugget=0.1))
-_, t = best(lambda: dev.greedy_ivar_step(ctx, sp, K3, X3, C3, Z3, 0.1))
-report("gpx_greedy_ivar_step", "costFunctionGP_IVAR.evaluate per candidate (experimentalDesign.py:79-117; SURVEY 8c composition)",
-       dict(N=N3, candidates=M3, nMC=nmc, d=d), t, flops=2.0 * nmc * M3 * N3 + 1.0 * N3 * N3 * (M3 + nmc),
-       note="rank-one scoring of every candidate: two N x (M + nMC) triangular solves + the nMC x M x N product")
-_, t = best(lambda: dev.greedy_var(ctx, sp, C3, 16))
-report("gpx_greedy_var", "performGreedyVarExperimentalDesign (experimentalDesign.py:787-845)", dict(candidates=M3, picks=16, d=d), t,
-       nbytes=8.0 * M3 * 16 * 16 / 2 + 8.0 * M3 * d * 16, note="incremental Cholesky rows; latency-bound (one launch chain per pick)")
-del K3
-d5 = 10
-sp5 = dev.KernelSpec(dev.K_SE, d5, list(0.5 + 0.03 * np.arange(d5)) + [1.0])
-Mm = 2048 if quick else 8192
-Cm = dev.points(ctx, rng.uniform(-1, 1, (Mm, d5)))
-_, t = best(lambda: dev.mi_greedy(ctx, sp5, Cm, 0.1, 8, 0))
-report("gpx_mi_greedy", "costFunctionGP_MI + performGreedyMIExperimentalDesign (experimentalDesign.py:223-285, 753-785)",
-       dict(candidates=Mm, picks=8, d=d5), t, flops=Mm ** 3 / 3.0 + 2.0 * Mm ** 3 / 3.0,
-       note="SURVEY 8d count: potrf M^3/3 + potri 2 M^3/3 = M^3 (round 4 charged a dense M^3 product on top that the code no "
-            "longer executes); then 7 rank-one down-dates (HBM: 16 M^2 bytes each)")
+if want("design"):
+    N3, M3, nmc = (4096, 16384, 1024) if quick else (16384, 65536, 4096)
+    rng = np.random.default_rng(16384)
+    X3h, C3h, Z3h = rng.uniform(-1, 1, (N3, d)), rng.uniform(-1, 1, (M3, d)), rng.uniform(-1, 1, (nmc, d))
+    X3, C3, Z3 = dev.points(ctx, X3h), dev.points(ctx, C3h), dev.points(ctx, Z3h)
+    K3 = dev.potrf(ctx, dev.kfill(ctx, sp, X3, nugget=0.1))
+    _, t = best(lambda: dev.greedy_ivar_step(ctx, sp, K3, X3, C3, Z3, 0.1))
+    report("gpx_greedy_ivar_step", "costFunctionGP_IVAR.evaluate per candidate (experimentalDesign.py:79-117; SURVEY 8c composition)",
+           dict(N=N3, candidates=M3, nMC=nmc, d=d), t, flops=2.0 * nmc * M3 * N3 + 1.0 * N3 * N3 * (M3 + nmc),
+           note="rank-one scoring of every candidate: two N x (M + nMC) triangular solves + the nMC x M x N product")
+    _, t = best(lambda: dev.greedy_var(ctx, sp, C3, 16))
+    report("gpx_greedy_var", "performGreedyVarExperimentalDesign (experimentalDesign.py:787-845)", dict(candidates=M3, picks=16, d=d), t,
+           nbytes=8.0 * M3 * 16 * 16 / 2 + 8.0 * M3 * d * 16, note="incremental Cholesky rows; latency-bound (one launch chain per pick)")
+    del K3
+if want("mi"):
+    d5 = 10
+    sp5 = dev.KernelSpec(dev.K_SE, d5, list(0.5 + 0.03 * np.arange(d5)) + [1.0])
+    Mm = 2048 if quick else 8192
+    Cm = dev.points(ctx, rng.uniform(-1, 1, (Mm, d5)))
+    _, t = best(lambda: dev.mi_greedy(ctx, sp5, Cm, 0.1, 8, 0))
+    report("gpx_mi_greedy", "costFunctionGP_MI + performGreedyMIExperimentalDesign (experimentalDesign.py:223-285, 753-785)",
+           dict(candidates=Mm, picks=8, d=d5), t, flops=Mm ** 3 / 3.0 + 2.0 * Mm ** 3 / 3.0,
+           note="SURVEY 8d count: potrf M^3/3 + potri 2 M^3/3 = M^3 (round 4 charged a dense M^3 product on top that the code no "
+                "longer executes); then 7 rank-one down-dates (HBM: 16 M^2 bytes each)")
 # ---- f4: FITC
-Nf = 8192 if quick else 32768
-nu = Nf // 8
-Xf = rng.uniform(-1, 1, (Nf, d))
-yf = np.sin(2 * np.pi * Xf.sum(1) / d) + np.sqrt(0.1) * rng.standard_normal(Nf)
-Xfd, Sd = dev.points(ctx, Xf), dev.points(ctx, Xf[rng.permutation(Nf)[:nu]].copy())
-m, t = best(lambda: dev.FitcModel(ctx, sp, Xfd, Sd, 0.1), reps=2)
-report("gpx_fitc_fit", "FITC branch of addNodesAndComputeCovariance (gp.py:182-210; gp_kernel_utilities.py:70-104)",
-       dict(N=Nf, nu=nu, d=d), t, flops=2.0 * nu ** 3 / 3.0 + 2.0 * Nf * nu * nu,
-       note="chol(Quu), Kuf, G = diag(K - Q), chol(Quu + Kuf G^-1 Kfu): two nu-order factorisations + two nu x nu x N products")
-_, t = best(lambda: m.solve(yf))
-report("gpx_fitc_solve", "GP.train with the Woodbury precision (gp.py:100-101)", dict(N=Nf, nu=nu), t, nbytes=2.0 * 8.0 * Nf * nu)
+if want("fitc"):
+    Nf = 8192 if quick else 32768
+    nu = Nf // 8
+    Xf = rng.uniform(-1, 1, (Nf, d))
+    yf = np.sin(2 * np.pi * Xf.sum(1) / d) + np.sqrt(0.1) * rng.standard_normal(Nf)
+    Xfd, Sd = dev.points(ctx, Xf), dev.points(ctx, Xf[rng.permutation(Nf)[:nu]].copy())
+    m, t = best(lambda: dev.FitcModel(ctx, sp, Xfd, Sd, 0.1), reps=2)
+    report("gpx_fitc_fit", "FITC branch of addNodesAndComputeCovariance (gp.py:182-210; gp_kernel_utilities.py:70-104)",
+           dict(N=Nf, nu=nu, d=d), t, flops=2.0 * nu ** 3 / 3.0 + 2.0 * Nf * nu * nu,
+           note="chol(Quu), Kuf, G = diag(K - Q), chol(Quu + Kuf G^-1 Kfu): two nu-order factorisations + two nu x nu x N products")
+    _, t = best(lambda: m.solve(yf))
+    report("gpx_fitc_solve", "GP.train with the Woodbury precision (gp.py:100-101)", dict(N=Nf, nu=nu), t, nbytes=2.0 * 8.0 * Nf * nu)
 # ---- f2: refit of the changed rows
-Nr = 4096 if quick else 16384
-Xr = rng.uniform(-1, 1, (Nr, d))
-Xrd = dev.points(ctx, Xr)
-Lr = dev.potrf(ctx, dev.kfill(ctx, sp, Xrd, nugget=0.1))
-keep = Nr - 512
-Xr2 = Xr.copy()
-Xr2[keep:] = rng.uniform(-1, 1, (Nr - keep, d))
-Xr2d = dev.points(ctx, Xr2)
-_, t = best(lambda: dev.refit_rows(ctx, sp, Xr2d, 0.1, Lr, keep))
-report("gpx_refit_rows", "ExperimentalDesignGreedyWithDerivatives batch loop (experimentalDesign.py:694-751)",
-       dict(N=Nr, changed_rows=Nr - keep), t, flops=1.0 * (Nr - keep) * Nr * Nr,
-       note="the leading %d rows of the factor are reused; only the last %d rows are re-assembled and re-solved" % (keep, Nr - keep))
+if want("refit"):
+    Nr = 4096 if quick else 16384
+    Xr = rng.uniform(-1, 1, (Nr, d))
+    Xrd = dev.points(ctx, Xr)
+    Lr = dev.potrf(ctx, dev.kfill(ctx, sp, Xrd, nugget=0.1))
+    keep = Nr - 512
+    Xr2 = Xr.copy()
+    Xr2[keep:] = rng.uniform(-1, 1, (Nr - keep, d))
+    Xr2d = dev.points(ctx, Xr2)
+    _, t = best(lambda: dev.refit_rows(ctx, sp, Xr2d, 0.1, Lr, keep))
+    report("gpx_refit_rows", "ExperimentalDesignGreedyWithDerivatives batch loop (experimentalDesign.py:694-751)",
+           dict(N=Nr, changed_rows=Nr - keep), t, flops=1.0 * (Nr - keep) * Nr * Nr,
+           note="the leading %d rows of the factor are reused; only the last %d rows are re-assembled and re-solved" % (keep, Nr - keep))

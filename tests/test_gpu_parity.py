@@ -154,6 +154,35 @@ def test_gemm_triangular_operands_longest_first_tile_order(dev, ctx, tri, m, n):
     assert np.all(np.isfinite(got)) and rel(got, want) <= 1e-13
 
 
+@pytest.mark.parametrize("mode,m,n,k,parts", [(0, 256, 384, 4096, 4), (1, 1152, 1152, 2048, 2), (1, 4096, 4096, 512, 4),
+                                               (2, 512, 1024, 1024, 4), (2, 192, 2048, 2048, 2), (3, 512, 1024, 1024, 4)])
+def test_gemm_in_slices_of_the_k_range(dev, ctx, mode, m, n, k, parts):
+    """Round 5: a small C under a long k range (FITC's nu x nu x N product; the few-row products of gpx_refit_rows) is computed as
+    slices of the k range whose partials are summed in slice order.  Every tile of every slice exactly once (the jobs are dealt
+    to the XCDs like the super-blocks of the main kernel); lower: only the diagonal tiles and below are touched; mode 3 writes
+    the product over its own left operand."""
+    rng = np.random.default_rng(31 * mode + m + k)
+    A = rng.standard_normal((m, k))
+    B = rng.standard_normal((n, k))
+    C0 = rng.standard_normal((m, n))
+    dA = dev.DeviceMatrix.from_host(ctx, A, pad=False)
+    dB = dev.DeviceMatrix.from_host(ctx, B, pad=False)
+    if mode == 3:
+        assert n == k
+        dev.dbg_gemm_ksplit(ctx, dA, dB, dA, mode, parts)
+        assert rel(dA.to_host(), A @ B.T) <= 1e-13
+        return
+    dC = dev.DeviceMatrix.from_host(ctx, C0, pad=False)
+    dev.dbg_gemm_ksplit(ctx, dA, dB, dC, mode, parts)
+    got, want = dC.to_host(), C0 - A @ B.T
+    if mode == 1:
+        i, j = np.indices((m, n))
+        low = j <= (i | 127)
+        assert rel(got[low], want[low]) <= 1e-13 and np.array_equal(got[~low], C0[~low])
+    else:
+        assert rel(got, want) <= 1e-13
+
+
 def test_gemm_lower_only(dev, ctx):
     rng = np.random.default_rng(6)
     A = rng.standard_normal((384, 64))

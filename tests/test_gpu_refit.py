@@ -56,6 +56,33 @@ def test_refit_rows_equals_full_factorisation(dev, ctx, n_old, n_new, keep, kind
     assert rel(np.tril(L_old.to_host()), np.linalg.cholesky(orc.cov_matrix(s, Xo, nug, row_loop=False))) <= 1e-11
 
 
+@pytest.mark.parametrize("n_old,n_new,keep", [(5000, 5000, 4608), (6200, 6100, 5120), (9000, 9000, 8064)])
+def test_refit_rows_few_rows_against_a_large_kept_factor(dev, ctx, n_old, n_new, keep):
+    """keep >= 4096: the strip solve goes through the kept factor's 1024-order block inverses, its few-row products as slices of
+    the k range (chol.hip trsm_few_rows), the trailing update as 1024-wide batches, and the copy of the kept rows runs on a side
+    stream underneath.  Same factor as a full factorisation; the kept rows arrive complete (the copy is joined)."""
+    rng = np.random.default_rng(n_old + keep)
+    d = 4
+    Xo = rng.uniform(-1, 1, (n_old, d))
+    Xn = rng.uniform(-1, 1, (n_new, d))
+    Xn[:keep] = Xo[:keep]
+    sp = dev.KernelSpec(dev.K_SE, d, [0.5, 0.6, 0.7, 0.8, 1.1])
+    nug = 0.1
+    L_old = dev.potrf(ctx, dev.kfill(ctx, sp, dev.points(ctx, Xo), nugget=nug))
+    old_before = np.tril(L_old.to_host())
+    Xd = dev.points(ctx, Xn)
+    L_ref = dev.potrf(ctx, dev.kfill(ctx, sp, Xd, nugget=nug))
+    for _ in range(2):          # (second call: the block inverses of the old factor are cached by then)
+        L_new = dev.refit_rows(ctx, sp, Xd, nug, L_old, keep)
+        a, b = np.tril(L_new.to_host()), np.tril(L_ref.to_host())
+        assert np.array_equal(a[:keep], old_before[:keep, :n_new])       # the kept rows: copied bit for bit
+        assert rel(a, b) <= 1e-11
+        y = rng.standard_normal(n_new)
+        assert rel(dev.potrs(ctx, L_new, y), dev.potrs(ctx, L_ref, y)) <= 1e-9
+        assert dev.logdet(ctx, L_new) == pytest.approx(dev.logdet(ctx, L_ref), rel=1e-12)
+    assert np.array_equal(np.tril(L_old.to_host()), old_before)
+
+
 def test_refit_rows_with_per_point_nugget_and_rejects_bad_keep(dev, ctx):
     rng = np.random.default_rng(5)
     n, d, keep = 520, 2, 256
