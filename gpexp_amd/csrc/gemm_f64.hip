@@ -620,9 +620,9 @@ int launch_gemm_batched(gpx_ctx* ctx, const double* A, int64_t lda, int64_t sa, 
   return 0;
 }
 
-// C -= A B^T over a long k range as `parts` slices (see gemm_f64_ksplit_kernel); P: parts * m * n doubles of scratch
+// C -= A B^T (assign: C = A B^T) over a long k range as `parts` slices (see gemm_f64_ksplit_kernel); P: parts * m * n doubles
 int launch_gemm_ksplit(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
-                       int64_t m, int64_t n, int64_t k, bool lower, int64_t parts, double* P) {
+                       int64_t m, int64_t n, int64_t k, bool lower, int64_t parts, double* P, bool assign) {
   if (m == 0 || n == 0) return 0;
   GPX_ARG(P && parts > 0 && parts <= 65535 && m % 128 == 0 && n % 128 == 0 && k % (parts * KB) == 0 && k > 0,
           "gemm_ksplit: m,n multiples of 128, k a multiple of 16 * parts");
@@ -642,7 +642,7 @@ int launch_gemm_ksplit(gpx_ctx* ctx, const double* A, int64_t lda, const double*
                          (int)parts, p.tm, p.tn, p.sbc, p.sb_shift);
   }
   hipLaunchKernelGGL(ksplit_sub_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)m), dim3(256), 0, ctx->stream, P, parts, m, n,
-                     C, ldc, lower ? 1 : 0, 0);
+                     C, ldc, lower ? 1 : 0, assign ? 1 : 0);
   GPX_HIP(hipGetLastError());
   return 0;
 }

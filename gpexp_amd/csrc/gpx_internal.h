@@ -252,7 +252,7 @@ int launch_gemm(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int
 int launch_gemm_tri(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
                     int64_t m, int64_t n, int64_t k, bool bt, bool accumulate, bool lower, int tri);
 int launch_gemm_ksplit(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
-                       int64_t m, int64_t n, int64_t k, bool lower, int64_t parts, double* P);
+                       int64_t m, int64_t n, int64_t k, bool lower, int64_t parts, double* P, bool assign = false);
 int launch_gemm_ksplit_small(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
                              int64_t m, int64_t n, int64_t k, bool assign, int64_t parts, double* P);
 int launch_gemm_batched(gpx_ctx* ctx, const double* A, int64_t lda, int64_t sa, const double* B, int64_t ldb, int64_t sb,

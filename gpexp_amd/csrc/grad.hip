@@ -130,6 +130,111 @@ __global__ __launch_bounds__(256) void ivar_grad_row_kernel(KParams kp, const do
   }
 }
 
+// The squared exponential's derivative is LINEAR in the coordinate difference: dk(u, p)[l] = c_l (u_l - p_l) k(u, p) with
+// c_l = -s / cl_l^2.  So a sum of w_j dk(u_j, p)[l] over pairs is c_l * sum_j w_j (u_jl - p_l): per pair the differences the
+// distance needs anyway, one exp and d fused multiply-adds -- instead of d derivative evaluations, which the generic kernels
+// above (kept for the Mehler kernel) unroll to GPX_MAXD = 32 predicated ones: 10.7 ms of gpx_ivar_grad's 120 at N = 8192,
+// M = 32768, d = 8 (3.4e8 pairs) against 1.3 ms of fp64 issue.  DMAX = d rounded up to a power of two.
+template <int DMAX>
+__device__ __forceinline__ double se_pair(const KParams& kp, const double* __restrict__ u, const double (&p)[DMAX],
+                                          double (&diff)[DMAX]) {
+  double r2 = 0.0;
+#pragma unroll
+  for (int l = 0; l < DMAX; ++l) {
+    diff[l] = 0.0;
+    if (l < kp.d) {
+      diff[l] = u[l] - p[l];
+      const double e = diff[l] * kp.scale[l];
+      r2 = fma(e, e, r2);
+    }
+  }
+  return kp.sig * exp(-0.5 * r2);
+}
+
+// c_l * s_l for every coordinate, reduced over the workgroup in the fixed tree order, written to out[0 .. d)
+template <int DMAX>
+__device__ __forceinline__ void se_finish(const KParams& kp, const double (&s1)[DMAX], double extra_w, const double* extra,
+                                          double scale_out, double* red, double* __restrict__ out) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int l = 0; l < DMAX; ++l) {
+    if (l < kp.d) {   // (uniform)
+      double v = -kp.sig * kp.scale[l] * kp.scale[l] * s1[l];
+      if (extra) v += extra_w * extra[l];
+      red[t] = v;
+      __syncthreads();
+      for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) red[t] += red[t + w];
+        __syncthreads();
+      }
+      if (t == 0) out[l] = scale_out * red[0];
+      __syncthreads();
+    }
+  }
+}
+
+template <int DMAX>
+__global__ __launch_bounds__(256) void ivar_grad_row_se_kernel(KParams kp, const double* __restrict__ X, int64_t n,
+                                                               const double* __restrict__ Z, int64_t m,
+                                                               const double* __restrict__ Bm, int64_t ldb,
+                                                               const double* __restrict__ S, int64_t lds_,
+                                                               const double* __restrict__ nd, double inv_m,
+                                                               double* __restrict__ grad) {
+  __shared__ double red[256];
+  const int64_t a = blockIdx.x;
+  const int d = kp.d, t = threadIdx.x;
+  double xa[DMAX], s1[DMAX], diff[DMAX];
+#pragma unroll
+  for (int l = 0; l < DMAX; ++l) {
+    xa[l] = l < d ? X[a * d + l] : 0.0;
+    s1[l] = 0.0;
+  }
+  // evaluation points: 2 beta[a][j] dk(z_j, x_a)
+  for (int64_t j = t; j < m; j += 256) {
+    const double w = 2.0 * Bm[a * ldb + j] * se_pair<DMAX>(kp, Z + j * d, xa, diff);
+#pragma unroll
+    for (int l = 0; l < DMAX; ++l) s1[l] = fma(w, diff[l], s1[l]);
+  }
+  // other design points: 2 S[a][i] dk(x_a, x_i) (the diagonal entry once); diff = x_i - x_a = -(u - p)
+  double dups = 0.0;
+  for (int64_t i = t; i < n; i += 256) {
+    const double sai = (i == a ? 1.0 : 2.0) * S[a * lds_ + i];
+    const double w = sai * se_pair<DMAX>(kp, X + i * d, xa, diff);
+#pragma unroll
+    for (int l = 0; l < DMAX; ++l) s1[l] = fma(-w, diff[l], s1[l]);
+    if (nd != nullptr) {
+      double q = 0.0;
+#pragma unroll
+      for (int l = 0; l < DMAX; ++l) q = fma(diff[l], diff[l], q);
+      if (i == a || sqrt(q) < 1e-10) dups += sai;   // coincident training points (gp.py:308)
+    }
+  }
+  se_finish<DMAX>(kp, s1, dups, nd ? nd + a * d : nullptr, inv_m, red, grad + a * d);
+}
+
+// out[m][l] = -2 sum_j dk(z_m, x_j)[l] beta[j][m] from beta^T (row m contiguous over j): one workgroup per evaluation point
+template <int DMAX>
+__global__ __launch_bounds__(256) void var_grad_newpt_se_kernel(KParams kp, const double* __restrict__ X, int64_t n,
+                                                                const double* __restrict__ Z,
+                                                                const double* __restrict__ betaT, int64_t ldt, int64_t col0,
+                                                                double* __restrict__ out) {
+  __shared__ double red[256];
+  const int64_t mm = blockIdx.x;
+  const int d = kp.d, t = threadIdx.x;
+  double zs[DMAX], s1[DMAX], diff[DMAX];
+#pragma unroll
+  for (int l = 0; l < DMAX; ++l) {
+    zs[l] = l < d ? Z[(col0 + mm) * d + l] : 0.0;
+    s1[l] = 0.0;
+  }
+  for (int64_t j = t; j < n; j += 256) {
+    const double w = -2.0 * betaT[mm * ldt + j] * se_pair<DMAX>(kp, X + j * d, zs, diff);   // diff = x_j - z = -(u - p)
+#pragma unroll
+    for (int l = 0; l < DMAX; ++l) s1[l] = fma(-w, diff[l], s1[l]);
+  }
+  se_finish<DMAX>(kp, s1, 0.0, nullptr, 1.0, red, out + (col0 + mm) * d);
+}
+
 // ---- full matrix: A_l[j][i] = c_jl[i] (np x np, zero outside the n x n block) ----------------------------------------
 __global__ __launch_bounds__(256) void dcov_kernel(KParams kp, const double* __restrict__ X, int64_t n, int l,
                                                    const double* __restrict__ nd, double* __restrict__ A, int64_t lda,
@@ -238,21 +343,63 @@ int check_args(int kind, int d, const gpx_mat* L, const gpx_mat* X, const gpx_ma
   return 0;
 }
 
-// beta (np x mcp, ld mcp) for the evaluation points Zc[0 .. mc): W = L^-1 (K(X, Zc) + bias), beta = L^-T W.
-// Wt is scratch (mcp x np); beta lands in W.
+// beta for the evaluation points Zc[0 .. mc): W = L^-1 (K(X, Zc) + bias), beta = L^-T W.  A, B: two buffers of np * mcp
+// doubles; *out = beta^T (mcp x np, row stride np) when `transposed`, else beta (np x mcp, row stride mcp) -- in whichever of
+// the two buffers it ends up in.  Large factors (T != NULL: mcp * chol_binv_order(np) doubles): both solves through the
+// factor's explicit block inverses -- forward out of place (chol_trsm_left_oop, the IVAR solve of bench.py), backward as the
+// right solve beta^T = W^T L^-1 (chol_trsm_right_n_leading) -- every product K >= 1024 on 128-tiles: 2 x 31 ms at N = 8192,
+// M = 32768 where the in-place leaf recursions took 2 x 36.
 int solve_beta(gpx_ctx* ctx, const KParams& kp, const gpx_mat* L, const gpx_mat* X, const double* Zc, int64_t mc,
-               int64_t mcp, const double* d_bias, double* W, double* Wt) {
+               int64_t mcp, const double* d_bias, double* A, double* B, double* T, int transposed, double** out) {
   const int64_t n = L->rows, np = L->prows;
-  GPX_TRY(launch_kfill(ctx, kp, X->p, n, Zc, mc, 0, nullptr, 0, 0.0, W, np, mcp, mcp));
+  GPX_TRY(launch_kfill(ctx, kp, X->p, n, Zc, mc, 0, nullptr, 0, 0.0, A, np, mcp, mcp));
   if (d_bias) {
     dim3 grid((unsigned)((mc + 255) / 256), (unsigned)n);
-    hipLaunchKernelGGL(add_row_bias_kernel, grid, dim3(256), 0, ctx->stream, W, mcp, n, mc, d_bias);
+    hipLaunchKernelGGL(add_row_bias_kernel, grid, dim3(256), 0, ctx->stream, A, mcp, n, mc, d_bias);
   }
-  GPX_TRY(chol_trsm_left(ctx, L->p, L->ld, L->aux, W, mcp, np, mcp));
-  GPX_TRY(launch_transpose(ctx, W, np, mcp, mcp, Wt, np));
-  GPX_TRY(chol_trsm_right_n(ctx, L->p, L->ld, L->aux, Wt, np, mcp, np));
-  return launch_transpose(ctx, Wt, mcp, np, np, W, mcp);
+  double *cur, *other;   // cur: beta^T
+  if (T != nullptr) {
+    gpx_mat* Lm = const_cast<gpx_mat*>(L);   // (the block inverses are a cache inside the factor)
+    GPX_TRY(chol_trsm_left_oop(ctx, Lm, A, mcp, B, mcp, mcp));
+    GPX_TRY(launch_transpose(ctx, B, np, mcp, mcp, A, np));
+    GPX_TRY(chol_trsm_right_n_leading(ctx, Lm, np, A, np, mcp, T));
+    cur = A;
+    other = B;
+  } else {
+    GPX_TRY(chol_trsm_left(ctx, L->p, L->ld, L->aux, A, mcp, np, mcp));
+    GPX_TRY(launch_transpose(ctx, A, np, mcp, mcp, B, np));
+    GPX_TRY(chol_trsm_right_n(ctx, L->p, L->ld, L->aux, B, np, mcp, np));
+    cur = B;
+    other = A;
+  }
+  if (transposed) {
+    *out = cur;
+    return 0;
+  }
+  *out = other;
+  return launch_transpose(ctx, cur, mcp, np, np, other, mcp);
 }
+
+// scratch of the block-inverse solves (NULL below the order where they pay)
+int solve_scratch(gpx_ctx* ctx, Scratch& sc, int64_t np, int64_t mcp, double** T) {
+  *T = nullptr;
+  if (np < 4096) return 0;
+  void* p;
+  GPX_TRY(sc.get(mcp * chol_binv_order(np) * 8, &p));
+  *T = (double*)p;
+  return 0;
+}
+
+// d rounded up to the instantiated register-array sizes
+#define GPX_SE_DISPATCH(d_, CALL) \
+  do {                            \
+    if ((d_) <= 1) { CALL(1); }   \
+    else if ((d_) <= 2) { CALL(2); } \
+    else if ((d_) <= 4) { CALL(4); } \
+    else if ((d_) <= 8) { CALL(8); } \
+    else if ((d_) <= 16) { CALL(16); } \
+    else { CALL(32); }            \
+  } while (0)
 
 int upload(gpx_ctx* ctx, Scratch& sc, const double* host, int64_t count, double** dev) {
   *dev = nullptr;
@@ -294,11 +441,24 @@ int gpx_ivar_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, co
   GPX_TRY(sc.get(n * d * 8, &pg));
   double* d_nd;
   GPX_TRY(upload(ctx, sc, noise_deriv, n * d, &d_nd));
-  double* W = (double*)pW;
-  GPX_TRY(solve_beta(ctx, kp, L, X, Z->p, m, mp, nullptr, W, (double*)pWt));
+  double *W, *T;
+  GPX_TRY(solve_scratch(ctx, sc, np, mp, &T));
+  GPX_TRY(solve_beta(ctx, kp, L, X, Z->p, m, mp, nullptr, (double*)pW, (double*)pWt, T, 0, &W));
   // S = beta beta^T: symmetric -- only the tiles on / below the diagonal are computed (N^2 M flops instead of 2 N^2 M), the
-  // rest is mirrored (the row kernel reads whole rows)
-  GPX_TRY(launch_gemm(ctx, W, mp, W, mp, (double*)pS, np, np, np, mp, true, false, true));
+  // rest is mirrored (the row kernel reads whole rows).  A SMALL C under a long k range: N = 8192 is 2080 lower 128-tiles
+  // for 512 resident workgroups -- 4.06 rounds, the last one nearly empty (36.5 ms = 60 TF/s at M = 32768) -- so the k range
+  // goes in slices (launch_gemm_ksplit; the buffer the solve no longer needs holds the partials when it is large enough).
+  {
+    const int64_t t128 = (np / 128) * (np / 128 + 1) / 2;
+    int64_t parts = 1;
+    while (parts < 8 && t128 * parts < 8192 && mp % (2 * parts * 16) == 0 && mp / (2 * parts) >= 4096) parts *= 2;
+    double* other = W == (double*)pW ? (double*)pWt : (double*)pW;
+    while (parts > 1 && parts * np * np > np * mp) parts /= 2;
+    if (parts > 1)
+      GPX_TRY(launch_gemm_ksplit(ctx, W, mp, W, mp, (double*)pS, np, np, np, mp, true, parts, other, true));
+    else
+      GPX_TRY(launch_gemm(ctx, W, mp, W, mp, (double*)pS, np, np, np, mp, true, false, true));
+  }
   {
     const int nt = (int)(np / 32);
     hipLaunchKernelGGL(mirror_lower_kernel, dim3((unsigned)((int64_t)nt * (nt + 1) / 2)), dim3(256), 0, ctx->stream, (double*)pS, np, nt);
@@ -306,8 +466,16 @@ int gpx_ivar_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, co
   }
   {
     ProfScope ps(ctx, GPX_PROF_REDUCE, 0.0, 8.0 * ((double)n * m + (double)n * n));
-    hipLaunchKernelGGL(ivar_grad_row_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, kp, X->p, n, Z->p, m,
-                       (const double*)W, mp, (const double*)pS, np, (const double*)d_nd, 1.0 / (double)m, (double*)pg);
+    if (kind == GPX_K_SE) {
+#define GPX_CALL(DM_)                                                                                                        \
+  hipLaunchKernelGGL((ivar_grad_row_se_kernel<DM_>), dim3((unsigned)n), dim3(256), 0, ctx->stream, kp, X->p, n, Z->p, m,     \
+                     (const double*)W, mp, (const double*)pS, np, (const double*)d_nd, 1.0 / (double)m, (double*)pg)
+      GPX_SE_DISPATCH(d, GPX_CALL);
+#undef GPX_CALL
+    } else {
+      hipLaunchKernelGGL(ivar_grad_row_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, kp, X->p, n, Z->p, m,
+                         (const double*)W, mp, (const double*)pS, np, (const double*)d_nd, 1.0 / (double)m, (double*)pg);
+    }
   }
   GPX_HIP(hipGetLastError());
   GPX_HIP(hipMemcpyAsync(grad, pg, (size_t)(n * d * 8), hipMemcpyDeviceToHost, ctx->stream));
@@ -337,13 +505,15 @@ int gpx_var_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, con
   GPX_TRY(upload(ctx, sc, noise_deriv, n * d, &d_nd));
   GPX_TRY(upload(ctx, sc, eval_bias, n, &d_eb));
   GPX_TRY(upload(ctx, sc, dk_bias, n * d, &d_db));
-  double* W = (double*)pW;
-  double* Cl = (double*)pWt;
+  double* T;
+  GPX_TRY(solve_scratch(ctx, sc, np, mc_alloc, &T));
   for (int64_t j0 = 0; j0 < M; j0 += mcmax) {
     const int64_t mc = (M - j0) < mcmax ? (M - j0) : mcmax;
     const int64_t mcp = gpx_round_up(mc, GPX_TILE);
     const double* Zc = Z->p + j0 * d;
-    GPX_TRY(solve_beta(ctx, kp, L, X, Zc, mc, mcp, d_eb, W, (double*)pWt));
+    double* W;
+    GPX_TRY(solve_beta(ctx, kp, L, X, Zc, mc, mcp, d_eb, (double*)pW, (double*)pWt, T, 0, &W));
+    double* Cl = W == (double*)pW ? (double*)pWt : (double*)pW;   // the buffer the solve no longer needs
     for (int l = 0; l < d; ++l) {
       dim3 ga((unsigned)((np + 255) / 256), (unsigned)np);
       hipLaunchKernelGGL(dcov_kernel, ga, dim3(256), 0, ctx->stream, kp, X->p, n, l, (const double*)d_nd, (double*)pA, np, np);
@@ -376,12 +546,24 @@ int gpx_var_grad_newpt(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhy
   GPX_TRY(sc.get(np * mc_alloc * 8, &pW));
   GPX_TRY(sc.get(np * mc_alloc * 8, &pWt));
   GPX_TRY(sc.get(M * d * 8, &pO));
+  double* T;
+  GPX_TRY(solve_scratch(ctx, sc, np, mc_alloc, &T));
   for (int64_t j0 = 0; j0 < M; j0 += mcmax) {
     const int64_t mc = (M - j0) < mcmax ? (M - j0) : mcmax;
     const int64_t mcp = gpx_round_up(mc, GPX_TILE);
-    GPX_TRY(solve_beta(ctx, kp, L, X, Z->p + j0 * d, mc, mcp, nullptr, (double*)pW, (double*)pWt));
-    hipLaunchKernelGGL(var_grad_newpt_kernel, dim3((unsigned)mc), dim3(256), 0, ctx->stream, kp, X->p, n, Z->p,
-                       (const double*)pW, mcp, j0, (double*)pO);
+    double* beta;
+    if (kind == GPX_K_SE) {   // beta^T: row m contiguous over the training points, and no transpose back
+      GPX_TRY(solve_beta(ctx, kp, L, X, Z->p + j0 * d, mc, mcp, nullptr, (double*)pW, (double*)pWt, T, 1, &beta));
+#define GPX_CALL(DM_)                                                                                                      \
+  hipLaunchKernelGGL((var_grad_newpt_se_kernel<DM_>), dim3((unsigned)mc), dim3(256), 0, ctx->stream, kp, X->p, n, Z->p,     \
+                     (const double*)beta, np, j0, (double*)pO)
+      GPX_SE_DISPATCH(d, GPX_CALL);
+#undef GPX_CALL
+    } else {
+      GPX_TRY(solve_beta(ctx, kp, L, X, Z->p + j0 * d, mc, mcp, nullptr, (double*)pW, (double*)pWt, T, 0, &beta));
+      hipLaunchKernelGGL(var_grad_newpt_kernel, dim3((unsigned)mc), dim3(256), 0, ctx->stream, kp, X->p, n, Z->p,
+                         (const double*)beta, mcp, j0, (double*)pO);
+    }
     GPX_HIP(hipGetLastError());
   }
   GPX_HIP(hipMemcpyAsync(out, pO, (size_t)(M * d * 8), hipMemcpyDeviceToHost, ctx->stream));

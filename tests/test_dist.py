@@ -85,7 +85,7 @@ def test_panel_loop_gloo_cpu(world, n, nb):
 
 
 @pytest.mark.parametrize("world,n,nb,grid", [(2, 700, 128, ""), (4, 1000, 256, ""), (6, 900, 128, ""), (8, 1300, 128, ""),
-                                             (8, 333, 256, ""), (4, 1100, 256, "4x1"), (4, 2100, 256, ""), (8, 1500, 128, "4x2")])
+                                             (8, 333, 256, ""), (4, 1100, 256, "4x1"), (4, 1700, 256, ""), (8, 1300, 128, "4x2")])
 def test_panel_loop_2d_gloo_cpu(world, n, nb, grid):
     """North-star layout: Pr x Pc block-cyclic ownership, column-communicator diagonal broadcast, all-rank panel pieces,
     look-ahead order, replicated + distributed factor, distributed substitution (reduce / bcast on sub-groups),
@@ -104,10 +104,10 @@ def test_panel_loop_2d_fewer_points_than_ranks_gloo_cpu():
     assert "world=4" in out
 
 
-@pytest.mark.parametrize("world,n,nb,grid,agg,bulk", [(4, 2100, 128, "", 4, "chunks"), (4, 1500, 128, "", 2, "chunks"),
-                                                     (2, 1700, 128, "", 3, "eval"), (8, 1500, 128, "", 8, "eval"),
-                                                     (4, 1500, 128, "", 1, "main"), (6, 1500, 128, "", 4, "bulk"),
-                                                     (2, 1700, 128, "", 5, "chunks"), (1, 1900, 128, "", 4, "eval")])
+@pytest.mark.parametrize("world,n,nb,grid,agg,bulk", [(4, 1700, 128, "", 4, "chunks"), (4, 1500, 128, "", 2, "chunks"),
+                                                     (2, 1700, 128, "", 3, "eval"), (8, 1300, 128, "", 8, "eval"),
+                                                     (4, 1500, 128, "", 1, "main"), (6, 1300, 128, "", 4, "bulk"),
+                                                     (2, 1700, 128, "", 5, "chunks"), (1, 1500, 128, "", 4, "eval")])
 def test_panel_loop_2d_schedules_gloo_cpu(world, n, nb, grid, agg, bulk):
     """The aggregated schedule of dist2_potrf in every mode: group sizes 1..8 (panels per trailing update; ragged last
     groups), the bulk update cut into chunks behind the near updates on MAIN / whole on a second stream, buffer-ring reuse
@@ -135,10 +135,10 @@ def test_panel_loop_2d_round4_knobs_gloo_cpu(world, n, nb, env):
 
 
 @pytest.mark.parametrize("world,n,nb,env", [
-    (4, 2100, 128, {"GPX_DIST_CHUNK_MIN_BLOCKS": "1", "GPX_DIST_CHUNK_HOLD": "1"}),    # the cut re-centred at every step
-    (4, 1900, 128, {"GPX_DIST_CHUNK_MIN_BLOCKS": "2", "GPX_DIST_CHUNK_HOLD": "3"}),
-    (8, 1500, 128, {"GPX_DIST_CHUNK_MIN_BLOCKS": "2", "GPX_DIST_CHUNK_HOLD": "2", "GPX_DIST_AGG": "2"}),
-    (2, 1900, 128, {"GPX_DIST_CHUNK_MIN_BLOCKS": "3", "GPX_DIST_CHUNK_HOLD": "8"}),    # chunk 0 shrinks to its one block row
+    (4, 1700, 128, {"GPX_DIST_CHUNK_MIN_BLOCKS": "1", "GPX_DIST_CHUNK_HOLD": "1"}),    # the cut re-centred at every step
+    (4, 1500, 128, {"GPX_DIST_CHUNK_MIN_BLOCKS": "2", "GPX_DIST_CHUNK_HOLD": "3"}),
+    (8, 1300, 128, {"GPX_DIST_CHUNK_MIN_BLOCKS": "2", "GPX_DIST_CHUNK_HOLD": "2", "GPX_DIST_AGG": "2"}),
+    (2, 1500, 128, {"GPX_DIST_CHUNK_MIN_BLOCKS": "3", "GPX_DIST_CHUNK_HOLD": "8"}),    # chunk 0 shrinks to its one block row
     (6, 1300, 128, {"GPX_DIST_PANEL_CHUNKS": "1"})])                                   # rounds 2-4: the panel in one piece
 def test_panel_loop_2d_row_chunks_gloo_cpu(world, n, nb, env):
     """Round 5: the panel travels in two row chunks, one stage apart on the solve / broadcast / near-update streams.  Every cut

@@ -128,6 +128,61 @@ def test_derivatives_vs_oracle_larger(kind, with_nf, dups):
     assert rel(cf.derivative(X), orc.ivar_grad(s, X, Z, noise, nf)) <= 1e-9
 
 
+def _se_gradients_numpy(cl, sig, X, Z, nug):
+    """The two squared-exponential gradients as dense NumPy algebra (the oracle's loops are O(N^2 d) Python iterations):
+    dk(u, p)[l] = -s (u_l - p_l) / cl_l^2 k(u, p) is linear in the difference, so both collapse to products with the
+    coordinate arrays.  Checked against the oracle at n = 150 below before it is trusted at n = 4100."""
+    cl = np.asarray(cl, dtype=float)
+    def K(A, B):
+        D = (A[:, None, :] - B[None, :, :]) / cl
+        return sig * np.exp(-0.5 * np.sum(D * D, axis=2))
+    K0, Kxz = K(X, X), K(X, Z)
+    beta = np.linalg.solve(K0 + nug * np.eye(len(X)), Kxz)
+    c = -sig / cl ** 2
+    Q = beta * Kxz                                   # N x M
+    g1 = 2.0 * c * (Q @ Z - X * Q.sum(axis=1, keepdims=True))
+    R = K0 * (beta @ beta.T)
+    g2 = 2.0 * c * (X * R.sum(axis=1, keepdims=True) - R @ X)
+    ivar_grad = ((g1 + g2) / Z.shape[0]).reshape(-1)
+    newpt = (-2.0 * c * (Z * Q.sum(axis=0)[:, None] - Q.T @ X)).reshape(-1)
+    # the (N d) x M matrix of gp.py:282-341 for the first evaluation points
+    mf = min(300, Z.shape[0])
+    b, kz = beta[:, :mf], Kxz[:, :mf]
+    K0b = K0 @ b
+    full = np.zeros((len(X), X.shape[1], mf))
+    for l in range(X.shape[1]):
+        t1 = c[l] * (Z[None, :mf, l] - X[:, None, l]) * kz
+        t2 = c[l] * (X[:, None, l] * K0b - K0 @ (X[:, None, l] * b))
+        full[:, l, :] = b * (2.0 * t1 + 2.0 * t2)
+    return ivar_grad, newpt, full.reshape(len(X) * X.shape[1], mf)
+
+
+def test_large_factor_path_of_the_gradients():
+    """From np >= 4096 both solves for beta go through the factor's block inverses, S = beta beta^T runs as slices of its k
+    range, and the row kernels are the squared exponential's linear-difference forms (grad.hip).  n = 4100 (ragged against the
+    128 tiles), M = 8200, d = 5; the dense NumPy algebra is first checked against the oracle at n = 150."""
+    from gpexp_amd import device as dev
+    ctx = dev.context()
+    d, sig, nug = 5, 1.3, 0.05
+    cl = [0.5, 0.6, 0.7, 0.8, 0.9]
+    s = dict(kind="se", cl=cl, signalSize=sig, d=d)
+    sp = dev.KernelSpec(dev.K_SE, d, cl + [sig])
+    for n, m, check_oracle in ((150, 333, True), (4100, 8200, False)):
+        rng = np.random.default_rng(n)
+        X, Z = rng.uniform(-1, 1, (n, d)), rng.uniform(-1, 1, (m, d))
+        want_g, want_n, want_f = _se_gradients_numpy(cl, sig, X, Z, nug)
+        if check_oracle:
+            model = orc.fit(s, X, None, nug)
+            assert rel(want_g, orc.ivar_grad(s, X, Z, nug)) <= 1e-10
+            assert rel(want_n, orc.variance_deriv_wrt_newpt(s, model, Z)) <= 1e-10
+            assert rel(want_f, orc.variance_derivative(s, model, Z[:300])) <= 1e-10
+        Xd, Zd = dev.points(ctx, X), dev.points(ctx, Z)
+        L = dev.potrf(ctx, dev.kfill(ctx, sp, Xd, nugget=nug))
+        assert rel(np.asarray(dev.ivar_grad(ctx, sp, L, Xd, Zd)).reshape(-1), want_g) <= 1e-9
+        assert rel(np.asarray(dev.var_grad_newpt(ctx, sp, L, Xd, Zd)).reshape(-1), want_n) <= 1e-9
+        assert rel(dev.var_grad(ctx, sp, L, Xd, dev.points(ctx, Z[:300])), want_f) <= 1e-9
+
+
 def test_unsupported_kernels_raise():
     from gpExp.gp import GP
     from gpExp.kernels import KernelIsoMatern, KernelMehlerND
