@@ -165,10 +165,10 @@ def test_wide_and_narrow_leaf_multiply_strips_agree(dev, ctx, monkeypatch):
     assert np.max(np.abs(Krows @ a2 - y2[rows])) <= 1e-9 * np.max(np.abs(y2))
 
 
-@pytest.mark.parametrize("n", [2047, 2177, 8200, 9000, 12929])
+@pytest.mark.parametrize("n", [2047, 2177, 4000, 8200, 9000, 12929])
 def test_round2_solver_paths_at_ragged_sizes(dev, ctx, n):
     """Sizes that are not multiples of the 1024-order inverse blocks or of the 4096-wide look-ahead panels (padded
-    2048 / 2304 / 8320 / 9088 / 13056): blocked look-ahead factorisation (N >= 8192), block-inverse potrs (ragged last
+    2048 / 2304 / 4096 / 8320 / 9088 / 13056; 2048 and 4096 = 128 * 2^q take the level-batched triangular inverse of gpx_potri): blocked look-ahead factorisation (N >= 8192), block-inverse potrs (ragged last
     block), out-of-place posterior solve (N >= 2048) -- against LAPACK on the host."""
     import scipy.linalg as sl
     rng = np.random.default_rng(n)
