@@ -846,6 +846,8 @@ int gpx_dist2_kfill(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, 
 // broadcast of the factor: the copy INTO the packed buffer runs before that arrival (the block's last update is then applied
 // to the copy, gpx_dist2_diag_update), the copies OUT of it behind the event that releases the broadcast -- three launches less
 // on the chain across ranks, whose per-step latency, summed, is the factorisation time of a multi-rank run.
+static int d2_scratch_ensure(gpx_ctx* ctx, int64_t nb);
+static int64_t d2_slices(int64_t m, int64_t n, int64_t k, int64_t nb);
 static int diag_region_check(const gpx_mat* A, int64_t lr, int64_t lc, int64_t w, const gpx_mat* G, int64_t doff, int64_t nb) {
   GPX_ARG(G, "NULL argument");
   GPX_TRY(check_local(A, lr, w, lc, w));
@@ -866,6 +868,12 @@ int gpx_dist2_diag_update(gpx_ctx* ctx, gpx_mat* G, int64_t doff, int64_t h, con
   const int64_t gld = gpx_g_ld(nb);
   GPX_ARG(nb > 0 && nb % GPX_TILE == 0 && h > 0 && h <= nb && h % GPX_TILE == 0 && w > 0 && w <= nb && w % 16 == 0 && doff >= 0 &&
               soff >= 0 && (doff + gpx_dist2_diag_elems(nb)) * 8 <= G->bytes && (soff + h * gld) * 8 <= S->bytes, "operand outside its buffer");
+  const int64_t parts = d2_slices(h, h, w, nb);
+  if (parts > 1) {
+    GPX_TRY(d2_scratch_ensure(ctx, nb));
+    return launch_gemm_ksplit_small(ctx, S->p + soff, gld, S->p + soff, gld, G->p + doff, nb, h, h, w, false, parts,
+                                    ctx->d2_scratch + 2 * nb * nb);
+  }
   return launch_gemm(ctx, S->p + soff, gld, S->p + soff, gld, G->p + doff, nb, h, h, w, true, true, false);
 }
 
@@ -943,8 +951,10 @@ int gpx_dist2_panel_trsm(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int64
   return gpx_dist2_panel_trsm_keep(ctx, A, lr0, m, lc, w, G, doff, roff, nb, -1);
 }
 
+// [0, nb^2): the explicit inverse of the step's diagonal block; [nb^2, 2 nb^2): its build scratch; [2 nb^2, 6 nb^2): partial
+// products of the chain's two small launches when they run as slices of their k range (d2_slices)
 static int d2_scratch_ensure(gpx_ctx* ctx, int64_t nb) {
-  const int64_t need = 2 * nb * nb * 8;
+  const int64_t need = 6 * nb * nb * 8;
   if (ctx->d2_scratch_bytes < need) {
     GPX_HIP(hipDeviceSynchronize());
     if (ctx->d2_scratch) (void)hipFree(ctx->d2_scratch);
@@ -962,6 +972,17 @@ static int d2_scratch_ensure(gpx_ctx* ctx, int64_t nb) {
 // inside the enqueue path -- hipDeviceSynchronize + hipFree + hipMalloc in the middle of a step that may have collectives in
 // flight (bench.py's preflight runs nb = 256 and the real runner 512), or inside a stream capture.  The runner's constructor
 // calls this; the hot path then finds them large enough.  Blocking.
+// The two products that sit on the chain ACROSS ranks with one block of rows -- the solve of block row k+1 against the
+// prepared inverse and the last update of the staged diagonal block: nb x nb x nb, 256 64-tiles under a serial k range of nb,
+// 55-60 us each -- as slices of the k range (launch_gemm_ksplit_small, as in gpx_refit_rows: 23 + 6 us).  GPX_DIST2_KSPLIT=0: off.
+static int64_t d2_slices(int64_t m, int64_t n, int64_t k, int64_t nb) {
+  static const int on = [] { const char* e = getenv("GPX_DIST2_KSPLIT"); return e ? atoi(e) : 1; }();
+  if (!on || m % 64 != 0 || n % 64 != 0 || m > nb || n > nb) return 1;
+  int64_t parts = 1;
+  while (parts < 4 && (m / 64) * (n / 64) * parts < 1024 && k % (2 * parts * 16) == 0 && k / (2 * parts) >= 256) parts *= 2;
+  return parts;
+}
+
 int gpx_dist2_reserve(gpx_ctx* ctx, int64_t nb, int64_t agg, int64_t mcols) {
   GPX_ARG(ctx && nb > 0 && nb % GPX_TILE == 0 && agg >= 1 && mcols >= 0, "bad arguments");
   GPX_TRY(d2_scratch_ensure(ctx, nb));
@@ -1082,7 +1103,11 @@ static int panel_trsm_impl(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int
     }
     // (use_prepared == 2: gpx_dist2_diag_store keeps the inverse, behind the broadcast's event -- not on the chain)
     if (dslot >= 0 && use_prepared != 2) GPX_TRY(keep_inverse(ctx, A, dslot, nb, inv));
-    GPX_TRY(launch_gemm_tri(ctx, X, A->ld, inv, w, G->p + roff, gld, m, w, w, true, false, false, 2));
+    const int64_t parts = prepared ? d2_slices(m, w, w, nb) : 1;   // (one block of rows: dense against the inverse's zero upper part)
+    if (parts > 1)
+      GPX_TRY(launch_gemm_ksplit_small(ctx, X, A->ld, inv, w, G->p + roff, gld, m, w, w, true, parts, inv + 2 * nb * nb));
+    else
+      GPX_TRY(launch_gemm_tri(ctx, X, A->ld, inv, w, G->p + roff, gld, m, w, w, true, false, false, 2));
     if (prepared && use_prepared == 2) return 0;     // gpx_dist2_panel_copyback follows behind the broadcast's event
     return gpx_copy2d(ctx, G->p + roff, gld, X, A->ld, m, w);
   }
