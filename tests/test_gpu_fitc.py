@@ -89,6 +89,40 @@ def test_fitc_against_the_oracle_beyond_one_tile(n, nu, d, kind):
         -0.5 * float(y @ coeff_acc) - 0.5 * np.linalg.slogdet(cov_ref)[1] - n / 2 * np.log(2 * np.pi), rel=1e-10)
 
 
+def test_fitc_at_a_size_where_the_woodbury_product_runs_in_slices():
+    """N = 8192, nu = 1024: the nu x nu x N product of the fit (Quu + Kuf G^-1 Kfu) is a small C under a long k range and runs
+    as slices of the k range (launch_gemm_ksplit, fitc.hip); Lu^-1 Kuf goes out of place through Lu's block inverses.  Against
+    the dense Q + G solved directly on the host (the reference's own dense formula loses digits at this size, see above)."""
+    import scipy.linalg as sl
+    from gpexp_amd import device as dev
+    ctx = dev.context()
+    n, nu, d, noise = 8192, 1024, 4, 0.05
+    rng = np.random.default_rng(n + nu)
+    X = rng.uniform(-1, 1, (n, d))
+    S = X[rng.permutation(n)[:nu]].copy()
+    y = np.sin(X.sum(1)) + 0.1 * rng.standard_normal(n)
+    cl = [0.6, 0.7, 0.8, 0.9]
+    sp, s = dev.KernelSpec(dev.K_SE, d, cl + [1.1]), dict(kind="se", cl=cl, signalSize=1.1, d=d)
+    Quu = orc.cov_matrix(s, S, noise, row_loop=False)
+    Kuf = orc.cross_matrix(s, S, X)
+    W = sl.solve_triangular(np.linalg.cholesky(Quu), Kuf, lower=True, check_finite=False)
+    g = orc.kernel_diag(s, X) + noise - np.sum(W * W, axis=0)
+    cov = W.T @ W
+    cov[np.diag_indices(n)] += g
+    m = dev.FitcModel(ctx, sp, dev.points(ctx, X), dev.points(ctx, S), noise)
+    coeff, quad = m.solve(y)
+    c = sl.cho_factor(cov, lower=True, check_finite=False)
+    coeff_acc = sl.cho_solve(c, y, check_finite=False)
+    assert rel(coeff, coeff_acc) <= 1e-7
+    assert quad == pytest.approx(float(y @ coeff_acc), rel=1e-9)
+    assert m.logdet() == pytest.approx(2.0 * float(np.sum(np.log(np.diag(c[0])))), rel=1e-9, abs=1e-7)
+    Z = rng.uniform(-1, 1, (257, d))
+    mean, var = m.posterior(coeff, dev.points(ctx, Z))
+    kv = orc.cross_matrix(s, Z, X)
+    assert rel(mean, kv @ coeff_acc) <= 1e-7
+    assert rel(var, orc.kernel_diag(s, Z) - np.einsum("ij,ji->i", kv, sl.cho_solve(c, kv.T, check_finite=False))) <= 1e-7
+
+
 def test_nystrom_basis_and_operator(golden):
     from gpExp.kernels import KernelSquaredExponential
     from gpExp.gp_kernel_utilities import calculateKernelBasisFunctionsMC, covTimesV, calculateCovarianceMatrix
