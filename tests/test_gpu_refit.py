@@ -130,9 +130,20 @@ def test_gp_reuses_the_leading_factor_transparently(dev, ctx):
     assert g._reusable_rows(X3, 1e-2, g.kernel._spec()) == 0
     g.addNodesAndComputeCovariance(X3); fresh.addNodesAndComputeCovariance(X3)
     assert rel(g.evaluateVariance(Z), fresh.evaluateVariance(Z)) <= 1e-10
+    # the kept factor itself when the very same fit is asked for again -- also by a likelihood evaluation, which never stores one
+    y3 = np.sin(X3.sum(1))
+    g.train(X3, y3)
+    kept = g._fcache[3]
+    assert g._cached_factor(X3, 1e-2, g.kernel._spec()) is kept and g._cached_factor(X3.copy(), 1e-2, g.kernel._spec()) is kept
+    assert g._cached_factor(X3[:-1], 1e-2, g.kernel._spec()) is None and g._cached_factor(X3 + 1e-16, 2e-2, g.kernel._spec()) is None
+    fresh.train(X3, y3)
+    assert g.computeLogLike(X3, y3) == pytest.approx(fresh.computeLogLike(X3, y3), rel=1e-12)
+    assert g._fcache[3] is kept                                   # consulted, not replaced
+    y4 = y3 + 0.1                                                  # other data, same points: still the kept factor
+    assert g.computeLogLike(X3, y4) == pytest.approx(fresh.computeLogLike(X3, y4), rel=1e-12)
     # so does a different noise
     g.noise = 2e-2
-    assert g._reusable_rows(X3, g.noise, g.kernel._spec()) == 0
+    assert g._reusable_rows(X3, g.noise, g.kernel._spec()) == 0 and g._cached_factor(X3, g.noise, g.kernel._spec()) is None
 
 
 def test_greedy_with_derivatives_driver_pins_earlier_batches(dev, ctx, capsys):
