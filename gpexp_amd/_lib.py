@@ -61,6 +61,7 @@ _SIGS = {
     "gpx_posterior_cov": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_dp]),
     "gpx_fit_ivar": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_dp]),
     "gpx_ivar": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_dp]),
+    "gpx_ivar_keep": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_dp, C.POINTER(c_vp)]),
     "gpx_greedy_var": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_dp, c_ip, c_i64, c_i64, c_ip]),
     "gpx_greedy_ivar_step": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_vp,
                                        C.c_double, c_dp, c_ip]),
@@ -144,6 +145,7 @@ _SIGS = {
     "gpx_event_wait": (C.c_int, [c_vp, C.c_int]),
     "gpx_dist_finish": (C.c_int, [c_vp, c_vp]),
     "gpx_ivar_grad": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_dp, c_dp]),
+    "gpx_ivar_grad_w": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_dp, c_vp, c_dp]),
     "gpx_var_grad": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_dp, c_dp, c_dp, c_dp]),
     "gpx_var_grad_newpt": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_dp]),
     "gpx_profile_enable": (C.c_int, [c_vp, C.c_int]),

@@ -1241,9 +1241,11 @@ static int64_t eval_chunk(int64_t np) {
 // var_dev (device, M doubles, nullable): receives the variances when the caller reduces them on the device (IVAR) -- then
 // nothing of length M crosses PCIe.
 static int posterior_impl(gpx_ctx* ctx, const KParams& kp, const gpx_mat* L, const gpx_mat* X, const double* alpha,
-                          const gpx_mat* Z, double* mean, double* var_host, double* var_dev = nullptr) {
+                          const gpx_mat* Z, double* mean, double* var_host, double* var_dev = nullptr,
+                          gpx_mat** keepW = nullptr) {
   const int64_t n = L->rows, np = L->prows, M = Z->rows, d = kp.d;
   const bool var = var_host != nullptr || var_dev != nullptr;
+  if (keepW) *keepW = nullptr;
   GPX_ARG(X->rows == n, "X does not match the factor");
   if (M == 0) return 0;
   const int64_t mcmax = eval_chunk(np);
@@ -1261,8 +1263,21 @@ static int posterior_impl(gpx_ctx* ctx, const KParams& kp, const gpx_mat* L, con
       if ((r = gpx_dev_alloc(ctx, M * 8, &pvar)) != 0) break;
       var_dev = (double*)pvar;
     }
-    if ((r = gpx_dev_alloc(ctx, bytesB, &pB)) != 0) break;
-    if (oop && (r = gpx_dev_alloc(ctx, bytesB, &pW)) != 0) break;
+    // keepW: the solved W = L^-1 K(X, Z) stays, as a matrix of its own, for the cost's gradient at the same design
+    // (gpx_ivar_grad_w) -- when all of Z is one chunk; it then IS the buffer the solution lands in
+    gpx_mat* Wm = nullptr;
+    if (keepW && var && M <= mcmax && gpx_mat_new(ctx, n, M, 1, &Wm) == 0 &&
+        (Wm->prows != np || Wm->ld != ldb_alloc || Wm->bytes < bytesB)) {
+      gpx_mat_free(ctx, Wm);
+      Wm = nullptr;
+    }
+    if (Wm) *keepW = Wm;
+    if (Wm && !oop) pB = Wm->p;
+    else if ((r = gpx_dev_alloc(ctx, bytesB, &pB)) != 0) break;
+    if (oop) {
+      if (Wm) pW = Wm->p;
+      else if ((r = gpx_dev_alloc(ctx, bytesB, &pW)) != 0) break;
+    }
     if ((r = gpx_dev_alloc(ctx, bytes_out, &pout)) != 0) break;
     if ((r = gpx_dev_alloc(ctx, bytes_out, &pkd)) != 0) break;
     if ((r = gpx_dev_alloc(ctx, bytes_part, &ppart)) != 0) break;
@@ -1308,8 +1323,15 @@ static int posterior_impl(gpx_ctx* ctx, const KParams& kp, const gpx_mat* L, con
   } while (0);
   (void)hipStreamSynchronize(ctx->stream);
   if (pvar) gpx_dev_release(ctx, pvar, M * 8);
-  gpx_dev_release(ctx, pB, bytesB);
-  if (pW) gpx_dev_release(ctx, pW, bytesB);
+  {
+    gpx_mat* Wm = keepW ? *keepW : nullptr;
+    if (pB && !(Wm && pB == (void*)Wm->p)) gpx_dev_release(ctx, pB, bytesB);
+    if (pW && !(Wm && pW == (void*)Wm->p)) gpx_dev_release(ctx, pW, bytesB);
+    if (Wm && r != 0) {
+      gpx_mat_free(ctx, Wm);
+      *keepW = nullptr;
+    }
+  }
   gpx_dev_release(ctx, pout, bytes_out);
   gpx_dev_release(ctx, pkd, bytes_out);
   gpx_dev_release(ctx, ppart, bytes_part);
@@ -1341,9 +1363,24 @@ static double pairwise_mean(std::vector<double>& v, int64_t count) {
   return v[0] / (double)count;
 }
 
+static int ivar_impl(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
+                     const gpx_mat* Z, double* out, gpx_mat** W);
+
 int gpx_ivar(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
              const gpx_mat* Z, double* out) {
+  return ivar_impl(ctx, kind, d, hyp, nhyp, L, X, Z, out, nullptr);
+}
+
+int gpx_ivar_keep(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
+                  const gpx_mat* Z, double* out, gpx_mat** W) {
+  GPX_ARG(W != nullptr, "W is NULL");
+  return ivar_impl(ctx, kind, d, hyp, nhyp, L, X, Z, out, W);
+}
+
+static int ivar_impl(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
+                     const gpx_mat* Z, double* out, gpx_mat** W) {
   GPX_ARG(ctx && X && Z && out, "NULL argument");
+  if (W) *W = nullptr;
   GPX_TRY(need_factor(L));
   KParams kp;
   GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
@@ -1352,7 +1389,7 @@ int gpx_ivar(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const g
   GPX_TRY(gpx_kparams_sets(ctx, &kp, X, Z));
   void* pv;
   GPX_TRY(gpx_dev_alloc(ctx, Z->rows * 8, &pv));
-  int r = posterior_impl(ctx, kp, L, X, nullptr, Z, nullptr, nullptr, (double*)pv);
+  int r = posterior_impl(ctx, kp, L, X, nullptr, Z, nullptr, nullptr, (double*)pv, W);
   if (r == 0) {
     hipLaunchKernelGGL(pairwise_mean_kernel, dim3(1), dim3(1024), 0, ctx->stream, (double*)pv, Z->rows, ctx->d_scal);
     if (hipMemcpyAsync(out, ctx->d_scal, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) r = -2;
@@ -1360,6 +1397,10 @@ int gpx_ivar(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const g
   (void)hipStreamSynchronize(ctx->stream);
   gpx_dev_release(ctx, pv, Z->rows * 8);
   if (r == -2) gpx_set_error("ivar: HIP copy failed");
+  if (r != 0 && W && *W) {
+    gpx_mat_free(ctx, *W);
+    *W = nullptr;
+  }
   return r;
 }
 

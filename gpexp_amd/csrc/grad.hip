@@ -349,15 +349,38 @@ int check_args(int kind, int d, const gpx_mat* L, const gpx_mat* X, const gpx_ma
 // factor's explicit block inverses -- forward out of place (chol_trsm_left_oop, the IVAR solve of bench.py), backward as the
 // right solve beta^T = W^T L^-1 (chol_trsm_right_n_leading) -- every product K >= 1024 on 128-tiles: 2 x 31 ms at N = 8192,
 // M = 32768 where the in-place leaf recursions took 2 x 36.
+// Wfwd != NULL: W = L^-1 K(X, Zc) is at hand (np x mcp; kept by gpx_ivar_keep at the same design) -- fill and forward solve are
+// skipped, a third of the gradient's work.
 int solve_beta(gpx_ctx* ctx, const KParams& kp, const gpx_mat* L, const gpx_mat* X, const double* Zc, int64_t mc,
-               int64_t mcp, const double* d_bias, double* A, double* B, double* T, int transposed, double** out) {
+               int64_t mcp, const double* d_bias, double* A, double* B, double* T, int transposed, double** out,
+               const gpx_mat* Wfwd = nullptr) {
   const int64_t n = L->rows, np = L->prows;
+  double *cur, *other;   // cur: beta^T
+  if (Wfwd != nullptr) {
+    GPX_ARG(!d_bias && Wfwd->prows == np && Wfwd->pcols == mcp, "solve_beta: the kept forward solve does not match");
+    if (T != nullptr) {
+      GPX_TRY(launch_transpose(ctx, Wfwd->p, np, mcp, Wfwd->ld, A, np));
+      GPX_TRY(chol_trsm_right_n_leading(ctx, const_cast<gpx_mat*>(L), np, A, np, mcp, T));
+      cur = A;
+      other = B;
+    } else {
+      GPX_TRY(launch_transpose(ctx, Wfwd->p, np, mcp, Wfwd->ld, B, np));
+      GPX_TRY(chol_trsm_right_n(ctx, L->p, L->ld, L->aux, B, np, mcp, np));
+      cur = B;
+      other = A;
+    }
+    if (transposed) {
+      *out = cur;
+      return 0;
+    }
+    *out = other;
+    return launch_transpose(ctx, cur, mcp, np, np, other, mcp);
+  }
   GPX_TRY(launch_kfill(ctx, kp, X->p, n, Zc, mc, 0, nullptr, 0, 0.0, A, np, mcp, mcp));
   if (d_bias) {
     dim3 grid((unsigned)((mc + 255) / 256), (unsigned)n);
     hipLaunchKernelGGL(add_row_bias_kernel, grid, dim3(256), 0, ctx->stream, A, mcp, n, mc, d_bias);
   }
-  double *cur, *other;   // cur: beta^T
   if (T != nullptr) {
     gpx_mat* Lm = const_cast<gpx_mat*>(L);   // (the block inverses are a cache inside the factor)
     GPX_TRY(chol_trsm_left_oop(ctx, Lm, A, mcp, B, mcp, mcp));
@@ -426,7 +449,13 @@ extern "C" {
 
 int gpx_ivar_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
                   const gpx_mat* Z, const double* noise_deriv, double* grad) {
+  return gpx_ivar_grad_w(ctx, kind, d, hyp, nhyp, L, X, Z, noise_deriv, nullptr, grad);
+}
+
+int gpx_ivar_grad_w(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
+                    const gpx_mat* Z, const double* noise_deriv, const gpx_mat* Wkept, double* grad) {
   GPX_ARG(ctx && grad, "NULL argument");
+  GPX_ARG(Wkept == nullptr || ctx->live_mats.count(Wkept), "ivar_grad: the kept solve is not a live matrix of this context");
   GPX_TRY(check_args(kind, d, L, X, Z));
   KParams kp;
   GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
@@ -443,7 +472,9 @@ int gpx_ivar_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, co
   GPX_TRY(upload(ctx, sc, noise_deriv, n * d, &d_nd));
   double *W, *T;
   GPX_TRY(solve_scratch(ctx, sc, np, mp, &T));
-  GPX_TRY(solve_beta(ctx, kp, L, X, Z->p, m, mp, nullptr, (double*)pW, (double*)pWt, T, 0, &W));
+  GPX_ARG(Wkept == nullptr || (Wkept->prows == np && Wkept->pcols == mp && Wkept->rows == n && Wkept->cols == m),
+          "ivar_grad: the kept solve has another shape");
+  GPX_TRY(solve_beta(ctx, kp, L, X, Z->p, m, mp, nullptr, (double*)pW, (double*)pWt, T, 0, &W, Wkept));
   // S = beta beta^T: symmetric -- only the tiles on / below the diagonal are computed (N^2 M flops instead of 2 N^2 M), the
   // rest is mirrored (the row kernel reads whole rows).  A SMALL C under a long k range: N = 8192 is 2080 lower 128-tiles
   // for 512 resident workgroups -- 4.06 rounds, the last one nearly empty (36.5 ms = 60 TF/s at M = 32768) -- so the k range

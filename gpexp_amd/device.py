@@ -361,10 +361,16 @@ def posterior_cov(ctx, spec, L, X, Z):
     return cov
 
 
-def ivar(ctx, spec, L, X, Z):
+def ivar(ctx, spec, L, X, Z, keep=False):
+    """Mean posterior variance over Z.  keep=True -> (cost, W): W = L^-1 K(X, Z) stays on the device for ivar_grad at the same
+    design (None when Z does not fit one evaluation chunk)."""
     v = C.c_double()
-    check(ctx.lib.gpx_ivar(ctx.h, *spec.args(), L.h, X.h, Z.h, C.byref(v)))
-    return v.value
+    if not keep:
+        check(ctx.lib.gpx_ivar(ctx.h, *spec.args(), L.h, X.h, Z.h, C.byref(v)))
+        return v.value
+    h = c_vp()
+    check(ctx.lib.gpx_ivar_keep(ctx.h, *spec.args(), L.h, X.h, Z.h, C.byref(v), C.byref(h)))
+    return v.value, (DeviceMatrix(ctx, h) if h.value else None)
 
 
 def fit_ivar(ctx, spec, K, X, Z):
@@ -634,12 +640,13 @@ def lml_grad_from_sums(spec, sums):
     return g
 
 
-def ivar_grad(ctx, spec, L, X, Z, noise_deriv=None):
+def ivar_grad(ctx, spec, L, X, Z, noise_deriv=None, W=None):
     """d IVAR / d design coordinates, flattened (N*d) in the reference's row order (point-major); noise_deriv (N, d) =
-    d noise(x_j)/d x_j of a heteroscedastic noise model."""
+    d noise(x_j)/d x_j of a heteroscedastic noise model; W = the forward solve kept by ivar(..., keep=True) for the same
+    L, X, Z."""
     out = np.empty(X.shape[0] * spec.d)
     nd = as_f64(noise_deriv) if noise_deriv is not None else None
-    check(ctx.lib.gpx_ivar_grad(ctx.h, *spec.args(), L.h, X.h, Z.h, dptr(nd), dptr(out)))
+    check(ctx.lib.gpx_ivar_grad_w(ctx.h, *spec.args(), L.h, X.h, Z.h, dptr(nd), W.h if W is not None else None, dptr(out)))
     return out
 
 

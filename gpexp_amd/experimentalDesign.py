@@ -82,7 +82,17 @@ class costFunctionGP_IVAR(costFunctionBase):
         sess = _dist.session()
         if sess is not None and (gp._Lc is not None or sess.use_eval(self.nMC)):   # MC points sharded over the ranks, partial sums in rank order
             return np.abs(sess.ivar(gp.kernel._spec(), gp._Lc or gp._L, gp._X, self.mcPoints, cache=self))
-        cost = _dev.ivar(_dev.context(), gp.kernel._spec(), gp._L, gp._X, self._mc())
+        # An optimiser asks for the cost and then for its gradient at the same design (SLSQP: experimentalDesign.py:471-489):
+        # from 1024 design points on the forward solve W = L^-1 K(X, Z) stays on the device for that gradient -- a third of
+        # its work (design state across optimiser iterations).  Keyed on the factor OBJECT: the same design
+        # gets the kept factor back from GP._cached_factor; one W at a time.
+        self._w_kept = None
+        if inputPoints.shape[0] >= 1024 and gp.reuseFactor and self.space.noiseFunc is None:
+            cost, W = _dev.ivar(_dev.context(), gp.kernel._spec(), gp._L, gp._X, self._mc(), keep=True)
+            if W is not None:
+                self._w_kept = (gp._L, W)
+        else:
+            cost = _dev.ivar(_dev.context(), gp.kernel._spec(), gp._L, gp._X, self._mc())
         return np.abs(cost)
 
     def derivative(self, inputPoints):
@@ -98,7 +108,10 @@ class costFunctionGP_IVAR(costFunctionBase):
             gp.addNodesAndComputeCovariance(inputPoints, noiseIn=self.space.noiseFunc(inputPoints))
             nd = np.asarray(self.space.noiseFunc.deriv(inputPoints), dtype=float).reshape(inputPoints.shape)
         gp._point_derivative_ready(self.mcPoints)
-        return _dev.ivar_grad(_dev.context(), gp.kernel._spec(), gp._L, gp._X, self._mc(), nd)
+        kept = getattr(self, "_w_kept", None)
+        W = kept[1] if (kept is not None and nd is None and kept[0] is gp._L) else None
+        self._w_kept = None                                   # (one use: the next cost evaluation brings its own)
+        return _dev.ivar_grad(_dev.context(), gp.kernel._spec(), gp._L, gp._X, self._mc(), nd, W=W)
 
 
 class costFunctionGP_MI(costFunctionBase):

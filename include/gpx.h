@@ -148,6 +148,11 @@ int gpx_posterior_cov(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp
 /* IVAR = (1/M) sum_j var_j (signed mean; caller applies abs)          experimentalDesign.py:104-117 */
 int gpx_ivar(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp,
              const gpx_mat* L, const gpx_mat* X, const gpx_mat* Z, double* out);
+/* The same cost, keeping W = L^-1 K(X, Z) (N x M, a matrix of the context: release with gpx_mat_free) for the gradient AT THE
+ * SAME DESIGN: an optimiser asks for the cost and then its gradient at one point (experimentalDesign.py:471-489), and the forward
+ * solve is a third of the gradient's work.  *W = NULL when Z does not fit one evaluation chunk. */
+int gpx_ivar_keep(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp,
+                  const gpx_mat* L, const gpx_mat* X, const gpx_mat* Z, double* out, gpx_mat** W);
 /* GP fit + IVAR in one call -- what costFunctionGP_IVAR.evaluate (experimentalDesign.py:104-117: refit, then
  * evaluateVariance over the MC points) amounts to per optimiser evaluation: K (assembled, gpx_kfill) is factored in place
  * as by gpx_potrf and *out receives what gpx_ivar would return on the finished factor.  With GPX_FIT_IVAR_STREAMED=1 the
@@ -205,6 +210,9 @@ int gpx_lml_grad_linv(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp
  * (costFunctionGP_IVAR.derivative, experimentalDesign.py:168-179 -> gp.py:282-341).  grad: host, N*d. */
 int gpx_ivar_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
                   const gpx_mat* Z, const double* noise_deriv, double* grad);
+/* ... with the forward solve kept by gpx_ivar_keep for the same L, X, Z (W == NULL: exactly gpx_ivar_grad) */
+int gpx_ivar_grad_w(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
+                    const gpx_mat* Z, const double* noise_deriv, const gpx_mat* W, double* grad);
 /* out[(j*d + l) * M + m] = d var(z_m) / d X[j][l]  (GP.evaluateVarianceDerivative, gp.py:282-341; host, (N*d) x M).
  * eval_bias (host N, nullable) / dk_bias (host N x d, nullable): the terms of gp.py:318-320 -- noise(x_j) added to
  * k(x_j, z_m) and noise'(x_j) subtracted from -dk(z_m, x_j)/dz for every m -- which the reference applies when the WHOLE

@@ -63,6 +63,28 @@ if want("f1"):
            "is two solves (2 N^2 M), S = beta beta^T as a lower SYRK is N^2 M more; tr(dK/dx S) needs S")
     _, t = best(lambda: dev.var_grad_newpt(ctx, sp, L, X, Z))
     report("gpx_var_grad_newpt", "GP.evaluateVarianceDerivWRTnewpt (gp.py:261-280)", dict(N=N, M=M, d=d), t, flops=2.0 * N * N * M)
+    # one optimiser iteration of a continuous design (SLSQP, experimentalDesign.py:471-489): cost, then gradient, same design
+    from gpExp.kernels import KernelSquaredExponential
+    from gpExp.gp import GP
+    from gpExp.approximation import Space
+    from gpExp.experimentalDesign import costFunctionGP_IVAR
+    space = Space(d, lambda size: rng.uniform(-1, 1, size), lambda p: np.ones(len(p)))
+    def iteration(reuse):
+        g = GP(KernelSquaredExponential(list(0.4 + 0.05 * np.arange(d)), 1.0, d), 0.1)
+        g.reuseFactor = reuse
+        cf = costFunctionGP_IVAR(g, N, space, mcPoints=Zh)
+        cf.evaluate(Xh); cf.derivative(Xh)                      # warm: pools, block inverses
+        Xq = Xh.copy(); Xq[-1] += 1e-3                          # a new design: both calls do their full work once
+        def both():
+            cf.evaluate(Xq)
+            return cf.derivative(Xq)
+        return best(both, reps=1)[1]
+    t_sep, t_shared = iteration(False), iteration(True)
+    report("design iteration: cost + gradient", "costFunctionGP_IVAR.evaluate + .derivative at one design (experimentalDesign.py:100-117, "
+           "168-179, 471-489)", dict(N=N, M=M, d=d), t_shared, flops=3.0 * N * N * M + N ** 3 / 3.0,
+           note="count = what one iteration needs: ONE fit (N^3/3), the forward solve once (N^2 M), backward solve and SYRK "
+                "(2 N^2 M); %.1f ms when the gradient call refits and solves forward again (reuseFactor = False: two fits, "
+                "4 N^2 M), %.1f ms with the kept factor and the kept forward solve" % (1e3 * t_sep, 1e3 * t_shared))
     Nv, Mv = (1024, 1024) if quick else (2048, 4096)
     Xv, Zv = dev.points(ctx, Xh[:Nv]), dev.points(ctx, Zh[:Mv])
     Lv = dev.potrf(ctx, dev.kfill(ctx, sp, Xv, nugget=0.1))

@@ -183,6 +183,43 @@ def test_large_factor_path_of_the_gradients():
         assert rel(dev.var_grad(ctx, sp, L, Xd, dev.points(ctx, Z[:300])), want_f) <= 1e-9
 
 
+@pytest.mark.parametrize("n,m", [(1100, 2000), (4100, 4500)])
+def test_cost_then_gradient_at_the_same_design_share_the_forward_solve(n, m):
+    """An optimiser evaluates the IVAR cost and then its gradient at one design (experimentalDesign.py:471-489).  From 1024
+    design points the cost keeps W = L^-1 K(X, Z) on the device (gpx_ivar_keep) and the gradient starts from it
+    (gpx_ivar_grad_w): same cost, same gradient as the stand-alone calls -- below and above the order from which the solves go
+    through the block inverses -- and through the class API the second refit is the kept factor."""
+    from gpexp_amd import device as dev
+    from gpExp.gp import GP
+    from gpExp.experimentalDesign import costFunctionGP_IVAR
+    ctx = dev.context()
+    d = 3
+    rng = np.random.default_rng(n + m)
+    X, Z = rng.uniform(-1, 1, (n, d)), rng.uniform(-1, 1, (m, d))
+    s = dict(kind="se", cl=[0.5, 0.7, 0.9], signalSize=1.3, d=d)
+    sp = dev.KernelSpec(dev.K_SE, d, [0.5, 0.7, 0.9, 1.3])
+    Xd, Zd = dev.points(ctx, X), dev.points(ctx, Z)
+    L = dev.potrf(ctx, dev.kfill(ctx, sp, Xd, nugget=0.05))
+    cost, W = dev.ivar(ctx, sp, L, Xd, Zd, keep=True)
+    assert W is not None and cost == dev.ivar(ctx, sp, L, Xd, Zd)
+    g0 = dev.ivar_grad(ctx, sp, L, Xd, Zd)
+    assert rel(dev.ivar_grad(ctx, sp, L, Xd, Zd, W=W), g0) <= 1e-12
+    del W
+    cf = costFunctionGP_IVAR(GP(kernel_of(s), 0.05), n, space_of(d, None), mcPoints=Z)
+    c1 = cf.evaluate(X)
+    assert cf._w_kept is not None and c1 == pytest.approx(abs(cost), rel=1e-13)
+    kept_factor = cf.gaussianProcess._L
+    g1 = cf.derivative(X)
+    assert cf.gaussianProcess._L is kept_factor and cf._w_kept is None      # no refit; the kept solve is used once
+    assert rel(g1, g0) <= 1e-12
+    assert rel(cf.derivative(X), g0) <= 1e-12                                  # without a kept solve: the stand-alone path
+    X2 = X.copy(); X2[-1] += 0.01
+    cf.evaluate(X)
+    g2 = cf.derivative(X2)                                                     # another design: the kept solve must not be used
+    fresh = costFunctionGP_IVAR(GP(kernel_of(s), 0.05), n, space_of(d, None), mcPoints=Z)
+    assert rel(g2, fresh.derivative(X2)) <= 1e-12
+
+
 def test_unsupported_kernels_raise():
     from gpExp.gp import GP
     from gpExp.kernels import KernelIsoMatern, KernelMehlerND
