@@ -1404,6 +1404,54 @@ static int ivar_impl(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp,
   return r;
 }
 
+// The cost again after a refit that KEPT the leading `keep` rows of the factor (gpx_refit_rows): W = L^-1 K(X, Z) of the previous
+// design is at hand (gpx_ivar_keep), and its leading rows are those of the new W -- forward substitution never looks ahead.  Only
+// the rows from `keep` on are re-assembled and re-solved, in place:  W2 <- L22^-1 (K(X2, Z) - L21 W1)  -- 2 (N - keep) keep M flops
+// instead of N^2 M -- and the cost is one pass over W (design state across optimiser iterations; the batch loop
+// of experimentalDesign.py:694-751 pins the earlier points and moves the last batch only).
+int gpx_ivar_update(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
+                    const gpx_mat* Z, gpx_mat* W, int64_t keep, double* out) {
+  GPX_ARG(ctx && X && Z && W && out, "NULL argument");
+  GPX_TRY(need_factor(L));
+  GPX_ARG(ctx->live_mats.count(W), "ivar_update: W is not a live matrix of this context");
+  KParams kp;
+  GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
+  GPX_ARG(X->cols == d && X->pcols == d && Z->cols == d && Z->pcols == d, "point sets must be unpadded (n x d)");
+  const int64_t n = L->rows, np = L->prows, M = Z->rows, mcp = gpx_round_up(M, GPX_TILE);
+  GPX_ARG(X->rows == n && M > 0, "X does not match the factor / no integration points");
+  GPX_ARG(W->rows == n && W->cols == M && W->prows == np && W->pcols == mcp, "ivar_update: W has another shape");
+  GPX_ARG(keep > 0 && keep < np && keep % GPX_TILE == 0, "ivar_update: keep must be a positive multiple of 128 below the padded order");
+  GPX_TRY(gpx_kparams_sets(ctx, &kp, X, Z));
+  const int64_t n2 = n - keep, n2p = np - keep, ldw = W->ld;
+  const int64_t bytes_out = mcp * 8, bytes_part = colreduce_partial_elems(np, mcp) * 8 + 8;
+  void *pout = nullptr, *pkd = nullptr, *ppart = nullptr, *pv = nullptr;
+  int r = 0;
+  do {
+    if ((r = gpx_dev_alloc(ctx, bytes_out, &pout)) != 0) break;
+    if ((r = gpx_dev_alloc(ctx, bytes_out, &pkd)) != 0) break;
+    if ((r = gpx_dev_alloc(ctx, bytes_part, &ppart)) != 0) break;
+    if ((r = gpx_dev_alloc(ctx, M * 8, &pv)) != 0) break;
+    double* W2 = W->p + keep * ldw;
+    if ((r = launch_kfill(ctx, kp, X->p + keep * d, n2, Z->p, M, 0, nullptr, 0, 0.0, W2, n2p, mcp, ldw)) != 0) break;
+    if ((r = launch_gemm(ctx, L->p + keep * L->ld, L->ld, W->p, ldw, W2, ldw, n2p, mcp, keep, false, true, false)) != 0) break;
+    if ((r = chol_trsm_left(ctx, L->p + keep * (L->ld + 1), L->ld, L->aux + (keep / GPX_TILE) * GPX_TILE * GPX_TILE, W2, ldw, n2p,
+                            mcp)) != 0) break;
+    if ((r = launch_colreduce(ctx, W->p, ldw, n, mcp, nullptr, (double*)pout, (double*)ppart)) != 0) break;
+    if ((r = launch_kdiag(ctx, kp, Z->p, M, (double*)pkd)) != 0) break;
+    hipLaunchKernelGGL(vec_diff_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)pkd,
+                       (const double*)pout, M, (double*)pv);
+    hipLaunchKernelGGL(pairwise_mean_kernel, dim3(1), dim3(1024), 0, ctx->stream, (double*)pv, M, ctx->d_scal);
+    if (hipMemcpyAsync(out, ctx->d_scal, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) r = -2;
+  } while (0);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (pout) gpx_dev_release(ctx, pout, bytes_out);
+  if (pkd) gpx_dev_release(ctx, pkd, bytes_out);
+  if (ppart) gpx_dev_release(ctx, ppart, bytes_part);
+  if (pv) gpx_dev_release(ctx, pv, M * 8);
+  if (r == -2) gpx_set_error("ivar_update: HIP copy failed");
+  return r;
+}
+
 // GP fit + IVAR in one call; optionally with the evaluation STREAMED underneath the factorisation (the single-GPU form of
 // the multi-GPU streamed evaluation, gpexp_amd/dist.py).  K holds the assembled covariance and is factored in place, exactly as
 // gpx_potrf does; *out = (1/M) sum_j var_j exactly as gpx_ivar computes it on the finished factor.  What changes is WHEN the

@@ -373,6 +373,14 @@ def ivar(ctx, spec, L, X, Z, keep=False):
     return v.value, (DeviceMatrix(ctx, h) if h.value else None)
 
 
+def ivar_update(ctx, spec, L, X, Z, W, keep):
+    """The cost after a refit that kept the leading `keep` rows of the factor: W (kept for the previous design) is updated in
+    place from row `keep` on (gpx_ivar_update)."""
+    v = C.c_double()
+    check(ctx.lib.gpx_ivar_update(ctx.h, *spec.args(), L.h, X.h, Z.h, W.h, int(keep), C.byref(v)))
+    return v.value
+
+
 def fit_ivar(ctx, spec, K, X, Z):
     """Factor the assembled covariance K in place and return the (signed) IVAR over Z, the evaluation solve streamed
     underneath the factorisation (gpx_fit_ivar).  Raises NotPositiveDefinite like potrf."""

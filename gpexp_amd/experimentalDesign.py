@@ -85,12 +85,24 @@ class costFunctionGP_IVAR(costFunctionBase):
         # An optimiser asks for the cost and then for its gradient at the same design (SLSQP: experimentalDesign.py:471-489):
         # from 1024 design points on the forward solve W = L^-1 K(X, Z) stays on the device for that gradient -- a third of
         # its work (design state across optimiser iterations).  Keyed on the factor OBJECT: the same design
-        # gets the kept factor back from GP._cached_factor; one W at a time.
-        self._w_kept = None
+        # gets the kept factor back from GP._cached_factor; one W at a time, (factor, W, signed cost).
+        # ... and a batch loop moves the last points only (experimentalDesign.py:694-751): when the refit kept the leading rows of
+        # the factor W belongs to, W keeps them too and only its trailing rows are solved again (gpx_ivar_update).
+        prev, self._w_kept = getattr(self, "_w_kept", None), None
         if inputPoints.shape[0] >= 1024 and gp.reuseFactor and self.space.noiseFunc is None:
-            cost, W = _dev.ivar(_dev.context(), gp.kernel._spec(), gp._L, gp._X, self._mc(), keep=True)
+            ctx, spec = _dev.context(), gp.kernel._spec()
+            lr = getattr(gp, "_last_refit", None)
+            if prev is not None and prev[0] is gp._L:                  # the very fit W and the cost belong to
+                self._w_kept = prev
+                return np.abs(prev[2])
+            if prev is not None and lr is not None and lr[0] is prev[0] and prev[1].shape[0] == inputPoints.shape[0]:
+                cost = _dev.ivar_update(ctx, spec, gp._L, gp._X, self._mc(), prev[1], lr[1])
+                self._w_kept = (gp._L, prev[1], cost)
+                return np.abs(cost)
+            del prev                                                   # (its W goes back to the pool before the next one is made)
+            cost, W = _dev.ivar(ctx, spec, gp._L, gp._X, self._mc(), keep=True)
             if W is not None:
-                self._w_kept = (gp._L, W)
+                self._w_kept = (gp._L, W, cost)
         else:
             cost = _dev.ivar(_dev.context(), gp.kernel._spec(), gp._L, gp._X, self._mc())
         return np.abs(cost)
@@ -109,8 +121,7 @@ class costFunctionGP_IVAR(costFunctionBase):
             nd = np.asarray(self.space.noiseFunc.deriv(inputPoints), dtype=float).reshape(inputPoints.shape)
         gp._point_derivative_ready(self.mcPoints)
         kept = getattr(self, "_w_kept", None)
-        W = kept[1] if (kept is not None and nd is None and kept[0] is gp._L) else None
-        self._w_kept = None                                   # (one use: the next cost evaluation brings its own)
+        W = kept[1] if (kept is not None and nd is None and kept[0] is gp._L) else None    # (read only: it stays for the next cost)
         return _dev.ivar_grad(_dev.context(), gp.kernel._spec(), gp._L, gp._X, self._mc(), nd, W=W)
 
 

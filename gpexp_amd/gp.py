@@ -147,14 +147,17 @@ class GP:
         prev_policy = getattr(ctx, "_potrf_policy", (0.0, False))   # a policy the user set on the shared context survives
         try:
             _dev.potrf_policy(ctx, tau, False)
+            self._last_refit = None    # (factor the last fit started from, rows it kept): costFunctionGP_IVAR updates its kept solve
             hit = self._cached_factor(nodes, nugget, spec)
             if hit is not None:
                 return X, hit, 0.0
             keep = self._reusable_rows(nodes, nugget, spec) if remember else 0
             if keep > 0:
                 try:
-                    L = _dev.refit_rows(ctx, spec, X, nugget, self._fcache[3], keep)
+                    old = self._fcache[3]
+                    L = _dev.refit_rows(ctx, spec, X, nugget, old, keep)
                     self._remember(nodes, nugget, spec, L)
+                    self._last_refit = (old, keep)
                     return X, L, 0.0
                 except NotPositiveDefinite:
                     pass  # fall through to the full path and its rank-deficient policy

@@ -153,6 +153,11 @@ int gpx_ivar(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp,
  * solve is a third of the gradient's work.  *W = NULL when Z does not fit one evaluation chunk. */
 int gpx_ivar_keep(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp,
                   const gpx_mat* L, const gpx_mat* X, const gpx_mat* Z, double* out, gpx_mat** W);
+/* The cost once more after gpx_refit_rows kept the leading `keep` rows of the factor: W (from gpx_ivar_keep / an earlier update, for
+ * the design whose factor the refit started from) keeps its leading rows, the rows from `keep` on are re-assembled and re-solved in
+ * place -- 2 (N - keep) keep M flops instead of N^2 M (the batch loop of experimentalDesign.py:694-751 moves the last batch only). */
+int gpx_ivar_update(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
+                    const gpx_mat* Z, gpx_mat* W, int64_t keep, double* out);
 /* GP fit + IVAR in one call -- what costFunctionGP_IVAR.evaluate (experimentalDesign.py:104-117: refit, then
  * evaluateVariance over the MC points) amounts to per optimiser evaluation: K (assembled, gpx_kfill) is factored in place
  * as by gpx_potrf and *out receives what gpx_ivar would return on the finished factor.  With GPX_FIT_IVAR_STREAMED=1 the

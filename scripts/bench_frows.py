@@ -74,11 +74,27 @@ if want("f1"):
         g.reuseFactor = reuse
         cf = costFunctionGP_IVAR(g, N, space, mcPoints=Zh)
         cf.evaluate(Xh); cf.derivative(Xh)                      # warm: pools, block inverses
-        Xq = Xh.copy(); Xq[-1] += 1e-3                          # a new design: both calls do their full work once
+        Xq = Xh * 0.999                                         # a new design in EVERY point: one full fit, one full forward solve
         def both():
             cf.evaluate(Xq)
             return cf.derivative(Xq)
         return best(both, reps=1)[1]
+    def batch_move(reuse, nb_=512):
+        g = GP(KernelSquaredExponential(list(0.4 + 0.05 * np.arange(d)), 1.0, d), 0.1)
+        g.reuseFactor = reuse
+        cf = costFunctionGP_IVAR(g, N, space, mcPoints=Zh)
+        cf.evaluate(Xh)
+        ts = []
+        for rep in range(3):
+            Xq = Xh.copy(); Xq[-nb_:] = np.random.default_rng(rep).uniform(-1, 1, (nb_, d))
+            ts.append(best(lambda: cf.evaluate(Xq), reps=1)[1])
+        return min(ts)
+    t_full, t_inc = batch_move(False), batch_move(True)
+    report("design cost after moving the last 512 points", "costFunctionGP_IVAR.evaluate inside the batch loop "
+           "(experimentalDesign.py:694-751: earlier batches pinned)", dict(N=N, M=M, moved=512, d=d), t_inc,
+           flops=2.0 * 512 * (N - 512) * M + 512.0 * 512 * M + 512.0 * N * N,
+           note="refit of the moved rows (rows N^2) + W2 = L22^-1 (K(X2, Z) - L21 W1) on the kept solve; %.1f ms when every evaluation "
+                "refits and solves from scratch (reuseFactor = False), %.1f ms incrementally" % (1e3 * t_full, 1e3 * t_inc))
     t_sep, t_shared = iteration(False), iteration(True)
     report("design iteration: cost + gradient", "costFunctionGP_IVAR.evaluate + .derivative at one design (experimentalDesign.py:100-117, "
            "168-179, 471-489)", dict(N=N, M=M, d=d), t_shared, flops=3.0 * N * N * M + N ** 3 / 3.0,

@@ -210,14 +210,29 @@ def test_cost_then_gradient_at_the_same_design_share_the_forward_solve(n, m):
     assert cf._w_kept is not None and c1 == pytest.approx(abs(cost), rel=1e-13)
     kept_factor = cf.gaussianProcess._L
     g1 = cf.derivative(X)
-    assert cf.gaussianProcess._L is kept_factor and cf._w_kept is None      # no refit; the kept solve is used once
+    assert cf.gaussianProcess._L is kept_factor and cf._w_kept[0] is kept_factor    # no refit; the kept solve stays (read only)
     assert rel(g1, g0) <= 1e-12
+    assert cf.evaluate(X) == c1                                                # the very same fit again: the kept cost
+    cf._w_kept = None
     assert rel(cf.derivative(X), g0) <= 1e-12                                  # without a kept solve: the stand-alone path
     X2 = X.copy(); X2[-1] += 0.01
     cf.evaluate(X)
     g2 = cf.derivative(X2)                                                     # another design: the kept solve must not be used
     fresh = costFunctionGP_IVAR(GP(kernel_of(s), 0.05), n, space_of(d, None), mcPoints=Z)
     assert rel(g2, fresh.derivative(X2)) <= 1e-12
+    # a batch loop moves the LAST points only (experimentalDesign.py:694-751): the refit keeps the leading rows of the factor and
+    # the kept solve keeps its leading rows -- only the trailing rows are solved again (gpx_ivar_update); twice in a row, then the
+    # gradient from the updated solve
+    cf.evaluate(X)
+    for step in range(2):
+        X3 = X.copy(); X3[-150:] = rng.uniform(-1, 1, (150, d))
+        W_before = cf._w_kept[1]
+        c3 = cf.evaluate(X3)
+        assert cf.gaussianProcess._last_refit is not None and cf._w_kept[1] is W_before     # refit of the rows + update in place
+        f3 = costFunctionGP_IVAR(GP(kernel_of(s), 0.05), n, space_of(d, None), mcPoints=Z)
+        f3.gaussianProcess.reuseFactor = False
+        assert c3 == pytest.approx(f3.evaluate(X3), rel=1e-12)
+        assert rel(cf.derivative(X3), f3.derivative(X3)) <= 1e-11
 
 
 def test_unsupported_kernels_raise():
