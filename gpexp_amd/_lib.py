@@ -147,6 +147,7 @@ _SIGS = {
     "gpx_dist_finish": (C.c_int, [c_vp, c_vp]),
     "gpx_ivar_grad": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_dp, c_dp]),
     "gpx_ivar_grad_w": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_dp, c_vp, c_dp]),
+    "gpx_ivar_grad_rows": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_dp]),
     "gpx_var_grad": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_dp, c_dp, c_dp, c_dp]),
     "gpx_var_grad_newpt": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_dp]),
     "gpx_profile_enable": (C.c_int, [c_vp, C.c_int]),

@@ -179,9 +179,13 @@ __global__ __launch_bounds__(256) void ivar_grad_row_se_kernel(KParams kp, const
                                                                const double* __restrict__ Bm, int64_t ldb,
                                                                const double* __restrict__ S, int64_t lds_,
                                                                const double* __restrict__ nd, double inv_m,
-                                                               double* __restrict__ grad) {
+                                                               double* __restrict__ grad, int64_t a0) {
+  // a0: design point of workgroup 0 -- Bm, S, nd and grad hold the rows a0 .. only (gpx_ivar_grad_rows; 0 = all points)
   __shared__ double red[256];
-  const int64_t a = blockIdx.x;
+  const int64_t a = a0 + blockIdx.x;
+  Bm -= a0 * ldb;
+  S -= a0 * lds_;
+  grad -= a0 * kp.d;
   const int d = kp.d, t = threadIdx.x;
   double xa[DMAX], s1[DMAX], diff[DMAX];
 #pragma unroll
@@ -500,7 +504,7 @@ int gpx_ivar_grad_w(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, 
     if (kind == GPX_K_SE) {
 #define GPX_CALL(DM_)                                                                                                        \
   hipLaunchKernelGGL((ivar_grad_row_se_kernel<DM_>), dim3((unsigned)n), dim3(256), 0, ctx->stream, kp, X->p, n, Z->p, m,     \
-                     (const double*)W, mp, (const double*)pS, np, (const double*)d_nd, 1.0 / (double)m, (double*)pg)
+                     (const double*)W, mp, (const double*)pS, np, (const double*)d_nd, 1.0 / (double)m, (double*)pg, (int64_t)0)
       GPX_SE_DISPATCH(d, GPX_CALL);
 #undef GPX_CALL
     } else {
@@ -510,6 +514,68 @@ int gpx_ivar_grad_w(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, 
   }
   GPX_HIP(hipGetLastError());
   GPX_HIP(hipMemcpyAsync(grad, pg, (size_t)(n * d * 8), hipMemcpyDeviceToHost, ctx->stream));
+  GPX_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// The gradient for the design points from r0 on ONLY -- the batch loop pins the earlier ones by equal bounds
+// (experimentalDesign.py:719-724), their entries are never used -- from the kept forward solve W = L^-1 K(X, Z), squared
+// exponential, homoscedastic.  With T the rows from r0 on:
+//     beta_T = L_TT^-T W_T                 (back substitution touches nothing above T:   (n - r0)^2 M flops)
+//     S_T    = beta_T beta^T = (beta_T W^T) L^-1          (one (n - r0) x N x M product + a few-row right solve)
+// and the row kernel for those rows: 2 (n - r0) N M flops where the full gradient needs the whole backward solve and the whole
+// S = beta beta^T (2 N^2 M).  grad: (n - r0) x d on the host, point-major.
+int gpx_ivar_grad_rows(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
+                       const gpx_mat* Z, const gpx_mat* W, int64_t r0, double* grad) {
+  GPX_ARG(ctx && grad && W, "NULL argument");
+  GPX_TRY(check_args(kind, d, L, X, Z));
+  GPX_ARG(kind == GPX_K_SE, "ivar_grad_rows: squared-exponential kernel only");
+  GPX_ARG(ctx->live_mats.count(W), "ivar_grad_rows: W is not a live matrix of this context");
+  KParams kp;
+  GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
+  GPX_TRY(gpx_kparams_sets(ctx, &kp, X, Z));
+  const int64_t n = L->rows, np = L->prows, m = Z->rows, mp = gpx_round_up(m, GPX_TILE);
+  GPX_ARG(W->rows == n && W->cols == m && W->prows == np && W->pcols == mp, "ivar_grad_rows: the kept solve has another shape");
+  GPX_ARG(r0 > 0 && r0 < n && r0 % GPX_TILE == 0, "ivar_grad_rows: r0 must be a positive multiple of 128 below the number of points");
+  const int64_t bp = np - r0, b = n - r0, ldw = W->ld;
+  Scratch sc(ctx);
+  void *pA, *pB, *pG, *pP = nullptr, *pT = nullptr, *pg;
+  GPX_TRY(sc.get(mp * bp * 8, &pA));
+  GPX_TRY(sc.get(bp * mp * 8, &pB));
+  GPX_TRY(sc.get(bp * np * 8, &pG));
+  GPX_TRY(sc.get(b * d * 8, &pg));
+  double *A = (double*)pA, *B = (double*)pB, *G = (double*)pG;
+  // beta_T^T = W_T^T L_TT^-1, then back to rows
+  GPX_TRY(launch_transpose(ctx, W->p + r0 * ldw, bp, mp, ldw, A, bp));
+  GPX_TRY(chol_trsm_right_n(ctx, L->p + r0 * (L->ld + 1), L->ld, L->aux + (r0 / GPX_TILE) * GPX_TILE * GPX_TILE, A, bp, mp, bp));
+  GPX_TRY(launch_transpose(ctx, A, mp, bp, bp, B, mp));
+  // G = beta_T W^T: few rows under the long k range M -- in slices of it when 128-tiles alone cannot fill the chip
+  {
+    int64_t parts = 1;
+    while (parts < 8 && (bp / 128) * (np / 128) * parts < 1024 && mp % (2 * parts * 16) == 0 && mp / (2 * parts) >= 4096) parts *= 2;
+    if (parts > 1 && sc.get(parts * bp * np * 8, &pP) != 0) parts = 1;
+    if (parts > 1)
+      GPX_TRY(launch_gemm_ksplit(ctx, B, mp, W->p, ldw, G, np, bp, np, mp, false, parts, (double*)pP, true));
+    else
+      GPX_TRY(launch_gemm(ctx, B, mp, W->p, ldw, G, np, bp, np, mp, true, false, false));
+  }
+  // S_T = G L^-1
+  if (np >= 4096) {
+    GPX_TRY(sc.get(bp * chol_binv_order(np) * 8, &pT));
+    GPX_TRY(chol_trsm_right_n_leading(ctx, const_cast<gpx_mat*>(L), np, G, np, bp, (double*)pT));
+  } else {
+    GPX_TRY(chol_trsm_right_n(ctx, L->p, L->ld, L->aux, G, np, bp, np));
+  }
+  {
+    ProfScope ps(ctx, GPX_PROF_REDUCE, 0.0, 8.0 * ((double)b * m + (double)b * n));
+#define GPX_CALL(DM_)                                                                                                        \
+  hipLaunchKernelGGL((ivar_grad_row_se_kernel<DM_>), dim3((unsigned)b), dim3(256), 0, ctx->stream, kp, X->p, n, Z->p, m,     \
+                     (const double*)B, mp, (const double*)G, np, (const double*)nullptr, 1.0 / (double)m, (double*)pg, r0)
+    GPX_SE_DISPATCH(d, GPX_CALL);
+#undef GPX_CALL
+  }
+  GPX_HIP(hipGetLastError());
+  GPX_HIP(hipMemcpyAsync(grad, pg, (size_t)(b * d * 8), hipMemcpyDeviceToHost, ctx->stream));
   GPX_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
 }

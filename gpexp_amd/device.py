@@ -658,6 +658,14 @@ def ivar_grad(ctx, spec, L, X, Z, noise_deriv=None, W=None):
     return out
 
 
+def ivar_grad_rows(ctx, spec, L, X, Z, W, r0):
+    """d IVAR / d coordinates of the design points r0.. only (flattened, (N - r0)*d), from the kept forward solve W
+    (gpx_ivar_grad_rows: squared exponential, homoscedastic)."""
+    out = np.empty((X.shape[0] - int(r0)) * spec.d)
+    check(ctx.lib.gpx_ivar_grad_rows(ctx.h, *spec.args(), L.h, X.h, Z.h, W.h, int(r0), dptr(out)))
+    return out
+
+
 def var_grad(ctx, spec, L, X, Z, noise_deriv=None, eval_bias=None, dk_bias=None):
     """(N*d, M) matrix d var(z_m) / d X[j][l] (GP.evaluateVarianceDerivative, gp.py:282-341)."""
     out = np.empty((X.shape[0] * spec.d, Z.shape[0]))

@@ -122,6 +122,14 @@ class costFunctionGP_IVAR(costFunctionBase):
         gp._point_derivative_ready(self.mcPoints)
         kept = getattr(self, "_w_kept", None)
         W = kept[1] if (kept is not None and nd is None and kept[0] is gp._L) else None    # (read only: it stays for the next cost)
+        # `pinnedPoints` (set by the batch driver, experimentalDesign.py:719-724: the leading points are fixed by equal bounds, so
+        # the optimiser never uses their entries): the gradient of the free points alone from the kept solve -- gpx_ivar_grad_rows,
+        # 2 (N - r0) N M flops instead of 2 N^2 M; the pinned entries are returned as zeros
+        r0 = (int(getattr(self, "pinnedPoints", 0)) // 128) * 128
+        if W is not None and r0 > 0 and gp.kernel._spec().kind == _dev.K_SE:
+            g = np.zeros(inputPoints.shape[0] * self.space.dimension)
+            g[r0 * self.space.dimension:] = _dev.ivar_grad_rows(_dev.context(), gp.kernel._spec(), gp._L, gp._X, self._mc(), W, r0)
+            return g
         return _dev.ivar_grad(_dev.context(), gp.kernel._spec(), gp._L, gp._X, self._mc(), nd, W=W)
 
 
@@ -294,6 +302,7 @@ class ExperimentalDesignGreedyWithDerivatives(ExperimentalDesignDerivative):
             lbounds[0:nPointsPrev * self.nDims] = points.reshape((nPointsPrev * self.nDims))
             rbounds[0:nPointsPrev * self.nDims] = points.reshape((nPointsPrev * self.nDims))
             currCost = costFunctionGP_IVAR(cf.gaussianProcess, nPointsAdded, cf.space, cf.version, mcPoints=cf.mcPoints)
+            currCost.pinnedPoints = nPointsPrev          # (large designs: cost and gradient touch the new batch's rows only)
             expCurr = ExperimentalDesignDerivative(currCost, nPointsAdded, self.nDims)
             points = expCurr.beginWithVarGreedy(nodesKeep=points, lbounds=lbounds, rbounds=rbounds)
             err = currCost.evaluate(points)

@@ -218,6 +218,10 @@ int gpx_ivar_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, co
 /* ... with the forward solve kept by gpx_ivar_keep for the same L, X, Z (W == NULL: exactly gpx_ivar_grad) */
 int gpx_ivar_grad_w(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
                     const gpx_mat* Z, const double* noise_deriv, const gpx_mat* W, double* grad);
+/* ... for the design points from r0 (a multiple of 128) on only: the batch loop pins the earlier ones by equal bounds
+ * (experimentalDesign.py:719-724).  Squared exponential, homoscedastic; grad: (N - r0) x d.  2 (N - r0) N M flops instead of 2 N^2 M. */
+int gpx_ivar_grad_rows(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
+                       const gpx_mat* Z, const gpx_mat* W, int64_t r0, double* grad);
 /* out[(j*d + l) * M + m] = d var(z_m) / d X[j][l]  (GP.evaluateVarianceDerivative, gp.py:282-341; host, (N*d) x M).
  * eval_bias (host N, nullable) / dk_bias (host N x d, nullable): the terms of gp.py:318-320 -- noise(x_j) added to
  * k(x_j, z_m) and noise'(x_j) subtracted from -dk(z_m, x_j)/dz for every m -- which the reference applies when the WHOLE

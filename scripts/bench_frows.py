@@ -89,6 +89,20 @@ if want("f1"):
             Xq = Xh.copy(); Xq[-nb_:] = np.random.default_rng(rep).uniform(-1, 1, (nb_, d))
             ts.append(best(lambda: cf.evaluate(Xq), reps=1)[1])
         return min(ts)
+    def batch_gradient(pinned, nb_=512):
+        g = GP(KernelSquaredExponential(list(0.4 + 0.05 * np.arange(d)), 1.0, d), 0.1)
+        cf = costFunctionGP_IVAR(g, N, space, mcPoints=Zh)
+        cf.pinnedPoints = pinned
+        cf.evaluate(Xh); cf.derivative(Xh)
+        Xq = Xh.copy(); Xq[-nb_:] = np.random.default_rng(7).uniform(-1, 1, (nb_, d))
+        cf.evaluate(Xq)
+        return best(lambda: cf.derivative(Xq), reps=2)[1]
+    t_gall, t_gfree = batch_gradient(0), batch_gradient(N - 512)
+    report("design gradient of the last 512 points", "costFunctionGP_IVAR.derivative inside the batch loop (experimentalDesign.py:"
+           "694-751: earlier batches pinned by equal bounds, :719-724)", dict(N=N, M=M, free=512, d=d), t_gfree,
+           flops=2.0 * 512 * N * M + 512.0 * 512 * M + 512.0 * N * N,
+           note="beta_T = L_TT^-T W_T, S_T = (beta_T W^T) L^-1 from the kept solve, row kernel for the free points: %.1f ms for "
+                "all points (kept forward solve), %.1f ms for the free ones" % (1e3 * t_gall, 1e3 * t_gfree))
     t_full, t_inc = batch_move(False), batch_move(True)
     report("design cost after moving the last 512 points", "costFunctionGP_IVAR.evaluate inside the batch loop "
            "(experimentalDesign.py:694-751: earlier batches pinned)", dict(N=N, M=M, moved=512, d=d), t_inc,
