@@ -261,10 +261,26 @@ class ExperimentalDesignDerivative(ExperimentalDesign):
             bounds = list(zip(-100.0 * np.ones(nvar), 100.0 * np.ones(nvar)))
         else:
             bounds = list(zip(lbounds, rbounds))
+        # `freeVariablesOnly` (opt-in; the reference hands SLSQP every coordinate, the pinned ones with equal bounds,
+        # experimentalDesign.py:719-724): the leading points whose bounds coincide are taken out of the optimiser's variable
+        # vector -- the same problem, but SLSQP's dense algebra is O(variables^3) per iteration and a batch of 64 new points on
+        # top of 4000 pinned ones is 64 d variables, not 4064 d.  Cost and gradient still see the whole design.
+        free0 = 0
+        if getattr(self, "freeVariablesOnly", False) and len(lbounds) > 0:
+            fixed = np.asarray(lbounds, dtype=float) == np.asarray(rbounds, dtype=float)
+            k = int(np.argmin(fixed)) if not fixed.all() else nvar
+            free0 = (k // self.nDims) * self.nDims
         sol = []
         obj = np.zeros((len(startValues)))
         for ii in range(len(startValues)):
-            pts = slsqp(func, startValues[ii].reshape((nvar)), fprime=grad, bounds=bounds, acc=1e-6)
+            x0 = startValues[ii].reshape((nvar))
+            if free0 > 0:
+                head = np.asarray(lbounds, dtype=float)[:free0]
+                tail = slsqp(lambda xf, *a: func(np.concatenate((head, xf))), x0[free0:],
+                             fprime=lambda xf, *a: grad(np.concatenate((head, xf)))[free0:], bounds=bounds[free0:], acc=1e-6)
+                pts = np.concatenate((head, np.atleast_1d(tail)))
+            else:
+                pts = slsqp(func, x0, fprime=grad, bounds=bounds, acc=1e-6)
             sol.append(pts)
             obj[ii] = func(pts)
         best = sol[int(np.argmin(obj))]
@@ -304,6 +320,7 @@ class ExperimentalDesignGreedyWithDerivatives(ExperimentalDesignDerivative):
             currCost = costFunctionGP_IVAR(cf.gaussianProcess, nPointsAdded, cf.space, cf.version, mcPoints=cf.mcPoints)
             currCost.pinnedPoints = nPointsPrev          # (large designs: cost and gradient touch the new batch's rows only)
             expCurr = ExperimentalDesignDerivative(currCost, nPointsAdded, self.nDims)
+            expCurr.freeVariablesOnly = getattr(self, "freeVariablesOnly", False)
             points = expCurr.beginWithVarGreedy(nodesKeep=points, lbounds=lbounds, rbounds=rbounds)
             err = currCost.evaluate(points)
             print("Current Error ", err)

@@ -170,6 +170,70 @@ def test_greedy_with_derivatives_driver_pins_earlier_batches(dev, ctx, capsys):
     assert c6 < c3
 
 
+def cf_last_cost(des, pts, mc, space, kern):
+    """The cost of a design through a cost object that DOES reuse (kept factor / kept solve): what the driver's optimiser saw."""
+    from gpExp.gp import GP
+    from gpExp.experimentalDesign import costFunctionGP_IVAR
+    c = costFunctionGP_IVAR(GP(kern(), 1e-2), len(pts), space, mcPoints=mc)
+    c.evaluate(pts)                                     # full solve
+    moved = pts.copy(); moved[-3:] *= 0.99
+    c.evaluate(moved)                                   # incremental
+    return c.evaluate(pts)                              # incremental back to the design
+
+
+def test_batch_driver_over_the_free_points_only(dev, ctx, capsys):
+    """`freeVariablesOnly` (opt-in): the pinned points leave SLSQP's variable vector; cost and gradient still see the whole design.
+    Small: the same design as the reference's all-variables run.  Large (1152 pinned + 128 new points): every cost evaluation of
+    the batch re-solves the moved rows of the kept forward solve only (gpx_ivar_update), every gradient is the free points' alone
+    (gpx_ivar_grad_rows); the pinned points stay, the cost goes down from the greedy start."""
+    from gpExp.kernels import KernelSquaredExponential
+    from gpExp.gp import GP
+    from gpExp.approximation import Space
+    from gpExp.experimentalDesign import costFunctionGP_IVAR, ExperimentalDesignGreedyWithDerivatives
+    rng = np.random.default_rng(5)
+    d = 2
+    mc = rng.uniform(-1, 1, (400, d))
+    space = Space(d, lambda size: rng.uniform(-1, 1, size), lambda p: np.all(np.abs(p) < 1.0, axis=1) * 0.25)
+    gp = GP(KernelSquaredExponential([0.5, 0.5], 1.0, d), 1e-4)
+    start = ExperimentalDesignGreedyWithDerivatives(costFunctionGP_IVAR(gp, 3, space, mcPoints=mc), 3, 3, d).begin()
+    runs = []
+    for free_only in (False, True):
+        des = ExperimentalDesignGreedyWithDerivatives(costFunctionGP_IVAR(gp, 6, space, mcPoints=mc), 6, 3, d)
+        des.freeVariablesOnly = free_only
+        runs.append(des.begin(startValues=start))
+    capsys.readouterr()
+    assert np.array_equal(runs[1][:3], start) and rel(runs[0][:3], start) <= 1e-12
+    c = [costFunctionGP_IVAR(gp, 6, space, mcPoints=mc).evaluate(r) for r in runs]
+    assert c[1] == pytest.approx(c[0], rel=1e-4)                                    # SLSQP stops at acc = 1e-6 either way
+    # large (d = 5: in two dimensions 1152 points leave SLSQP nothing to do)
+    n0, nb, d = 1152, 128, 5
+    space = Space(d, lambda size: rng.uniform(-1, 1, size), lambda p: np.all(np.abs(p) < 1.0, axis=1) * 0.25)
+    mc = rng.uniform(-1, 1, (4096, d))
+    pinned = rng.uniform(-1, 1, (n0, d))
+    kern = lambda: KernelSquaredExponential([0.5] * d, 1.0, d)
+    gp = GP(kern(), 1e-2)
+    cf = costFunctionGP_IVAR(gp, n0 + nb, space, mcPoints=mc)
+    des = ExperimentalDesignGreedyWithDerivatives(cf, n0 + nb, nb, d)
+    des.freeVariablesOnly = True
+    calls = {"update": 0, "rows": 0}
+    upd, rows = dev.ivar_update, dev.ivar_grad_rows
+    dev.ivar_update = lambda *a, **k: (calls.__setitem__("update", calls["update"] + 1), upd(*a, **k))[1]
+    dev.ivar_grad_rows = lambda *a, **k: (calls.__setitem__("rows", calls["rows"] + 1), rows(*a, **k))[1]
+    try:
+        pts = des.begin(startValues=pinned)
+    finally:
+        dev.ivar_update, dev.ivar_grad_rows = upd, rows
+    capsys.readouterr()
+    assert pts.shape == (n0 + nb, d) and np.array_equal(pts[:n0], pinned)
+    assert calls["update"] >= 5 and calls["rows"] >= 2                         # SLSQP iterates here: line searches + gradients
+    fresh = costFunctionGP_IVAR(GP(kern(), 1e-2), n0 + nb, space, mcPoints=mc)
+    fresh.gaussianProcess.reuseFactor = False
+    c_end = fresh.evaluate(pts)
+    assert c_end == pytest.approx(cf_last_cost(des, pts, mc, space, kern), rel=1e-10)
+    c_pinned_only = costFunctionGP_IVAR(GP(kern(), 1e-2), n0, space, mcPoints=mc).evaluate(pinned)
+    assert c_end < c_pinned_only
+
+
 def test_refit_factor_with_nan_poisoned_upper_part_feeds_every_consumer(dev):
     """gpx_refit_rows copies the old factor's LOWER triangle only, so the new factor's strict upper part is whatever the
     pool handed out.  Under GPX_ALLOC_GUARD=2 every pooled block starts NaN-filled: the refit factor's upper part IS NaN here,
