@@ -604,28 +604,58 @@ int gpx_var_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, con
   GPX_TRY(upload(ctx, sc, dk_bias, n * d, &d_db));
   double* T;
   GPX_TRY(solve_scratch(ctx, sc, np, mc_alloc, &T));
+  // The (N d) x M result goes to PAGEABLE host memory by contract: every strided copy blocks the calling thread.  So the
+  // coordinates are pipelined -- coordinate l+1's kernels are queued BEFORE the copy of coordinate l is issued (two output
+  // buffers, the copy on the low-priority stream behind an event), and the GPU computes while the host sits in the copy.
+  void* pO_b;
+  GPX_TRY(sc.get(n * mc_alloc * 8, &pO_b));
+  double* const obuf[2] = {(double*)pO, (double*)pO_b};
+  hipStream_t Ms = ctx->stream, Cs = ctx->streams[4];
+  hipEvent_t evd[2] = {nullptr, nullptr};
+  const bool piped = Cs != Ms && hipEventCreateWithFlags(&evd[0], hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&evd[1], hipEventDisableTiming) == hipSuccess;
+  struct Item { int64_t j0, mc, mcp; int l; };
+  std::vector<Item> items;
   for (int64_t j0 = 0; j0 < M; j0 += mcmax) {
     const int64_t mc = (M - j0) < mcmax ? (M - j0) : mcmax;
-    const int64_t mcp = gpx_round_up(mc, GPX_TILE);
-    const double* Zc = Z->p + j0 * d;
-    double* W;
-    GPX_TRY(solve_beta(ctx, kp, L, X, Zc, mc, mcp, d_eb, (double*)pW, (double*)pWt, T, 0, &W));
-    double* Cl = W == (double*)pW ? (double*)pWt : (double*)pW;   // the buffer the solve no longer needs
-    for (int l = 0; l < d; ++l) {
-      dim3 ga((unsigned)((np + 255) / 256), (unsigned)np);
-      hipLaunchKernelGGL(dcov_kernel, ga, dim3(256), 0, ctx->stream, kp, X->p, n, l, (const double*)d_nd, (double*)pA, np, np);
-      GPX_TRY(launch_gemm(ctx, (double*)pA, np, W, mcp, Cl, mcp, np, mcp, np, false, false, false));  // C_l = A_l beta
-      dim3 gf((unsigned)((mc + 255) / 256), (unsigned)n);
-      hipLaunchKernelGGL(var_grad_finish_kernel, gf, dim3(256), 0, ctx->stream, kp, X->p, n, Zc, mc, l, (const double*)W,
-                         mcp, (const double*)Cl, (const double*)pA, np, (const double*)d_db, (double*)pO, mc);
-      GPX_HIP(hipGetLastError());
-      // rows j*d + l of the (N*d x M) result, columns [j0, j0+mc)
-      GPX_HIP(hipMemcpy2DAsync(out + (int64_t)l * M + j0, (size_t)d * M * 8, pO, (size_t)mc * 8, (size_t)mc * 8, (size_t)n,
-                               hipMemcpyDeviceToHost, ctx->stream));
-      GPX_HIP(hipStreamSynchronize(ctx->stream));  // pO is rewritten by the next coordinate
-    }
+    for (int l = 0; l < d; ++l) items.push_back({j0, mc, gpx_round_up(mc, GPX_TILE), l});
   }
-  return 0;
+  double *W = nullptr, *Cl = nullptr;
+  auto compute = [&](const Item& it, int b) -> int {
+    const double* Zc = Z->p + it.j0 * d;
+    if (it.l == 0) {
+      GPX_TRY(solve_beta(ctx, kp, L, X, Zc, it.mc, it.mcp, d_eb, (double*)pW, (double*)pWt, T, 0, &W));
+      Cl = W == (double*)pW ? (double*)pWt : (double*)pW;   // the buffer the solve no longer needs
+    }
+    dim3 ga((unsigned)((np + 255) / 256), (unsigned)np);
+    hipLaunchKernelGGL(dcov_kernel, ga, dim3(256), 0, ctx->stream, kp, X->p, n, it.l, (const double*)d_nd, (double*)pA, np, np);
+    GPX_TRY(launch_gemm(ctx, (double*)pA, np, W, it.mcp, Cl, it.mcp, np, it.mcp, np, false, false, false));  // C_l = A_l beta
+    dim3 gf((unsigned)((it.mc + 255) / 256), (unsigned)n);
+    hipLaunchKernelGGL(var_grad_finish_kernel, gf, dim3(256), 0, ctx->stream, kp, X->p, n, Zc, it.mc, it.l, (const double*)W,
+                       it.mcp, (const double*)Cl, (const double*)pA, np, (const double*)d_db, obuf[b], it.mc);
+    GPX_HIP(hipGetLastError());
+    if (piped) GPX_HIP(hipEventRecord(evd[b], Ms));
+    return 0;
+  };
+  auto copy_out = [&](const Item& it, int b) -> int {
+    hipStream_t st = piped ? Cs : Ms;
+    if (piped) GPX_HIP(hipStreamWaitEvent(Cs, evd[b], 0));
+    // rows j*d + l of the (N*d x M) result, columns [j0, j0+mc)
+    GPX_HIP(hipMemcpy2DAsync(out + (int64_t)it.l * M + it.j0, (size_t)d * M * 8, obuf[b], (size_t)it.mc * 8, (size_t)it.mc * 8,
+                             (size_t)n, hipMemcpyDeviceToHost, st));
+    GPX_HIP(hipStreamSynchronize(st));   // the buffer is rewritten two coordinates on
+    return 0;
+  };
+  int r = items.empty() ? 0 : compute(items[0], 0);
+  for (size_t i = 0; i < items.size() && r == 0; ++i) {
+    if (piped && i + 1 < items.size()) r = compute(items[i + 1], (int)((i + 1) & 1));
+    if (r == 0) r = copy_out(items[i], (int)(i & 1));
+    if (r == 0 && !piped && i + 1 < items.size()) r = compute(items[i + 1], (int)((i + 1) & 1));
+  }
+  (void)hipDeviceSynchronize();
+  for (int b = 0; b < 2; ++b)
+    if (evd[b]) (void)hipEventDestroy(evd[b]);
+  return r;
 }
 
 int gpx_var_grad_newpt(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
