@@ -15,7 +15,9 @@ for N in [int(a) for a in sys.argv[1:]] or [32768]:
         dev.kfill_into(ctx, sp, X, K, nugget=0.1); ctx.sync()
         t0 = time.perf_counter(); dev.potrf(ctx, K); ctx.sync(); ts.append(time.perf_counter() - t0)
     best = min(ts[1:])
-    print("potrf N=%d: %.1f ms  %.1f TF/s  logdet=%.15g  [%s]" % (N, 1e3 * best, N**3 / 3 / best / 1e12, dev.logdet(ctx, K),
+    yv = np.sin(np.arange(N) * 0.37)
+    print("potrf N=%d: %.1f ms  %.1f TF/s  logdet=%.15g  yTa=%.15g  [%s]" % (N, 1e3 * best, N**3 / 3 / best / 1e12, dev.logdet(ctx, K),
+          float(yv @ dev.potrs(ctx, K, yv)),
           " ".join("%s=%s" % (k, v) for k, v in sorted(os.environ.items()) if k.startswith("GPX_POTRF"))), flush=True)
     del K
     ctx.trim()

@@ -1,0 +1,117 @@
+"""Full-size configurations pinned BY VALUE: C4 (N = 32768, both Materns), C3 (N = 16384, 65536 candidates)
+and C5-lite (N = 16384, d = 10) against `tests/golden/gpexp_golden_r6.npz` -- LAPACK values, NOT the reference: the reference
+cannot run these sizes (pinv of a 32768-order matrix: hours), so `tests/golden/make_golden_r6.py` evaluates the same closed forms
+(gp.py:373-440, gp.py:213-259, experimentalDesign.py:104-117, gp.py:444-466) by an independent route in the build container
+(NumPy assembly from coordinate differences, dpotrf / dtrtrs / dpotri).  1e-10 relative, as for the reference fixtures.
+They supersede the property-only checks this file's predecessors made at the same sizes (residuals on a few rows, 0 < var < noise)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from gpexp_amd import device
+    return device
+
+
+@pytest.fixture(scope="module")
+def ctx(dev):
+    return dev.context()
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(HERE, "golden", "gpexp_golden_r6.npz"))
+
+
+def rel(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / np.max(np.abs(b)))
+
+
+@pytest.mark.parametrize("kind", ["matern52", "matern32"])
+def test_c4_full_size_values(dev, ctx, gold, kind):
+    """The bench workload (bench.py workload(): N = 32768, d = 8, rho = 0.5, noise = 0.1, seed 32768), nu = 5/2 (the headline
+    kernel; absent in the reference) and nu = 3/2 (kernels.py:85-89): log-marginal, log det, y^T alpha, the leading alpha entries,
+    IVAR over the first 4096 MC points, 256 posterior means and variances.  Bit-level repeatability of a second fit."""
+    N, d, noise = 32768, 8, 0.1
+    rng = np.random.default_rng(32768)
+    Xh = rng.uniform(-1, 1, (N, d))
+    y = np.sin(2 * np.pi * Xh.sum(1) / d) + np.sqrt(noise) * rng.standard_normal(N)
+    Zh = rng.uniform(-1, 1, (N, d))
+    sp = dev.KernelSpec(dev.K_MATERN52 if kind == "matern52" else dev.K_MATERN32, d, [0.5, 1.0])
+    g = lambda name: gold["c4_%s/%s" % (kind, name)]
+    X = dev.points(ctx, Xh)
+    K = dev.kfill(ctx, sp, X, nugget=noise)
+    dev.potrf(ctx, K)
+    alpha = dev.potrs(ctx, K, y)
+    ld = dev.logdet(ctx, K)
+    yta = float(y @ alpha)
+    ll = -0.5 * yta - 0.5 * ld - N / 2 * np.log(2 * np.pi)
+    assert ld == pytest.approx(float(g("logdet")), rel=1e-10)
+    assert yta == pytest.approx(float(g("yTalpha")), rel=1e-10)
+    assert ll == pytest.approx(float(g("loglike")), rel=1e-10)
+    assert rel(alpha[:256], g("alpha_head")) < 1e-10
+    iv = dev.ivar(ctx, sp, K, X, dev.points(ctx, Zh[:4096]))
+    assert abs(iv) == pytest.approx(float(g("ivar4096")), rel=1e-10)
+    mean, var = dev.posterior(ctx, sp, K, X, alpha, dev.points(ctx, Zh[:256]))
+    assert rel(var, g("var256")) < 1e-10 and rel(mean, g("mean256")) < 1e-10
+    assert np.max(np.abs(var - g("var256")) / np.abs(g("var256"))) < 1e-9
+    # a second assembly + factorisation: bit-identical (deterministic reductions)
+    dev.kfill_into(ctx, sp, X, K, nugget=noise)
+    dev.potrf(ctx, K)
+    assert dev.logdet(ctx, K) == ld and np.array_equal(dev.potrs(ctx, K, y), alpha)
+    del K
+    ctx.trim()
+
+
+def test_c3_full_size_values(dev, ctx, gold):
+    """BASELINE config 3 (N = 16384, d = 8 ARD-SE, 65536 candidates, nMC = 4096, seed 16384): the integrated variance of the
+    start design and the greedy-IVAR step's cost of 256 fixed candidates (IVAR after adding the candidate,
+    experimentalDesign.py:104-117 on the extended design), by value."""
+    N, d, M, nmc = 16384, 8, 65536, 4096
+    rng = np.random.default_rng(16384)
+    Xh = rng.uniform(-1, 1, (N, d))
+    Ch, Zh = rng.uniform(-1, 1, (M, d)), rng.uniform(-1, 1, (nmc, d))
+    sp = dev.KernelSpec(dev.K_SE, d, list(0.4 + 0.05 * np.arange(d)) + [1.0])
+    X, C, Z = dev.points(ctx, Xh), dev.points(ctx, Ch), dev.points(ctx, Zh)
+    K = dev.potrf(ctx, dev.kfill(ctx, sp, X, nugget=0.1))
+    assert abs(dev.ivar(ctx, sp, K, X, Z)) == pytest.approx(float(gold["c3/ivar0"]), rel=1e-10)
+    best, costs = dev.greedy_ivar_step(ctx, sp, K, X, C, Z, 0.1)
+    idx = gold["c3/cand_index"]
+    assert rel(costs[idx], gold["c3/cand_cost"]) < 1e-10
+    assert best == int(np.argmin(costs)) and costs[best] <= gold["c3/cand_cost"].min() * (1 + 1e-12)
+
+
+def test_c5_lite_loglike_and_gradient_values(dev, ctx, gold):
+    """C5's arithmetic at N = 16384 (d = 10 ARD-SE l_k = 0.5 + 0.03 k, noise = 0.1, seed 65536): log-marginal and its 12
+    derivatives against a dense dpotri inverse (gp.py:444-466 with kernels.py:125-144's dK/dl_k); every form of the gradient the
+    library has (explicit inverse, L^-1 once, rows of L^-1, row slabs) gives the same 12 numbers."""
+    N, d, noise = 16384, 10, 0.1
+    rng = np.random.default_rng(65536)
+    Xh = rng.uniform(-1, 1, (N, d))
+    y = np.sin(2 * np.pi * Xh.sum(1) / d) + np.sqrt(noise) * rng.standard_normal(N)
+    hyp = list(0.5 + 0.03 * np.arange(d)) + [1.0]
+    sp = dev.KernelSpec(dev.K_SE, d, hyp)
+    X = dev.points(ctx, Xh)
+    K = dev.potrf(ctx, dev.kfill(ctx, sp, X, nugget=noise))
+    alpha = dev.potrs(ctx, K, y)
+    ld = dev.logdet(ctx, K)
+    ll = -0.5 * float(y @ alpha) - 0.5 * ld - N / 2 * np.log(2 * np.pi)
+    assert ld == pytest.approx(float(gold["c5_lite/logdet"]), rel=1e-10)
+    assert ll == pytest.approx(float(gold["c5_lite/loglike"]), rel=1e-10)
+    gref = gold["c5_lite/grad"]
+    forms = {
+        "potri": dev.lml_grad_full(ctx, sp, K, X, alpha),
+        "linv": dev.lml_grad_from_sums(sp, dev.lml_grad_linv(ctx, sp, K, X, alpha)),
+        "rows": dev.lml_grad_from_sums(sp, dev.lml_grad_rows(ctx, sp, K, X, alpha, 0, N, 4)),
+    }
+    b = dev.lml_grad_slab_bounds(N, 4)
+    forms["slabs"] = dev.lml_grad_from_sums(sp, sum(dev.lml_grad_slab(ctx, sp, K, X, alpha, r0, r1) for r0, r1 in zip(b[:-1], b[1:])
+                                                    if r1 > r0))
+    for name, g in forms.items():
+        assert np.max(np.abs(g - gref) / np.abs(gref)) < 1e-9, (name, g, gref)
