@@ -150,6 +150,8 @@ _SIGS = {
     "gpx_ivar_grad_rows": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_dp]),
     "gpx_var_grad": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_dp, c_dp, c_dp, c_dp]),
     "gpx_var_grad_newpt": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_vp, c_dp]),
+    "gpx_fitc_var_grad": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_dp, c_dp, c_dp, c_dp]),
+    "gpx_fitc_var_grad_newpt": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp, c_dp]),
     "gpx_profile_enable": (C.c_int, [c_vp, C.c_int]),
     "gpx_profile_reset": (C.c_int, [c_vp]),
     "gpx_profile_get": (C.c_int, [c_vp, C.c_int, c_ip, c_dp, c_dp, c_dp]),
@@ -168,7 +170,6 @@ _SIGS = {
     "gpx_dbg_spin_until": (C.c_int, [c_vp, C.c_int, c_i64]),
     "gpx_dbg_event_elapsed": (C.c_int, [c_vp, C.c_int, C.c_int, c_dp]),
     "gpx_dbg_leaf_stamps": (C.c_int, [c_vp, c_vp, C.c_int, C.POINTER(c_i64)]),
-    "gpx_dbg_coop_stamps": (C.c_int, [c_vp, C.POINTER(c_i64)]),
 }
 
 _lib = None

@@ -378,8 +378,6 @@ int gpx_create(int device, gpx_ctx** out) {
   c->pw_binv = c->pw_tmp_build = c->pw_tmp_T = nullptr;
   c->pw_ib = 0;
   c->pw_done = 0;
-  c->panel_width = 0;
-  c->panel_count = 0;
   c->prof_on = 0;
   for (int i = 0; i < GPX_PROF_NCLASS; ++i) {
     c->prof_launches[i] = 0;
@@ -392,15 +390,8 @@ int gpx_create(int device, gpx_ctx** out) {
     // device has three levels.  It carries the updates that gate the next panel; beside a low-priority stream full of
     // bulk / evaluation GEMMs its workgroups are dispatched first (measured in the distributed replay: with the bulk updates
     // on a stream of HIGHER priority than this one a factorisation took 269 instead of 211 ms -- dispatch priority does decide
-    // between two chip-filling kernels, although it does nothing for a kernel that does not fit).  GPX_MAIN_PRIORITY overrides.
-    int mainp = lo;
-    {
-      const char* mp = getenv("GPX_MAIN_PRIORITY");
-      if (mp) mainp = atoi(mp);
-      else if (lo - hi >= 2) mainp = (lo + hi) / 2;
-      if (mainp > lo) mainp = lo;
-      if (mainp < hi) mainp = hi;
-    }
+    // between two chip-filling kernels, although it does nothing for a kernel that does not fit).
+    const int mainp = (lo - hi >= 2) ? (lo + hi) / 2 : lo;
     GPX_HIP(hipStreamCreateWithPriority(&c->streams[0], hipStreamNonBlocking, mainp));
     GPX_HIP(hipStreamCreateWithPriority(&c->streams[1], hipStreamNonBlocking, hi));
     GPX_HIP(hipStreamCreateWithPriority(&c->streams[2], hipStreamNonBlocking, hi));
@@ -419,18 +410,11 @@ int gpx_create(int device, gpx_ctx** out) {
     const int words = (c->cus + 31) / 32;
     std::vector<uint32_t> mask((size_t)words, 0xffffffffu);
     if (c->cus % 32) mask[(size_t)words - 1] = (1u << (c->cus % 32)) - 1u;
-    const char* rs = getenv("GPX_CUMASK_RESERVE");  // comma-separated CU indices (within every XCD) kept free; default 0-3
-    std::string reserve = rs ? rs : "0,1,2,3";
-    for (size_t pos = 0; pos < reserve.size();) {
-      const int cu = atoi(reserve.c_str() + pos);
+    for (int cu = 0; cu < 4; ++cu)      // CUs 0-3 of every XCD stay free
       for (int x = 0; x < 8; ++x) {
         const int bit = 8 * cu + x;
-        if (cu >= 0 && bit < c->cus) mask[(size_t)bit / 32] &= ~(1u << (bit % 32));
+        if (bit < c->cus) mask[(size_t)bit / 32] &= ~(1u << (bit % 32));
       }
-      const size_t nx = reserve.find(',', pos);
-      if (nx == std::string::npos) break;
-      pos = nx + 1;
-    }
     // two streams with that mask: 3 = background (copies into the replicated factor, streamed evaluation), 5 = bulk (the
     // aggregated trailing updates of the 2-D distributed factorisation: long chip-filling launches beside the diagonal chain)
     for (int si : {3, 5}) {
@@ -440,26 +424,6 @@ int gpx_create(int device, gpx_ctx** out) {
         GPX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
         GPX_HIP(hipStreamCreateWithPriority(&c->streams[si], hipStreamNonBlocking, lo));
       }
-    }
-  }
-  {
-    // GPX_STREAM_ALIAS="3=4,5=4" (experiment): stream index a becomes the SAME HIP stream as index b -- fewer hardware queues.
-    // (Measured: the number and kind of streams a context creates changes how fast the others run -- a seventh, idle,
-    // high-priority stream cost the distributed replay 20 %, DESIGN.md 6.2 -- so the mapping is worth being able to vary.)
-    const char* al = getenv("GPX_STREAM_ALIAS");
-    std::string spec = al ? al : "";
-    for (size_t pos = 0; pos < spec.size();) {
-      int a = -1, b = -1;
-      if (sscanf(spec.c_str() + pos, "%d=%d", &a, &b) == 2 && a > 0 && a < GPX_NSTREAMS && b >= 0 && b < GPX_NSTREAMS && a != b &&
-          c->streams[a] != c->streams[b]) {
-        bool shared = false;
-        for (int i = 0; i < GPX_NSTREAMS; ++i) shared = shared || (i != a && c->streams[i] == c->streams[a]);
-        if (!shared) (void)hipStreamDestroy(c->streams[a]);
-        c->streams[a] = c->streams[b];
-      }
-      const size_t nx = spec.find(',', pos);
-      if (nx == std::string::npos) break;
-      pos = nx + 1;
     }
   }
   GPX_HIP(hipMalloc((void**)&c->d_info, 256));
@@ -572,7 +536,6 @@ int gpx_destroy(gpx_ctx* ctx) {
   if (ctx->trsv_scratch) (void)hipFree(ctx->trsv_scratch);
   if (ctx->d2_scratch) (void)hipFree(ctx->d2_scratch);
   if (ctx->dbg_stamps) (void)hipFree(ctx->dbg_stamps);
-  if (ctx->coop_state) (void)hipFree(ctx->coop_state);
   if (ctx->ev_scratch) (void)hipFree(ctx->ev_scratch);
   for (auto ev : ctx->sync_events) (void)hipEventDestroy(ev);
   for (auto ev : ctx->la_events) (void)hipEventDestroy(ev);
@@ -582,7 +545,6 @@ int gpx_destroy(gpx_ctx* ctx) {
     for (int j = 0; j < i; ++j) seen = seen || ctx->streams[j] == ctx->streams[i];
     if (!seen) (void)hipStreamDestroy(ctx->streams[i]);
   }
-  for (auto ev : ctx->panel_events) (void)hipEventDestroy(ev);
   delete ctx;
   return 0;
 }
@@ -903,9 +865,8 @@ int gpx_kdiag(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const 
 }
 
 // ---- factorisation and solves ----------------------------------------------------------------------
-// The factorisation in two halves: potrf_begin enqueues everything (nothing blocks: gpx_fit_ivar queues the evaluation
-// solve behind the panel events while the factorisation is still running), potrf_end waits, reads the pivot flag, returns
-// the scratch and completes the block inverses.
+// The factorisation in two halves: potrf_begin enqueues everything (nothing blocks), potrf_end waits, reads the pivot flag,
+// returns the scratch and completes the block inverses.
 struct PotrfJob {
   bool blocked, built;
   void *ptb, *ptt;
@@ -913,7 +874,7 @@ struct PotrfJob {
   int rc;
 };
 
-static int potrf_begin(gpx_ctx* ctx, gpx_mat* K, PotrfJob* J, int64_t panel_hook) {
+static int potrf_begin(gpx_ctx* ctx, gpx_mat* K, PotrfJob* J) {
   GPX_ARG(ctx && K, "NULL argument");
   GPX_ARG(K->rows == K->cols && K->prows == K->pcols && K->prows % GPX_TILE == 0, "potrf needs a padded square matrix");
   if (!K->aux) {
@@ -957,14 +918,11 @@ static int potrf_begin(gpx_ctx* ctx, gpx_mat* K, PotrfJob* J, int64_t panel_hook
     ctx->pw_tmp_T = (double*)J->ptt;
   }
   ctx->pw_done = 0;
-  ctx->panel_width = panel_hook;
-  ctx->panel_count = 0;
   J->rc = chol_potrf(ctx, K->p, K->ld, np, K->aux, K->rows);
   J->built = ctx->pw_done != 0;
   ctx->pw_binv = ctx->pw_tmp_build = ctx->pw_tmp_T = nullptr;
   ctx->pw_ib = 0;
   ctx->pw_done = 0;
-  ctx->panel_width = 0;
   return 0;
 }
 
@@ -996,7 +954,7 @@ static int potrf_end(gpx_ctx* ctx, gpx_mat* K, PotrfJob* J) {
 
 int gpx_potrf(gpx_ctx* ctx, gpx_mat* K) {
   PotrfJob J;
-  GPX_TRY(potrf_begin(ctx, K, &J, 0));
+  GPX_TRY(potrf_begin(ctx, K, &J));
   return potrf_end(ctx, K, &J);
 }
 
@@ -1452,15 +1410,12 @@ int gpx_ivar_update(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, 
   return r;
 }
 
-// GP fit + IVAR in one call; optionally with the evaluation STREAMED underneath the factorisation (the single-GPU form of
-// the multi-GPU streamed evaluation, gpexp_amd/dist.py).  K holds the assembled covariance and is factored in place, exactly as
-// gpx_potrf does; *out = (1/M) sum_j var_j exactly as gpx_ivar computes it on the finished factor.  What changes is WHEN the
-// N^2 M flops of W = L^-1 K(X,Z) run: the blocked look-ahead factorisation records an event per finished 4096-wide panel of
-// L, and the solve advances panel by panel on a low-priority stream of its own (W_k from the block inverses, then
-// B[below] -= L[below, k] W_k with K = 4096), filling the time the factorisation's main stream spends waiting for its
-// latency-bound diagonal chains (35 of its 192 ms at N = 32768) and overlapping the rest.  Falls back to potrf followed by
-// the ordinary solve when the matrix is too small for the blocked path or Z needs more than one chunk.  Returns the pivot
-// status of gpx_potrf.
+// GP fit + IVAR in one call: K holds the assembled covariance and is factored in place exactly as gpx_potrf does; *out =
+// (1/M) sum_j var_j exactly as gpx_ivar computes it on the finished factor.  Returns the pivot status of gpx_potrf.
+// (Rounds 2-5 could run the evaluation solve STREAMED underneath the factorisation, panel by panel on a low-priority stream:
+// measured 720-739 ms per C4 step against 710 for factor-then-solve -- two chip-filling GEMM streams share the CUs at a loss and
+// the diagonal chain starves behind the solve's long workgroups -- and removed in round 6; the idea lives on where it pays, in
+// the multi-GPU panel loop of gpexp_amd/dist.py.)
 int gpx_fit_ivar(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, gpx_mat* K, const gpx_mat* X, const gpx_mat* Z,
                  double* out) {
   GPX_ARG(ctx && K && X && Z && out, "NULL argument");
@@ -1470,90 +1425,14 @@ int gpx_fit_ivar(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, gpx
   GPX_ARG(K->rows == X->rows && Z->rows > 0, "K does not match X / IVAR needs at least one integration point");
   GPX_ARG(ctx->stream == ctx->streams[0], "gpx_fit_ivar runs from the main stream");
   GPX_TRY(gpx_kparams_sets(ctx, &kp, X, Z));
-  const int64_t n = K->rows, np = K->prows, M = Z->rows, mcp = gpx_round_up(M, GPX_TILE);
-  const int64_t Bw = chol_potrf_panel_width(np), ib = chol_binv_order(np);
-  // Streaming is OPT-IN (GPX_FIT_IVAR_STREAMED=1).  Measured on one MI355X at C4 (one call, bench.py): factor-then-solve
-  // 710 ms per step, streamed 720 (right-looking panel steps) / 739 (left-looking): the factorisation's idle time (35 ms)
-  // is real, but two chip-filling GEMM streams share the CUs at a loss, the chain starves behind the solve's long workgroups,
-  // and the panel-wise solve is ~10 % more work-time than the recursive one.  It pays where the factorisation leaves a GPU
-  // mostly idle -- the multi-GPU panel loop (gpexp_amd/dist.py), which is where the idea comes from.
-  const char* on = getenv("GPX_FIT_IVAR_STREAMED");
-  const bool streamed = Bw > 0 && Bw % ib == 0 && M <= eval_chunk(np) && on && on[0] == '1';
+  const int64_t M = Z->rows;
   PotrfJob J;
-  if (!streamed) {
-    GPX_TRY(potrf_begin(ctx, K, &J, 0));
-    int info = potrf_end(ctx, K, &J);
-    if (info != 0) return info;
-    std::vector<double> var((size_t)M);
-    GPX_TRY(posterior_impl(ctx, kp, K, X, nullptr, Z, nullptr, var.data()));
-    *out = pairwise_mean(var, M);
-    return 0;
-  }
-  const int64_t ldb = gpx_skew_ld(mcp), bytesB = np * ldb * 8, bytes_out = mcp * 8;
-  const int64_t bytes_part = colreduce_partial_elems(np, mcp) * 8 + 8;
-  void *pB = nullptr, *pW = nullptr, *pout = nullptr, *pkd = nullptr, *ppart = nullptr;
-  int r = 0, info = 0;
-  hipStream_t M0 = ctx->stream, E = ctx->streams[4];
-  std::vector<double> hs((size_t)M), hk((size_t)M);
-  bool begun = false;
-  do {
-    if ((r = gpx_dev_alloc(ctx, bytesB, &pB)) != 0) break;
-    if ((r = gpx_dev_alloc(ctx, bytesB, &pW)) != 0) break;
-    if ((r = gpx_dev_alloc(ctx, bytes_out, &pout)) != 0) break;
-    if ((r = gpx_dev_alloc(ctx, bytes_out, &pkd)) != 0) break;
-    if ((r = gpx_dev_alloc(ctx, bytes_part, &ppart)) != 0) break;
-    // evaluation stream: everything that does not need the factor first
-    ctx->stream = E;
-    r = launch_kfill(ctx, kp, X->p, n, Z->p, M, 0, nullptr, 0, 0.0, (double*)pB, np, mcp, ldb);
-    if (r == 0) r = launch_kdiag(ctx, kp, Z->p, M, (double*)pkd);
-    ctx->stream = M0;
-    if (r != 0) break;
-    // the factorisation, with a panel event per finished look-ahead panel
-    if ((r = potrf_begin(ctx, K, &J, Bw)) != 0) break;
-    begun = true;
-    if (J.rc != 0) break;
-    const int npanel = ctx->panel_count;
-    if (npanel != (int)((np + Bw - 1) / Bw)) {  // the factorisation did not take the hooked path: solve after it
-      info = potrf_end(ctx, K, &J);
-      begun = false;
-      if (info != 0) break;
-      ctx->stream = E;
-      r = chol_trsm_left_oop(ctx, K, (double*)pB, ldb, (double*)pW, ldb, mcp);
-      ctx->stream = M0;
-      if (r != 0) break;
-    } else {
-      ctx->stream = E;
-      for (int k = 0; k < npanel && r == 0; ++k) {
-        const int64_t r0 = (int64_t)k * Bw, r1 = (r0 + Bw) < np ? (r0 + Bw) : np;
-        if (hipStreamWaitEvent(E, ctx->panel_events[(size_t)k], 0) != hipSuccess) { r = -2; break; }
-        r = chol_trsm_left_oop_panel(ctx, K->p, K->ld, np, K->binv, ib, (double*)pB, ldb, (double*)pW, ldb, mcp, r0, r1);
-      }
-      ctx->stream = M0;
-      if (r != 0) break;
-    }
-    ctx->stream = E;
-    r = launch_colreduce(ctx, (const double*)pW, ldb, n, mcp, nullptr, (double*)pout, (double*)ppart);
-    if (r == 0 && (hipMemcpyAsync(hs.data(), pout, (size_t)M * 8, hipMemcpyDeviceToHost, E) != hipSuccess ||
-                   hipMemcpyAsync(hk.data(), pkd, (size_t)M * 8, hipMemcpyDeviceToHost, E) != hipSuccess))
-      r = -2;
-    ctx->stream = M0;
-  } while (0);
-  if (begun) {
-    const int pe = potrf_end(ctx, K, &J);  // device-wide synchronisation
-    if (info == 0) info = pe;
-  } else {
-    (void)hipDeviceSynchronize();
-  }
-  gpx_dev_release(ctx, pB, bytesB);
-  gpx_dev_release(ctx, pW, bytesB);
-  gpx_dev_release(ctx, pout, bytes_out);
-  gpx_dev_release(ctx, pkd, bytes_out);
-  gpx_dev_release(ctx, ppart, bytes_part);
-  if (r == -2) gpx_set_error("fit_ivar: HIP call failed: %s", hipGetErrorString(hipGetLastError()));
-  if (r != 0) return r;
+  GPX_TRY(potrf_begin(ctx, K, &J));
+  int info = potrf_end(ctx, K, &J);
   if (info != 0) return info;
-  for (int64_t j = 0; j < M; ++j) hk[(size_t)j] -= hs[(size_t)j];
-  *out = pairwise_mean(hk, M);
+  std::vector<double> var((size_t)M);
+  GPX_TRY(posterior_impl(ctx, kp, K, X, nullptr, Z, nullptr, var.data()));
+  *out = pairwise_mean(var, M);
   return 0;
 }
 
@@ -1670,9 +1549,7 @@ int gpx_dbg_gemm(gpx_ctx* ctx, const gpx_mat* A, const gpx_mat* B, gpx_mat* C, i
   GPX_ARG(bt ? (B->prows == n && B->pcols == k) : (B->prows == k && B->pcols == n), "B shape");
   GPX_TRY(launch_gemm(ctx, A->p, A->ld, B->p, B->ld, C->p, C->ld, m, n, k, bt != 0, accumulate != 0,
                       lower != 0));
-  static int nosync = -1;  // GPX_DBG_NOSYNC=1: leave the launch in flight (back-to-back timing experiments)
-  if (nosync < 0) nosync = getenv("GPX_DBG_NOSYNC") ? 1 : 0;
-  if (!nosync) GPX_HIP(hipStreamSynchronize(ctx->stream));
+  GPX_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
 }
 

@@ -660,187 +660,6 @@ __global__ __launch_bounds__(256, 2) void leaf_mul_left_kernel(double* __restric
   }
 }
 
-// ---- one diagonal block of order <= 1024 factored in ONE launch (round 5) ------------------------------
-// potrf_right_looking spends three launches per 128 columns (leaf, strip multiply, rank-128 update): 22 dependent launches for
-// a 1024-order block, 0.33 ms on an idle chip -- but beside chip-filling trailing updates every one of them waits for a retirement
-// wave of the GEMM's workgroups (0.6-0.95 ms per block on the owner's diagonal chain of the 2-D distributed loop).
-// Here the whole block is ONE kernel of 1 + H workgroups that stay resident and hand work to each other through flags in global
-// memory:
-//   workgroup 0 ("chain")   factors the 128-leaves, one after the other (leaf_body), and nothing else;
-//   workgroups 1..H         strips  X(I, p) <- X(I, p) inv_p^T      in quarters of 32 rows   (leaf_mul_right_wave)
-//                           updates C(I, J) -= L(I, p) L(J, p)^T    in sub-tiles of 64 x 64  (coop_update_tile, K = 128)
-// Every task has ONE owner -- task number modulo H in an enumeration all workgroups share: step p, strips by block row, then
-// updates column by column (so what the next leaf and the next strips wait for comes first).  That enumeration is a topological
-// order of the dependency graph and every workgroup runs its tasks in that order, so the earliest unfinished task's owner is never
-// waiting for anything later: no deadlock whatever the placement, as long as every workgroup eventually gets a slot (nothing
-// else on the device waits for this kernel).  Hand-over = agent-scope release (all waves done, thread 0 fences and adds to the
-// flag) / acquire (thread 0 spins, fences, barrier) -- correct for any placement of the workgroups on the XCDs; the spins give up
-// after ~2 s (abort flag -> the kernel ends, the pivot report carries an error) instead of hanging the device.
-struct CoopState {
-  int leaf_done[8];
-  int strip_cnt[8][8];   // [p][I]: quarters of strip (I, p) done (4 = all)
-  int upd_cnt[8][8];     // [I][J]: 64 x 64 sub-tile updates applied to block (I, J) so far
-  int abort;
-  int pad[7];
-  long long t_wait[8], t_leaf[8], t_done[8];   // chain, 100 MHz wall clock: block p awaited / its leaf starts / its flag is out
-};
-
-__device__ __forceinline__ void coop_signal(int* flag) {
-  __syncthreads();  // every wave's stores are issued and complete (workgroup-scope release)
-  if (threadIdx.x == 0) {
-    __threadfence();  // agent-scope release: this CU's stores leave its L2 slice's dirty state before the flag moves
-    __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-// returns false when the kernel is being aborted (a spin ran out somewhere)
-__device__ __forceinline__ bool coop_wait(const int* flag, int target, int* abort_flag) {
-  if (threadIdx.x == 0) {
-    int it = 0;
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-      if (++it > (1 << 21)) {
-        __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(8);
-    }
-    __threadfence();  // agent-scope acquire: this CU's L1 forgets what it held
-  }
-  __syncthreads();
-  return __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
-}
-
-// C (64 x 64 at Cg, row stride ld) -= A (64 x 128 at Ag) * B (64 x 128 at Bg)^T, all row stride ld; one workgroup; Ls >= 2 * 64 * 65
-__device__ __forceinline__ void coop_update_tile(double* __restrict__ Ls, double* __restrict__ Cg, const double* __restrict__ Ag,
-                                                 const double* __restrict__ Bg, int64_t ld) {
-  constexpr int LDA = 65;
-  double* As = Ls;
-  double* Bs = Ls + 64 * LDA;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, q = lane & 15;
-  const int wm = wave >> 1, wn = wave & 1;
-  d4 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll 1
-  for (int kh = 0; kh < 2; ++kh) {
-    // stage the 64 x 64 halves of both operands: 8 16-byte loads per thread and operand, all in flight
-    double2 va[8], vb[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int idx = t + 256 * i, r = idx >> 5, c = 2 * (idx & 31);
-      va[i] = *reinterpret_cast<const double2*>(Ag + (int64_t)r * ld + 64 * kh + c);
-      vb[i] = *reinterpret_cast<const double2*>(Bg + (int64_t)r * ld + 64 * kh + c);
-    }
-    if (kh) __syncthreads();  // the first half's fragments have been read
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int idx = t + 256 * i, r = idx >> 5, c = 2 * (idx & 31);
-      As[r * LDA + c] = va[i].x;
-      As[r * LDA + c + 1] = va[i].y;
-      Bs[r * LDA + c] = vb[i].x;
-      Bs[r * LDA + c + 1] = vb[i].y;
-    }
-    __syncthreads();
-    const double* ap = As + (32 * wm + q) * LDA + g;
-    const double* bp = Bs + (32 * wn + q) * LDA + g;
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const double a0 = ap[4 * s], a1 = ap[16 * LDA + 4 * s];
-      const double b0 = bp[4 * s], b1 = bp[16 * LDA + 4 * s];
-      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        double* cp = Cg + (int64_t)(32 * wm + 16 * i + g + 4 * v) * ld + 32 * wn + 16 * j + q;
-        *cp -= acc[i][j][v];
-      }
-  __syncthreads();  // the LDS images are free for the next task
-}
-
-// 32 rows of a strip: X (32 x 128 at Xg) <- X inv^T, in place; Ls >= 32 * 129
-__device__ __forceinline__ void coop_strip_quarter(double* __restrict__ Ls, double* __restrict__ Xg, int64_t ld,
-                                                   const double* __restrict__ inv) {
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, q = lane & 15;
-  double2 xv[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int idx = t + 256 * i, r = idx >> 6, c = 2 * (idx & 63);
-    xv[i] = *reinterpret_cast<const double2*>(Xg + (int64_t)r * ld + c);
-  }
-  switch (wave) {
-    case 0: leaf_mul_right_wave<32, 0>(Ls, Xg, ld, inv, xv, t, g, q); break;
-    case 1: leaf_mul_right_wave<32, 1>(Ls, Xg, ld, inv, xv, t, g, q); break;
-    case 2: leaf_mul_right_wave<32, 2>(Ls, Xg, ld, inv, xv, t, g, q); break;
-    default: leaf_mul_right_wave<32, 3>(Ls, Xg, ld, inv, xv, t, g, q); break;
-  }
-  __syncthreads();
-}
-
-__global__ __launch_bounds__(256, 1) void potrf_coop_kernel(double* A, int64_t ld, int nl, double* inv, int64_t base_index,
-                                                         int64_t n_valid, int* __restrict__ info, double piv_min, int skip,
-                                                         int hiprio, CoopState* st) {
-  __shared__ double S[36 * BSZ];
-  __shared__ __attribute__((aligned(16))) double CB[LEAF_CB];
-  if (hiprio) __builtin_amdgcn_s_setprio(3);
-  int* const abort_flag = &st->abort;
-  const int H = (int)gridDim.x - 1;
-  if (blockIdx.x == 0) {
-    // the chain: leaf after leaf; block (p, p) is complete once the 3 p lower sub-tile updates of the steps before p are in
-    for (int p = 0; p < nl; ++p) {
-      if (threadIdx.x == 0) st->t_wait[p] = (long long)wall_clock64();
-      if (p > 0 && !coop_wait(&st->upd_cnt[p][p], 3 * p, abort_flag)) break;
-      if (threadIdx.x == 0) st->t_leaf[p] = (long long)wall_clock64();
-      leaf_body(S, CB, A + (int64_t)(NB * p) * (ld + 1), ld, inv + (int64_t)p * NB * NB, base_index + NB * p, n_valid, info, piv_min,
-                skip, 1, nullptr);
-      coop_signal(&st->leaf_done[p]);
-      if (threadIdx.x == 0) st->t_done[p] = (long long)wall_clock64();
-    }
-    if (threadIdx.x == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
-      atomicCAS(info, 0, (int)(base_index + 1));   // a spin ran out: the factorisation is reported as failed, not hung
-    return;
-  }
-  const int h = (int)blockIdx.x - 1;
-  int task = 0;   // position in the enumeration every helper walks
-  for (int p = 0; p + 1 < nl; ++p) {
-    const double* invp = inv + (int64_t)p * NB * NB;
-    // strips of step p, block row by block row (row p+1 first: the next leaf's update and the next step's strips need it)
-    for (int I = p + 1; I < nl; ++I)
-      for (int qd = 0; qd < 4; ++qd, ++task) {
-        if (task % H != h) continue;
-        if (!coop_wait(&st->leaf_done[p], 1, abort_flag)) return;
-        if (p > 0 && !coop_wait(&st->upd_cnt[I][p], 4 * p, abort_flag)) return;
-        coop_strip_quarter(S, A + (int64_t)(NB * I + 32 * qd) * ld + NB * p, ld, invp);
-        coop_signal(&st->strip_cnt[p][I]);
-      }
-    // updates of step p, block column by block column, the diagonal block of the column first
-    for (int J = p + 1; J < nl; ++J)
-      for (int I = J; I < nl; ++I)
-        for (int sub = 0; sub < 4; ++sub) {
-          const int a = sub >> 1, b = sub & 1;
-          if (I == J && b > a) continue;   // diagonal block: the lower sub-tiles only
-          const int mine = task++;
-          if (mine % H != h) continue;
-          if (!coop_wait(&st->strip_cnt[p][I], 4, abort_flag)) return;
-          if (I != J && !coop_wait(&st->strip_cnt[p][J], 4, abort_flag)) return;
-          if (p > 0 && !coop_wait(&st->upd_cnt[I][J], (I == J ? 3 : 4) * p, abort_flag)) return;
-          coop_update_tile(S, A + (int64_t)(NB * I + 64 * a) * ld + NB * J + 64 * b, A + (int64_t)(NB * I + 64 * a) * ld + NB * p,
-                           A + (int64_t)(NB * J + 64 * b) * ld + NB * p, ld);
-          coop_signal(&st->upd_cnt[I][J]);
-        }
-  }
-}
-
 // ---- TRSV pieces (potrs) ---------------------------------------------------------------------------
 // The sweeps follow the same recursion as the factorisation: solve the first half, subtract the off-diagonal block
 // times that solution from the second half as ONE bandwidth-bound GEMV over the whole block, solve the second half
@@ -1110,18 +929,10 @@ static int launch_leaf_mul_left(gpx_ctx* ctx, double* B, int64_t ldb, const doub
 
 int launch_leaf(gpx_ctx* ctx, double* A, int64_t ld, double* inv, int64_t base_index, int64_t n_valid) {
   ProfScope ps(ctx, GPX_PROF_LEAF, 2.0 * NB * NB * NB / 3.0, 0.0);
-  static const int fast = getenv("GPX_LEAF_DIAG") ? atoi(getenv("GPX_LEAF_DIAG")) : 1;  // 0: round 1-4's leaf_diag throughout
+  const int fast = 1;   // round 5's diagonal step (gpx_dbg_leaf_stamps can still time the general one, which is also the bad-pivot fall-back)
   hipLaunchKernelGGL(leaf_kernel, dim3(1), dim3(256), 0, ctx->stream, A, ld, inv, base_index, n_valid, ctx->d_info,
                      ctx->piv_min, ctx->piv_skip, gpx_chain_prio(ctx), fast, (long long*)nullptr);
   GPX_HIP(hipGetLastError());
-  return 0;
-}
-
-// debug (gpx_debug.h): the chain's time stamps of the LAST potrf_coop_kernel launch of this context (3 x 8 values, 100 MHz)
-extern "C" int gpx_dbg_coop_stamps(gpx_ctx* ctx, int64_t* out24) {
-  GPX_ARG(ctx && out24 && ctx->coop_state, "coop stamps: no cooperative factorisation has run on this context");
-  GPX_HIP(hipDeviceSynchronize());
-  GPX_HIP(hipMemcpy(out24, (char*)ctx->coop_state + offsetof(CoopState, t_wait), 24 * sizeof(long long), hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -1197,14 +1008,11 @@ static int potrf_right_looking(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, d
   return 0;
 }
 
-static int64_t potrf_rl_max() {
-  static int64_t v = -1;
-  if (v < 0) {
-    const char* e = getenv("GPX_POTRF_RL");  // diagonal blocks up to this order are factored right-looking
-    v = e ? atoll(e) : 4096;
-  }
-  return v;
-}
+// diagonal blocks up to this order are factored right-looking (leaf, strip multiply, rank-128 update per 128 columns); the panel
+// width of the blocked look-ahead factorisation above it.  Re-swept in round 5 (profiles/r05_potrf_variants.txt): right-looking
+// limit 2048 / 1024: +1.6 / +3.5 ms at N = 32768; panel 2048 / 8192: +6.7 / +6.3 ms.
+constexpr int64_t POTRF_RL_MAX = 4096;
+constexpr int64_t POTRF_PANEL = 4096;
 
 static int64_t env_i64(const char* name, int64_t dflt) {
   const char* e = getenv(name);
@@ -1223,10 +1031,7 @@ static int binv_build_range(gpx_ctx* ctx, const double* Ld, int64_t ld, const do
 // FEW rows (m <= 1024: one batch of design points against the kept factor, gpx_refit_rows): the products of the lower levels are
 // m x ib x ib -- 128 64-tiles under a serial k range of 1024, 55-60 us each on half the chip, 2 ms of the 3.6 ms of a
 // 512 x 15872 solve whose flops are 1.6 ms.  Those run as slices of the k range (launch_gemm_ksplit_small): >= 512 workgroups.
-static inline bool trsm_few_rows(int64_t m) {
-  static const int64_t rows = env_i64("GPX_TRSM_FEW_ROWS", 1024);   // (0: one launch per product for every shape, A/B)
-  return m <= rows && m % 64 == 0;
-}
+static inline bool trsm_few_rows(int64_t m) { return m <= 1024 && m % 64 == 0; }
 static inline int64_t slices_for(int64_t m, int64_t n, int64_t k) {
   if (n % 64 != 0) return 1;
   const int64_t tiles = (m / 64) * (n / 64);
@@ -1269,7 +1074,7 @@ static int trsm_right_binv_rec(gpx_ctx* ctx, const double* Ld, int64_t ldl, cons
 
 // X (m x n) <- X L^-1 (NOT transposed) with the same block inverses: block columns from the last to the first, X_b <- X_b Binv_b
 // -- round 5: as a triangular-operand product with the inverse itself (k x n lower, not transposed: the k range of a column tile
-// starts at its diagonal; `binv` = the lower inverses, `binvT` their transposes, kept for the dense form: GPX_TRSM_N_DENSE=1) --,
+// starts at its diagonal; `binv` = the lower inverses, `binvT` their transposes for callers that only hold those) --,
 // between them X[:, earlier] -= X[:, done] L[done, earlier] with K >= ib.  The leaf-level recursion of chol_trsm_right_n spends
 // its time in K = 128..512 products.
 static int trsm_right_n_binv_rec(gpx_ctx* ctx, const double* Ld, int64_t ldl, const double* binvT, int64_t ib, double* X,
@@ -1277,8 +1082,7 @@ static int trsm_right_n_binv_rec(gpx_ctx* ctx, const double* Ld, int64_t ldl, co
   auto off = [&](int64_t b) { return b * ib < n ? b * ib : n; };
   if (b1 - b0 == 1) {
     const int64_t o = off(b0), sz = off(b0 + 1) - o;
-    static const int64_t dense = env_i64("GPX_TRSM_N_DENSE", 0);
-    if (binv && !dense)
+    if (binv)
       GPX_TRY(launch_gemm_tri(ctx, X + o, ldx, binv + b0 * ib * ib, ib, T, ib, m, sz, sz, false, false, false, 4));
     else
       GPX_TRY(launch_gemm(ctx, X + o, ldx, binvT + b0 * ib * ib, ib, T, ib, m, sz, sz, true, false, false));
@@ -1332,25 +1136,22 @@ int chol_trsm_right_n_leading(gpx_ctx* ctx, gpx_mat* Lm, int64_t ncols, double* 
 
 // Blocked right-looking factorisation with panels of width B (4096) and ONE PANEL OF LOOK-AHEAD for large matrices.
 // Per panel k: solve the rows below the diagonal block, then the trailing update A22 -= P P^T with K = B.  The diagonal
-// block of panel k+1 -- a chain of ~100 latency-bound kernels (128-wide leaves, strip multiplies, rank-128 updates: 2.3 ms
-// per 4096 block on an otherwise idle chip, 18 ms per factorisation at N = 32768) -- only needs block column k+1 of that
-// update.  So column k+1 is updated first, the chain moves to the high-priority side stream, and the first `chunk` rows of
-// the remaining update run beside it on the CU-masked stream (a chip-filling kernel starves small kernels on other streams
-// whatever their priority, scripts/cumask_check.hip; the mask leaves 4 CUs per XCD to the chain); the bulk of the update
-// follows on the whole chip once the chain is done.  Measured (profiles/r02_potrf_lookahead.txt, r02_potrf_phases.txt):
-// beside the chunk the chain takes 5.5 ms instead of 2.3 (its rank-128 updates have 32 CUs).  A kernel on the masked stream
-// runs at exactly its CU share (0.875) -- the chunk is slow because an 8192^2 lower launch is (2080 tiles = 4.06 rounds of
-// the 512 resident workgroups: 55 TF/s on the whole chip).  Putting ALL large kernels on a masked stream so that the chain
-// never blocks them costs that share all the time (226-233 ms against 190); relying on the side stream's priority alone (no
-// mask) leaves the chain behind the whole update (195.8 ms = no look-ahead); two unmasked streams for the independent
-// launches of one update (+6 %) and one trapezoid launch instead of triangle + rectangle (+2 %) were measured and dropped.
-// Main stream only (the streams are the context's).
+// block of panel k+1 -- a chain of ~100 latency-bound kernels (128-wide leaves, strip multiplies, rank-128 updates: 1.9 ms
+// per 4096 block on an otherwise idle chip) -- only needs block row k+1 of the panel and the diagonal block (k+1, k+1) of that
+// update.  CRITICAL PATH FIRST (round 3): solve THOSE rows, update THAT block ("top"), start the chain on the high-priority
+// side stream -- and only then solve the rest of the panel, update the rest of block column k+1 and the bulk, all underneath
+// the chain, whose kernels fit beside resident GEMM workgroups (leaf 78 KB LDS / 184 VGPRs, strip multiplies 33-66 KB:
+// scripts/dispatch_check2.hip) and get a slot whenever one retires.
+// History of what this replaced, all measured and removed (profiles/r02_potrf_lookahead.txt, r02_potrf_phases.txt,
+// r04_potrf_two_panel_lookahead.txt, r06_potrf_panel_inverse_ab.txt): the chain behind the whole column update (8.7 + 2.5 ms
+// exposed at N = 32768); a CU-masked chunk of the update beside the chain (a kernel on a masked stream runs at exactly its CU
+// share; 190-195 ms); all large kernels masked (226-233 ms); two panels of look-ahead (the bulk update stretches by what the thin
+// "top" launches take beside it); the update in slices of its k range; the rest solve as one product with a 4096-order inverse.
+// Main stream only (the streams are the context's).  GPX_POTRF_TIMING=1 (debug): per-panel phase spans on stderr.
 static int potrf_blocked(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double* invd, int64_t base, int64_t n_valid,
                          int64_t B) {
-  static const int64_t la_on = env_i64("GPX_POTRF_LA", 1), chunk_rows = env_i64("GPX_POTRF_LA_CHUNK", 8192) / NB * NB;
-  hipStream_t M = ctx->stream, S = ctx->streams[1], Kq = ctx->streams[3];
-  const bool la = la_on && M == ctx->streams[0];
-  // GPX_POTRF_TIMING=1 (debug): per-panel phase spans from timing events, printed after a device sync at the end
+  hipStream_t M = ctx->stream, S = ctx->streams[1];
+  const bool la = M == ctx->streams[0];
   static const int64_t timing = env_i64("GPX_POTRF_TIMING", 0);
   struct Span { const char* what; int64_t panel; hipEvent_t a, b; };
   std::vector<Span> spans;
@@ -1360,7 +1161,7 @@ static int potrf_blocked(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double*
     return e;
   };
   if (la && ctx->la_events.empty()) {
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 2; ++i) {
       hipEvent_t ev;
       GPX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
       ctx->la_events.push_back(ev);
@@ -1371,109 +1172,38 @@ static int potrf_blocked(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double*
   const int64_t ib = ctx->pw_ib;
   const bool bi = ctx->pw_binv != nullptr && ib > 0 && base % ib == 0 && B % ib == 0;
   auto binv_at = [&](int64_t row) { return ctx->pw_binv + ((base + row) / ib) * ib * ib; };
-  constexpr int64_t CHAIN_MAX = 1024;  // the chain (few CUs beside the masked chunk) inverts up to this order ...
+  auto solve = [&](int64_t j0, int64_t w, double* X, int64_t m) -> int {   // X (m x w) <- X D^-T, D the diagonal block at j0
+    if (bi) return trsm_right_binv_rec(ctx, A + j0 * (ld + 1), ld, binv_at(j0), ib, X, ld, m, w, 0, (w + ib - 1) / ib, ctx->pw_tmp_T);
+    return chol_trsm_right(ctx, A + j0 * (ld + 1), ld, invd + (j0 / NB) * NB * NB, X, ld, m, w);
+  };
   GPX_TRY(potrf_rec(ctx, A, ld, n < B ? n : B, invd, base, n_valid));
   if (bi) GPX_TRY(binv_build_range(ctx, A, ld, invd, binv_at(0), ib, n < B ? n : B, ctx->pw_tmp_build));
-  // streamed evaluation hook: panel k of L is final once its rows below the diagonal block are solved
-  const bool hook = ctx->panel_width == B && base == 0;
-  auto panel_done = [&](int64_t k) -> int {
-    if (!hook) return 0;
-    while ((int64_t)ctx->panel_events.size() <= k) {
-      hipEvent_t ev;
-      GPX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-      ctx->panel_events.push_back(ev);
-    }
-    GPX_HIP(hipEventRecord(ctx->panel_events[(size_t)k], ctx->stream));
-    ctx->panel_count = (int)k + 1;
-    return 0;
-  };
   for (int64_t j0 = 0; j0 < n; j0 += B) {
     const int64_t w = (n - j0) < B ? (n - j0) : B, below = n - j0 - w;
-    if (below == 0) {
-      GPX_TRY(panel_done(j0 / B));  // the last diagonal block: the main stream has already waited for its chain
-      break;
-    }
+    if (below == 0) break;                     // the last diagonal block: the main stream has already waited for its chain
     double* P = A + (j0 + w) * ld + j0;        // below x w panel
     double* C = A + (j0 + w) * (ld + 1);       // trailing block, below x below
-    static const int64_t la_mode = env_i64("GPX_POTRF_LA_MODE", 2);
-    if (la && bi && la_mode == 2) {
-      // Round 3, critical path first: only block row k+1 of the panel and the diagonal block (k+1, k+1) stand between this
-      // panel and the next diagonal chain.  So: solve THOSE rows, update THAT block, start the chain on the side stream --
-      // and only then solve the rest of the panel, update the rest of block column k+1 and the bulk, all underneath the
-      // chain (its kernels fit beside resident GEMM workgroups).  The chain used to start behind the whole solve and the
-      // whole column update and outlasted the bulk update from the fourth panel on (8.7 + 2.5 ms exposed at N = 32768).
-      const int64_t w2 = below < B ? below : B, rest = below - w2;
-      double* invn = invd + ((j0 + w) / NB) * NB * NB;
-      hipEvent_t ev_col = ctx->la_events[0], ev_diag = ctx->la_events[1];
-      hipEvent_t t0 = mark(M);
-      GPX_TRY(trsm_right_binv_rec(ctx, A + j0 * (ld + 1), ld, binv_at(j0), ib, P, ld, w2, w, 0, (w + ib - 1) / ib, ctx->pw_tmp_T));
-      GPX_TRY(launch_gemm(ctx, P, ld, P, ld, C, ld, w2, w2, w, true, true, true));
-      spans.push_back({"top", j0 / B, t0, mark(M)});
-      GPX_HIP(hipEventRecord(ev_col, M));
-      ctx->stream = S;
-      int r = 0;
-      if (hipStreamWaitEvent(S, ev_col, 0) != hipSuccess) r = -2;
-      t0 = mark(S);
-      if (r == 0) r = potrf_rec(ctx, C, ld, w2, invn, base + j0 + w, n_valid);
-      if (r == 0) r = binv_build_range(ctx, C, ld, invn, binv_at(j0 + w), ib, w2, ctx->pw_tmp_build, 0, CHAIN_MAX);
-      spans.push_back({"chain", j0 / B, t0, mark(S)});
-      if (r == 0 && hipEventRecord(ev_diag, S) != hipSuccess) r = -2;
-      ctx->stream = M;
-      if (r != 0) {
-        if (r == -2) gpx_set_error("potrf: look-ahead stream plumbing failed");
-        return r;
-      }
-      if (rest > 0) {
-        double* P2 = P + w2 * ld;
-        t0 = mark(M);
-        // (its own scratch: the top rows' solve may still be running through pw_tmp_T -- same stream, so in order)
-        GPX_TRY(trsm_right_binv_rec(ctx, A + j0 * (ld + 1), ld, binv_at(j0), ib, P2, ld, rest, w, 0, (w + ib - 1) / ib,
-                                    ctx->pw_tmp_T));
-        spans.push_back({"solve", j0 / B, t0, mark(M)});
-        GPX_TRY(panel_done(j0 / B));
-        t0 = mark(M);
-        GPX_TRY(launch_gemm(ctx, P2, ld, P, ld, C + w2 * ld, ld, rest, w2, w, true, true, false));
-        spans.push_back({"column", j0 / B, t0, mark(M)});
-        t0 = mark(M);
-        GPX_TRY(launch_gemm(ctx, P2, ld, P2, ld, C + w2 * (ld + 1), ld, rest, rest, w, true, true, true));
-        spans.push_back({"bulk", j0 / B, t0, mark(M)});
-      } else {
-        GPX_TRY(panel_done(j0 / B));
-      }
-      GPX_HIP(hipStreamWaitEvent(M, ev_diag, 0));
-      if (bi) GPX_TRY(binv_build_range(ctx, C, ld, invn, binv_at(j0 + w), ib, w2, ctx->pw_tmp_build, CHAIN_MAX, INT64_MAX));
-      continue;
-    }
-    hipEvent_t t0 = mark(M);
-    if (bi)
-      GPX_TRY(trsm_right_binv_rec(ctx, A + j0 * (ld + 1), ld, binv_at(j0), ib, P, ld, below, w, 0, (w + ib - 1) / ib,
-                                  ctx->pw_tmp_T));
-    else
-      GPX_TRY(chol_trsm_right(ctx, A + j0 * (ld + 1), ld, invd + (j0 / NB) * NB * NB, P, ld, below, w));
-    spans.push_back({"solve", j0 / B, t0, mark(M)});
-    GPX_TRY(panel_done(j0 / B));
     const int64_t w2 = below < B ? below : B, rest = below - w2;
     double* invn = invd + ((j0 + w) / NB) * NB * NB;
-    if (!la) {
+    if (!la) {   // (a caller on another stream of the context: no side stream to put the chain on)
+      GPX_TRY(solve(j0, w, P, below));
       GPX_TRY(launch_gemm(ctx, P, ld, P, ld, C, ld, below, below, w, true, true, true));
       GPX_TRY(potrf_rec(ctx, C, ld, w2, invn, base + j0 + w, n_valid));
       if (bi) GPX_TRY(binv_build_range(ctx, C, ld, invn, binv_at(j0 + w), ib, w2, ctx->pw_tmp_build));
       continue;
     }
-    hipEvent_t ev_col = ctx->la_events[0], ev_diag = ctx->la_events[1], ev_top = ctx->la_events[2];
-    // block column k+1 of the update first: its diagonal block (lower) and the rows below it
-    t0 = mark(M);
+    hipEvent_t ev_col = ctx->la_events[0], ev_diag = ctx->la_events[1];
+    hipEvent_t t0 = mark(M);
+    GPX_TRY(solve(j0, w, P, w2));
     GPX_TRY(launch_gemm(ctx, P, ld, P, ld, C, ld, w2, w2, w, true, true, true));
-    if (rest > 0) GPX_TRY(launch_gemm(ctx, P + w2 * ld, ld, P, ld, C + w2 * ld, ld, rest, w2, w, true, true, false));
-    spans.push_back({"column", j0 / B, t0, mark(M)});
+    spans.push_back({"top", j0 / B, t0, mark(M)});
     GPX_HIP(hipEventRecord(ev_col, M));
-    // the diagonal chain of panel k+1 (+ its block inverses) on the side stream
     ctx->stream = S;
     int r = 0;
     if (hipStreamWaitEvent(S, ev_col, 0) != hipSuccess) r = -2;
     t0 = mark(S);
     if (r == 0) r = potrf_rec(ctx, C, ld, w2, invn, base + j0 + w, n_valid);
-    if (r == 0 && bi) r = binv_build_range(ctx, C, ld, invn, binv_at(j0 + w), ib, w2, ctx->pw_tmp_build, 0, CHAIN_MAX);
+    if (r == 0 && bi) r = binv_build_range(ctx, C, ld, invn, binv_at(j0 + w), ib, w2, ctx->pw_tmp_build);
     spans.push_back({"chain", j0 / B, t0, mark(S)});
     if (r == 0 && hipEventRecord(ev_diag, S) != hipSuccess) r = -2;
     ctx->stream = M;
@@ -1481,54 +1211,19 @@ static int potrf_blocked(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double*
       if (r == -2) gpx_set_error("potrf: look-ahead stream plumbing failed");
       return r;
     }
-    if (rest > 0 && la_mode >= 1) {
-      // Round 3: the chain's kernels now fit beside resident GEMM workgroups (leaf 78 KB / 240 VGPRs, strip multiplies 33-66
-      // KB; scripts/dispatch_check2.hip), so they get a slot whenever one GEMM workgroup retires -- no reserved CUs, no
-      // masked chunk: the WHOLE remaining update runs on the main stream, all CUs, with the chain of the next diagonal block
-      // underneath it on the high-priority side stream.
+    if (rest > 0) {
       double* P2 = P + w2 * ld;
-      double* C2 = C + w2 * (ld + 1);
       t0 = mark(M);
-      // GPX_POTRF_KSPLIT > 1 (experiment): the update as that many launches over slices of the k range -- shorter
-      // retirement waves of the GEMM workgroups (the chain's kernels get their slots at those), more traffic on C
-      static const int64_t ksplit = env_i64("GPX_POTRF_KSPLIT", 1);
-      const int64_t kparts = (ksplit > 1 && w % (ksplit * 16) == 0) ? ksplit : 1, kw = w / kparts;
-      for (int64_t kp = 0; kp < kparts; ++kp)
-        GPX_TRY(launch_gemm(ctx, P2 + kp * kw, ld, P2 + kp * kw, ld, C2, ld, rest, rest, kw, true, true, true));
+      GPX_TRY(solve(j0, w, P2, rest));   // (scratch shared with the top rows' solve: same stream, so in order)
+      spans.push_back({"solve", j0 / B, t0, mark(M)});
+      t0 = mark(M);
+      GPX_TRY(launch_gemm(ctx, P2, ld, P, ld, C + w2 * ld, ld, rest, w2, w, true, true, false));
+      spans.push_back({"column", j0 / B, t0, mark(M)});
+      t0 = mark(M);
+      GPX_TRY(launch_gemm(ctx, P2, ld, P2, ld, C + w2 * (ld + 1), ld, rest, rest, w, true, true, true));
       spans.push_back({"bulk", j0 / B, t0, mark(M)});
-      GPX_HIP(hipStreamWaitEvent(M, ev_diag, 0));
-    } else if (rest > 0) {
-      double* P2 = P + w2 * ld;
-      double* C2 = C + w2 * (ld + 1);
-      const int64_t top = rest < chunk_rows ? rest : chunk_rows;
-      // beside the chain, on the masked stream: the first `top` rows of the remaining update
-      ctx->stream = Kq;
-      if (hipStreamWaitEvent(Kq, ev_col, 0) != hipSuccess) r = -2;
-      t0 = mark(Kq);
-      if (r == 0) r = launch_gemm(ctx, P2, ld, P2, ld, C2, ld, top, top, w, true, true, true);
-      spans.push_back({"chunk", j0 / B, t0, mark(Kq)});
-      if (r == 0 && hipEventRecord(ev_top, Kq) != hipSuccess) r = -2;
-      ctx->stream = M;
-      if (r != 0) {
-        if (r == -2) gpx_set_error("potrf: look-ahead stream plumbing failed");
-        return r;
-      }
-      GPX_HIP(hipStreamWaitEvent(M, ev_diag, 0));  // the bulk gets the whole chip: after the chain
-      GPX_HIP(hipStreamWaitEvent(M, ev_top, 0));
-      if (rest > top) {
-        t0 = mark(M);
-        GPX_TRY(launch_gemm(ctx, P2 + top * ld, ld, P2, ld, C2 + top * ld, ld, rest - top, top, w, true, true, false));
-        GPX_TRY(launch_gemm(ctx, P2 + top * ld, ld, P2 + top * ld, ld, C2 + top * (ld + 1), ld, rest - top, rest - top, w, true,
-                            true, true));
-        spans.push_back({"bulk", j0 / B, t0, mark(M)});
-      }
-    } else {
-      GPX_HIP(hipStreamWaitEvent(M, ev_diag, 0));
     }
-    // ... and the whole chip completes the inverse of the diagonal block (orders 2048, 4096) behind the chain
-    t0 = mark(M);
-    if (bi) GPX_TRY(binv_build_range(ctx, C, ld, invn, binv_at(j0 + w), ib, w2, ctx->pw_tmp_build, CHAIN_MAX, INT64_MAX));
-    spans.push_back({"binv-top", j0 / B, t0, mark(M)});
+    GPX_HIP(hipStreamWaitEvent(M, ev_diag, 0));
   }
   if (bi && base == 0) ctx->pw_done = 1;
   if (timing && base == 0 && !spans.empty()) {
@@ -1547,35 +1242,15 @@ static int potrf_blocked(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double*
   return 0;
 }
 
-int64_t chol_potrf_panel_width(int64_t n) {
-  const int64_t blk = env_i64("GPX_POTRF_BLOCK", 4096) / NB * NB;
-  return (blk >= potrf_rl_max() && n >= 2 * blk && n > potrf_rl_max()) ? blk : 0;
-}
-
-// one launch of potrf_coop_kernel for a diagonal block of order 256 .. 1024 (GPX_POTRF_COOP=0: the launch chain of rounds 1-4;
-// GPX_COOP_HELPERS: workgroups beside the chain, default 16)
-static int launch_potrf_coop(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double* invd, int64_t base, int64_t n_valid) {
-  static const int helpers = (int)env_i64("GPX_COOP_HELPERS", 16);
-  if (!ctx->coop_state) GPX_HIP(hipMalloc((void**)&ctx->coop_state, sizeof(CoopState)));
-  GPX_HIP(hipMemsetAsync(ctx->coop_state, 0, sizeof(CoopState), ctx->stream));
-  ProfScope ps(ctx, GPX_PROF_LEAF, (double)n * n * n / 3.0, 0.0);
-  const int H = helpers < 1 ? 1 : (helpers > 64 ? 64 : helpers);
-  hipLaunchKernelGGL(potrf_coop_kernel, dim3(1 + H), dim3(256), 0, ctx->stream, A, ld, (int)(n / NB), invd, base, n_valid,
-                     ctx->d_info, ctx->piv_min, ctx->piv_skip, gpx_chain_prio(ctx), (CoopState*)ctx->coop_state);
-  GPX_HIP(hipGetLastError());
-  return 0;
-}
+int64_t chol_potrf_panel_width(int64_t n) { return n >= 2 * POTRF_PANEL ? POTRF_PANEL : 0; }
 
 static int potrf_rec(gpx_ctx* ctx, double* A, int64_t ld, int64_t n, double* invd, int64_t base, int64_t n_valid) {
   if (n == NB) return launch_leaf(ctx, A, ld, invd, base, n_valid);
-  // (default OFF: measured -- profiles/r05_potrf_coop_ab.txt -- the one-launch form is no faster than the launch chain on an idle
-  // chip, 0.33 ms per 1024 block either way since the leaf itself takes 21 of a step's ~40 us, and the paced 2 x 4 replay is 1.3 ms
-  // SLOWER with it: 17-29 resident workgroups of 81 KB LDS each take CU slots from the trailing updates the ranks are bound by)
-  static const int64_t coop_on = env_i64("GPX_POTRF_COOP", 0), coop_max = env_i64("GPX_POTRF_COOP_MAX", 1024);
-  if (coop_on && n <= coop_max && n <= 8 * NB) return launch_potrf_coop(ctx, A, ld, n, invd, base, n_valid);
-  if (n <= potrf_rl_max()) return potrf_right_looking(ctx, A, ld, n, invd, base, n_valid);
-  static const int64_t blk = env_i64("GPX_POTRF_BLOCK", 4096) / NB * NB;  // 0: recursive halving at every level (round 1)
-  if (blk >= potrf_rl_max() && n >= 2 * blk) return potrf_blocked(ctx, A, ld, n, invd, base, n_valid, blk);
+  // (a one-launch cooperative form of the diagonal block -- one chain workgroup + helper workgroups handing work over through flags
+  // in global memory -- was built in round 5 and measured no faster than this launch chain: profiles/r05_potrf_coop_ab.txt; removed
+  // in round 6)
+  if (n <= POTRF_RL_MAX) return potrf_right_looking(ctx, A, ld, n, invd, base, n_valid);
+  if (n >= 2 * POTRF_PANEL) return potrf_blocked(ctx, A, ld, n, invd, base, n_valid, POTRF_PANEL);
   const int64_t n1 = split(n), n2 = n - n1;
   GPX_TRY(potrf_rec(ctx, A, ld, n1, invd, base, n_valid));
   double* A21 = A + n1 * ld;
@@ -1625,16 +1300,11 @@ static int trsv_bwd_rec(gpx_ctx* ctx, const double* L, int64_t ld, const double*
 
 // ---- potrs through block inverses: host side -----------------------------------------------------------------------------
 static int64_t potrs_block(int64_t n) {
-  static int64_t forced = -1;
-  if (forced < 0) {
-    const char* e = getenv("GPX_POTRS_IB");  // order of the explicitly inverted diagonal blocks (multiple of 128)
-    forced = e ? atoll(e) : 0;
-  }
   // 1024 minimises build + one solve.  (Order 4096 -- the whole diagonal block of a look-ahead panel, its panel solve then ONE
   // long-K triangular product, potrs 1.75 ms instead of 2.5 -- was measured too: the factorisation loses 13 ms at N = 32768
-  // and 3 ms at N = 8192, because a triangular product on few rows cannot use its shorter k ranges: 4096^3 gains 1.2x.)
-  int64_t ib = forced > 0 ? forced / NB * NB : 1024;
-  if (ib < NB) ib = NB;
+  // and 3 ms at N = 8192, because a triangular product on few rows cannot use its shorter k ranges: 4096^3 gains 1.2x.  Round 6:
+  // the 4096-order inverse for the rows BELOW block row k+1 only, built off the chain: profiles/r06_potrf_panel_inverse_ab.txt.)
+  int64_t ib = 1024;
   if (ib > n) ib = n;
   return ib;
 }
@@ -1657,11 +1327,7 @@ static int binv_build_rec(gpx_ctx* ctx, const double* L, int64_t ld, int64_t sl,
   // T = C A^-1 ; R = 0 - B^-1 T
   if (batch == 1 && s1 >= 1024) {  // one large block: the tuned kernel, both inverses as triangular operands (A^-1: k range
     // of a column tile starts at its diagonal, mode 4; B^-1: ends at it, mode 1) -- n^3 / 3 for the whole recursion
-    static const bool tri_a = !(getenv("GPX_TRTRI_DENSE_A") && atoi(getenv("GPX_TRTRI_DENSE_A")) != 0);
-    if (tri_a)
-      GPX_TRY(launch_gemm_tri(ctx, C, ld, Ai, ib, tmp, s1, s2, s1, s1, false, false, false, 4));
-    else
-      GPX_TRY(launch_gemm(ctx, C, ld, Ai, ib, tmp, s1, s2, s1, s1, false, false, false));
+    GPX_TRY(launch_gemm_tri(ctx, C, ld, Ai, ib, tmp, s1, s2, s1, s1, false, false, false, 4));
     return launch_gemm_tri(ctx, Bi, ib, tmp, s1, R, ib, s2, s1, s2, false, true, false, 1);
   }
   GPX_TRY(launch_gemm_batched(ctx, C, ld, sl, Ai, ib, ib * ib, tmp, s1, ib * ib, s2, s1, s1, false, false, batch));
@@ -1695,8 +1361,7 @@ static int binv_build_range(gpx_ctx* ctx, const double* Ld, int64_t ld, const do
   if (lo == 0)
     hipLaunchKernelGGL(binv_init_kernel, dim3((unsigned)((rows * (ib / 2) + 255) / 256)), dim3(256), 0, ctx->stream, invd, binv,
                        ib, n);
-  static const bool levels = env_i64("GPX_BINV_LEVELS", 1) != 0;
-  if (levels && nfull == 1 && tail == 0 && ib <= 1024 && ((ib / NB) & (ib / NB - 1)) == 0) {
+  if (nfull == 1 && tail == 0 && ib <= 1024 && ((ib / NB) & (ib / NB - 1)) == 0) {
     GPX_TRY(binv_build_levels(ctx, Ld, ld, binv, ib, ib, tmp, lo, hi));
     GPX_HIP(hipGetLastError());
     return 0;
@@ -1726,8 +1391,7 @@ int chol_trtri(gpx_ctx* ctx, const gpx_mat* Lm, double* Linv, double* tmp) {
   // n = 128 * 2^q: the levels up to order 1024 for ALL diagonal blocks at once, one batched pair of launches per level (6
   // launches instead of 2 (n / 128 - n / 1024): 112 at n = 8192, 1.5 ms of the mutual-information design's 6 ms inverse);
   // the recursion then only combines from 1024 up, with the triangular-operand products.
-  static const bool levels = env_i64("GPX_TRTRI_LEVELS", 1) != 0;
-  if (levels && n >= 2048 && ((n / NB) & (n / NB - 1)) == 0) {
+  if (n >= 2048 && ((n / NB) & (n / NB - 1)) == 0) {
     GPX_TRY(binv_build_levels(ctx, Lm->p, Lm->ld, Linv, n, n, tmp, 0, 1024));
     return binv_build_rec(ctx, Lm->p, Lm->ld, 0, Linv, n, 0, n, tmp, 1, 1024);
   }
@@ -1857,29 +1521,6 @@ static int trsm_left_oop_rec(gpx_ctx* ctx, const PotrsPlan& P, int64_t b0, int64
   GPX_TRY(launch_gemm(ctx, P.L + r0 * P.ld + c0, P.ld, W + c0 * ldw, ldw, B + r0 * ldb, ldb, r1 - r0, m, r0 - c0, false, true,
                       false));
   return trsm_left_oop_rec(ctx, P, mid, b1, B, ldb, W, ldw, m);
-}
-
-int chol_trsm_left_oop_panel(gpx_ctx* ctx, const double* L, int64_t ld, int64_t n, const double* binv, int64_t ib, double* B,
-                             int64_t ldb, double* W, int64_t ldw, int64_t m, int64_t r0, int64_t r1) {
-  GPX_ARG(L && binv && B && W && B != W && ib > 0 && r0 % ib == 0 && r0 < r1 && r1 <= n, "trsm panel: bad arguments");
-  if (m == 0) return 0;
-  PotrsPlan P;
-  P.L = L;
-  P.ld = ld;
-  P.n = r1;  // blocks beyond the panel do not exist yet
-  P.ib = P.sib = ib;
-  P.nblk = (r1 + ib - 1) / ib;
-  P.binv = binv;
-  P.binvT = nullptr;
-  P.part = nullptr;
-  // RIGHT-looking across panels (all rows below take this panel's contribution at once, K = r1 - r0): the work sits in the
-  // early panels, which is what an overlap with the factorisation needs.  (Left-looking -- one long-K product per panel, the
-  // shape the GEMM kernel is fastest at -- leaves most of the solve behind the last panel: 739 ms per bench step against
-  // 720 with this form and 710 for factor-then-solve.)
-  GPX_TRY(trsm_left_oop_rec(ctx, P, r0 / ib, P.nblk, B, ldb, W, ldw, m));
-  if (r1 < n)
-    GPX_TRY(launch_gemm(ctx, L + r1 * ld + r0, ld, W + r0 * ldw, ldw, B + r1 * ldb, ldb, n - r1, m, r1 - r0, false, true, false));
-  return 0;
 }
 
 int chol_trsm_left_oop(gpx_ctx* ctx, gpx_mat* Lm, double* B, int64_t ldb, double* W, int64_t ldw, int64_t m) {

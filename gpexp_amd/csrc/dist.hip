@@ -312,16 +312,9 @@ int gpx_comm_allreduce_host(gpx_ctx* ctx, double* inout, int64_t n) {
 //   phase 1 (scatter)     the root sends chunk q to its q-th peer          -- root egress spread over all its links
 //   phase 2 (all-gather)  every peer forwards its chunk to the other peers  -- every link of the mesh carries 1/(W-1)
 // as two grouped sets of ncclSend / ncclRecv: 2/(W-1) of the region's bytes per link instead of all of them.  Regions
-// below GPX_SAG_MIN doubles go from the root to every peer directly (one phase, latency-bound anyway).
+// below 2^16 doubles go from the root to every peer directly (one phase, latency-bound anyway).
 // Asynchronous on the selected stream; every rank must call it with identical arguments.
-static int64_t sag_min_elems() {
-  static int64_t v = -1;
-  if (v < 0) {
-    const char* e = getenv("GPX_SAG_MIN");
-    v = e ? atoll(e) : (int64_t)1 << 16;
-  }
-  return v;
-}
+static int64_t sag_min_elems() { return (int64_t)1 << 16; }
 
 }  // extern "C"
 
@@ -638,10 +631,8 @@ int gpx_dist_ivar_group_at(gpx_ctx* ctx, const gpx_mat* K, int64_t k0, int64_t k
   double* Bk = B->p + r0 * B->ld;
   // The group's triangle through EXPLICIT inverses of its nb-order diagonal blocks (built here from the leaf inverses, batched:
   // ~0.1 ms per group): tri-GEMMs + K >= nb updates instead of the leaf-level recursion (128-row strip kernels and K = 128..1024
-  // products: 15-20 ms of the evaluation stream per C4 step on a rank of 8, against 4 ms of flops).  GPX_IVAR_GROUP_IB: order of
-  // the inverses (default nb; 0 = the leaf recursion).
-  static const int64_t ib_env = getenv("GPX_IVAR_GROUP_IB") ? atoll(getenv("GPX_IVAR_GROUP_IB")) : -1;
-  const int64_t ib = ib_env < 0 ? nb : ib_env / GPX_TILE * GPX_TILE;
+  // products: 15-20 ms of the evaluation stream per C4 step on a rank of 8, against 4 ms of flops).  Order of the inverses: nb.
+  const int64_t ib = nb;
   if (ib >= GPX_TILE && w > ib) {
     const int64_t nblk = (w + ib - 1) / ib;
     const int64_t need = (2 * nblk * ib * ib + w * mcp) * 8;
@@ -974,10 +965,9 @@ static int d2_scratch_ensure(gpx_ctx* ctx, int64_t nb) {
 // calls this; the hot path then finds them large enough.  Blocking.
 // The two products that sit on the chain ACROSS ranks with one block of rows -- the solve of block row k+1 against the
 // prepared inverse and the last update of the staged diagonal block: nb x nb x nb, 256 64-tiles under a serial k range of nb,
-// 55-60 us each -- as slices of the k range (launch_gemm_ksplit_small, as in gpx_refit_rows: 23 + 6 us).  GPX_DIST2_KSPLIT=0: off.
+// 55-60 us each -- as slices of the k range (launch_gemm_ksplit_small, as in gpx_refit_rows: 23 + 6 us).
 static int64_t d2_slices(int64_t m, int64_t n, int64_t k, int64_t nb) {
-  static const int on = [] { const char* e = getenv("GPX_DIST2_KSPLIT"); return e ? atoi(e) : 1; }();
-  if (!on || m % 64 != 0 || n % 64 != 0 || m > nb || n > nb) return 1;
+  if (m % 64 != 0 || n % 64 != 0 || m > nb || n > nb) return 1;
   int64_t parts = 1;
   while (parts < 4 && (m / 64) * (n / 64) * parts < 1024 && k % (2 * parts * 16) == 0 && k / (2 * parts) >= 256) parts *= 2;
   return parts;
@@ -1085,11 +1075,7 @@ static int panel_trsm_impl(gpx_ctx* ctx, gpx_mat* A, int64_t lr0, int64_t m, int
   if (m == 0) return 0;
   const double* D = G->p + doff;
   double* X = A->p + lr0 * A->ld + lc;
-  static int64_t inv_min = -1;
-  if (inv_min < 0) {
-    const char* e = getenv("GPX_DIST2_INV_MIN");  // rows from which the explicit inverse is used, in units of nb; 0 = never
-    inv_min = e ? atoll(e) : 2;
-  }
+  const int64_t inv_min = 2;   // rows from which the explicit inverse is used, in units of nb
   const bool prepared = use_prepared != 0 && w == nb && w > GPX_TILE;   // use_prepared == 2: the caller copies back later
   GPX_ARG(!prepared || (ctx->d2_inv_src == D && ctx->d2_inv_nb == nb), "panel solve: no inverse was prepared for this diagonal block");
   if (prepared || (inv_min > 0 && m >= inv_min * nb && w == nb && w > GPX_TILE)) {
@@ -1254,8 +1240,7 @@ int gpx_dist2_trsv_diag(gpx_ctx* ctx, const gpx_mat* A, int64_t lr, int64_t lc, 
     GPX_HIP(hipMalloc((void**)&ctx->trsv_scratch, (size_t)need));
     ctx->trsv_scratch_bytes = need;
   }
-  static const bool use_dinv = !(getenv("GPX_DIST2_DINV") && atoi(getenv("GPX_DIST2_DINV")) == 0);
-  if (use_dinv && A->dinv && w == A->dinv_nb && lr % w == 0 && (size_t)(lr / w) < A->dinv_ok.size() && A->dinv_ok[(size_t)(lr / w)]) {
+  if (A->dinv && w == A->dinv_nb && lr % w == 0 && (size_t)(lr / w) < A->dinv_ok.size() && A->dinv_ok[(size_t)(lr / w)]) {
     // the block's explicit inverse is at hand (kept by the panel solve): v <- Dinv v or Dinv^T v as a row-per-wave GEMV
     // (the transposed form reads the stored transpose), through the scratch vector
     v->bbox_ok = 0;
@@ -1320,27 +1305,14 @@ int gpx_dist_finish(gpx_ctx* ctx, gpx_mat* K) {
 // =====================================================================================================================
 #include <chrono>
 
-static bool g_in_capture = false;   // debug aid of gpx_program_capture (GPX_PROGRAM_SKIP applies to captures only)
 
 extern "C" {
 
 int gpx_program_run(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const int64_t* extra, int64_t nextra, double* host_ms) {
   GPX_ARG(ctx && (ops || nops == 0) && nops >= 0 && nextra >= 0, "bad program");
   const auto t0 = std::chrono::steady_clock::now();
-  static const bool trace = getenv("GPX_PROGRAM_TRACE") != nullptr;  // debug: name every row on stderr before it is issued
   for (int64_t i = 0; i < nops; ++i) {
     const int64_t* o = ops + 16 * i;
-    if (trace) {
-      fprintf(stderr, "gpx_program_run: row %lld op %lld\n", (long long)i, (long long)o[0]);
-      fflush(stderr);
-      static const char* skip = getenv("GPX_PROGRAM_SKIP");   // debug: comma-separated opcodes NOT to execute (bisecting a capture)
-      if (skip && g_in_capture) {
-        char key[16];
-        snprintf(key, sizeof key, ",%lld,", (long long)o[0]);
-        std::string sk = std::string(",") + skip + ",";
-        if (sk.find(key) != std::string::npos) continue;
-      }
-    }
     gpx_mat* h0 = reinterpret_cast<gpx_mat*>((uintptr_t)o[1]);
     gpx_mat* h1 = reinterpret_cast<gpx_mat*>((uintptr_t)o[2]);
     gpx_mat* h2 = reinterpret_cast<gpx_mat*>((uintptr_t)o[3]);
@@ -1475,14 +1447,9 @@ int gpx_program_capture(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const in
   hipStream_t origin = ctx->streams[0];
   ctx->stream = origin;
   GPX_HIP(hipStreamBeginCapture(origin, hipStreamCaptureModeRelaxed));
-  g_in_capture = true;
   int r = gpx_program_run(ctx, ops, nops, extra, nextra, nullptr);
-  g_in_capture = false;
   hipGraph_t graph = nullptr;
-  static const bool trace = getenv("GPX_PROGRAM_TRACE") != nullptr;
-  if (trace) { fprintf(stderr, "capture: rows issued (rc %d), ending capture\n", r); fflush(stderr); }
   hipError_t e = hipStreamEndCapture(origin, &graph);
-  if (trace) { fprintf(stderr, "capture: hipStreamEndCapture -> %s\n", hipGetErrorString(e)); fflush(stderr); }
   ctx->stream = origin;
   if (r != 0 || e != hipSuccess || !graph) {
     if (graph) (void)hipGraphDestroy(graph);
@@ -1496,9 +1463,7 @@ int gpx_program_capture(gpx_ctx* ctx, const int64_t* ops, int64_t nops, const in
   size_t n = 0;
   (void)hipGraphGetNodes(graph, nullptr, &n);
   g->nodes = (int64_t)n;
-  if (trace) { fprintf(stderr, "capture: %zu nodes, instantiating\n", n); fflush(stderr); }
   e = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
-  if (trace) { fprintf(stderr, "capture: hipGraphInstantiate -> %s\n", hipGetErrorString(e)); fflush(stderr); }
   if (e != hipSuccess) {
     gpx_set_error("program capture: hipGraphInstantiate -> %s", hipGetErrorString(e));
     gpx_graph_free(ctx, g);

@@ -148,6 +148,44 @@ struct Tmp {  // scratch buffers released on scope exit (after a stream sync)
   }
 };
 
+// Bt[m][i] *= s[i] (row-major m x cols, row stride ld)
+__global__ __launch_bounds__(256) void scale_cols_kernel(double* __restrict__ Bt, int64_t ld, const double* __restrict__ s,
+                                                         int64_t cols) {
+  const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+  const int64_t r = blockIdx.y;
+  if (c >= cols) return;
+  double2 v = *reinterpret_cast<double2*>(Bt + r * ld + c);
+  const double2 w = *reinterpret_cast<const double2*>(s + c);
+  v.x *= w.x;
+  v.y *= w.y;
+  *reinterpret_cast<double2*>(Bt + r * ld + c) = v;
+}
+
+}  // namespace
+
+int64_t fitc_n(const gpx_fitc* f) { return f->n; }
+int64_t fitc_np(const gpx_fitc* f) { return f->np; }
+int64_t fitc_nup(const gpx_fitc* f) { return f->nup; }
+
+// beta^T = (P B)^T for B = np x mcp right-hand sides (row stride mcp; K(X, Z) of one chunk of evaluation points) under the
+// Woodbury precision P = Gi - Ks^T A^-1 Ks (Ks = -Kuf Gi, A = La La^T): the point-derivative routines of the reference read
+// `precisionMatrix`, which for a FITC model is exactly this P (gp.py:194-206, 275, 322).  Nothing N x N is formed:
+//   Bt = B^T (mcp x np);  U = Bt Ks^T (mcp x nup);  U <- U La^-T La^-1 = (A^-1 Ks B)^T;  Bt <- Bt Gi - U Ks.
+// Bt: mcp x np doubles (row stride np) = the result; U: mcp x nup doubles of scratch.
+int fitc_solve_beta_t(gpx_ctx* ctx, const gpx_fitc* f, const double* B, int64_t mcp, double* Bt, double* U) {
+  const int64_t np = f->np, nup = f->nup;
+  GPX_TRY(launch_transpose(ctx, B, np, mcp, mcp, Bt, np));
+  GPX_TRY(launch_gemm(ctx, Bt, np, f->Ks->p, f->Ks->ld, U, nup, mcp, nup, np, true, false, false));
+  GPX_TRY(chol_trsm_right(ctx, f->La->p, f->La->ld, f->La->aux, U, nup, mcp, nup));
+  GPX_TRY(chol_trsm_right_n(ctx, f->La->p, f->La->ld, f->La->aux, U, nup, mcp, nup));
+  dim3 grid((unsigned)((np / 2 + 255) / 256), (unsigned)mcp);
+  hipLaunchKernelGGL(scale_cols_kernel, grid, dim3(256), 0, ctx->stream, Bt, np, f->ginv, np);
+  GPX_TRY(launch_gemm(ctx, U, nup, f->Ks->p, f->Ks->ld, Bt, np, mcp, np, nup, false, true, false));
+  GPX_HIP(hipGetLastError());
+  return 0;
+}
+
+namespace {
 }  // namespace
 
 extern "C" {

@@ -372,8 +372,6 @@ __device__ __forceinline__ void gemm_tile(Smem<BT, TE>& sm, const double* A, int
 // TRI (triangular-operand modes, see launch_gemm_tri) is a TEMPLATE parameter: the dense instantiations must stay exactly
 // the hand-scheduled kernel -- with `tri` as a run-time argument the IVAR solve lost 2 % (490 -> 500 ms), hipcc's
 // scheduling of the k-loop is that sensitive to what surrounds it.
-__device__ int g_tri2_lpt = 1;   // GPX_TRI2_LPT=0 (A/B): the row-major order inside a super-block for triangular-operand launches
-
 template <bool BT, bool ACC, bool LOWER, int TE, int TRI>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64_t lda, const double* B, int64_t ldb,
                                                           double* C, int64_t ldc, int nk, int tiles_m, int tiles_n,
@@ -398,9 +396,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const double* A, int64
   const int xcd = w & 7, q = w >> 3;
   const int sbs2 = 2 * sb_shift;
   int by, bx;
-  const int lpt_order = (TRI == 1 || TRI == 2 || TRI == 4) ? g_tri2_lpt : 0;
+  // (triangular operands: longest k range first inside a super-block, tile_of's rot 2 / 3 / 4)
   if (!tile_of<LOWER>((q >> sbs2) * 8 + xcd, q & ((1 << sbs2) - 1), tiles_m, tiles_n, sb_cols, sb_shift, &by, &bx,
-                      tri == 2 ? (lpt_order ? 2 : 1) : (tri == 4 ? (lpt_order ? 3 : 1) : (tri == 1 && lpt_order ? 4 : 0))))
+                      tri == 2 ? 2 : (tri == 4 ? 3 : (tri == 1 ? 4 : 0))))
     return;
   // (Dealing single tiles of a triangular product to XCDs diagonally balances them too, but gives up the super-blocks'
   // operand reuse in L2: measured 11.9 ms against 13.1 dense for 28672 x 4096 x 4096 -- fabric-bound.)
@@ -681,17 +679,9 @@ int launch_gemm_tri(gpx_ctx* ctx, const double* A, int64_t lda, const double* B,
   GPX_ARG(m % 128 == 0 && n % 128 == 0 && k % KB == 0 && k > 0, "gemm: m,n must be multiples of 128 and k of 16");
   GPX_ARG((lda % 2) == 0 && (ldb % 2) == 0, "gemm: leading dimensions must be even (16-byte loads)");
   GPX_ARG(!lower || m == n, "gemm: lower-only update needs a square C");
-  static int lpt_set = -1;
-  if (lpt_set < 0) {
-    const char* e5 = getenv("GPX_TRI2_LPT");
-    lpt_set = e5 ? atoi(e5) : 1;
-    if (lpt_set != 1) GPX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tri2_lpt), &lpt_set, sizeof(int)));
-  }
-  static int small_max = -1;
-  if (small_max < 0) {
-    const char* e3 = getenv("GPX_GEMM_SMALL_MAX");    // use 64x64 tiles while the 128-tile count is below this
-    small_max = e3 ? atoi(e3) : 1024;  // C4 potrf: 270 ms without, 251 ms at 256, 247 ms at 1024
-  }
+  // 64x64 tiles while the 128-tile count is below this (C4 potrf, round 1: 270 ms without, 251 ms at 256, 247 ms at 1024;
+  // round 6, same question on today's factorisation: 256 / 512 -> +3.4 / +0.8 ms, profiles/r06_potrf_panel_inverse_ab.txt)
+  constexpr int small_max = 1024;
   const double tiles128 =
       lower ? 0.5 * (double)(m / 128) * ((double)(m / 128) + 1.0) : (double)(m / 128) * (double)(n / 128);
   // In-place leaf products (C aliases A or B, n or m == 128) are race-free only when ONE workgroup's tile spans the
@@ -703,11 +693,7 @@ int launch_gemm_tri(gpx_ctx* ctx, const double* A, int64_t lda, const double* B,
   // tiles = 4.06 rounds, 53 -> 55 TF/s with the tail; 16384^2: 65.2 -> 66.2).  Rectangular launches measured 1-4 % SLOWER
   // with it: their tile counts divide evenly, and what looks like a drain there is the clock/fabric ramp after a stretch
   // of small kernels (the same launch repeated back to back goes 4.86 -> 3.84 ms over ~30 ms, scripts/probe_b2b.py).
-  static int tail_target = -1;
-  if (tail_target < 0) {
-    const char* e4 = getenv("GPX_GEMM_TAIL");  // 64-tiles wanted in the tail; 0 switches the tail off
-    tail_target = e4 ? atoi(e4) : 512;
-  }
+  constexpr int tail_target = 512;  // 64-tiles wanted in the tail
   int64_t tr = 0;
   if (te == 128 && lower && !aliased && tail_target > 0 && m >= 512) {
     const int64_t tm = m / 128, tn = n / 128;
@@ -818,11 +804,7 @@ int launch_dist2_update(gpx_ctx* ctx, double* C, int64_t ldc, int64_t lr0, int64
     }
   }
   if (tiles128 == 0.0) return 0;
-  static int small_max = -1;
-  if (small_max < 0) {
-    const char* e3 = getenv("GPX_DIST2_SMALL_MAX");  // 64-tiles while fewer 128-tiles than this have work
-    small_max = e3 ? atoi(e3) : 512;
-  }
+  constexpr int small_max = 512;  // 64-tiles while fewer 128-tiles than this have work
   const int te = tiles128 < (double)small_max ? 64 : 128;
   const int tm = (int)(m / te), tn = (int)(n / te), tpb = (int)(nb / te);
   u.nsc = (tn + 7) / 8;
@@ -848,12 +830,6 @@ int launch_dist2_update(gpx_ctx* ctx, double* C, int64_t ldc, int64_t lr0, int64
     int64_t by_full = (li_full - lr0 / nb) * tpb;                        // first tile row with every column of the super-block active
     if (by_full < 0) by_full = 0;
     int srf = (int)((by_full + 7) / 8);
-    static int full_first = -1;
-    if (full_first < 0) {
-      const char* e5 = getenv("GPX_DIST2_FULL_FIRST");   // 0: round 3's order (every column's staircase blocks in place)
-      full_first = e5 ? atoi(e5) : 1;
-    }
-    if (!full_first) srf = srm;
     if (srf < srm) srf = srm;
     if (srf > u.nsr) srf = u.nsr;
     u.sr_full[sc] = srf;

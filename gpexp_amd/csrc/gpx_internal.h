@@ -48,15 +48,7 @@ static inline int64_t gpx_round_up(int64_t v, int64_t m) { return (v + m - 1) / 
 // Leading dimension for a padded row of `cols` doubles: one extra 128-byte line per row when the row stride would
 // be a large power of two (N = 32768 -> 256 KiB).  Measured NEUTRAL on MI355X (GEMM 66.98 vs 66.97 TF/s: the L2 /
 // channel address hashing already spreads such strides); kept because it decouples ld from the padded width.
-static inline int64_t gpx_skew_ld(int64_t cols) {
-  static int64_t skew = -1;   // GPX_LD_SKEW (experiment): doubles added to a power-of-two-ish row stride; default 16 = one 128-byte line
-  if (skew < 0) {
-    const char* e = getenv("GPX_LD_SKEW");
-    skew = e ? atoll(e) : 16;
-    if (skew < 0 || (skew & 1)) skew = 16;
-  }
-  return (cols >= 1024 && cols % 256 == 0) ? cols + skew : cols;
-}
+static inline int64_t gpx_skew_ld(int64_t cols) { return (cols >= 1024 && cols % 256 == 0) ? cols + 16 : cols; }
 
 // Row stride of the rows region of a packed panel piece (dist.hip): nb + GPX_G_SKEW doubles.  At nb = 512 a stride of nb is
 // exactly 4 KiB, the textbook channel-conflict stride; measured on MI355X it makes NO difference (66.0 TF/s with skew 0, 65.9
@@ -136,7 +128,6 @@ struct gpx_ctx {
                              // 4 = evaluation (low priority, unmasked): the streamed IVAR solve beside the factorisation,
                              // 3 = background, 5 = bulk: CU-masked (leave 4 CUs per XCD to the other streams) when the runtime allows
   std::vector<hipEvent_t> sync_events;  // gpx_event_record / gpx_event_wait ids
-  void* coop_state = nullptr;   // flags of potrf_coop_kernel (chol.hip), zeroed on the stream before every launch
   std::unordered_set<const gpx_mat*> live_mats;  // every matrix this context handed out and has not freed (gpx_program_run checks its rows against it)
   // work buffers of a blocked factorisation in flight (set by gpx_potrf around chol_potrf, NULL otherwise): storage of the
   // explicit block inverses being built, order of those blocks, scratch for their build and for the panel solves
@@ -145,12 +136,7 @@ struct gpx_ctx {
   double* pw_tmp_build;
   double* pw_tmp_T;
   int pw_done;   // set by the factorisation when it has built every block inverse into pw_binv
-  // streamed evaluation (gpx_fit_ivar): the blocked factorisation records panel_events[k] once panel k of L (its diagonal
-  // block, the rows below it and the block inverses) is final; panel_width = its panel width, 0 = no hook
-  std::vector<hipEvent_t> panel_events;
-  int64_t panel_width;
-  int panel_count;
-  std::vector<hipEvent_t> la_events;    // look-ahead factorisation (chol.hip): column ready / chain done / masked chunk done
+  std::vector<hipEvent_t> la_events;    // look-ahead factorisation (chol.hip): block row k+1 + next diagonal block ready / chain done
   hipEvent_t ev_side = nullptr;         // fork / join of gpx_refit_rows' copy of the kept rows on the low-priority stream
   int cus;
   // cached device allocations (exact-size reuse)
@@ -240,12 +226,8 @@ int launch_kfill_rows(gpx_ctx* ctx, const KParams& kp, const double* X, int64_t 
 // gemm_f64.hip:  C[m x n] = (accumulate ? C - A*op(B) : A*op(B)),  m,n multiples of 128, k multiple of 16
 // Kernels of the latency-bound chains (the diagonal block's factorisation and inversion, the panel stream of the distributed
 // loop) run BESIDE chip-filling updates and share their CUs with resident GEMM waves; launched on the context's chain stream
-// (streams[1]) they raise their waves' issue priority (s_setprio 3) so that the CU's arbiter serves them first.  GPX_CHAIN_PRIO=0
-// switches it off (A/B).
-static inline int gpx_chain_prio(const gpx_ctx* ctx) {
-  static const int on = [] { const char* e = getenv("GPX_CHAIN_PRIO"); return e ? atoi(e) : 1; }();
-  return (on && ctx->stream == ctx->streams[1]) ? 1 : 0;
-}
+// (streams[1]) they raise their waves' issue priority (s_setprio 3) so that the CU's arbiter serves them first.
+static inline int gpx_chain_prio(const gpx_ctx* ctx) { return ctx->stream == ctx->streams[1] ? 1 : 0; }
 int launch_gemm(gpx_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
                 int64_t m, int64_t n, int64_t k, bool bt, bool accumulate, bool lower);
 
@@ -304,8 +286,6 @@ int chol_trsm_left_group(gpx_ctx* ctx, const double* Lg, int64_t ld, const doubl
                          double* B, int64_t ldb, int64_t m, double* inv, double* tmp, double* W, int64_t ldw);
 // one right-looking panel step of that solve with the rows [r0, r1) of the factor only (a finished look-ahead panel): W[r0:r1]
 // from B[r0:r1] through the block inverses at `binv` (order ib, row stride ib), then B[r1:] -= L[r1:, r0:r1] W[r0:r1]
-int chol_trsm_left_oop_panel(gpx_ctx* ctx, const double* L, int64_t ld, int64_t n, const double* binv, int64_t ib, double* B,
-                             int64_t ldb, double* W, int64_t ldw, int64_t m, int64_t r0, int64_t r1);
 int64_t chol_potrf_panel_width(int64_t n);  // width of the look-ahead panels chol_potrf uses for order n (0: not blocked)
 int64_t chol_potrs_scratch_bytes(int64_t n);
 int chol_potrs(gpx_ctx* ctx, gpx_mat* L, double* v, double* scratch);
@@ -313,6 +293,13 @@ int chol_potrs(gpx_ctx* ctx, gpx_mat* L, double* v, double* scratch);
 int launch_gemv_sub(gpx_ctx* ctx, const double* A, int64_t ld, int64_t rows, int64_t cols, const double* x, double* y);
 int chol_block_transpose(gpx_ctx* ctx, const double* in, double* out, int64_t n);
 int chol_tri_gemv(gpx_ctx* ctx, const double* M, int64_t ld, int64_t sz, const double* y, double* x, int lower);
+
+// fitc.hip: what grad.hip needs of a FITC model (the struct is private to fitc.hip)
+struct gpx_fitc;
+int64_t fitc_n(const gpx_fitc* f);
+int64_t fitc_np(const gpx_fitc* f);
+int64_t fitc_nup(const gpx_fitc* f);
+int fitc_solve_beta_t(gpx_ctx* ctx, const gpx_fitc* f, const double* B, int64_t mcp, double* Bt, double* U);
 
 // reduce.hip
 // out[j] = sum_i B[i][j] * v[i]   (v == nullptr: sum_i B[i][j]^2), i < rows, j < pcols; deterministic

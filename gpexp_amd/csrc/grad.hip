@@ -336,14 +336,14 @@ struct Scratch {
   }
 };
 
-int check_args(int kind, int d, const gpx_mat* L, const gpx_mat* X, const gpx_mat* Z) {
-  GPX_ARG(L && X && Z, "NULL argument");
-  GPX_ARG(L->factored && L->aux, "matrix has not been factored by gpx_potrf");
+int check_args(int kind, int d, const gpx_mat* L, const gpx_mat* X, const gpx_mat* Z, const gpx_fitc* fitc = nullptr) {
+  GPX_ARG((L || fitc) && X && Z, "NULL argument");
+  GPX_ARG(fitc || (L->factored && L->aux), "matrix has not been factored by gpx_potrf");
   GPX_ARG(kind == GPX_K_SE || (kind == GPX_K_MEHLER && d == 1),
           "point derivatives exist for the squared-exponential and the 1-D Mehler kernel only "
           "(as in the reference: kernels.py:146-181, 295-324)");
   GPX_ARG(X->cols == d && X->pcols == d && Z->cols == d && Z->pcols == d, "point sets must be unpadded (n x d)");
-  GPX_ARG(X->rows == L->rows && Z->rows > 0, "X does not match the factor / no evaluation points");
+  GPX_ARG(X->rows == (fitc ? fitc_n(fitc) : L->rows) && Z->rows > 0, "X does not match the factor / no evaluation points");
   return 0;
 }
 
@@ -357,9 +357,25 @@ int check_args(int kind, int d, const gpx_mat* L, const gpx_mat* X, const gpx_ma
 // skipped, a third of the gradient's work.
 int solve_beta(gpx_ctx* ctx, const KParams& kp, const gpx_mat* L, const gpx_mat* X, const double* Zc, int64_t mc,
                int64_t mcp, const double* d_bias, double* A, double* B, double* T, int transposed, double** out,
-               const gpx_mat* Wfwd = nullptr) {
-  const int64_t n = L->rows, np = L->prows;
+               const gpx_mat* Wfwd = nullptr, const gpx_fitc* fitc = nullptr, double* U = nullptr) {
+  const int64_t n = fitc ? fitc_n(fitc) : L->rows, np = fitc ? fitc_np(fitc) : L->prows;
   double *cur, *other;   // cur: beta^T
+  if (fitc != nullptr) {
+    // FITC model: beta = P (K(X, Zc) + bias) with the Woodbury precision (fitc.hip); U = mcp x nup doubles of scratch
+    GPX_ARG(U != nullptr && Wfwd == nullptr, "solve_beta: the FITC form needs its scratch");
+    GPX_TRY(launch_kfill(ctx, kp, X->p, n, Zc, mc, 0, nullptr, 0, 0.0, A, np, mcp, mcp));
+    if (d_bias) {
+      dim3 grid((unsigned)((mc + 255) / 256), (unsigned)n);
+      hipLaunchKernelGGL(add_row_bias_kernel, grid, dim3(256), 0, ctx->stream, A, mcp, n, mc, d_bias);
+    }
+    GPX_TRY(fitc_solve_beta_t(ctx, fitc, A, mcp, B, U));
+    if (transposed) {
+      *out = B;
+      return 0;
+    }
+    *out = A;
+    return launch_transpose(ctx, B, mcp, np, np, A, mcp);
+  }
   if (Wfwd != nullptr) {
     GPX_ARG(!d_bias && Wfwd->prows == np && Wfwd->pcols == mcp, "solve_beta: the kept forward solve does not match");
     if (T != nullptr) {
@@ -580,15 +596,16 @@ int gpx_ivar_grad_rows(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhy
   return 0;
 }
 
-int gpx_var_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
-                 const gpx_mat* Z, const double* noise_deriv, const double* eval_bias, const double* dk_bias,
-                 double* out) {
+// gpx_var_grad / gpx_fitc_var_grad: `fitc` != NULL takes beta from the FITC model's Woodbury precision instead of the factor L
+static int var_grad_impl(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_fitc* fitc,
+                         const gpx_mat* X, const gpx_mat* Z, const double* noise_deriv, const double* eval_bias,
+                         const double* dk_bias, double* out) {
   GPX_ARG(ctx && out, "NULL argument");
-  GPX_TRY(check_args(kind, d, L, X, Z));
+  GPX_TRY(check_args(kind, d, L, X, Z, fitc));
   KParams kp;
   GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
   GPX_TRY(gpx_kparams_sets(ctx, &kp, X, Z));
-  const int64_t n = L->rows, np = L->prows, M = Z->rows;
+  const int64_t n = fitc ? fitc_n(fitc) : L->rows, np = fitc ? fitc_np(fitc) : L->prows, M = Z->rows;
   GPX_ARG(np <= 65535, "var_grad: at most 65535 training points");
   const int64_t mcmax = grad_chunk(np);
   const int64_t mc_alloc = gpx_round_up(M < mcmax ? M : mcmax, GPX_TILE);
@@ -602,8 +619,10 @@ int gpx_var_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, con
   GPX_TRY(upload(ctx, sc, noise_deriv, n * d, &d_nd));
   GPX_TRY(upload(ctx, sc, eval_bias, n, &d_eb));
   GPX_TRY(upload(ctx, sc, dk_bias, n * d, &d_db));
-  double* T;
-  GPX_TRY(solve_scratch(ctx, sc, np, mc_alloc, &T));
+  double* T = nullptr;
+  void* pU = nullptr;
+  if (fitc) GPX_TRY(sc.get(mc_alloc * fitc_nup(fitc) * 8, &pU));
+  else GPX_TRY(solve_scratch(ctx, sc, np, mc_alloc, &T));
   // The (N d) x M result goes to PAGEABLE host memory by contract: every strided copy blocks the calling thread.  So the
   // coordinates are pipelined -- coordinate l+1's kernels are queued BEFORE the copy of coordinate l is issued (two output
   // buffers, the copy on the low-priority stream behind an event), and the GPU computes while the host sits in the copy.
@@ -624,7 +643,7 @@ int gpx_var_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, con
   auto compute = [&](const Item& it, int b) -> int {
     const double* Zc = Z->p + it.j0 * d;
     if (it.l == 0) {
-      GPX_TRY(solve_beta(ctx, kp, L, X, Zc, it.mc, it.mcp, d_eb, (double*)pW, (double*)pWt, T, 0, &W));
+      GPX_TRY(solve_beta(ctx, kp, L, X, Zc, it.mc, it.mcp, d_eb, (double*)pW, (double*)pWt, T, 0, &W, nullptr, fitc, (double*)pU));
       Cl = W == (double*)pW ? (double*)pWt : (double*)pW;   // the buffer the solve no longer needs
     }
     dim3 ga((unsigned)((np + 255) / 256), (unsigned)np);
@@ -658,14 +677,14 @@ int gpx_var_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, con
   return r;
 }
 
-int gpx_var_grad_newpt(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
-                       const gpx_mat* Z, double* out) {
+static int var_grad_newpt_impl(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_fitc* fitc,
+                        const gpx_mat* X, const gpx_mat* Z, double* out) {
   GPX_ARG(ctx && out, "NULL argument");
-  GPX_TRY(check_args(kind, d, L, X, Z));
+  GPX_TRY(check_args(kind, d, L, X, Z, fitc));
   KParams kp;
   GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
   GPX_TRY(gpx_kparams_sets(ctx, &kp, X, Z));
-  const int64_t n = L->rows, np = L->prows, M = Z->rows;
+  const int64_t n = fitc ? fitc_n(fitc) : L->rows, np = fitc ? fitc_np(fitc) : L->prows, M = Z->rows;
   const int64_t mcmax = grad_chunk(np);
   const int64_t mc_alloc = gpx_round_up(M < mcmax ? M : mcmax, GPX_TILE);
   Scratch sc(ctx);
@@ -673,21 +692,25 @@ int gpx_var_grad_newpt(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhy
   GPX_TRY(sc.get(np * mc_alloc * 8, &pW));
   GPX_TRY(sc.get(np * mc_alloc * 8, &pWt));
   GPX_TRY(sc.get(M * d * 8, &pO));
-  double* T;
-  GPX_TRY(solve_scratch(ctx, sc, np, mc_alloc, &T));
+  double* T = nullptr;
+  void* pU = nullptr;
+  if (fitc) GPX_TRY(sc.get(mc_alloc * fitc_nup(fitc) * 8, &pU));
+  else GPX_TRY(solve_scratch(ctx, sc, np, mc_alloc, &T));
   for (int64_t j0 = 0; j0 < M; j0 += mcmax) {
     const int64_t mc = (M - j0) < mcmax ? (M - j0) : mcmax;
     const int64_t mcp = gpx_round_up(mc, GPX_TILE);
     double* beta;
     if (kind == GPX_K_SE) {   // beta^T: row m contiguous over the training points, and no transpose back
-      GPX_TRY(solve_beta(ctx, kp, L, X, Z->p + j0 * d, mc, mcp, nullptr, (double*)pW, (double*)pWt, T, 1, &beta));
+      GPX_TRY(solve_beta(ctx, kp, L, X, Z->p + j0 * d, mc, mcp, nullptr, (double*)pW, (double*)pWt, T, 1, &beta, nullptr, fitc,
+                         (double*)pU));
 #define GPX_CALL(DM_)                                                                                                      \
   hipLaunchKernelGGL((var_grad_newpt_se_kernel<DM_>), dim3((unsigned)mc), dim3(256), 0, ctx->stream, kp, X->p, n, Z->p,     \
                      (const double*)beta, np, j0, (double*)pO)
       GPX_SE_DISPATCH(d, GPX_CALL);
 #undef GPX_CALL
     } else {
-      GPX_TRY(solve_beta(ctx, kp, L, X, Z->p + j0 * d, mc, mcp, nullptr, (double*)pW, (double*)pWt, T, 0, &beta));
+      GPX_TRY(solve_beta(ctx, kp, L, X, Z->p + j0 * d, mc, mcp, nullptr, (double*)pW, (double*)pWt, T, 0, &beta, nullptr, fitc,
+                         (double*)pU));
       hipLaunchKernelGGL(var_grad_newpt_kernel, dim3((unsigned)mc), dim3(256), 0, ctx->stream, kp, X->p, n, Z->p,
                          (const double*)beta, mcp, j0, (double*)pO);
     }
@@ -696,6 +719,32 @@ int gpx_var_grad_newpt(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhy
   GPX_HIP(hipMemcpyAsync(out, pO, (size_t)(M * d * 8), hipMemcpyDeviceToHost, ctx->stream));
   GPX_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
+}
+
+int gpx_var_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
+                 const gpx_mat* Z, const double* noise_deriv, const double* eval_bias, const double* dk_bias,
+                 double* out) {
+  return var_grad_impl(ctx, kind, d, hyp, nhyp, L, nullptr, X, Z, noise_deriv, eval_bias, dk_bias, out);
+}
+
+int gpx_var_grad_newpt(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, const gpx_mat* L, const gpx_mat* X,
+                       const gpx_mat* Z, double* out) {
+  return var_grad_newpt_impl(ctx, kind, d, hyp, nhyp, L, nullptr, X, Z, out);
+}
+
+// The same two derivatives on a FITC model (round 6): the reference computes them from whatever `precisionMatrix` holds, for
+// FITC the Woodbury precision (gp.py:194-206, 275, 322); beta = P K(X, Z) comes from the model's factors (fitc.hip), the rest is
+// the dense path's kernels.  (kind, d, hyp): the kernel the model was fitted with.
+int gpx_fitc_var_grad(gpx_ctx* ctx, const gpx_fitc* f, int kind, int d, const double* hyp, int nhyp, const gpx_mat* X,
+                      const gpx_mat* Z, const double* noise_deriv, const double* eval_bias, const double* dk_bias, double* out) {
+  GPX_ARG(f != nullptr, "fitc model is NULL");
+  return var_grad_impl(ctx, kind, d, hyp, nhyp, nullptr, f, X, Z, noise_deriv, eval_bias, dk_bias, out);
+}
+
+int gpx_fitc_var_grad_newpt(gpx_ctx* ctx, const gpx_fitc* f, int kind, int d, const double* hyp, int nhyp, const gpx_mat* X,
+                            const gpx_mat* Z, double* out) {
+  GPX_ARG(f != nullptr, "fitc model is NULL");
+  return var_grad_newpt_impl(ctx, kind, d, hyp, nhyp, nullptr, f, X, Z, out);
 }
 
 }  // extern "C"

@@ -18,7 +18,31 @@ namespace {
 constexpr int TS = 64;
 
 // ---- lml_grad ------------------------------------------------------------------------------------------
-// partial[block][q], q = 0..d-1: sum T_ij K0_ij e_k^2 (scaled differences), q = d: sum T_ij K0_ij, q = d+1: sum_i T_ii
+// One pair of points under a stationary kernel with hyper-parameter derivatives: acc = the scaled squared distance (SE: sum_k
+// e_k^2; Matern: t^2 with t = sqrt(nu') r / rho).  kv = k(a, b) without the nugget; dv = rho dk/d rho for the isotropic Materns
+// (round 6; the reference's own Matern raises, kernels.py:93-97):
+//   nu = 3/2: k = s (1 + t) e^-t,           dk/dt = -s t e^-t            rho dk/d rho = -t dk/dt = s t^2 e^-t
+//   nu = 5/2: k = s (1 + t + t^2/3) e^-t,   dk/dt = -s t (1 + t) e^-t / 3                     = s t^2 (1 + t) e^-t / 3
+__device__ __forceinline__ void lml_pair(const KParams& kp, double acc, double* kv, double* dv) {
+  if (kp.kind == GPX_K_SE) {
+    *kv = kp.sig * exp(-0.5 * acc);
+    *dv = 0.0;
+    return;
+  }
+  const double t = sqrt(acc), e = kp.sig * exp(-t);
+  if (kp.kind == GPX_K_MATERN32) {
+    *kv = (1.0 + t) * e;
+    *dv = acc * e;
+  } else {
+    *kv = (1.0 + t + acc * (1.0 / 3.0)) * e;
+    *dv = acc * (1.0 + t) * e * (1.0 / 3.0);
+  }
+}
+// number of length-type hyper-parameters in the trace sums: d correlation lengths (SE) or the one rho (Matern)
+__host__ __device__ __forceinline__ int lml_nd(int kind, int d) { return kind == GPX_K_SE ? d : 1; }
+
+// partial[block][q], q = 0..nd-1: sum T_ij K0_ij e_k^2 (SE: scaled differences, nd = d) or sum T_ij rho dK_ij/d rho (Matern, nd = 1),
+// q = nd: sum T_ij K0_ij, q = nd+1: sum_i T_ii
 __global__ __launch_bounds__(256) void lmlgrad_kernel(KParams kp, const double* __restrict__ X, int64_t n,
                                                       const double* __restrict__ P, int64_t ld,
                                                       const double* __restrict__ alpha,
@@ -44,7 +68,7 @@ __global__ __launch_bounds__(256) void lmlgrad_kernel(KParams kp, const double* 
   __syncthreads();
   const int tx = t & 31, ty = t >> 5;
   double tk[16];  // T_ij * K0_ij of this thread's 8 rows x 2 columns
-  double diag = 0.0;
+  double diag = 0.0, drho = 0.0;
 #pragma unroll
   for (int a = 0; a < 8; ++a) {
     const int r = ty + 8 * a;
@@ -61,16 +85,22 @@ __global__ __launch_bounds__(256) void lmlgrad_kernel(KParams kp, const double* 
           acc = fma(e, e, acc);
         }
         const double tij = alpha[gi] * alpha[gj] - psign * (gi >= gj ? P[gi * ld + gj] : P[gj * ld + gi]);
-        v = weight * tij * kp.sig * exp(-0.5 * acc);
+        double kv, dv;
+        lml_pair(kp, acc, &kv, &dv);
+        v = weight * tij * kv;
+        drho = fma(weight * tij, dv, drho);
         if (gi == gj) diag += tij;
       }
       tk[a * 2 + c] = v;
     }
   }
   const int lane = t & 63, wave = t >> 6;
-  for (int q = 0; q <= d + 1; ++q) {
+  const int nd = lml_nd(kp.kind, d);
+  for (int q = 0; q <= nd + 1; ++q) {
     double s = 0.0;
-    if (q < d) {
+    if (q < nd && kp.kind != GPX_K_SE) {
+      s = drho;
+    } else if (q < nd) {
 #pragma unroll
       for (int a = 0; a < 8; ++a) {
         const int r = ty + 8 * a;
@@ -80,7 +110,7 @@ __global__ __launch_bounds__(256) void lmlgrad_kernel(KParams kp, const double* 
           s = fma(tk[a * 2 + c], e * e, s);
         }
       }
-    } else if (q == d) {
+    } else if (q == nd) {
 #pragma unroll
       for (int a = 0; a < 16; ++a) s += tk[a];
     } else {
@@ -91,7 +121,7 @@ __global__ __launch_bounds__(256) void lmlgrad_kernel(KParams kp, const double* 
     if (lane == 0) red[wave] = s;
     __syncthreads();
     if (t == 0)
-      partial[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (d + 2) + q] = (red[0] + red[1]) + (red[2] + red[3]);
+      partial[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (nd + 2) + q] = (red[0] + red[1]) + (red[2] + red[3]);
   }
 }
 
@@ -136,7 +166,7 @@ __global__ __launch_bounds__(256) void lmlgrad_slab_kernel(KParams kp, const dou
   __syncthreads();
   const int tx = t & 31, ty = t >> 5;
   double tk[16];
-  double diag = 0.0;
+  double diag = 0.0, drho = 0.0;
 #pragma unroll
   for (int a = 0; a < 8; ++a) {
     const int r = ty + 8 * a;
@@ -153,16 +183,23 @@ __global__ __launch_bounds__(256) void lmlgrad_slab_kernel(KParams kp, const dou
           acc = fma(e, e, acc);
         }
         const double tij = alpha[gi] * alpha[gj] - Z[(li0 + r) * ldz + (lj0 + cc)];
-        v = (gj == gi ? 1.0 : 2.0) * tij * kp.sig * exp(-0.5 * acc);
+        double kv, dv;
+        lml_pair(kp, acc, &kv, &dv);
+        const double w = gj == gi ? 1.0 : 2.0;
+        v = w * tij * kv;
+        drho = fma(w * tij, dv, drho);
         if (gi == gj) diag += tij;
       }
       tk[a * 2 + c] = v;
     }
   }
   const int lane = t & 63, wave = t >> 6;
-  for (int q = 0; q <= d + 1; ++q) {
+  const int nd = lml_nd(kp.kind, d);
+  for (int q = 0; q <= nd + 1; ++q) {
     double s = 0.0;
-    if (q < d) {
+    if (q < nd && kp.kind != GPX_K_SE) {
+      s = drho;
+    } else if (q < nd) {
 #pragma unroll
       for (int a = 0; a < 8; ++a) {
         const int r = ty + 8 * a;
@@ -172,7 +209,7 @@ __global__ __launch_bounds__(256) void lmlgrad_slab_kernel(KParams kp, const dou
           s = fma(tk[a * 2 + c], e * e, s);
         }
       }
-    } else if (q == d) {
+    } else if (q == nd) {
 #pragma unroll
       for (int a = 0; a < 16; ++a) s += tk[a];
     } else {
@@ -183,7 +220,7 @@ __global__ __launch_bounds__(256) void lmlgrad_slab_kernel(KParams kp, const dou
     if (lane == 0) red[wave] = s;
     __syncthreads();
     if (t == 0)
-      partial[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (d + 2) + q] = (red[0] + red[1]) + (red[2] + red[3]);
+      partial[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (nd + 2) + q] = (red[0] + red[1]) + (red[2] + red[3]);
   }
 }
 
@@ -338,8 +375,9 @@ int gpx_lml_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, con
                  const double* alpha, double* grad) {
   GPX_ARG(ctx && L && X && alpha && grad, "NULL argument");
   GPX_ARG(L->factored && L->aux, "matrix has not been factored by gpx_potrf");
-  GPX_ARG(kind == GPX_K_SE, "lml_grad: only the squared-exponential kernel has hyper-parameter derivatives "
-                            "(the reference raises for the others, kernels.py:93-97)");
+  GPX_ARG(kind == GPX_K_SE || kind == GPX_K_MATERN32 || kind == GPX_K_MATERN52,
+          "lml_grad: hyper-parameter derivatives exist for the squared exponential (kernels.py:125-144) and -- round 6, absent in the "
+          "reference, whose Matern raises (kernels.py:93-97) -- the isotropic Materns");
   KParams kp;
   GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
   GPX_ARG(X->cols == d && X->pcols == d && X->rows == L->rows, "X does not match the factor");
@@ -351,7 +389,7 @@ int gpx_lml_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, con
     Scratch sc(ctx);
     void *pal, *ppart, *pout;
     const int64_t tiles = gpx_round_up(n, TS) / TS;
-    const int nq = d + 2;
+    const int nq = lml_nd(kind, d) + 2;
     do {
       if ((r = sc.get(n * 8, &pal)) != 0) break;
       if ((r = sc.get(tiles * tiles * nq * 8, &ppart)) != 0) break;
@@ -370,9 +408,11 @@ int gpx_lml_grad(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, con
       if (hipMemcpyAsync(h.data(), pout, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
           hipStreamSynchronize(ctx->stream) != hipSuccess) { r = -2; break; }
       // scaled difference e_k = D_k / cl_k  ->  dK/d cl_k = K0 D_k^2 / cl_k^3 = K0 e_k^2 / cl_k
-      for (int k = 0; k < d; ++k) grad[k] = 0.5 * h[(size_t)k] / hyp[k];
-      grad[d] = 0.5 * h[(size_t)d] / hyp[d];   // dK/d signalSize = K0 / signalSize
-      grad[d + 1] = 0.5 * h[(size_t)d + 1];    // dK/d noise = I (caller scales by 2*noise, gp.py:463-464)
+      // (Matern: one entry, sum T rho dK/d rho -> / rho; hyp = [rho, signalSize])
+      const int nd = nq - 2;
+      for (int k = 0; k < nd; ++k) grad[k] = 0.5 * h[(size_t)k] / hyp[k];
+      grad[nd] = 0.5 * h[(size_t)nd] / hyp[nd];   // dK/d signalSize = K0 / signalSize
+      grad[nd + 1] = 0.5 * h[(size_t)nd + 1];     // dK/d noise = I (caller scales by 2*noise, gp.py:463-464)
     } while (0);
   }
   gpx_mat_free(ctx, P);
@@ -392,14 +432,15 @@ int gpx_lml_grad_slab(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp
                       const double* alpha, int64_t r0, int64_t r1, double* sums) {
   GPX_ARG(ctx && L && X && alpha && sums, "NULL argument");
   GPX_ARG(L->factored && L->aux, "matrix has not been factored by gpx_potrf");
-  GPX_ARG(kind == GPX_K_SE, "lml_grad: only the squared-exponential kernel has hyper-parameter derivatives "
-                            "(the reference raises for the others, kernels.py:93-97)");
+  GPX_ARG(kind == GPX_K_SE || kind == GPX_K_MATERN32 || kind == GPX_K_MATERN52,
+          "lml_grad: hyper-parameter derivatives exist for the squared exponential (kernels.py:125-144) and -- round 6, absent in the "
+          "reference, whose Matern raises (kernels.py:93-97) -- the isotropic Materns");
   KParams kp;
   GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
   GPX_ARG(X->cols == d && X->pcols == d && X->rows == L->rows, "X does not match the factor");
   const int64_t n = L->rows, np = L->prows;
   GPX_ARG(r0 >= 0 && r0 < r1 && r1 <= np && r0 % GPX_TILE == 0 && r1 % GPX_TILE == 0, "slab bounds must be multiples of 128 inside the padded order");
-  const int nq = d + 2;
+  const int nq = lml_nd(kind, d) + 2;
   for (int q = 0; q < nq; ++q) sums[q] = 0.0;
   if (r0 >= n) return 0;  // padding rows only
   const int64_t s = r1 - r0, n2 = np - r0, ldz = gpx_skew_ld(n2);
@@ -464,15 +505,16 @@ int gpx_lml_grad_rows(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp
                       const double* alpha, int64_t r0, int64_t r1, int nsub, double* sums) {
   GPX_ARG(ctx && L && X && alpha && sums, "NULL argument");
   GPX_ARG(L->factored && L->aux, "matrix has not been factored by gpx_potrf");
-  GPX_ARG(kind == GPX_K_SE, "lml_grad: only the squared-exponential kernel has hyper-parameter derivatives "
-                            "(the reference raises for the others, kernels.py:93-97)");
+  GPX_ARG(kind == GPX_K_SE || kind == GPX_K_MATERN32 || kind == GPX_K_MATERN52,
+          "lml_grad: hyper-parameter derivatives exist for the squared exponential (kernels.py:125-144) and -- round 6, absent in the "
+          "reference, whose Matern raises (kernels.py:93-97) -- the isotropic Materns");
   KParams kp;
   GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
   GPX_ARG(X->cols == d && X->pcols == d && X->rows == L->rows, "X does not match the factor");
   const int64_t n = L->rows, np = L->prows;
   GPX_ARG(r0 >= 0 && r0 < r1 && r1 <= np && r0 % GPX_TILE == 0 && r1 % GPX_TILE == 0 && nsub >= 1,
           "row bounds must be multiples of 128 inside the padded order");
-  const int nq = d + 2;
+  const int nq = lml_nd(kind, d) + 2;
   for (int q = 0; q < nq; ++q) sums[q] = 0.0;
   // sub-slabs of EQUAL HEIGHT inside [r0, r1), rounded to 128.  A sub-slab [c0, c1) costs (c1 - c0) c1^2 -- every one of its rows
   // is solved against the leading c1-order block --, so the sum over the sub-slabs exceeds the integral of r^2: by 9.6 % with 16
@@ -563,13 +605,14 @@ int gpx_lml_grad_linv(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp
                       const double* alpha, double* sums) {
   GPX_ARG(ctx && L && X && alpha && sums, "NULL argument");
   GPX_ARG(L->factored && L->aux, "matrix has not been factored by gpx_potrf");
-  GPX_ARG(kind == GPX_K_SE, "lml_grad: only the squared-exponential kernel has hyper-parameter derivatives "
-                            "(the reference raises for the others, kernels.py:93-97)");
+  GPX_ARG(kind == GPX_K_SE || kind == GPX_K_MATERN32 || kind == GPX_K_MATERN52,
+          "lml_grad: hyper-parameter derivatives exist for the squared exponential (kernels.py:125-144) and -- round 6, absent in the "
+          "reference, whose Matern raises (kernels.py:93-97) -- the isotropic Materns");
   KParams kp;
   GPX_TRY(gpx_make_kparams(kind, d, hyp, nhyp, &kp));
   GPX_ARG(X->cols == d && X->pcols == d && X->rows == L->rows, "X does not match the factor");
   const int64_t n = L->rows, np = L->prows;
-  const int nq = d + 2;
+  const int nq = lml_nd(kind, d) + 2;
   for (int q = 0; q < nq; ++q) sums[q] = 0.0;
   int r = 0;
   {

@@ -165,6 +165,17 @@ class KernelSpec:
     def args(self):
         return (self.kind, self.d, dptr(self.hyp), int(self.hyp.size))
 
+    @property
+    def nlen(self):
+        """Length-type hyper-parameters in the log-marginal gradient: d correlation lengths (squared exponential) or the one rho
+        (isotropic Matern)."""
+        return self.d if self.kind == K_SE else 1
+
+    @property
+    def nsums(self):
+        """Trace sums the gradient entry points return: nlen + signalSize + noise."""
+        return self.nlen + 2
+
 
 def points(ctx, x):
     """Upload an (n, d) point set unpadded."""
@@ -296,6 +307,21 @@ class FitcModel:
         co = as_f64(coeff) if want_mean else None
         check(self.ctx.lib.gpx_fitc_posterior(self.ctx.h, self.h, self.X.h, dptr(co), Z.h, dptr(mean), dptr(var)))
         return mean, var
+
+    def var_grad(self, spec, Z, noise_deriv=None, eval_bias=None, dk_bias=None):
+        """(N*d, M) matrix d var(z_m) / d X[j][l] with the FITC precision (gp.py:282-341 reads `precisionMatrix`, gp.py:194-206)."""
+        out = np.empty((self.n * spec.d, Z.shape[0]))
+        nd = as_f64(noise_deriv) if noise_deriv is not None else None
+        eb = as_f64(eval_bias) if eval_bias is not None else None
+        db = as_f64(dk_bias) if dk_bias is not None else None
+        check(self.ctx.lib.gpx_fitc_var_grad(self.ctx.h, self.h, *spec.args(), self.X.h, Z.h, dptr(nd), dptr(eb), dptr(db), dptr(out)))
+        return out
+
+    def var_grad_newpt(self, spec, Z):
+        """(M*d,) vector d var(z_m) / d z_m with the FITC precision (gp.py:261-280)."""
+        out = np.empty(Z.shape[0] * spec.d)
+        check(self.ctx.lib.gpx_fitc_var_grad_newpt(self.ctx.h, self.h, *spec.args(), self.X.h, Z.h, dptr(out)))
+        return out
 
     def dense(self, cov=True, prec=True):
         c = np.empty((self.n, self.n)) if cov else None
@@ -478,7 +504,7 @@ def lml_grad_linv(ctx, spec, L, X, alpha):
     """Raw trace sums (d+2) over all rows through ONE explicit L^-1 and the lower triangle of K^-1 written over it
     (gpx_lml_grad_linv): the single-GPU form for large N when two more N x N buffers fit."""
     alpha = as_f64(alpha)
-    out = np.empty(spec.d + 2)
+    out = np.empty(spec.nsums)
     check(ctx.lib.gpx_lml_grad_linv(ctx.h, *spec.args(), L.h, X.h, dptr(alpha), dptr(out)))
     return out
 
@@ -492,7 +518,8 @@ def lml_grad_linv_fits(ctx, n):
 
 
 def lml_grad(ctx, spec, L, X, alpha, slabs=None):
-    """[d/d hyp_0 .. d/d hyp_{n-1}, raw d/d noise] of the log marginal likelihood (SE kernel; gp.py:444-466).
+    """[d/d hyp_0 .. d/d hyp_{n-1}, raw d/d noise] of the log marginal likelihood (squared exponential: gp.py:444-466; the
+    isotropic Materns: round 6, absent in the reference).
     Large factors: the traces are summed over `slabs` row slabs of K^-1 of equal work (gpx_lml_grad_slab: two triangular solves
     against the trailing factor per slab) -- the same flops as potri in the limit, but no N x N inverse in memory (34 GB at
     N = 65536, whose first allocation alone costs seconds) and the form the multi-GPU path shards; small ones: gpx_lml_grad."""
@@ -522,7 +549,7 @@ def lml_grad(ctx, spec, L, X, alpha, slabs=None):
                 raise
             ctx.trim()
     b = lml_grad_slab_bounds(n, int(slabs))
-    sums = np.zeros(spec.d + 2)
+    sums = np.zeros(spec.nsums)
     for r0, r1 in zip(b[:-1], b[1:]):
         if r1 > r0:
             sums += lml_grad_slab(ctx, spec, L, X, alpha, r0, r1)
@@ -582,7 +609,7 @@ def lml_grad_slab_bounds(n, parts):
 def lml_grad_slab(ctx, spec, L, X, alpha, r0, r1):
     """Raw trace sums (d+2) of the log-marginal gradient over the row slab [r0, r1) of K^-1 (gpx_lml_grad_slab)."""
     alpha = as_f64(alpha)
-    out = np.empty(spec.d + 2)
+    out = np.empty(spec.nsums)
     check(ctx.lib.gpx_lml_grad_slab(ctx.h, *spec.args(), L.h, X.h, dptr(alpha), int(r0), int(r1), dptr(out)))
     return out
 
@@ -633,14 +660,15 @@ def lml_grad_rows(ctx, spec, L, X, alpha, r0, r1, nsub=1):
     """Raw trace sums (d+2) of the log-marginal gradient contributed by the rows [r0, r1) of L^-1 (gpx_lml_grad_rows; the range
     is worked in `nsub` sub-slabs of equal work whose products accumulate in one matrix, traced once)."""
     alpha = as_f64(alpha)
-    out = np.empty(spec.d + 2)
+    out = np.empty(spec.nsums)
     check(ctx.lib.gpx_lml_grad_rows(ctx.h, *spec.args(), L.h, X.h, dptr(alpha), int(r0), int(r1), int(nsub), dptr(out)))
     return out
 
 
 def lml_grad_from_sums(spec, sums):
-    """[d/d cl_0 .. d/d cl_{d-1}, d/d signalSize, raw d/d noise] from the summed slab traces (as gpx_lml_grad returns them)."""
-    d = spec.d
+    """[d/d cl_0 .. d/d cl_{d-1} (Matern: d/d rho), d/d signalSize, raw d/d noise] from the summed slab traces (as gpx_lml_grad
+    returns them)."""
+    d = spec.nlen
     g = np.empty(d + 2)
     g[:d] = 0.5 * sums[:d] / spec.hyp[:d]
     g[d] = 0.5 * sums[d] / spec.hyp[d]

@@ -40,7 +40,7 @@ import sys
 import numpy as np
 
 from . import device as _dev
-from ._lib import check, dptr, as_f64, c_i64
+from ._lib import check, dptr, as_f64, c_i64, GpxError
 
 TILE = 128
 
@@ -903,10 +903,10 @@ def default_nb(n, world=8, streamed=False):
 def ring_size(agg):
     """Packed panel buffers the loop cycles through: a panel's buffer is read until the bulk update of ITS group has run,
     which may finish one group late (it runs beside the next group's chain) -- at least two groups of buffers.  Round 4: at
-    least GPX_DIST_RING (8) of them whatever the group size: the communication stream may not overwrite a buffer before the bulk
+    least 8 of them whatever the group size: the communication stream may not overwrite a buffer before the bulk
     update that reads it has run, so a SHORT ring ties the chain across ranks to the slowest rank's backlog of bulk updates
     (paced replay, two panels per update: with 4 buffers the last panel reached the two busiest ranks 8 ms after the others)."""
-    return max(2 * agg, int(os.environ.get("GPX_DIST_RING", "8")))
+    return max(2 * agg, 8)
 
 
 def dist2_potrf(ops, comm, geo, A, G, L=None, on_stored=None, agg=None, window=0, E=None):
@@ -1483,7 +1483,7 @@ def streamed_ivar_hook(ops, geo, L, B, q, window=0, stream=None, fwd=None):
     "keep L distributed": every panel reaches every rank anyway for the trailing update, the evaluation consumes it then)."""
     last = geo.nblk - 1
     if stream is None:
-        stream = EVAL if os.environ.get("GPX_DIST_IVAR_STREAM", "eval") == "eval" else BACK
+        stream = EVAL
 
     def hook(k):
         if k % q == q - 1 or k == last:
@@ -1526,10 +1526,10 @@ class DistFitIvar2D:
         # (against the rank's replica).  Round 3 streamed from 4 ranks because a rank's BUSY time was lower that way; the paced
         # replay of round 4 says the opposite for the time of the GRID: the streamed solve's GEMMs slow the chain
         # across ranks (2 x 4 at C4: 121-133 ms streamed against 53 + 62 + 4 = 119 ms fit-then-evaluate; 2 x 2: 206 against 200).
-        # Streaming remains the memory-saving form: default from N = GPX_DIST_STREAM_MIN_N (98304: a replica of 77 GB), where a
+        # Streaming remains the memory-saving form: default from N = 98304 (a replica of 77 GB), where a
         # rank's own work also dwarfs the chain.  GPX_DIST_STREAM_IVAR=0/1 overrides.
         env = os.environ.get("GPX_DIST_STREAM_IVAR")
-        big = Xh.shape[0] >= int(os.environ.get("GPX_DIST_STREAM_MIN_N", "98304"))
+        big = Xh.shape[0] >= 98304
         self.streamed = (comm.world >= 4 and big) if streamed is None else bool(streamed)
         if env is not None:
             self.streamed = env == "1"
@@ -1550,12 +1550,9 @@ class DistFitIvar2D:
         self.E = ([self.ops.alloc_vec(nb * self.geo.gld) for _ in self.G]
                   if os.environ.get("GPX_DIST_EARLY_BUF", "1") == "1" and hasattr(comm, "bcast_grp2") else None)
         # The finished factor: with the STREAMED evaluation nothing reads a panel after its group's solve step, so the rank
-        # keeps a window of two groups of block columns (N x 2 agg nb) instead of an N x N replica (`replicate`, or
-        # GPX_DIST_REPLICATE=1, forces the replica; the C5 gradient needs it).
-        env_r = os.environ.get("GPX_DIST_REPLICATE")
+        # keeps a window of two groups of block columns (N x 2 agg nb) instead of an N x N replica (`replicate`
+        # forces the replica; the C5 gradient needs it).
         self.replicate = (not self.streamed) if replicate is None else bool(replicate)
-        if env_r is not None:
-            self.replicate = env_r == "1"
         if not self.streamed:
             self.replicate = True
         self.window = 0 if self.replicate else 2 * self.agg
@@ -1574,7 +1571,7 @@ class DistFitIvar2D:
         # The forward substitution L w = y rides along the streamed evaluation when EVERY rank streams (all have evaluation
         # points): each rank then ends the factorisation with the complete w and the distributed substitution keeps only its
         # backward sweep (half the block steps and collectives).  Decided from (M, world) alone: the same on every rank.
-        self.fused_fwd = bool(self.window) and Zh.shape[0] >= comm.world and os.environ.get("GPX_DIST_FUSED_FWD", "1") == "1"
+        self.fused_fwd = bool(self.window) and Zh.shape[0] >= comm.world
         self.yv = self.ops.alloc_vec(self.geo.np)
         self.y0 = self.ops.alloc_vec(self.geo.np)
         ypad = np.zeros(self.geo.np)
@@ -1587,18 +1584,17 @@ class DistFitIvar2D:
         self.B = self.ops.alloc_cross(self.n, hi - lo) if (self.streamed and hi > lo) else None
         if hasattr(self.ops, "reserve"):
             self.ops.reserve(nb, self.agg, (hi - lo) if self.B is not None else 0)
-        # recorded programs (device ops + a recordable communicator only; GPX_DIST_RECORD=0 interprets every step)
+        # recorded programs (device ops + a recordable communicator only; `force_interpret` interprets every step)
         self.programs = None
-        self.recordable = (type(self.ops) is DeviceOps2D and getattr(comm, "recordable", False)
-                           and os.environ.get("GPX_DIST_RECORD", "1") == "1")
-        # hipGraph replay of the recorded programs: EXPERIMENTAL, off unless GPX_DIST_GRAPH=1.  The programs fork every stream
+        self.recordable = type(self.ops) is DeviceOps2D and getattr(comm, "recordable", False)
+        # hipGraph replay of the recorded programs: EXPERIMENTAL, off (scripts/graph_capture_bisect.py sets `use_graph`).  The programs fork every stream
         # off MAIN and join it again, so they are capturable in principle (gpx_program_capture), and small ones are (four
         # panels: 68 nodes, one hipGraphLaunch per step) -- but on ROCm 7.2 hipStreamEndCapture SEGFAULTS on the full loop's
         # cross-stream event pattern: first on a side stream waiting for an event recorded on that same stream (now dropped
         # by DeviceOps2D.wait), then on the panel stream's buffer-reuse waits from the ninth panel on
         # (scripts/graph_capture_bisect.py cuts the recorded program to the first failing row; scripts/graph_check.hip shows the
         # elementary patterns work).  RCCL under capture is unvalidated on top of that.  Row-by-row replay stays the product path.
-        self.use_graph = self.recordable and os.environ.get("GPX_DIST_GRAPH", "0") == "1"
+        self.use_graph = False
         self.host_ms = {}
         self._runs = {}
 
@@ -1812,7 +1808,7 @@ class CyclicFactor:
 # =====================================================================================================================
 # BASELINE config C5 on N GPUs: hyper-parameter gradient of the log marginal likelihood + mutual-information design
 # =====================================================================================================================
-def dist_lml_grad(ctx, comm, spec, L, X, alpha, be=None, slabs=None):
+def dist_lml_grad(ctx, comm, spec, L, X, alpha, be=None, slabs=None, form=None):
     """Gradient of the log marginal likelihood w.r.t. (cl_0..cl_{d-1}, signalSize, noise [raw: the caller scales by 2 noise,
     gp.py:463-464]) with the TRACES SHARDED over the ranks (gp.py:444-466 builds an (N, N, d+2) array and needs all of
     K^-1).  Every rank holds the complete factor L (replicated by the distributed fit); rank r forms only the row slab
@@ -1825,23 +1821,43 @@ def dist_lml_grad(ctx, comm, spec, L, X, alpha, be=None, slabs=None):
     # A rank's share is cut further into `sub` slabs of equal work (the solves of a slab run against the trailing factor below
     # its FIRST row: one slab over all rows costs 2 N^3, many slabs approach 2 N^3 / 3 -- single GPU, N = 65536: 7.8 s with one
     # slab, 3.5 s with 16); about 16 slabs in total, at least one per rank.
-    sub = max(1, int(os.environ.get("GPX_C5_SLABS", "16")) // comm.world) if slabs is None else max(1, int(slabs))
-    # Round 5: the ROWS form (GPX_DIST_GRAD_FORM=rows, the default where the backend has it): rank r takes rows of L^-1 -- one
-    # right solve against the leading block of the factor + one large lower SYRK per slab instead of the slab form's two solves
-    # with K = 1024 block inverses (gpx_lml_grad_rows; the slab form measured 54 TF/s at C5, 0.69 of the MFMA roof).
-    rows_form = os.environ.get("GPX_DIST_GRAD_FORM", "rows") == "rows" and hasattr(be, "lml_grad_rows")
-    sums = np.zeros(spec.d + 2)
+    sub = max(1, 16 // comm.world) if slabs is None else max(1, int(slabs))
+    # Round 5: the ROWS form (the default where the backend has it): rank r takes rows of L^-1 -- one right solve against the
+    # leading block of the factor + one large lower SYRK per slab instead of the slab form's two solves with K = 1024 block
+    # inverses (gpx_lml_grad_rows; the slab form measured 54 TF/s at C5, 0.69 of the MFMA roof).  The rank whose range ends at the
+    # padded order allocates an N x N accumulator on top of its replica, so the ranks' memory needs differ: a rank that runs out
+    # of memory must not leave the others waiting in the exchange below -- every rank reports whether its share
+    # succeeded, and when ANY failed ALL fall back to the slab form, which needs no N x N buffer.
+    rows_form = hasattr(be, "lml_grad_rows") and form != "slabs"
+    sums = np.zeros(getattr(spec, 'nsums', spec.d + 2))
     if rows_form:
-        b = be.lml_grad_rows_bounds(n, comm.world, sub)     # one range of rows per rank, `sub` sub-slabs inside (one trace)
-        if b[comm.rank + 1] > b[comm.rank]:
-            sums = sums + be.lml_grad_rows(ctx, spec, L, X, alpha, b[comm.rank], b[comm.rank + 1], sub)
-    else:
+        ok, err = 1.0, None
+        try:
+            b = be.lml_grad_rows_bounds(n, comm.world, sub)     # one range of rows per rank, `sub` sub-slabs inside (one trace)
+            if b[comm.rank + 1] > b[comm.rank]:
+                sums = sums + be.lml_grad_rows(ctx, spec, L, X, alpha, b[comm.rank], b[comm.rank + 1], sub)
+        except GpxError as e:
+            if "hipMalloc" not in str(e) and "memory" not in str(e).lower():
+                ok = -1.0          # not an allocation failure: re-raised below, after the other ranks have been told
+            else:
+                ok = 0.0
+            err = e
+        flags = comm.allgather(np.array([ok]))
+        worst = min(float(f[0]) for f in flags)
+        if worst < 0.0:
+            raise err if err is not None else RuntimeError("dist_lml_grad: another rank failed in its share of the gradient")
+        if worst == 0.0:
+            if hasattr(ctx, "trim"):
+                ctx.trim()
+            rows_form = False
+            sums = np.zeros(getattr(spec, 'nsums', spec.d + 2))
+    if not rows_form:
         b = be.lml_grad_slab_bounds(n, comm.world * sub)
         for i in range(comm.rank * sub, (comm.rank + 1) * sub):
             if b[i + 1] > b[i]:
                 sums = sums + be.lml_grad_slab(ctx, spec, L, X, alpha, b[i], b[i + 1])
     allsums = comm.allgather(sums)
-    tot = np.zeros(spec.d + 2)
+    tot = np.zeros(getattr(spec, 'nsums', spec.d + 2))
     for r in range(comm.world):
         tot += allsums[r]
     return be.lml_grad_from_sums(spec, tot)
@@ -1950,19 +1966,19 @@ class Session:
         self.ctx, self.comm = ctx, comm
         self.be = be or _dev
         self.ops_factory = ops_factory or (lambda: DeviceOps2D(ctx))
-        self.min_n = int(os.environ.get("GPX_DIST_MIN_N", "2048")) if min_n is None else int(min_n)
-        self.min_m = int(os.environ.get("GPX_DIST_MIN_M", "4096")) if min_m is None else int(min_m)
-        self.check = (os.environ.get("GPX_DIST_CHECK", "1") == "1") if check is None else bool(check)
+        self.min_n = 2048 if min_n is None else int(min_n)
+        self.min_m = 4096 if min_m is None else int(min_m)
+        self.check = True if check is None else bool(check)
         self._runner = None          # (key, DistFitIvar2D): buffers + recorded programs of the last problem size
         self._scratch_runner = None  # the same for fits nobody keeps (likelihood evaluations) in the distributed-factor mode
         self.stats = dict(fits=0, evals=0, grads=0)
-        # Round 5, distributed-factor mode (GPX_DIST_FACTOR=cyclic | replica; default: cyclic from GPX_DIST_CYCLIC_MIN_N = 65536
+        # Round 5, distributed-factor mode (GPX_DIST_FACTOR=cyclic | replica; default: cyclic from 65536
         # training points, where two N x N replicas per rank stop being cheap): the fit leaves the factor block-cyclic on the
         # ranks -- N^2 / W per rank + the ring of packed panel buffers -- and the class API works on THAT: coeff / log-marginal by
         # distributed substitution, evaluate / evaluateVariance / the IVAR cost by re-streaming the panels against a window
         # (dist2_restream_enqueue); a dense replica is assembled only when an entry point needs one (CyclicFactor.dense).
         self.factor_mode = os.environ.get("GPX_DIST_FACTOR", "auto")
-        self.cyclic_min_n = int(os.environ.get("GPX_DIST_CYCLIC_MIN_N", "65536"))
+        self.cyclic_min_n = 65536
 
     @property
     def rank(self):
@@ -2061,15 +2077,18 @@ class Session:
         run.X = run.ops.points(nodes)
         run.noise = nugget if isinstance(nugget, np.ndarray) else float(nugget)
         # Round 5: the caller gets the runner's replica ITSELF, not a gpx_mat_clone of it (8.6 GB copied at C4 on every call,
-        # every likelihood evaluation of an optimiser loop included, and two N x N matrices resident per rank).  A factor that
-        # is still referenced when the next fit of this size comes (GP.train keeps it; loglikeParams(remember=False) drops it at
-        # once) stays with its holder: the runner then takes a fresh matrix and re-records its program (the recorded rows carry
-        # the matrix handle).  2 = the runner's own reference + getrefcount's argument.
-        if sys.getrefcount(run.L) > 2:
+        # every likelihood evaluation of an optimiser loop included, and two N x N matrices resident per rank).  Round 6 (ADVICE
+        # r5): OWNERSHIP IS EXPLICIT -- keep = True hands the matrix over for good (GP.train keeps it; a state object may hold
+        # only its C handle, which no reference count sees), and the runner takes a fresh one for its next fit, re-recording its
+        # program (the recorded rows carry the matrix handle); keep = False (a likelihood evaluation: the caller is done with
+        # the factor before it asks for the next) leaves it with the runner, which refits in place.
+        if getattr(run, "_handed_over", False):
             run.L = run.ops.alloc_matrix(run.n)
             run.programs, run._runs = None, {}
+            run._handed_over = False
             self.stats["replicas_handed_over"] = self.stats.get("replicas_handed_over", 0) + 1
         run.fit()
+        run._handed_over = bool(keep)
         self.stats["fits"] += 1
         return run.X, run.L
 
@@ -2195,9 +2214,6 @@ def attach(comm=None, ctx=None, **opts):
     if comm is None:
         comm = init_from_env(ctx)
     _session = Session(ctx, comm, **opts)
-    if comm.world > 1 and int(os.environ.get("RANK", "0")) == 0 and os.environ.get("GPX_DIST_QUIET", "0") != "1":
-        print("gpexp_amd: class API attached to %d ranks (fit distributed from N >= %d, evaluation sharded from M >= %d)"
-              % (comm.world, _session.min_n, _session.min_m), flush=True)
     import atexit
     atexit.register(detach)
     return _session

@@ -55,17 +55,34 @@ class costFunctionGP_IVAR(costFunctionBase):
         if self.version != 1:
             raise NotImplementedError("IVAR version 0 needs a Mercer eigen-basis that no kernel class provides "
                                       "(dead code in the reference, experimentalDesign.py:119-146)")
+        self._mc_dev = None  # MC points stay resident in HBM across optimiser evaluations
         if 'mcPoints' in kwargs:
             self.mcPoints = kwargs['mcPoints']
-            self.nMC = len(self.mcPoints)
         else:
-            self.nMC = 10000
-            self.mcPoints = space.sample((self.nMC, space.dimension))
-        self._mc_dev = None  # MC points stay resident in HBM across optimiser evaluations
+            self.mcPoints = space.sample((10000, space.dimension))
+
+    # `mcPoints` is an attribute users reassign (the reference's drivers do): everything derived from the set -- its device copy, the
+    # forward solve W kept for the gradient (N x M doubles: 2 GB at N = 8192, M = 32768) and the cost that goes with it -- is
+    # dropped with it (the kept cost / gradient would otherwise belong to the previous set).
+    @property
+    def mcPoints(self):
+        return self._mcPoints
+
+    @mcPoints.setter
+    def mcPoints(self, pts):
+        self._mcPoints = pts
+        self.nMC = len(pts)
+        self.reset()
+
+    def reset(self):
+        """Drop the device state kept across optimiser iterations (MC points, forward solve, cost); the batch driver calls it
+        when a batch ends."""
+        self._mc_dev = None
+        self._w_kept = None
 
     def _mc(self):
         if self._mc_dev is None:
-            self._mc_dev = _dev.points(_dev.context(), self.mcPoints)
+            self._mc_dev = _dev.points(_dev.context(), self._mcPoints)
         return self._mc_dev
 
     def evaluate(self, inputPoints):
@@ -111,7 +128,8 @@ class costFunctionGP_IVAR(costFunctionBase):
         """d IVAR / d design coordinates, flattened (experimentalDesign.py:168-179): gpx_ivar_grad --
         two triangular solves, one MFMA GEMM and a fused row reduction instead of the reference's (N*d x M) matrix --
         for the kernels the reference differentiates (squared exponential, 1-D Mehler), with the heteroscedastic terms of
-        `space.noiseFunc` when there is one."""
+        `space.noiseFunc` when there is one.  With `pinnedPoints` set (the batch driver: the leading points are fixed by equal
+        bounds) the entries of the pinned points are returned as ZEROS -- not the full gradient."""
         gp = self.gaussianProcess
         nd = None
         if self.space.noiseFunc is None:
@@ -120,6 +138,11 @@ class costFunctionGP_IVAR(costFunctionBase):
             gp.addNodesAndComputeCovariance(inputPoints, noiseIn=self.space.noiseFunc(inputPoints))
             nd = np.asarray(self.space.noiseFunc.deriv(inputPoints), dtype=float).reshape(inputPoints.shape)
         gp._point_derivative_ready(self.mcPoints)
+        if gp._fitc is not None:
+            # FITC model: the reference sums evaluateVarianceDerivative over the MC points (experimentalDesign.py:171-177), which
+            # reads the Woodbury precision (gp.py:322); gpx_fitc_var_grad, then the same mean over the MC points
+            dv = gp._fitc.var_grad(gp.kernel._spec(), self._mc(), nd)
+            return np.sum(dv, axis=1) / float(len(self.mcPoints))
         kept = getattr(self, "_w_kept", None)
         W = kept[1] if (kept is not None and nd is None and kept[0] is gp._L) else None    # (read only: it stays for the next cost)
         # `pinnedPoints` (set by the batch driver, experimentalDesign.py:719-724: the leading points are fixed by equal bounds, so
@@ -324,6 +347,7 @@ class ExperimentalDesignGreedyWithDerivatives(ExperimentalDesignDerivative):
             points = expCurr.beginWithVarGreedy(nodesKeep=points, lbounds=lbounds, rbounds=rbounds)
             err = currCost.evaluate(points)
             print("Current Error ", err)
+            currCost.reset()                             # the batch is over: its forward solve (N x M doubles) leaves the device
         return points
 
 

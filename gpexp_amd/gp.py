@@ -354,8 +354,8 @@ class GP:
     def _point_derivative_ready(self, newpt):
         assert self.pts is not None, "must specify training points before running this"
         assert newpt.shape[1] == self.kernel.dimension, "evaluation points for GP is incorrect shape"
-        if not self._has_factor():
-            raise NotImplementedError("variance derivatives need the dense factor (not available with FITC)")
+        if not self._has_factor() and self._fitc is None:
+            raise NotImplementedError("variance derivatives need a fitted model")
         if not hasattr(self.kernel, "derivative") or (self.kernel._spec().kind == _dev.K_MEHLER
                                                       and self.kernel.dimension != 1):
             # the reference defines Kernel.derivative for the squared exponential and the 1-D Mehler kernel only
@@ -365,6 +365,8 @@ class GP:
         """d var(newpt_i) / d newpt_i, flattened (gp.py:261-280): gpx_var_grad_newpt."""
         self._point_derivative_ready(newpt)
         ctx = _dev.context()
+        if self._fitc is not None:    # the reference reads `precisionMatrix`: for FITC the Woodbury precision (gp.py:204-206)
+            return self._fitc.var_grad_newpt(self.kernel._spec(), _dev.points(ctx, newpt))
         return _dev.var_grad_newpt(ctx, self.kernel._spec(), self._L, self._X, _dev.points(ctx, newpt))
 
     def evaluateVarianceDerivative(self, newpt, noiseFunc=None):
@@ -384,6 +386,8 @@ class GP:
                 if hit.any():
                     eb = np.where(hit, np.asarray(noiseFunc(self.pts), dtype=float), 0.0)
                     db = np.where(hit[:, None], nd, 0.0)
+        if self._fitc is not None:
+            return self._fitc.var_grad(self.kernel._spec(), _dev.points(ctx, newpt), nd, eb, db)
         return _dev.var_grad(ctx, self.kernel._spec(), self._L, self._X, _dev.points(ctx, newpt), nd, eb, db)
 
     def generateSamples(self, x, noise=1e-10):

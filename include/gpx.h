@@ -255,6 +255,13 @@ int gpx_fitc_posterior(gpx_ctx* ctx, const gpx_fitc* f, const gpx_mat* X, const 
                        double* mean, double* var);
 /* dense Q + G and P (host n x n, each nullable): the covarianceMatrix / precisionMatrix attributes (gp.py:200-206) */
 int gpx_fitc_dense(gpx_ctx* ctx, const gpx_fitc* f, double* cov, double* prec);
+/* GP.evaluateVarianceDerivative / evaluateVarianceDerivWRTnewpt on a FITC model: the reference computes both from whatever
+ * `precisionMatrix` holds (gp.py:275, 322), for FITC the Woodbury precision of gp.py:204-206.  Same outputs and optional
+ * arguments as gpx_var_grad / gpx_var_grad_newpt; (kind, d, hyp) = the kernel the model was fitted with. */
+int gpx_fitc_var_grad(gpx_ctx* ctx, const gpx_fitc* f, int kind, int d, const double* hyp, int nhyp, const gpx_mat* X,
+                      const gpx_mat* Z, const double* noise_deriv, const double* eval_bias, const double* dk_bias, double* out);
+int gpx_fitc_var_grad_newpt(gpx_ctx* ctx, const gpx_fitc* f, int kind, int d, const double* hyp, int nhyp, const gpx_mat* X,
+                            const gpx_mat* Z, double* out);
 
 /* ---- measurement ------------------------------------------------------------------------------- */
 /* when enabled every kernel launch of a class is bracketed by HIP events on the launch stream */

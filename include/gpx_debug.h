@@ -63,10 +63,6 @@ int gpx_dbg_event_elapsed(gpx_ctx* ctx, int id0, int id1, double* ms);
    done; shader clocks; 28 / 29: the constant 100 MHz clock at start / end).  fast = 1: round 5's diagonal step, 0: the general one throughout.  scripts/probe_leaf.py. */
 int gpx_dbg_leaf_stamps(gpx_ctx* ctx, gpx_mat* K, int fast, int64_t* out30);
 
-/* Chain time stamps of the context's LAST cooperative diagonal-block factorisation (potrf_coop_kernel): out24 = t_wait[8],
-   t_leaf[8], t_done[8] -- block p awaited / its leaf starts / its flag is out; 100 MHz wall clock.  scripts/probe_small_potrf.py. */
-int gpx_dbg_coop_stamps(gpx_ctx* ctx, int64_t* out24);
-
 #ifdef __cplusplus
 }
 #endif

@@ -186,10 +186,12 @@ def loglike(spec, X, y, noise):
 
 
 def hyp_keys(spec):
-    """Key order of kernel.hyperParam + ['noise'] (gp.py:442; SE keys kernels.py:108-111)."""
+    """Key order of kernel.hyperParam + ['noise'] (gp.py:442; SE keys kernels.py:108-111, Matern keys kernels.py:74-79)."""
     if spec["kind"] == "se":
         return ["cl%d" % i for i in range(spec["d"])] + ["signalSize", "noise"]
-    raise NotImplementedError("reference raises for non-SE kernels (kernels.py:93-97)")
+    if spec["kind"] in ("matern32", "matern52"):
+        return ["rho", "signalSize", "noise"]
+    raise NotImplementedError("no hyper-parameter derivatives for this kernel")
 
 
 def loglike_grad(spec, X, y, noise):
@@ -197,13 +199,12 @@ def loglike_grad(spec, X, y, noise):
     kernels.py:125-144:  dK/d signalSize = exp(.),  dK/d cl_k = K * D_k^2 / cl_k^3,  dK/d noise = I,
     out[key] = 1/2 tr((a a^T - P) dK_key); the 'noise' entry is then multiplied by 2*noise
     (gp.py:463-464).  UNPINNED: the reference's own code raises IndexError (kernels.py:140-141);
-    tests cross-check this against central differences of the runnable loglike().
+    tests cross-check this against central differences of the runnable loglike().  Matern kernels (round 6): an extension
+    with no reference counterpart, pinned the same way -- by central differences of loglike(), which IS pinned for nu = 3/2.
     Returns (value, {key: derivative}) like the reference.
     """
-    assert spec["kind"] == "se"
     X = np.asarray(X, dtype=float)
     n, d = X.shape
-    cl = _cl(spec)
     K0 = cov_matrix(spec, X, 0.0, row_loop=False)
     K = K0 + np.diag(_nugget_vec(noise, n))
     P = np.linalg.pinv(K)
@@ -212,9 +213,24 @@ def loglike_grad(spec, X, y, noise):
     val = -0.5 * (y @ a) - 0.5 * logdet - n / 2.0 * np.log(2.0 * np.pi)
     T = np.outer(a, a) - P
     out = {}
-    for k in range(d):
-        D2 = (X[:, k][:, None] - X[:, k][None, :]) ** 2.0
-        out["cl%d" % k] = 0.5 * np.trace(T @ (K0 * D2 / cl[k] ** 3.0))
+    if spec["kind"] == "se":
+        cl = _cl(spec)
+        for k in range(d):
+            D2 = (X[:, k][:, None] - X[:, k][None, :]) ** 2.0
+            out["cl%d" % k] = 0.5 * np.trace(T @ (K0 * D2 / cl[k] ** 3.0))
+    else:
+        # EXTENSION (round 6): the reference's Matern has no derivativeWrtHypParams at all (kernels.py:93-97 raises).  Closed
+        # forms with t = sqrt(2 nu) r / rho:  nu = 3/2: dk/d rho = s t^2 e^-t / rho;  nu = 5/2: dk/d rho = s t^2 (1 + t) e^-t / (3 rho).
+        assert spec["kind"] in ("matern32", "matern52")
+        r = np.sqrt(np.maximum(((X[:, None, :] - X[None, :, :]) ** 2.0).sum(-1), 0.0))
+        rho, sg = spec["rho"], spec["signalSize"]
+        if spec["kind"] == "matern32":
+            t = np.sqrt(3.0) * r / rho
+            dK = sg * t * t * np.exp(-t) / rho
+        else:
+            t = np.sqrt(5.0) * r / rho
+            dK = sg * t * t * (1.0 + t) * np.exp(-t) / (3.0 * rho)
+        out["rho"] = 0.5 * np.trace(T @ dK)
     out["signalSize"] = 0.5 * np.trace(T @ (K0 / spec["signalSize"]))
     out["noise"] = 0.5 * np.trace(T) * noise * 2.0
     return val, out

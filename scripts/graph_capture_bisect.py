@@ -1,4 +1,4 @@
-"""Bisects hipGraph capture of the recorded 2-D panel loop (gpexp_amd/dist.py, GPX_DIST_GRAPH): captures only the first
+"""Bisects hipGraph capture of the recorded 2-D panel loop (gpexp_amd/dist.py, DistFitIvar2D.use_graph): captures only the first
 `ncut` rows of the factorisation program (plus the join rows) of a 1 x 1 replay and launches the graph.  On ROCm 7.2
 hipStreamEndCapture segfaults from the first buffer-reuse wait of the panel stream on (n = 4096, nb = 256: row 339), while every
 shorter prefix captures and runs -- run it per cut in a fresh process:  python scripts/graph_capture_bisect.py NCUT [N]"""
@@ -18,7 +18,6 @@ spec = dev.KernelSpec(dev.K_MATERN52, d, [0.5, 1.0])
 X = dev.points(ctx, Xh)
 Lref = dev.potrf(ctx, dev.kfill(ctx, spec, X, nugget=0.1))
 comm = ReplayComm(ctx, 1, 0, Lref)
-os.environ["GPX_DIST_GRAPH"] = "0"
 run = dist.DistFitIvar2D(ctx, comm, spec, Xh, yh, Zh, 0.1, nb=256, grid=(1, 1), agg=4, streamed=False, fit_only=True)
 run.step(); ctx.sync()
 full = run.programs["factor"]

@@ -17,7 +17,8 @@ def pytest_configure(config):
 class Golden:
     """tests/golden/gpexp_golden.npz: vectors produced by the reference itself (make_golden.py)."""
 
-    FILES = ["gpexp_golden", "gpexp_golden_r2", "gpexp_golden_r4"]   # make_golden.py, make_golden_r2.py, make_golden_r4.py
+    # make_golden.py, make_golden_r2.py, make_golden_r4.py, make_golden_r6_ref.py (all import the reference)
+    FILES = ["gpexp_golden", "gpexp_golden_r2", "gpexp_golden_r4", "gpexp_golden_r6_ref"]
 
     def __init__(self):
         d = os.path.join(ROOT, "tests", "golden")

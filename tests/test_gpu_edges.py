@@ -216,12 +216,11 @@ def test_refactor_in_place_invalidates_block_inverses(dev, ctx):
     assert np.array_equal(out[0], out[2]) and rel(out[1], out[0]) > 1e-3
 
 
-@pytest.mark.parametrize("n,m", [(700, 300), (8192, 4096), (9000, 2500), (12929, 1111)])
-def test_fit_ivar_streamed_equals_fit_then_ivar(dev, ctx, n, m, monkeypatch):
-    """gpx_fit_ivar with the evaluation solve streamed underneath the blocked look-ahead factorisation (opt-in; from
-    N = 8192, plain sequence below) against gpx_potrf followed by gpx_ivar on the same inputs: same factor bit for bit,
-    IVAR to 1e-12 (the solve is blocked differently)."""
-    monkeypatch.setenv("GPX_FIT_IVAR_STREAMED", "1")
+@pytest.mark.parametrize("n,m", [(700, 300), (9000, 2500)])
+def test_fit_ivar_equals_fit_then_ivar(dev, ctx, n, m):
+    """gpx_fit_ivar (one call: factor in place, then the evaluation solve) against gpx_potrf followed by gpx_ivar on the same
+    inputs: same factor and block inverses bit for bit, same IVAR, repeatable.  (The streamed variant of rounds 2-5 was
+    removed in round 6: measured slower on one GPU.)"""
     rng = np.random.default_rng(n + m)
     d = 5
     X = dev.points(ctx, rng.uniform(-1, 1, (n, d)))
@@ -231,15 +230,12 @@ def test_fit_ivar_streamed_equals_fit_then_ivar(dev, ctx, n, m, monkeypatch):
     iv1 = dev.ivar(ctx, sp, K1, X, Z)
     K2 = dev.kfill(ctx, sp, X, nugget=0.05)
     iv2 = dev.fit_ivar(ctx, sp, K2, X, Z)
-    assert abs(iv2 - iv1) <= 1e-12 * abs(iv1)
+    assert iv2 == iv1
     assert dev.logdet(ctx, K2) == dev.logdet(ctx, K1)
     y = rng.standard_normal(n)
     assert np.array_equal(dev.potrs(ctx, K2, y), dev.potrs(ctx, K1, y))    # factor and block inverses identical
     dev.kfill_into(ctx, sp, X, K2, nugget=0.05)
     assert dev.fit_ivar(ctx, sp, K2, X, Z) == iv2                           # repeatable bit for bit
-    monkeypatch.setenv("GPX_FIT_IVAR_STREAMED", "0")
-    dev.kfill_into(ctx, sp, X, K2, nugget=0.05)
-    assert abs(dev.fit_ivar(ctx, sp, K2, X, Z) - iv1) <= 1e-13 * abs(iv1)   # default: factor, then the ordinary solve
     del K1, K2
     ctx.trim()
 

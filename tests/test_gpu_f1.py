@@ -271,7 +271,10 @@ def test_ivar_cost_with_fitc_model(golden):
     cost = cf.evaluate(X)
     assert np.array_equal(cf.gaussianProcess.fitcnodes, golden(c, "fitcnodes"))
     assert cost == pytest.approx(abs(np.mean(golden(c, "var_signed"))), rel=1e-9)
-    with pytest.raises(NotImplementedError):
-        cf.derivative(X)
+    # round 6: the gradient too -- the reference sums evaluateVarianceDerivative (Woodbury precision, gp.py:322) over the MC points
+    # (experimentalDesign.py:171-177; fixture fitc_deriv: the reference's (N d, M) matrix on the same X, Z and inducing points)
+    want = np.sum(golden("fitc_deriv", "dvar_dpts"), axis=1) / float(len(Z))
+    got = cf.derivative(X)
+    assert got.shape == want.shape and np.max(np.abs(got - want)) <= 1e-8 * np.max(np.abs(want))
     with pytest.raises(NotImplementedError):
         greedyIVARStep(cf.gaussianProcess, X[:5], Z)

@@ -115,3 +115,38 @@ def test_c5_lite_loglike_and_gradient_values(dev, ctx, gold):
                                                     if r1 > r0))
     for name, g in forms.items():
         assert np.max(np.abs(g - gref) / np.abs(gref)) < 1e-9, (name, g, gref)
+
+
+@pytest.mark.parametrize("kind", ["matern52", "matern32"])
+def test_matern_gradient_forms_agree_at_blocked_size(dev, ctx, kind):
+    """Round 6: the log-marginal gradient of the isotropic Materns (the headline kernel can now be fitted with ONE factorisation
+    per optimiser iterate instead of d + 2 finite-difference fits) at a size that takes the blocked factorisation and the
+    1024-order block inverses (N = 8192, d = 8): the four forms of the trace (explicit inverse, L^-1 once, rows of L^-1 in two
+    ranges, row slabs) agree to 1e-10, and d/d rho, d/d signalSize, d/d noise match central differences of the device
+    likelihood to 2e-6."""
+    N, d, noise = 8192, 8, 0.1
+    rng = np.random.default_rng(8192)
+    Xh = rng.uniform(-1, 1, (N, d))
+    y = np.sin(2 * np.pi * Xh.sum(1) / d) + np.sqrt(noise) * rng.standard_normal(N)
+    K_ = dev.K_MATERN52 if kind == "matern52" else dev.K_MATERN32
+    X = dev.points(ctx, Xh)
+
+    def fit(rho, s, nz):
+        sp = dev.KernelSpec(K_, d, [rho, s])
+        L = dev.potrf(ctx, dev.kfill(ctx, sp, X, nugget=nz))
+        a = dev.potrs(ctx, L, y)
+        return -0.5 * float(y @ a) - 0.5 * dev.logdet(ctx, L) - N / 2 * np.log(2 * np.pi), L, a, sp
+
+    _, L, a, sp = fit(0.5, 1.0, noise)
+    assert sp.nsums == 3
+    g0 = dev.lml_grad_full(ctx, sp, L, X, a)
+    forms = {"linv": dev.lml_grad_from_sums(sp, dev.lml_grad_linv(ctx, sp, L, X, a)),
+             "rows": dev.lml_grad_from_sums(sp, dev.lml_grad_rows(ctx, sp, L, X, a, 0, 4096, 2) + dev.lml_grad_rows(ctx, sp, L, X, a, 4096, N, 2))}
+    b = dev.lml_grad_slab_bounds(N, 4)
+    forms["slabs"] = dev.lml_grad_from_sums(sp, sum(dev.lml_grad_slab(ctx, sp, L, X, a, r0, r1) for r0, r1 in zip(b[:-1], b[1:]) if r1 > r0))
+    for name, g in forms.items():
+        assert g.shape == (3,) and np.max(np.abs(g - g0) / np.abs(g0)) < 1e-10, (name, g, g0)
+    h = 1e-5
+    assert g0[0] == pytest.approx((fit(0.5 + h, 1.0, noise)[0] - fit(0.5 - h, 1.0, noise)[0]) / (2 * h), rel=2e-6)
+    assert g0[1] == pytest.approx((fit(0.5, 1.0 + h, noise)[0] - fit(0.5, 1.0 - h, noise)[0]) / (2 * h), rel=2e-6)
+    assert g0[2] == pytest.approx((fit(0.5, 1.0, noise + 1e-6)[0] - fit(0.5, 1.0, noise - 1e-6)[0]) / 2e-6, rel=2e-6)

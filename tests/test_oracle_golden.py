@@ -239,6 +239,32 @@ def test_loglike_grad_vs_finite_differences(golden):
         assert g[k] == pytest.approx(want, rel=2e-6), k
 
 
+def test_matern_loglike_grad_vs_reference_finite_differences(golden):
+    """Round 6, an extension (the reference's Matern has no derivativeWrtHypParams, kernels.py:93-97): the oracle's closed-form
+    d/d rho, d/d signalSize, d/d noise of the log-marginal likelihood for nu = 3/2 against central differences of the
+    REFERENCE's runnable loglikeParams (fixture lml_fd_matern32, make_golden_r6_ref.py); nu = 5/2 (no reference at all) against
+    central differences of the oracle's own likelihood."""
+    c = "lml_fd_matern32"
+    spec = golden.index[c]["kernel"]
+    nz = golden.index[c]["noise"]
+    X, y = golden(c, "X"), golden(c, "y")
+    val, g = orc.loglike_grad(spec, X, y, nz)
+    assert val == pytest.approx(float(golden(c, "loglike")), rel=1e-12)
+    keys = golden.index[c]["keys"]
+    assert keys == orc.hyp_keys(spec) == ["rho", "signalSize", "noise"]
+    for k, f in zip(keys, golden(c, "fd_grad_raw")):
+        want = f * (2.0 * nz) if k == "noise" else f
+        assert g[k] == pytest.approx(want, rel=2e-6), k
+    s52 = dict(spec, kind="matern52")
+    _, g52 = orc.loglike_grad(s52, X, y, nz)
+    for k in ("rho", "signalSize"):
+        h = 1e-6
+        fd = (orc.loglike(dict(s52, **{k: s52[k] + h}), X, y, nz) - orc.loglike(dict(s52, **{k: s52[k] - h}), X, y, nz)) / (2 * h)
+        assert g52[k] == pytest.approx(fd, rel=2e-6), k
+    fdn = (orc.loglike(s52, X, y, nz + 1e-7) - orc.loglike(s52, X, y, nz - 1e-7)) / 2e-7
+    assert g52["noise"] == pytest.approx(fdn * 2.0 * nz, rel=2e-6)
+
+
 def test_matern52_unpinned_sanity():
     # no reference oracle (kernels.py:85-91); sanity: k(x,x)=s and monotone decay, below matern32 smoothness tail
     s52 = dict(kind="matern52", rho=0.5, signalSize=1.3, d=2)
