@@ -46,6 +46,12 @@ PEAK_FP64_MFMA_TFLOPS = 78.6   # 256 CU x 2.4 GHz x 128 flop/clk/CU (SURVEY.md 8
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E
 
 
+def hdot(a, b):
+    """sum a_i b_i without BLAS (gpexp_amd._lib.hdot: np.dot wakes OpenBLAS' 64 threads, whose spinning stalls the next step's kernel
+    launches in a CPU-quota'd container)."""
+    return float(np.sum(np.multiply(a, b)))
+
+
 def workload(n, d, m, seed):
     rng = np.random.default_rng(seed)
     noise = 0.1
@@ -223,7 +229,7 @@ def bench_c5(args, ctx, dev, world, rank, stdout_fd):
             dev.kfill_into(ctx, spec, X, K, nugget=noise)
             dev.potrf(ctx, K)
             alpha = dev.potrs(ctx, K, yh)
-            ll = -0.5 * float(yh @ alpha) - 0.5 * dev.logdet(ctx, K) - N / 2.0 * np.log(2 * np.pi)
+            ll = -0.5 * hdot(yh, alpha) - 0.5 * dev.logdet(ctx, K) - N / 2.0 * np.log(2 * np.pi)
             t1 = time.perf_counter()
             if linv_form:        # one explicit L^-1, lower K^-1 over it (gpx_lml_grad_linv: 2 N^2 + N^2/4 doubles of scratch)
                 sums = dev.lml_grad_linv(ctx, spec, K, X, alpha)
@@ -311,7 +317,7 @@ def dist_preflight(ctx, comm, dist, dev, spec, d, nb=256, two_d=True, n=2048, m=
     X = dev.points(ctx, Xh)
     K1 = dev.potrf(ctx, dev.kfill(ctx, spec, X, nugget=noise))
     a1 = dev.potrs(ctx, K1, yh)
-    ll1 = -0.5 * float(yh @ a1) - 0.5 * dev.logdet(ctx, K1) - n / 2.0 * np.log(2 * np.pi)
+    ll1 = -0.5 * hdot(yh, a1) - 0.5 * dev.logdet(ctx, K1) - n / 2.0 * np.log(2 * np.pi)
     iv1 = abs(dev.ivar(ctx, spec, K1, X, dev.points(ctx, Zh)))
     out = {"N": n, "M": m, "nb": nb, "layout": "2d" if two_d else "1d", "loglike": ll, "ivar": iv,
            "rel_err_loglike": abs(ll - ll1) / abs(ll1) if (two_d or comm.rank == 0) else 0.0,
@@ -645,7 +651,7 @@ def main():
             logdet = dev.logdet(ctx, K)
             ctx.sync()
             alpha = alpha_dev.to_host()[:N, 0]
-            ll = -0.5 * float(yh @ alpha) - 0.5 * logdet - N / 2.0 * np.log(2 * np.pi)
+            ll = -0.5 * hdot(yh, alpha) - 0.5 * logdet - N / 2.0 * np.log(2 * np.pi)   # (no BLAS: _lib.hdot)
             return ll, iv
 
         def barrier():

@@ -196,6 +196,16 @@ def load():
     return lib
 
 
+def hdot(a, b):
+    """sum_i a_i b_i on the host WITHOUT BLAS (NumPy's pairwise sum of the element-wise product).  np.dot on a vector of a few
+    thousand entries wakes OpenBLAS' whole thread pool (64 threads on the MI355X boxes), whose workers then spin for a while: in
+    a CPU-quota'd container that burns the cgroup's CFS quota and stalls the NEXT fit's ~2000 kernel launches for most of a
+    100 ms period -- measured in round 6: a likelihood evaluation at N = 16384 took 98 ms instead of 31 (scripts/bench_frows.py
+    f3).  Deterministic, like everything else on the path."""
+    import numpy as _np
+    return float(_np.sum(_np.multiply(a, b)))
+
+
 def exported_symbols():
     return sorted(_SIGS)
 

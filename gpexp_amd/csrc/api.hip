@@ -1088,6 +1088,9 @@ int gpx_refit_rows(gpx_ctx* ctx, int kind, int d, const double* hyp, int nhyp, c
     }
   } while (0);
   (void)hipStreamSynchronize(ctx->stream);
+  //  an error between the fork and the join leaves the copy of the kept rows in flight on the side stream: it writes K
+  // and reads Lold -- both may be freed right after this returns
+  if (ctx->ev_side && ctx->streams[4] != ctx->stream) (void)hipStreamSynchronize(ctx->streams[4]);
   if (d_nug) gpx_dev_release(ctx, d_nug, nug_bytes);
   if (r != 0) {
     gpx_mat_free(ctx, K);

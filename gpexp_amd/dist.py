@@ -40,7 +40,7 @@ import sys
 import numpy as np
 
 from . import device as _dev
-from ._lib import check, dptr, as_f64, c_i64, GpxError
+from ._lib import check, dptr, as_f64, c_i64, GpxError, hdot
 
 TILE = 128
 
@@ -511,7 +511,7 @@ class DistFitIvar:
             logdet = _dev.logdet(ctx, self.K)
             ctx.sync()
             alpha = self.alpha_dev.to_host()[:self.n, 0]
-            ll = -0.5 * float(self.yh @ alpha) - 0.5 * logdet - self.n / 2.0 * np.log(2 * np.pi)
+            ll = -0.5 * hdot(self.yh, alpha) - 0.5 * logdet - self.n / 2.0 * np.log(2 * np.pi)
         iv = abs(ordered_sum(comm.allgather(np.array([part]))[:, 0]) / self.m)
         return ll, iv
 
@@ -1685,12 +1685,12 @@ class DistFitIvar2D:
             ops.replica_solve(self.L, self.y0, self.alpha)
             logdet = ops.replica_logdet(self.L)
             alpha = ops.vec_to_host(self.alpha, self.n)
-            ll = -0.5 * float(self.yh @ alpha) - 0.5 * logdet - self.n / 2.0 * np.log(2 * np.pi)
+            ll = -0.5 * hdot(self.yh, alpha) - 0.5 * logdet - self.n / 2.0 * np.log(2 * np.pi)
             return ll, alpha
         self._run("solve", self._enqueue_solve)
         logdet = float(comm.allreduce_host(np.array([ops.vec_to_host(self.scal, 1)[0]]))[0])
         alpha = ops.vec_to_host(self.alpha, self.n)
-        ll = -0.5 * float(self.yh @ alpha) - 0.5 * logdet - self.n / 2.0 * np.log(2 * np.pi)
+        ll = -0.5 * hdot(self.yh, alpha) - 0.5 * logdet - self.n / 2.0 * np.log(2 * np.pi)
         return ll, alpha
 
     def step(self):

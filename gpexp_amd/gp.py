@@ -34,7 +34,7 @@ import numpy as np
 
 from . import device as _dev
 from . import dist as _dist
-from ._lib import NotPositiveDefinite
+from ._lib import NotPositiveDefinite, hdot as _hdot
 from .gp_kernel_utilities import calculateCovarianceMatrix, _check_nugget  # noqa: F401  (re-export like the reference)
 
 try:  # the reference prefers nlopt and falls back to SciPy (gp.py:28-41); only the SciPy branch is provided
@@ -421,7 +421,7 @@ class GP:
         else:
             alpha = _dev.potrs(ctx, L, evals)
             logdet = _dev.logdet(ctx, L)
-        out = -0.5 * np.dot(evals, alpha) - 0.5 * logdet - len(evals) / 2.0 * np.log(2.0 * np.pi)
+        out = -0.5 * _hdot(evals, alpha) - 0.5 * logdet - len(evals) / 2.0 * np.log(2.0 * np.pi)
         if returnDeriv == 1:
             keys = list(self.kernel.hyperParam.keys()) + ['noise']
             sess = _dist.session()

@@ -3,7 +3,7 @@
 entry point with its size, best-of-3 time, the algorithmic work and the achieved rate against the roof that bounds it.
 Run it under `rocprofv3 --kernel-trace --stats` for the per-kernel table (profiles/r03_frows_kernel_stats.csv).
 
-    python scripts/bench_frows.py [--quick] [--only f1,design,mi,fitc,refit]
+    python scripts/bench_frows.py [--quick] [--only f1,design,mi,fitc,refit,f3]
 """
 import json
 import os
@@ -176,3 +176,48 @@ if want("refit"):
     report("gpx_refit_rows", "ExperimentalDesignGreedyWithDerivatives batch loop (experimentalDesign.py:694-751)",
            dict(N=Nr, changed_rows=Nr - keep), t, flops=1.0 * (Nr - keep) * Nr * Nr,
            note="the leading %d rows of the factor are reused; only the last %d rows are re-assembled and re-solved" % (keep, Nr - keep))
+# ---- f3: the hyper-parameter loop (findOptParamsLogLike / chooseParams, gp.py:498-639)
+if want("f3"):
+    from gpExp.kernels import KernelSquaredExponential, KernelIsoMatern
+    from gpExp.gp import GP
+
+    def f3_case(label, kern, N3, d3, maxiter):
+        r3 = np.random.default_rng(N3)
+        Xo = r3.uniform(-1, 1, (N3, d3))
+        yo = np.sin(2 * np.pi * Xo.sum(1) / d3) + np.sqrt(0.1) * r3.standard_normal(N3)
+        out = {}
+        for analytic in (False, True):
+            g = GP(kern(), 0.1)
+            counts = dict(fits=0, grads=0)
+            inner = g.loglikeParams
+
+            def counted(pts, evals, returnDeriv=0, noiseIn=None):
+                counts["fits"] += 1
+                counts["grads"] += int(returnDeriv == 1)
+                return inner(pts, evals, returnDeriv=returnDeriv, noiseIn=noiseIn)
+
+            g.loglikeParams = counted
+            g.loglikeParams(Xo, yo)                        # warm: pools, kernel attributes
+            counts.update(fits=0, grads=0)
+            ctx.sync()
+            t0 = time.perf_counter()
+            params, opt = g.findOptParamsLogLike(Xo, yo, maxiter=maxiter, analyticGradient=analytic)
+            ctx.sync()
+            out[analytic] = (time.perf_counter() - t0, dict(counts), float(opt))
+        (tn, cn, on), (ta, ca, oa) = out[False], out[True]
+        nhyp = len(kern().hyperParam) + 1
+        # an L-BFGS-B iterate with numerical gradients = 1 + nhyp likelihood evaluations (approx_grad: forward differences)
+        report("findOptParamsLogLike (%s)" % label, "GP.findOptParamsLogLike / chooseParams (gp.py:498-639)",
+               dict(N=N3, d=d3, hyper_parameters=nhyp, maxfun=maxiter), ta / max(ca["grads"], 1),
+               flops=N3 ** 3 / 3.0 + 2.0 * N3 ** 3 / 3.0,
+               note="ms per likelihood + gradient evaluation with analyticGradient=True (one factorisation N^3/3 + the trace "
+                    "through L^-1, 2 N^3/3): %d evaluations in %.2f s, optimum %.6g; numerical gradients as in the reference "
+                    "(maxfun = %d likelihood evaluations = %d factorisations, about %d per L-BFGS iterate): %.2f s, %.1f ms per "
+                    "factorisation, optimum %.6g" % (ca["grads"], ta, -oa, maxiter, cn["fits"], nhyp + 1, tn, 1e3 * tn / max(cn["fits"], 1), -on))
+
+    if quick:
+        f3_case("C2-lite: N=1024 d=3 iso-SE", lambda: KernelSquaredExponential([0.5], 1.0, 3), 1024, 3, 20)
+    else:
+        f3_case("C2: N=4096 d=3 iso-SE", lambda: KernelSquaredExponential([0.5], 1.0, 3), 4096, 3, 40)
+        f3_case("N=16384 d=8 Matern-5/2", lambda: KernelIsoMatern(0.7, 1.0, 8, nu=2.5), 16384, 8, 24)
+        f3_case("N=16384 d=8 ARD-SE", lambda: KernelSquaredExponential(list(0.5 + 0.05 * np.arange(8)), 1.0, 8), 16384, 8, 24)
