@@ -1143,7 +1143,7 @@ int chol_trsm_right_n_leading(gpx_ctx* ctx, gpx_mat* Lm, int64_t ncols, double* 
 // the chain, whose kernels fit beside resident GEMM workgroups (leaf 78 KB LDS / 184 VGPRs, strip multiplies 33-66 KB:
 // scripts/dispatch_check2.hip) and get a slot whenever one retires.
 // History of what this replaced, all measured and removed (profiles/r02_potrf_lookahead.txt, r02_potrf_phases.txt,
-// r04_potrf_two_panel_lookahead.txt, r06_potrf_panel_inverse_ab.txt): the chain behind the whole column update (8.7 + 2.5 ms
+// r04_potrf_two_panel_lookahead.txt, r06_potrf_variants.txt): the chain behind the whole column update (8.7 + 2.5 ms
 // exposed at N = 32768); a CU-masked chunk of the update beside the chain (a kernel on a masked stream runs at exactly its CU
 // share; 190-195 ms); all large kernels masked (226-233 ms); two panels of look-ahead (the bulk update stretches by what the thin
 // "top" launches take beside it); the update in slices of its k range; the rest solve as one product with a 4096-order inverse.
@@ -1303,7 +1303,7 @@ static int64_t potrs_block(int64_t n) {
   // 1024 minimises build + one solve.  (Order 4096 -- the whole diagonal block of a look-ahead panel, its panel solve then ONE
   // long-K triangular product, potrs 1.75 ms instead of 2.5 -- was measured too: the factorisation loses 13 ms at N = 32768
   // and 3 ms at N = 8192, because a triangular product on few rows cannot use its shorter k ranges: 4096^3 gains 1.2x.  Round 6:
-  // the 4096-order inverse for the rows BELOW block row k+1 only, built off the chain: profiles/r06_potrf_panel_inverse_ab.txt.)
+  // the 4096-order inverse for the rows BELOW block row k+1 only, built off the chain: profiles/r06_potrf_variants.txt.)
   int64_t ib = 1024;
   if (ib > n) ib = n;
   return ib;

@@ -680,7 +680,7 @@ int launch_gemm_tri(gpx_ctx* ctx, const double* A, int64_t lda, const double* B,
   GPX_ARG((lda % 2) == 0 && (ldb % 2) == 0, "gemm: leading dimensions must be even (16-byte loads)");
   GPX_ARG(!lower || m == n, "gemm: lower-only update needs a square C");
   // 64x64 tiles while the 128-tile count is below this (C4 potrf, round 1: 270 ms without, 251 ms at 256, 247 ms at 1024;
-  // round 6, same question on today's factorisation: 256 / 512 -> +3.4 / +0.8 ms, profiles/r06_potrf_panel_inverse_ab.txt)
+  // round 6, same question on today's factorisation: 256 / 512 -> +3.4 / +0.8 ms, profiles/r06_potrf_variants.txt)
   constexpr int small_max = 1024;
   const double tiles128 =
       lower ? 0.5 * (double)(m / 128) * ((double)(m / 128) + 1.0) : (double)(m / 128) * (double)(n / 128);
