@@ -787,7 +787,7 @@ def main():
         traffic, traffic_src = None, None
         try:  # PMC counters cannot be read from inside the process: take the committed rocprofv3 --pmc passes of this
             # same command (profiles/), per launch like `achieved`; null when the profile is for another config
-            pmc = [f for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+            pmc = [f for f in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
                    if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
             with open(os.path.join(ROOT, "profiles", pmc)) as f:
                 pj = json.load(f)

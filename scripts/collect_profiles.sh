@@ -5,7 +5,7 @@ set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/final
 rm -rf $O && mkdir -p $O
-cd $R && timeout -k 10 500 python3 bench.py > $O/bench.json 2> $O/bench.err || exit 1
+cd $R && timeout -k 10 900 python3 bench.py > $O/bench.json 2> $O/bench.err || exit 1
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-replay > $O/stats.log 2>&1 || exit 2
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o run -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-replay > $O/pmc_fetch.log 2>&1 || exit 3
