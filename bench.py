@@ -139,7 +139,7 @@ def _fair_chol(n, m, d, seed, kind="matern52"):
 T_START = time.perf_counter()   # the default run keeps to a wall-clock budget: see cpu_baseline
 
 
-def cpu_baseline(d, full=False, kind="matern52", budget_s=330.0):
+def cpu_baseline(d, full=False, kind="matern52", budget_s=360.0):
     """SURVEY.md 8d protocol: the reference algorithm at N = 2048, 4096 and -- when the run's wall-clock budget allows (it
     predicts the N = 8192 run from the N = 4096 one, x 8.5; 163 s on 64 threads) -- 8192 (M = 512 evaluation points), a
     least-squares fit of t = c N^3 through the measured fits, and the reference's time at the BENCH configuration (N = M = 32768)

@@ -692,7 +692,7 @@ int launch_gemm_tri(gpx_ctx* ctx, const double* A, int64_t lda, const double* B,
   // triangular (SYRK) launches only: their tile counts are never a multiple of the 512 resident workgroups (8192^2: 2080
   // tiles = 4.06 rounds, 53 -> 55 TF/s with the tail; 16384^2: 65.2 -> 66.2).  Rectangular launches measured 1-4 % SLOWER
   // with it: their tile counts divide evenly, and what looks like a drain there is the clock/fabric ramp after a stretch
-  // of small kernels (the same launch repeated back to back goes 4.86 -> 3.84 ms over ~30 ms, scripts/probe_b2b.py).
+  // of small kernels (the same launch repeated back to back goes 4.86 -> 3.84 ms over ~30 ms: round-2 probe, profiles/r02_*).
   constexpr int tail_target = 512;  // 64-tiles wanted in the tail
   int64_t tr = 0;
   if (te == 128 && lower && !aliased && tail_target > 0 && m >= 512) {

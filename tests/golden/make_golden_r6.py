@@ -16,6 +16,7 @@ same order of draws as bench.py's workload()).
         individual posterior variances.
   c3    N = 16384, d = 8 ARD squared exponential l_k = 0.4 + 0.05 k, noise = 0.1, seed 16384, 65536 candidates, nMC = 4096:
         IVAR of the start design and the greedy-IVAR step's cost (IVAR after adding the candidate) of 256 fixed candidates.
+  c5_full   N = 65536, d = 10 (the full BASELINE config 5): log-marginal, log det, y^T alpha, 256 entries of alpha, 256 variances.
   c5_lite   N = 16384, d = 10 ARD squared exponential l_k = 0.5 + 0.03 k, noise = 0.1, seed 65536: log-marginal and its 12
         derivatives (10 length scales, signalSize, noise) from a dense dpotri inverse.
 """
@@ -218,6 +219,40 @@ def c5_lite_case():
     return {case + "/loglike": ll, case + "/logdet": logdet, case + "/grad": g}
 
 
+def c5_full_case():
+    """BASELINE config 5 at its FULL size (N = 65536, d = 10 ARD-SE l_k = 0.5 + 0.03 k, noise = 0.1, seed 65536: the inputs of
+    tests/test_gpu_scale.py::test_c5_full_size_fit_on_one_gpu): log-marginal, log det, y^T alpha, 256 entries of alpha and the
+    posterior variance at the first 256 training points.  K is 34.4 GB in host memory; the factorisation is chol_blocked."""
+    case = "c5_full"
+    N, d, noise, nvar = 65536, 10, 0.1, 256
+    rng = np.random.default_rng(65536)
+    X = rng.uniform(-1, 1, (N, d))
+    y = np.sin(2 * np.pi * X.sum(1) / d) + np.sqrt(noise) * rng.standard_normal(N)
+    cl = 0.5 + 0.03 * np.arange(d)
+    t0 = time.time()
+    K = np.empty((N, N))
+    for i0 in range(0, N, 4096):                     # row chunks: in place, no second N x N array
+        blk = K[i0:i0 + 4096]
+        sqdist(X[i0:i0 + 4096], X, cl ** -2.0, out=blk)
+        blk *= -0.5
+        np.exp(blk, out=blk)
+    K[np.diag_indices(N)] += noise
+    print("%s: assembly %.0f s" % (case, time.time() - t0), flush=True)
+    L = chol_blocked(K)
+    print("%s: factor %.0f s" % (case, time.time() - t0), flush=True)
+    logdet = 2.0 * float(np.sum(np.log(np.diag(L))))
+    u = fwd_blocked(L, y)
+    yta = float(u @ u)
+    alpha = bwd_blocked(L, u)
+    ll = -0.5 * yta - 0.5 * logdet - N / 2.0 * np.log(2 * np.pi)
+    Kz = kern("se", sqdist(X, X[:nvar], cl ** -2.0))
+    W = fwd_blocked(L, Kz)
+    var = 1.0 - np.sum(W * W, axis=0)
+    print("%s: done %.0f s  loglike %.15g  logdet %.15g" % (case, time.time() - t0, ll, logdet), flush=True)
+    return {case + "/loglike": ll, case + "/logdet": logdet, case + "/yTalpha": yta, case + "/alpha_head": alpha[:256].copy(),
+            case + "/var256_at_training_points": var}
+
+
 def main():
     want = sys.argv[1:] or ["c4_matern52", "c4_matern32", "c3", "c5_lite"]
     arrays = dict(np.load(NPZ)) if os.path.exists(NPZ) else {}
@@ -228,6 +263,8 @@ def main():
             arrays.update(c3_case())
         elif name == "c5_lite":
             arrays.update(c5_lite_case())
+        elif name == "c5_full":
+            arrays.update(c5_full_case())
         np.savez(NPZ, **{k: np.asarray(v) for k, v in arrays.items()})
     index = {k: dict(shape=list(np.shape(v)), source=LABEL) for k, v in sorted(arrays.items())}
     with open(JSN, "w") as f:
