@@ -170,6 +170,13 @@ def test_c5_full_size_fit_on_one_gpu(dev, ctx):
     assert np.isfinite(ll)
     _, var = dev.posterior(ctx, sp, K, X, None, dev.points(ctx, Xh[:2048]), want_mean=False)
     assert np.all(var > 0) and np.all(var < 0.1)
+    # round 6: BY VALUE against the LAPACK fixture of the same inputs (tests/golden/make_golden_r6.py c5_full; not reference)
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gpexp_golden_r6.npz"))
+    assert ld == pytest.approx(float(gold["c5_full/logdet"]), rel=1e-10)
+    assert float(y @ alpha) == pytest.approx(float(gold["c5_full/yTalpha"]), rel=1e-10)
+    assert ll == pytest.approx(float(gold["c5_full/loglike"]), rel=1e-10)
+    assert np.max(np.abs(alpha[:256] - gold["c5_full/alpha_head"])) <= 1e-10 * np.max(np.abs(gold["c5_full/alpha_head"]))
+    assert np.max(np.abs(var[:256] - gold["c5_full/var256_at_training_points"])) <= 1e-10 * np.max(np.abs(var[:256]))
     # hyper-parameter gradient at full size (d + 2 = 12 entries)
     g = timed("lml_grad_s", lambda: dev.lml_grad(ctx, sp, K, X, alpha))
     assert g.shape == (d + 2,) and np.all(np.isfinite(g))
